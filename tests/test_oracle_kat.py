@@ -1,0 +1,179 @@
+"""Pins the CPU oracle with every known-answer vector the reference's own tests hold for the hot
+path.  Each test names the reference test it mirrors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def kats():
+    with open(os.path.join(GOLDEN, "reference_kats.json")) as f:
+        return json.load(f)
+
+
+def test_fdct_libjpeg(oracle, kats):
+    """src/fdct.rs:276-285 test_fdct_libjpeg — exact 64 outputs for both blocks."""
+    for case in kats["fdct"]:
+        out = oracle.fdct(case["input"], oracle.FDCT_SCALAR)
+        assert out.tolist() == case["output"]
+
+
+def test_rgb_to_ycbcr(oracle, kats):
+    """src/image_buffer.rs:324-422 test_rgb_to_ycbcr — 5 primaries + 88 libjpeg triples."""
+    assert len(kats["rgb_to_ycbcr"]) == 93
+    for rgb, ycc in kats["rgb_to_ycbcr"]:
+        assert list(oracle.rgb_to_ycbcr(*rgb)) == ycc
+
+
+def test_rgb_to_ycbcr_exhaustive_range(oracle):
+    """The `as u8` casts at image_buffer.rs:30 never truncate: a numpy restatement of the formula
+    without the cast stays in 0..255 for all 2^24 inputs, and agrees with the oracle on a sample."""
+    v = np.arange(256, dtype=np.int64)
+    r, g, b = np.meshgrid(v, v, v, indexing="ij")
+    y = (19595 * r + 38470 * g + 7471 * b + 0x7FFF) >> 16
+    cb = (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 0x7FFF) >> 16
+    cr = (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 0x7FFF) >> 16
+    for plane in (y, cb, cr):
+        assert plane.min() >= 0 and plane.max() <= 255
+    rng = np.random.default_rng(7)
+    for rr, gg, bb in rng.integers(0, 256, (500, 3)):
+        assert oracle.rgb_to_ycbcr(int(rr), int(gg), int(bb)) == (y[rr, gg, bb], cb[rr, gg, bb], cr[rr, gg, bb])
+
+
+def test_cmyk_to_ycck(oracle):
+    """src/image_buffer.rs:33-38"""
+    for c, m, y, k in [(0, 0, 0, 0), (255, 255, 255, 255), (12, 200, 77, 3)]:
+        yy, cb, cr = oracle.rgb_to_ycbcr(c, m, y)
+        assert oracle.cmyk_to_ycck(c, m, y, k) == (yy, cb, cr, 255 - k)
+
+
+def test_new_100(oracle):
+    """src/quantization.rs:314-329 test_new_100 — q=100 makes every divisor 1<<3."""
+    for luma in (True, False):
+        t = oracle.qtable(100, luma)
+        assert list(t.table) == [8] * 64
+
+
+def test_new_100_quantize(oracle):
+    """src/quantization.rs:331-338 test_new_100_quantize"""
+    t = oracle.qtable(100, True)
+    for i in range(-255, 255):
+        assert oracle.quantize(t, i << 3, 0) == i
+
+
+def test_compute_reciprocal_spot_values(oracle):
+    """SURVEY.md Appendix A spot values for quantization.rs:187-207 and :261-283."""
+    t = oracle.qtable(100, True)
+    assert (t.recip[0], t.corr[0]) == (4096, 4)           # divisor 8
+    zz = oracle.lib().orc_zigzag()
+    for q, first8 in [(80, [6, 4, 4, 6, 10, 16, 20, 24]), (90, [3, 2, 2, 3, 5, 8, 10, 12]),
+                      (95, [2, 1, 1, 2, 2, 4, 5, 6])]:
+        t = oracle.qtable(q, True)
+        assert [t.table[i] >> 3 for i in range(8)] == first8
+    t = oracle.qtable(50, True)                            # scale 100: Annex K itself
+    assert t.table[0] == 16 << 3 and (t.recip[0], t.corr[0]) == (256, 64)
+    custom = [2] * 64
+    custom[1], custom[2], custom[3] = 3, 99, 0
+    t = oracle.qtable(1, True, oracle.Q_CUSTOM, custom)    # custom tables ignore quality
+    assert (t.table[0], t.recip[0], t.corr[0]) == (16, 2048, 8)
+    assert (t.table[1], t.recip[1], t.corr[1]) == (24, 1365, 13)
+    assert (t.table[2], t.recip[2], t.corr[2]) == (792, 41, 397)
+    assert t.table[3] == 8                                 # clamp(1, 2048) << 3
+    t = oracle.qtable(1, True, oracle.Q_CUSTOM, [65535] * 64)
+    assert t.table[0] == 2048 << 3
+    assert zz[2] == 8 and zz[63] == 63
+
+
+def test_reciprocal_is_not_division(oracle):
+    """The quantiser is multiply-shift (quantization.rs:291-307), not a rounded division."""
+    custom = list(range(1, 65))
+    t = oracle.qtable(50, True, oracle.Q_CUSTOM, custom)
+    diffs = 0
+    for idx in range(64):
+        d = t.table[idx]
+        for v in range(0, 16385, 7):
+            exact = (v + d // 2) // d
+            if oracle.quantize(t, v, idx) != exact:
+                diffs += 1
+            assert oracle.quantize(t, -v, idx) == -oracle.quantize(t, v, idx)
+    assert diffs > 0
+
+
+def test_get_num_bits(oracle):
+    """src/encoder.rs:1286-1300 test_get_num_bits — category == get_code().0 on +-8192."""
+    for value in range(-(2 ** 13), 2 ** 13 + 1):
+        size, bits = oracle.get_code(value)
+        assert oracle.num_bits(value) == size
+        if value > 0:
+            assert bits == value
+        elif value < 0:
+            assert bits == (value - 1) & ((1 << size) - 1)
+
+
+def test_sampling_factors(kats):
+    """src/encoder.rs:1302-1321 sampling_factors — enum value decodes to (h, v)."""
+    enum = kats["sampling_factor_enum"]
+    for name, h, v in kats["sampling_factors"]:
+        value = enum[name]
+        assert ((value >> 4) & 0x07, value & 0xF) == (h, v)
+
+
+def test_simd_fdct_variant(oracle):
+    """The `simd` feature's FDCT (src/avx2/fdct.rs) differs from the scalar one only at natural
+    positions 1,3,5,7 and 33,35,37,39, by 0 or -1 (rounding constant built with 32-bit lanes).
+    Vectors: lane-accurate emulation, see tests/golden/README.md."""
+    with open(os.path.join(GOLDEN, "simd_fdct_vectors.json")) as f:
+        vectors = json.load(f)["vectors"]
+    quirk = {1, 3, 5, 7, 33, 35, 37, 39}
+    differing = 0
+    for v in vectors:
+        scalar = oracle.fdct(v["input"], oracle.FDCT_SCALAR).tolist()
+        simd = oracle.fdct(v["input"], oracle.FDCT_SIMD).tolist()
+        assert scalar == v["scalar"]
+        assert simd == v["simd"]
+        for i, (a, b) in enumerate(zip(scalar, simd)):
+            if a != b:
+                assert i in quirk and b == a - 1
+                differing += 1
+    assert differing > 0
+
+
+def test_huffman_default_tables_are_prefix_codes(oracle):
+    """Annex K.3 defaults (src/huffman.rs:14-64) through create_lookup_table (:277-288)."""
+    bits = [0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]   # luma DC, Table K.3
+    size, code = oracle.huffman_lookup(bits, list(range(12)))
+    assert size[:12] == [2, 3, 3, 3, 3, 3, 4, 5, 6, 7, 8, 9]
+    assert code[:12] == [0b00, 0b010, 0b011, 0b100, 0b101, 0b110, 0b1110, 0b11110, 0b111110,
+                         0b1111110, 0b11111110, 0b111111110]
+
+
+def test_huffman_optimized_properties(oracle):
+    """HuffmanTable::new_optimized (src/huffman.rs:99-221): lengths <= 16, Kraft-valid, more
+    frequent symbols never get longer codes, symbol 256 never appears."""
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        freq = np.zeros(257, dtype=np.uint32)
+        n = int(rng.integers(1, 200))
+        idx = rng.choice(256, n, replace=False)
+        freq[idx] = rng.integers(1, 10 ** int(rng.integers(1, 7)), n)
+        freq[256] = 1
+        bits, vals = oracle.huffman_optimized(freq)
+        assert sum(bits) == len(vals) == n
+        assert sorted(vals) == sorted(int(i) for i in idx)
+        kraft = sum(b / (1 << (i + 1)) for i, b in enumerate(bits))
+        assert kraft < 1.0
+        size, _ = oracle.huffman_lookup(bits, vals)
+        order = sorted(vals, key=lambda s: -int(freq[s]))
+        for a, b in zip(order, order[1:]):
+            if freq[a] > freq[b]:
+                assert size[a] <= size[b]
+    # single used symbol (the 1x1-image case of src/lib.rs:541-553): one 1-bit code
+    freq = np.zeros(257, dtype=np.uint32)
+    freq[5] = 1
+    freq[256] = 1
+    bits, vals = oracle.huffman_optimized(freq)
+    assert vals == [5] and bits[0] == 1 and sum(bits) == 1
