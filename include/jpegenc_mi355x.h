@@ -1,0 +1,224 @@
+/*
+ * jpegenc_mi355x.h — C ABI of the MI355X (gfx950) JPEG block-encode pipeline.
+ *
+ * Drop-in boundary for vstroebel/jpeg-encoder v0.7.0.  The reference has no FFI: its seams are the
+ * statically dispatched `trait Operations` (src/encoder.rs:1259-1272, the slot `AVX2Operations`
+ * plugs into, src/avx2.rs:8-15) and `trait ImageBuffer` (src/image_buffer.rs:86-98).  Per-block
+ * calls cannot cross a device boundary, so the boundary sits one level up:
+ *
+ *   jpegenc_blocks_*      replaces  Encoder::encode_blocks                (src/encoder.rs:977-1056)
+ *                         and the block_y/block_x body of
+ *                         Encoder::encode_image_interleaved               (src/encoder.rs:727-802)
+ *                         i.e. fill_buffers + edge replication + get_block + Operations::fdct +
+ *                         Operations::quantize_block for every block of the image
+ *   jpegenc_histogram_*   replaces  the counting half of optimize_huffman_table
+ *                                                                         (src/encoder.rs:1086-1200)
+ *   jpegenc_qtable_init   replaces  QuantizationTable::new_with_quality   (src/quantization.rs:216-248)
+ *   jpegenc_encoder_*     mirrors   struct Encoder and its public methods (src/encoder.rs:213-515)
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every function returns a jpegenc_status
+ * (0 = success) unless stated otherwise and never aborts.  A handle is not thread-safe; distinct
+ * handles may be used from distinct threads (one HIP stream set per handle).
+ * There is no CPU fallback: compute entry points fail with JPEGENC_ERR_NO_DEVICE / _HIP when no
+ * gfx950 device is usable.
+ */
+#ifndef JPEGENC_MI355X_H
+#define JPEGENC_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JPEGENC_ABI_VERSION 1
+
+/* EncodingError (src/error.rs:5-28) + device errors. */
+typedef enum jpegenc_status {
+    JPEGENC_OK = 0,
+    JPEGENC_ERR_INVALID_APP_SEGMENT = 1,   /* InvalidAppSegment(nr)      encoder.rs:375-376 */
+    JPEGENC_ERR_APP_SEGMENT_TOO_LARGE = 2, /* AppSegmentTooLarge(len)    encoder.rs:377-378 */
+    JPEGENC_ERR_ICC_TOO_LARGE = 3,         /* IccTooLarge(len)           encoder.rs:402-404 */
+    JPEGENC_ERR_BAD_IMAGE_DATA = 4,        /* BadImageData{length,required} encoder.rs:449-454 */
+    JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS = 5, /* ZeroImageDimensions        encoder.rs:521-526 */
+    JPEGENC_ERR_WRITE = 6,                 /* IoError / Write from the sink */
+    JPEGENC_ERR_INVALID_ARGUMENT = 7,      /* where the reference panics (e.g. encoder.rs:329-333) */
+    JPEGENC_ERR_HIP = 8,                   /* a HIP runtime call failed; see jpegenc_last_error() */
+    JPEGENC_ERR_NO_DEVICE = 9,             /* no usable gfx950 device */
+    JPEGENC_ERR_BUFFER_TOO_SMALL = 10
+} jpegenc_status;
+
+/* enum ColorType (src/encoder.rs:72-99), same order. */
+typedef enum jpegenc_color_type {
+    JPEGENC_LUMA = 0, JPEGENC_RGB = 1, JPEGENC_RGBA = 2, JPEGENC_BGR = 3, JPEGENC_BGRA = 4,
+    JPEGENC_YCBCR = 5, JPEGENC_CMYK = 6, JPEGENC_CMYK_AS_YCCK = 7, JPEGENC_YCCK = 8
+} jpegenc_color_type;
+
+/* enum JpegColorType (src/encoder.rs:23-35). */
+typedef enum jpegenc_jpeg_color_type {
+    JPEGENC_J_LUMA = 0, JPEGENC_J_YCBCR = 1, JPEGENC_J_CMYK = 2, JPEGENC_J_YCCK = 3
+} jpegenc_jpeg_color_type;
+
+/* enum SamplingFactor (src/encoder.rs:113-153): the same discriminants, (h << 4) | v, aliases
+ * carry 0x80. */
+typedef enum jpegenc_sampling_factor {
+    JPEGENC_F_1_1 = 1 << 4 | 1, JPEGENC_F_2_1 = 2 << 4 | 1, JPEGENC_F_1_2 = 1 << 4 | 2,
+    JPEGENC_F_2_2 = 2 << 4 | 2, JPEGENC_F_4_1 = 4 << 4 | 1, JPEGENC_F_4_2 = 4 << 4 | 2,
+    JPEGENC_F_1_4 = 1 << 4 | 4, JPEGENC_F_2_4 = 2 << 4 | 4,
+    JPEGENC_R_4_4_4 = 0x80 | 1 << 4 | 1, JPEGENC_R_4_4_0 = 0x80 | 1 << 4 | 2,
+    JPEGENC_R_4_4_1 = 0x80 | 1 << 4 | 4, JPEGENC_R_4_2_2 = 0x80 | 2 << 4 | 1,
+    JPEGENC_R_4_2_0 = 0x80 | 2 << 4 | 2, JPEGENC_R_4_2_1 = 0x80 | 2 << 4 | 4,
+    JPEGENC_R_4_1_1 = 0x80 | 4 << 4 | 1, JPEGENC_R_4_1_0 = 0x80 | 4 << 4 | 2
+} jpegenc_sampling_factor;
+
+/* enum QuantizationTableType (src/quantization.rs:8-40); CUSTOM carries 64 u16 values. */
+typedef enum jpegenc_qtable_type {
+    JPEGENC_Q_DEFAULT = 0, JPEGENC_Q_FLAT = 1, JPEGENC_Q_CUSTOM_MS_SSIM = 2,
+    JPEGENC_Q_CUSTOM_PSNR_HVS = 3, JPEGENC_Q_IMAGE_MAGICK = 4,
+    JPEGENC_Q_KLEIN_SILVERSTEIN_CARNEY = 5, JPEGENC_Q_DENTAL_XRAYS = 6,
+    JPEGENC_Q_VISUAL_DETECTION_MODEL = 7, JPEGENC_Q_IMPROVED_DETECTION_MODEL = 8,
+    JPEGENC_Q_CUSTOM = 9
+} jpegenc_qtable_type;
+
+/* enum PixelDensityUnit (src/writer.rs:48-59). */
+typedef enum jpegenc_density_unit {
+    JPEGENC_DENSITY_PIXEL_ASPECT_RATIO = 0, JPEGENC_DENSITY_INCHES = 1, JPEGENC_DENSITY_CENTIMETERS = 2
+} jpegenc_density_unit;
+
+/* Order of the emitted coefficient blocks. */
+typedef enum jpegenc_block_order {
+    JPEGENC_ORDER_MCU = 0,    /* encode_image_interleaved: per MCU, per component, v_off, h_off */
+    JPEGENC_ORDER_PLANAR = 1  /* encode_blocks: component-major, row-major blocks */
+} jpegenc_block_order;
+
+/* Which of the reference's two FDCT builds to reproduce bit-for-bit.
+ * SCALAR = src/fdct.rs (default features; pinned by the reference's own KAT).
+ * SIMD   = src/avx2/fdct.rs as it behaves with `--features simd` on an AVX2 host: identical except
+ *          that natural coefficients (0|4, odd column) are floored, not rounded, in pass 2. */
+typedef enum jpegenc_fdct_variant { JPEGENC_FDCT_SCALAR = 0, JPEGENC_FDCT_SIMD = 1 } jpegenc_fdct_variant;
+
+/* struct QuantizationTable (src/quantization.rs:209-213): divisors pre-multiplied by 8, 15-bit
+ * reciprocals and rounding corrections, all in natural (row-major) order. */
+typedef struct jpegenc_qtable {
+    uint16_t table[64];
+    int32_t  reciprocals[64];
+    int32_t  corrections[64];
+} jpegenc_qtable;
+
+/* Per-component geometry as init_components derives it (src/encoder.rs:569-631). */
+typedef struct jpegenc_layout {
+    int32_t num_components;
+    int32_t max_h, max_v;
+    int32_t h[4], v[4];
+    int32_t table[4];            /* quantisation = DC = AC table destination */
+    uint64_t blocks[4];          /* blocks contributed by each component in the chosen order */
+    uint64_t total_blocks;
+    uint64_t mcus;               /* MCU count (interleaved geometry) */
+} jpegenc_layout;
+
+/* ---- library / device ------------------------------------------------------------------ */
+int         jpegenc_abi_version(void);
+int         jpegenc_device_count(void);            /* 0 when no HIP device is visible */
+const char *jpegenc_last_error(void);              /* thread-local text of the last failure */
+const char *jpegenc_status_string(int status);
+
+/* ---- host-side table / geometry preparation -------------------------------------------- */
+/* QuantizationTable::new_with_quality (quantization.rs:216-248). `custom` is read only for
+ * JPEGENC_Q_CUSTOM (values clamped to 1..=2048, not quality-scaled, :250-259). */
+int jpegenc_qtable_init(jpegenc_qtable *out, int table_type, const uint16_t custom[64],
+                        int quality, int luma);
+/* ColorType::get_bytes_per_pixel (encoder.rs:101-111); 0 for an unknown type. */
+int jpegenc_bytes_per_pixel(int color_type);
+/* init_components + block-count rules of both drivers (encoder.rs:569-631, 713-717, 1012-1025). */
+int jpegenc_layout_init(jpegenc_layout *out, int width, int height, int color_type,
+                        int h_sampling, int v_sampling, int order);
+
+/* ---- the hot path: pixels -> quantised zig-zag coefficient blocks ----------------------- */
+/* Device-resident batch.  `d_pixels` holds `num_frames` images of identical geometry,
+ * `pixel_frame_stride` bytes apart, interleaved 8-bit samples, rows tightly packed (w*bpp bytes).
+ * `d_coeffs` receives, per frame, layout.total_blocks blocks of 64 little-endian i16 in zig-zag
+ * order (writer.rs:64-68), `coeff_frame_stride` BLOCKS apart (>= total_blocks).  Launches on
+ * `hip_stream` (a hipStream_t, NULL = default stream) and returns without synchronising.
+ * Bit-exact with the reference for every ColorType / SamplingFactor / order. */
+int jpegenc_blocks_device(const void *d_pixels, size_t pixel_frame_stride, int num_frames,
+                          int width, int height, int color_type, int h_sampling, int v_sampling,
+                          const jpegenc_qtable tables[2], int order, int fdct_variant,
+                          void *d_coeffs, size_t coeff_frame_stride, void *hip_stream);
+
+/* Host-resident convenience: H2D + kernel + D2H + synchronise on `device`.  `pixels_len` is
+ * validated like Encoder::encode (encoder.rs:447-454); `coeffs_capacity` is in i16 values. */
+int jpegenc_blocks_host(int device, const uint8_t *pixels, size_t pixels_len, int width, int height,
+                        int color_type, int h_sampling, int v_sampling,
+                        const jpegenc_qtable tables[2], int order, int fdct_variant,
+                        int16_t *coeffs, size_t coeffs_capacity);
+
+/* ---- optimised-Huffman statistics (config 5) ------------------------------------------- */
+/* Counts on PLANAR-order blocks exactly as optimize_huffman_table does (encoder.rs:1086-1200):
+ * d_freq is uint32[2 tables][2 (0=DC,1=AC)][257], zeroed and filled by the call (entry 256 = 1).
+ * progressive_scans = 0 for sequential, else 2..64 (AC bands as encoder.rs:1123-1134). */
+int jpegenc_histogram_device(const void *d_coeffs_planar, const jpegenc_layout *layout,
+                             int progressive_scans, void *d_freq, void *hip_stream);
+
+/* ---- Encoder-shaped API (struct Encoder, src/encoder.rs:213-515) ------------------------ */
+typedef struct jpegenc_encoder jpegenc_encoder;
+
+/* JfifWrite::write_all (writer.rs:76-82): return 0 on success, non-zero to abort with
+ * JPEGENC_ERR_WRITE. */
+typedef int (*jpegenc_write_fn)(void *user, const uint8_t *data, size_t len);
+
+jpegenc_encoder *jpegenc_encoder_new(int quality);                       /* Encoder::new :239 */
+void jpegenc_encoder_free(jpegenc_encoder *e);
+int  jpegenc_encoder_set_device(jpegenc_encoder *e, int device);         /* GPU this handle drives */
+int  jpegenc_encoder_set_fdct_variant(jpegenc_encoder *e, int variant);  /* default SCALAR */
+
+int  jpegenc_encoder_set_density(jpegenc_encoder *e, int unit, uint16_t x, uint16_t y);   /* :280 */
+int  jpegenc_encoder_density(const jpegenc_encoder *e, int *unit, uint16_t *x, uint16_t *y);
+int  jpegenc_encoder_set_sampling_factor(jpegenc_encoder *e, int sampling_factor);        /* :290 */
+int  jpegenc_encoder_sampling_factor(const jpegenc_encoder *e);
+int  jpegenc_encoder_set_quantization_tables(jpegenc_encoder *e, int luma_type,
+                                             const uint16_t luma_custom[64], int chroma_type,
+                                             const uint16_t chroma_custom[64]);           /* :300 */
+int  jpegenc_encoder_quantization_tables(const jpegenc_encoder *e, int types[2]);
+int  jpegenc_encoder_set_progressive(jpegenc_encoder *e, int progressive);                /* :317 */
+int  jpegenc_encoder_set_progressive_scans(jpegenc_encoder *e, int scans);  /* 2..=64, :328 */
+int  jpegenc_encoder_progressive_scans(const jpegenc_encoder *e);           /* 0 = None */
+int  jpegenc_encoder_set_restart_interval(jpegenc_encoder *e, uint16_t interval);         /* :345 */
+int  jpegenc_encoder_restart_interval(const jpegenc_encoder *e);            /* 0 = None */
+int  jpegenc_encoder_set_optimized_huffman_tables(jpegenc_encoder *e, int optimize);      /* :357 */
+int  jpegenc_encoder_optimized_huffman_tables(const jpegenc_encoder *e);
+int  jpegenc_encoder_add_app_segment(jpegenc_encoder *e, int segment_nr, const uint8_t *data,
+                                     size_t len);                                         /* :374 */
+int  jpegenc_encoder_add_icc_profile(jpegenc_encoder *e, const uint8_t *data, size_t len); /* :392 */
+int  jpegenc_encoder_add_exif_metadata(jpegenc_encoder *e, const uint8_t *data, size_t len); /* :426 */
+
+/* Encoder::encode (encoder.rs:440-503).  Unlike the Rust method it does not consume the handle:
+ * the same configuration can encode further images.  Output goes to `sink` in order. */
+int  jpegenc_encoder_encode(jpegenc_encoder *e, const uint8_t *data, size_t len, int width,
+                            int height, int color_type, jpegenc_write_fn sink, void *user);
+/* Same, into a caller buffer; *out_len is always set to the size the file needs. */
+int  jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len,
+                                      int width, int height, int color_type, uint8_t *out,
+                                      size_t out_capacity, size_t *out_len);
+/* Encoder::encode_image with a user ImageBuffer (image_buffer.rs:86-98): `fill_row(user, y,
+ * planes)` must append `width` already-converted samples of row y to each of the
+ * jpeg_color_type's planes (1, 3 or 4 pointers, each `width` bytes). */
+typedef void (*jpegenc_fill_row_fn)(void *user, uint16_t y, uint8_t *const planes[4]);
+int  jpegenc_encoder_encode_image(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
+                                  jpegenc_fill_row_fn fill_row, void *image_user,
+                                  jpegenc_write_fn sink, void *sink_user);
+/* Batch of same-geometry frames on this handle's device, double-buffered (H2D / kernel / D2H /
+ * host entropy coding overlapped).  frames[i] -> sink(users[i], ...). */
+int  jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len,
+                                  int num_frames, int width, int height, int color_type,
+                                  jpegenc_write_fn sink, void *const *users);
+
+/* free functions re-exported by the crate (src/lib.rs:45-49) — host arithmetic, for callers that
+ * implement their own ImageBuffer. */
+void jpegenc_rgb_to_ycbcr(uint8_t r, uint8_t g, uint8_t b, uint8_t out[3]);
+void jpegenc_cmyk_to_ycck(uint8_t c, uint8_t m, uint8_t y, uint8_t k, uint8_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEGENC_MI355X_H */

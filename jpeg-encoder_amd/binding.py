@@ -1,0 +1,323 @@
+"""ctypes binding of libjpegenc_mi355x.so — the same C ABI a Rust/cgo/JNI host would bind
+(include/jpegenc_mi355x.h).  Python here is plumbing for tests and bench.py only.
+
+The library must exist: there is no CPU fallback and no silent degradation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpegenc_mi355x.so")
+
+# enum jpegenc_color_type == reference `enum ColorType` order (src/encoder.rs:72-99)
+LUMA, RGB, RGBA, BGR, BGRA, YCBCR, CMYK, CMYK_AS_YCCK, YCCK = range(9)
+J_LUMA, J_YCBCR, J_CMYK, J_YCCK = range(4)
+ORDER_MCU, ORDER_PLANAR = 0, 1
+FDCT_SCALAR, FDCT_SIMD = 0, 1
+(Q_DEFAULT, Q_FLAT, Q_CUSTOM_MS_SSIM, Q_CUSTOM_PSNR_HVS, Q_IMAGE_MAGICK, Q_KLEIN_SILVERSTEIN_CARNEY,
+ Q_DENTAL_XRAYS, Q_VISUAL_DETECTION_MODEL, Q_IMPROVED_DETECTION_MODEL, Q_CUSTOM) = range(10)
+DENSITY_PIXEL_ASPECT_RATIO, DENSITY_INCHES, DENSITY_CENTIMETERS = range(3)
+(OK, ERR_INVALID_APP_SEGMENT, ERR_APP_SEGMENT_TOO_LARGE, ERR_ICC_TOO_LARGE, ERR_BAD_IMAGE_DATA,
+ ERR_ZERO_IMAGE_DIMENSIONS, ERR_WRITE, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE,
+ ERR_BUFFER_TOO_SMALL) = range(11)
+BPP = {LUMA: 1, RGB: 3, RGBA: 4, BGR: 3, BGRA: 4, YCBCR: 3, CMYK: 4, CMYK_AS_YCCK: 4, YCCK: 4}
+
+
+def sampling_factor(h, v):
+    """SamplingFactor discriminant (src/encoder.rs:120-153): (h << 4) | v."""
+    return (h << 4) | v
+
+
+F_1_1, F_2_1, F_1_2, F_2_2 = 0x11, 0x21, 0x12, 0x22
+F_4_1, F_4_2, F_1_4, F_2_4 = 0x41, 0x42, 0x14, 0x24
+
+# every symbol include/jpegenc_mi355x.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "jpegenc_abi_version", "jpegenc_device_count", "jpegenc_last_error", "jpegenc_status_string",
+    "jpegenc_qtable_init", "jpegenc_bytes_per_pixel", "jpegenc_layout_init",
+    "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_histogram_device",
+    "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
+    "jpegenc_encoder_set_fdct_variant", "jpegenc_encoder_set_density", "jpegenc_encoder_density",
+    "jpegenc_encoder_set_sampling_factor", "jpegenc_encoder_sampling_factor",
+    "jpegenc_encoder_set_quantization_tables", "jpegenc_encoder_quantization_tables",
+    "jpegenc_encoder_set_progressive", "jpegenc_encoder_set_progressive_scans",
+    "jpegenc_encoder_progressive_scans", "jpegenc_encoder_set_restart_interval",
+    "jpegenc_encoder_restart_interval", "jpegenc_encoder_set_optimized_huffman_tables",
+    "jpegenc_encoder_optimized_huffman_tables", "jpegenc_encoder_add_app_segment",
+    "jpegenc_encoder_add_icc_profile", "jpegenc_encoder_add_exif_metadata",
+    "jpegenc_encoder_encode", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_image",
+    "jpegenc_encoder_encode_batch", "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
+]
+
+
+class QTable(C.Structure):
+    _fields_ = [("table", C.c_uint16 * 64), ("reciprocals", C.c_int32 * 64), ("corrections", C.c_int32 * 64)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("num_components", C.c_int32), ("max_h", C.c_int32), ("max_v", C.c_int32),
+                ("h", C.c_int32 * 4), ("v", C.c_int32 * 4), ("table", C.c_int32 * 4),
+                ("blocks", C.c_uint64 * 4), ("total_blocks", C.c_uint64), ("mcus", C.c_uint64)]
+
+
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+FILL_ROW_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint16, C.POINTER(C.POINTER(C.c_uint8)))
+
+
+class JpegEncError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"jpegenc status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one
+        # process cannot both own the GPU, so when torch is installed let it load first: the
+        # dynamic loader then resolves our libamdhip64.so.7 dependency to the copy already mapped.
+        # (A torch-free host — the Rust/C embedding — simply gets /opt/rocm's runtime.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        l = C.CDLL(LIB_PATH)
+        l.jpegenc_last_error.restype = C.c_char_p
+        l.jpegenc_status_string.restype = C.c_char_p
+        l.jpegenc_status_string.argtypes = [C.c_int]
+        l.jpegenc_qtable_init.argtypes = [C.POINTER(QTable), C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int]
+        l.jpegenc_layout_init.argtypes = [C.POINTER(Layout)] + [C.c_int] * 6
+        l.jpegenc_blocks_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.POINTER(QTable), C.c_int, C.c_int,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]
+        l.jpegenc_blocks_host.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.POINTER(QTable), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        l.jpegenc_histogram_device.argtypes = [C.c_void_p, C.POINTER(Layout), C.c_int, C.c_void_p, C.c_void_p]
+        l.jpegenc_encoder_new.restype = C.c_void_p
+        l.jpegenc_encoder_new.argtypes = [C.c_int]
+        l.jpegenc_encoder_free.argtypes = [C.c_void_p]
+        l.jpegenc_encoder_free.restype = None
+        for name in ("set_device", "set_fdct_variant", "set_sampling_factor", "set_progressive",
+                     "set_progressive_scans", "set_optimized_huffman_tables"):
+            getattr(l, "jpegenc_encoder_" + name).argtypes = [C.c_void_p, C.c_int]
+        for name in ("sampling_factor", "progressive_scans", "restart_interval", "optimized_huffman_tables"):
+            getattr(l, "jpegenc_encoder_" + name).argtypes = [C.c_void_p]
+        l.jpegenc_encoder_set_restart_interval.argtypes = [C.c_void_p, C.c_uint16]
+        l.jpegenc_encoder_set_density.argtypes = [C.c_void_p, C.c_int, C.c_uint16, C.c_uint16]
+        l.jpegenc_encoder_density.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint16),
+                                              C.POINTER(C.c_uint16)]
+        l.jpegenc_encoder_set_quantization_tables.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint16),
+                                                              C.c_int, C.POINTER(C.c_uint16)]
+        l.jpegenc_encoder_quantization_tables.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        l.jpegenc_encoder_add_app_segment.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+        l.jpegenc_encoder_add_icc_profile.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        l.jpegenc_encoder_add_exif_metadata.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        l.jpegenc_encoder_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                             WRITE_FN, C.c_void_p]
+        l.jpegenc_encoder_encode_to_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                                       C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.jpegenc_encoder_encode_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, FILL_ROW_FN,
+                                                   C.c_void_p, WRITE_FN, C.c_void_p]
+        l.jpegenc_encoder_encode_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_int,
+                                                   C.c_int, C.c_int, C.c_int, WRITE_FN, C.POINTER(C.c_void_p)]
+        l.jpegenc_rgb_to_ycbcr.argtypes = [C.c_uint8] * 3 + [C.POINTER(C.c_uint8)]
+        l.jpegenc_cmyk_to_ycck.argtypes = [C.c_uint8] * 4 + [C.POINTER(C.c_uint8)]
+        _lib = l
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        raise JpegEncError(status, lib().jpegenc_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return lib().jpegenc_device_count()
+
+
+def qtables(quality, types=(Q_DEFAULT, Q_DEFAULT), customs=(None, None)):
+    """[luma, chroma] QuantizationTable::new_with_quality (src/encoder.rs:528-531)."""
+    arr = (QTable * 2)()
+    for i in range(2):
+        cust = None
+        if types[i] == Q_CUSTOM:
+            cust = (C.c_uint16 * 64)(*[int(v) for v in customs[i]])
+        check(lib().jpegenc_qtable_init(C.byref(arr[i]), types[i], cust, quality, 1 if i == 0 else 0))
+    return arr
+
+
+def layout(width, height, color_type, hs, vs, order):
+    L = Layout()
+    check(lib().jpegenc_layout_init(C.byref(L), width, height, color_type, hs, vs, order))
+    return L
+
+
+def blocks_host(pixels, width, height, color_type, hs, vs, quality=None, order=ORDER_MCU,
+                variant=FDCT_SCALAR, q=None, device=0):
+    """numpy pixels -> (nblocks, 64) int16 via H2D + kernel + D2H (jpegenc_blocks_host)."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
+    if q is None:
+        q = qtables(quality)
+    total = 0
+    if width > 0 and height > 0 and px.size >= width * height * BPP[color_type]:
+        total = layout(width, height, color_type, hs, vs, order).total_blocks
+    out = np.empty((max(total, 1), 64), dtype=np.int16)
+    check(lib().jpegenc_blocks_host(device, px.ctypes.data, px.size, width, height, color_type, hs, vs, q,
+                                    order, variant, out.ctypes.data, out.size))
+    return out[:total]
+
+
+def blocks_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, color_type, hs, vs, q,
+                  order, variant, d_coeffs_ptr, coeff_frame_stride, stream_ptr=0):
+    """Raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous on `stream_ptr`."""
+    check(lib().jpegenc_blocks_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, color_type,
+                                      hs, vs, q, order, variant, d_coeffs_ptr, coeff_frame_stride, stream_ptr))
+
+
+def histogram_device(d_coeffs_ptr, L, progressive_scans, d_freq_ptr, stream_ptr=0):
+    check(lib().jpegenc_histogram_device(d_coeffs_ptr, C.byref(L), progressive_scans, d_freq_ptr, stream_ptr))
+
+
+class Encoder:
+    """Python mirror of `struct Encoder` (src/encoder.rs:213-515) over the C handle API.
+
+    Method names and argument meaning follow the Rust crate so the tests read like the
+    reference's own (src/lib.rs:188-553).  Errors surface as JpegEncError with the status that
+    mirrors the EncodingError variant.
+    """
+
+    def __init__(self, quality, device=0):
+        self._h = lib().jpegenc_encoder_new(quality)
+        if not self._h:
+            raise MemoryError("jpegenc_encoder_new failed")
+        check(lib().jpegenc_encoder_set_device(self._h, device))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().jpegenc_encoder_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_density(self, unit, x, y):
+        check(lib().jpegenc_encoder_set_density(self._h, unit, x, y))
+
+    def density(self):
+        u, x, y = C.c_int(), C.c_uint16(), C.c_uint16()
+        check(lib().jpegenc_encoder_density(self._h, C.byref(u), C.byref(x), C.byref(y)))
+        return u.value, x.value, y.value
+
+    def set_sampling_factor(self, sf):
+        check(lib().jpegenc_encoder_set_sampling_factor(self._h, sf))
+
+    def sampling_factor(self):
+        return lib().jpegenc_encoder_sampling_factor(self._h)
+
+    def set_quantization_tables(self, luma, chroma, luma_custom=None, chroma_custom=None):
+        lc = (C.c_uint16 * 64)(*[int(v) for v in luma_custom]) if luma_custom is not None else None
+        cc = (C.c_uint16 * 64)(*[int(v) for v in chroma_custom]) if chroma_custom is not None else None
+        check(lib().jpegenc_encoder_set_quantization_tables(self._h, luma, lc, chroma, cc))
+
+    def quantization_tables(self):
+        t = (C.c_int * 2)()
+        check(lib().jpegenc_encoder_quantization_tables(self._h, t))
+        return t[0], t[1]
+
+    def set_progressive(self, progressive):
+        check(lib().jpegenc_encoder_set_progressive(self._h, 1 if progressive else 0))
+
+    def set_progressive_scans(self, scans):
+        check(lib().jpegenc_encoder_set_progressive_scans(self._h, scans))
+
+    def progressive_scans(self):
+        n = lib().jpegenc_encoder_progressive_scans(self._h)
+        return n if n else None
+
+    def set_restart_interval(self, interval):
+        check(lib().jpegenc_encoder_set_restart_interval(self._h, interval))
+
+    def restart_interval(self):
+        n = lib().jpegenc_encoder_restart_interval(self._h)
+        return n if n else None
+
+    def set_optimized_huffman_tables(self, optimize):
+        check(lib().jpegenc_encoder_set_optimized_huffman_tables(self._h, 1 if optimize else 0))
+
+    def optimized_huffman_tables(self):
+        return bool(lib().jpegenc_encoder_optimized_huffman_tables(self._h))
+
+    def set_fdct_variant(self, variant):
+        check(lib().jpegenc_encoder_set_fdct_variant(self._h, variant))
+
+    def add_app_segment(self, nr, data):
+        check(lib().jpegenc_encoder_add_app_segment(self._h, nr, bytes(data), len(data)))
+
+    def add_icc_profile(self, data):
+        check(lib().jpegenc_encoder_add_icc_profile(self._h, bytes(data), len(data)))
+
+    def add_exif_metadata(self, data):
+        check(lib().jpegenc_encoder_add_exif_metadata(self._h, bytes(data), len(data)))
+
+    def encode(self, data, width, height, color_type):
+        """Encoder::encode -> bytes (the sink is an in-memory Vec<u8>)."""
+        px = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        chunks = []
+
+        def sink(_user, ptr, n):
+            chunks.append(C.string_at(ptr, n))
+            return 0
+
+        cb = WRITE_FN(sink)
+        check(lib().jpegenc_encoder_encode(self._h, px.ctypes.data, px.size, width, height, color_type, cb, None))
+        return b"".join(chunks)
+
+    def encode_image(self, jpeg_color_type, width, height, fill_buffers):
+        """Encoder::encode_image with a user ImageBuffer: fill_buffers(y) -> list of per-plane rows."""
+        chunks = []
+
+        def sink(_user, ptr, n):
+            chunks.append(C.string_at(ptr, n))
+            return 0
+
+        def fill(_user, y, planes):
+            rows = fill_buffers(y)
+            for i, row in enumerate(rows):
+                r = np.ascontiguousarray(row, dtype=np.uint8)
+                C.memmove(planes[i], r.ctypes.data, width)
+
+        cb, fb = WRITE_FN(sink), FILL_ROW_FN(fill)
+        check(lib().jpegenc_encoder_encode_image(self._h, jpeg_color_type, width, height, fb, None, cb, None))
+        return b"".join(chunks)
+
+    def encode_batch(self, frames, width, height, color_type):
+        """frames: list of equally sized uint8 arrays -> list of bytes (frame-parallel on one GPU)."""
+        arrs = [np.ascontiguousarray(f, dtype=np.uint8).reshape(-1) for f in frames]
+        n = len(arrs)
+        outs = [[] for _ in range(n)]
+
+        def sink(user, ptr, nbytes):
+            outs[(user or 0)].append(C.string_at(ptr, nbytes))
+            return 0
+
+        cb = WRITE_FN(sink)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        users = (C.c_void_p * max(n, 1))(*[i for i in range(n)])
+        flen = arrs[0].size if n else 0
+        check(lib().jpegenc_encoder_encode_batch(self._h, ptrs, flen, n, width, height, color_type, cb, users))
+        return [b"".join(o) for o in outs]

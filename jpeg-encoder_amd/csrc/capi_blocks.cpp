@@ -1,0 +1,332 @@
+// capi_blocks.cpp — C-ABI entry points of the hot path (include/jpegenc_mi355x.h): table and
+// geometry preparation on the host, kernel launches on the device.  No CPU fallback: the compute
+// entry points fail with JPEGENC_ERR_NO_DEVICE / JPEGENC_ERR_HIP when no MI355X is usable.
+#include <string.h>
+
+#include <string>
+
+#include "host_common.h"
+#include "tables_data.inc"
+
+namespace jpegenc {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+int fail(int status, const std::string &msg) { g_last_error = msg; return status; }
+int hip_fail(hipError_t e, const char *what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? JPEGENC_ERR_NO_DEVICE : JPEGENC_ERR_HIP;
+}
+
+int ensure_device_ready(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(JPEGENC_ERR_NO_DEVICE, "no HIP device visible (jpegenc has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(JPEGENC_ERR_NO_DEVICE, "device index out of range");
+    JPEGENC_HIP(hipSetDevice(device));
+    return JPEGENC_OK;
+}
+
+int jpeg_color_type_of(int ct) {
+    switch (ct) {
+    case JPEGENC_LUMA: return JPEGENC_J_LUMA;
+    case JPEGENC_RGB: case JPEGENC_RGBA: case JPEGENC_BGR: case JPEGENC_BGRA: case JPEGENC_YCBCR:
+        return JPEGENC_J_YCBCR;
+    case JPEGENC_CMYK: return JPEGENC_J_CMYK;
+    case JPEGENC_CMYK_AS_YCCK: case JPEGENC_YCCK: return JPEGENC_J_YCCK;
+    }
+    return -1;
+}
+
+// Encoder::init_components — encoder.rs:569-619; get_max_sampling_size — :621-631
+int components_for(int jct, int hs, int vs, jpegenc_layout *L) {
+    memset(L, 0, sizeof *L);
+    auto add = [&](int dest, int h, int v) {
+        int i = L->num_components++;
+        L->h[i] = h; L->v[i] = v; L->table[i] = dest;
+    };
+    switch (jct) {
+    case JPEGENC_J_LUMA: add(0, 1, 1); break;                      // sampling ignored for Luma
+    case JPEGENC_J_YCBCR: add(0, hs, vs); add(1, 1, 1); add(1, 1, 1); break;
+    case JPEGENC_J_CMYK: add(1, 1, 1); add(1, 1, 1); add(1, 1, 1); add(0, hs, vs); break;
+    case JPEGENC_J_YCCK: add(0, hs, vs); add(1, 1, 1); add(1, 1, 1); add(0, hs, vs); break;
+    default: return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown JPEG colour type");
+    }
+    L->max_h = L->max_v = 1;
+    for (int i = 0; i < L->num_components; i++) {
+        if (L->h[i] > L->max_h) L->max_h = L->h[i];
+        if (L->v[i] > L->max_v) L->max_v = L->v[i];
+    }
+    return JPEGENC_OK;
+}
+
+static uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+static bool valid_sampling(int hs, int vs) {   // SamplingFactor::from_factors, encoder.rs:157-171
+    return (hs == 1 || hs == 2 || hs == 4) && (vs == 1 || vs == 2 || vs == 4) && !(hs == 4 && vs == 4);
+}
+
+static void fill_quant(QuantDev *d, const jpegenc_qtable &t) {
+    for (int i = 0; i < 64; i++) {
+        d->r2[i] = 2u * (uint32_t)t.reciprocals[i];
+        d->c2[i] = 2u * (uint32_t)t.corrections[i] * (uint32_t)t.reciprocals[i];
+    }
+}
+
+static void fill_geometry(BlockKernelParams *p, const jpegenc_layout &L, int width, int height, int order,
+                          const jpegenc_qtable tables[2]) {
+    p->width = width; p->height = height;
+    p->ncomp = L.num_components; p->hmax = L.max_h; p->vmax = L.max_v; p->order = order;
+    uint32_t first = 0, waves = 0, tasks = 0;
+    uint64_t off = 0;
+    p->mcus_x = (uint32_t)cdiv((uint64_t)width, 8u * (uint64_t)L.max_h);
+    p->total_mcus = (uint32_t)L.mcus;
+    for (int c = 0; c < L.num_components; c++) {
+        p->h[c] = L.h[c]; p->v[c] = L.v[c]; p->qsel[c] = L.table[c];
+        p->sx[c] = L.max_h / L.h[c]; p->sy[c] = L.max_v / L.v[c];
+        p->comp_first[c] = first; first += (uint32_t)(L.h[c] * L.v[c]);
+        p->wave_start[c] = waves; waves += (uint32_t)(L.h[c] * L.v[c]);
+        p->cols[c] = (uint32_t)cdiv(cdiv((uint64_t)width, 8), (uint64_t)p->sx[c]);
+        p->nblocks[c] = (uint32_t)L.blocks[c];
+        p->comp_off[c] = off; off += L.blocks[c];
+        p->task_start[c] = tasks; tasks += (uint32_t)cdiv(L.blocks[c], 64);
+    }
+    p->bpm = first;
+    p->wave_start[L.num_components] = waves;
+    p->task_start[L.num_components] = tasks;
+    fill_quant(&p->q[0], tables[0]);
+    fill_quant(&p->q[1], tables[1]);
+}
+
+int build_block_params(BlockKernelParams *p, const jpegenc_layout &L, int width, int height,
+                       int color_type, const jpegenc_qtable tables[2], int order) {
+    memset(p, 0, sizeof *p);
+    fill_geometry(p, L, width, height, order, tables);
+    p->bpp = jpegenc_bytes_per_pixel(color_type);
+    p->o[0] = 0; p->o[1] = 1; p->o[2] = 2;
+    switch (color_type) {
+    case JPEGENC_LUMA: p->xform = XF_LUMA; break;
+    case JPEGENC_RGB: case JPEGENC_RGBA: p->xform = XF_RGB2YCC; break;            // (.., 0, 1, 2)
+    case JPEGENC_BGR: case JPEGENC_BGRA: p->xform = XF_RGB2YCC; p->o[0] = 2; p->o[2] = 0; break;
+    case JPEGENC_YCBCR: case JPEGENC_YCCK: p->xform = XF_PASS; break;
+    case JPEGENC_CMYK: p->xform = XF_CMYK_INVERT; break;
+    case JPEGENC_CMYK_AS_YCCK: p->xform = XF_CMYK2YCCK; break;
+    default: return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");
+    }
+    return JPEGENC_OK;
+}
+
+int build_block_params_planes(BlockKernelParams *p, const jpegenc_layout &L, int width, int height,
+                              const jpegenc_qtable tables[2], int order) {
+    memset(p, 0, sizeof *p);
+    fill_geometry(p, L, width, height, order, tables);
+    p->bpp = 1;
+    p->xform = XF_PLANES;
+    p->plane_stride = (uint64_t)width * (uint64_t)height;
+    return JPEGENC_OK;
+}
+
+}  // namespace jpegenc
+
+using namespace jpegenc;
+
+extern "C" {
+
+int jpegenc_abi_version(void) { return JPEGENC_ABI_VERSION; }
+
+int jpegenc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *jpegenc_last_error(void) { return g_last_error.c_str(); }
+
+const char *jpegenc_status_string(int s) {
+    switch (s) {
+    case JPEGENC_OK: return "ok";
+    case JPEGENC_ERR_INVALID_APP_SEGMENT: return "Invalid app segment number";
+    case JPEGENC_ERR_APP_SEGMENT_TOO_LARGE: return "App segment exceeds maximum allowed data length of 65533";
+    case JPEGENC_ERR_ICC_TOO_LARGE: return "ICC profile exceeds maximum allowed data length";
+    case JPEGENC_ERR_BAD_IMAGE_DATA: return "Image data too small for dimensions and color_type";
+    case JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS: return "Image dimensions must be non zero";
+    case JPEGENC_ERR_WRITE: return "write error";
+    case JPEGENC_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case JPEGENC_ERR_HIP: return "HIP runtime error";
+    case JPEGENC_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case JPEGENC_ERR_BUFFER_TOO_SMALL: return "output buffer too small";
+    }
+    return "unknown status";
+}
+
+int jpegenc_bytes_per_pixel(int ct) {   // encoder.rs:101-111
+    switch (ct) {
+    case JPEGENC_LUMA: return 1;
+    case JPEGENC_RGB: case JPEGENC_BGR: case JPEGENC_YCBCR: return 3;
+    case JPEGENC_RGBA: case JPEGENC_BGRA: case JPEGENC_CMYK: case JPEGENC_CMYK_AS_YCCK: case JPEGENC_YCCK: return 4;
+    }
+    return 0;
+}
+
+// quantization.rs:187-207
+static void compute_reciprocal(uint32_t divisor, int32_t *recip, int32_t *corr) {
+    if (divisor <= 1) { *recip = 1; *corr = 0; return; }
+    uint32_t r = (1u << 15) / divisor;
+    const uint32_t frac = (1u << 15) % divisor;
+    uint32_t c = divisor / 2;
+    if (frac != 0) {
+        if (frac <= c) c++; else r++;
+    }
+    *recip = (int32_t)r; *corr = (int32_t)c;
+}
+
+int jpegenc_qtable_init(jpegenc_qtable *out, int table_type, const uint16_t custom[64], int quality, int luma) {
+    if (!out) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null table");
+    if (table_type == JPEGENC_Q_CUSTOM) {                      // get_user_table :250-259
+        if (!custom) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "custom table requires 64 values");
+        for (int i = 0; i < 64; i++) {
+            uint32_t v = custom[i];
+            v = v < 1 ? 1 : v > 2048 ? 2048 : v;
+            out->table[i] = (uint16_t)(v << 3);
+        }
+    } else if (table_type >= 0 && table_type < JPEGENC_Q_CUSTOM) {   // get_with_quality :261-283
+        const uint16_t *base = luma ? k_qpreset_luma[table_type] : k_qpreset_chroma[table_type];
+        const uint32_t q = (uint32_t)(quality < 1 ? 1 : quality > 100 ? 100 : quality);
+        const uint32_t scale = q < 50 ? 5000 / q : 200 - q * 2;
+        for (int i = 0; i < 64; i++) {
+            uint32_t v = ((uint32_t)base[i] * scale + 50) / 100;
+            v = v < 1 ? 1 : v > 255 ? 255 : v;
+            out->table[i] = (uint16_t)(v << 3);                // pre-multiplied: the DCT is scaled by 8
+        }
+    } else {
+        return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown quantisation table type");
+    }
+    for (int i = 0; i < 64; i++) compute_reciprocal(out->table[i], &out->reciprocals[i], &out->corrections[i]);
+    return JPEGENC_OK;
+}
+
+int jpegenc_layout_init(jpegenc_layout *out, int width, int height, int color_type, int hs, int vs, int order) {
+    if (!out) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null layout");
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
+        return fail(width == 0 || height == 0 ? JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS : JPEGENC_ERR_INVALID_ARGUMENT,
+                    "image dimensions must be 1..65535");
+    if (!valid_sampling(hs, vs)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unsupported sampling factor");
+    if (order != JPEGENC_ORDER_MCU && order != JPEGENC_ORDER_PLANAR)
+        return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown block order");
+    const int jct = color_type >= 100 ? color_type - 100 : jpeg_color_type_of(color_type);   // 100+J = planar source
+    if (jct < 0) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");
+    int rc = components_for(jct, hs, vs, out);
+    if (rc) return rc;
+    out->mcus = cdiv((uint64_t)width, 8u * (uint64_t)out->max_h) * cdiv((uint64_t)height, 8u * (uint64_t)out->max_v);
+    out->total_blocks = 0;
+    for (int c = 0; c < out->num_components; c++) {
+        if (order == JPEGENC_ORDER_MCU) {                      // encoder.rs:713-714, 759-761
+            out->blocks[c] = out->mcus * (uint64_t)(out->h[c] * out->v[c]);
+        } else {                                               // encoder.rs:1012-1025
+            out->blocks[c] = cdiv(cdiv((uint64_t)width, 8), (uint64_t)(out->max_h / out->h[c])) *
+                             cdiv(cdiv((uint64_t)height, 8), (uint64_t)(out->max_v / out->v[c]));
+        }
+        out->total_blocks += out->blocks[c];
+    }
+    return JPEGENC_OK;
+}
+
+int jpegenc_blocks_device(const void *d_pixels, size_t pixel_frame_stride, int num_frames, int width, int height,
+                          int color_type, int hs, int vs, const jpegenc_qtable tables[2], int order,
+                          int fdct_variant, void *d_coeffs, size_t coeff_frame_stride, void *hip_stream) {
+    if (!d_pixels || !d_coeffs || !tables) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    if (num_frames <= 0) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "num_frames must be positive");
+    if (fdct_variant != JPEGENC_FDCT_SCALAR && fdct_variant != JPEGENC_FDCT_SIMD)
+        return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown FDCT variant");
+    jpegenc_layout L;
+    int rc = jpegenc_layout_init(&L, width, height, color_type, hs, vs, order);
+    if (rc) return rc;
+    if (coeff_frame_stride < L.total_blocks) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "coeff_frame_stride < total_blocks");
+    if (num_frames > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "at most 65535 frames per call");
+    BlockKernelParams p;
+    rc = build_block_params(&p, L, width, height, color_type, tables, order);
+    if (rc) return rc;
+    p.pixels = (const uint8_t *)d_pixels;
+    p.coeffs = d_coeffs;
+    p.pixel_frame_stride = pixel_frame_stride;
+    p.coeff_frame_stride = coeff_frame_stride;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipError_t err = hipSuccess;
+    if (!launch_blocks_fast(p, num_frames, fdct_variant, stream, &err))
+        err = launch_blocks_generic(p, num_frames, fdct_variant, stream);
+    if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+    return JPEGENC_OK;
+}
+
+int jpegenc_blocks_host(int device, const uint8_t *pixels, size_t pixels_len, int width, int height, int color_type,
+                        int hs, int vs, const jpegenc_qtable tables[2], int order, int fdct_variant,
+                        int16_t *coeffs, size_t coeffs_capacity) {
+    const int bpp = jpegenc_bytes_per_pixel(color_type);
+    if (!bpp) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");
+    if (width < 0 || height < 0 || width > 65535 || height > 65535)
+        return fail(JPEGENC_ERR_INVALID_ARGUMENT, "image dimensions must fit u16");
+    const size_t required = (size_t)width * (size_t)height * (size_t)bpp;
+    if (pixels_len < required)                                         // encoder.rs:447-454
+        return fail(JPEGENC_ERR_BAD_IMAGE_DATA, "Image data too small for dimensions and color_type: " +
+                    std::to_string(pixels_len) + " need at least " + std::to_string(required));
+    if (width == 0 || height == 0)                                     // encoder.rs:521-526
+        return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "Image dimensions must be non zero");
+    if (!pixels || !coeffs) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    jpegenc_layout L;
+    int rc = jpegenc_layout_init(&L, width, height, color_type, hs, vs, order);
+    if (rc) return rc;
+    if (coeffs_capacity < L.total_blocks * 64) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "coefficient buffer too small");
+    rc = ensure_device_ready(device);
+    if (rc) return rc;
+    void *d_px = nullptr, *d_co = nullptr;
+    JPEGENC_HIP(hipMalloc(&d_px, required));
+    hipError_t e = hipMalloc(&d_co, L.total_blocks * 128);
+    if (e != hipSuccess) { (void)hipFree(d_px); return hip_fail(e, "hipMalloc(coefficients)"); }
+    auto cleanup = [&]() { (void)hipFree(d_px); (void)hipFree(d_co); };
+    e = hipMemcpy(d_px, pixels, required, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpy(H2D)"); }
+    rc = jpegenc_blocks_device(d_px, required, 1, width, height, color_type, hs, vs, tables, order, fdct_variant,
+                               d_co, L.total_blocks, nullptr);
+    if (rc) { cleanup(); return rc; }
+    e = hipMemcpy(coeffs, d_co, L.total_blocks * 128, hipMemcpyDeviceToHost);   // synchronises
+    cleanup();
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(D2H)");
+    return JPEGENC_OK;
+}
+
+int jpegenc_histogram_device(const void *d_coeffs_planar, const jpegenc_layout *L, int progressive_scans,
+                             void *d_freq, void *hip_stream) {
+    if (!d_coeffs_planar || !L || !d_freq) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    if (progressive_scans != 0 && (progressive_scans < 2 || progressive_scans > 64))
+        return fail(JPEGENC_ERR_INVALID_ARGUMENT, "progressive_scans must be 0 or 2..64");
+    HistKernelParams p;
+    memset(&p, 0, sizeof p);
+    p.coeffs = (const int16_t *)d_coeffs_planar;
+    p.freq = (uint32_t *)d_freq;
+    p.ncomp = L->num_components;
+    p.progressive_scans = progressive_scans;
+    uint64_t off = 0;
+    for (int c = 0; c < L->num_components; c++) {
+        p.nblocks[c] = (uint32_t)L->blocks[c];
+        p.comp_off[c] = off; off += L->blocks[c];
+        p.table[c] = L->table[c];
+    }
+    hipError_t e = launch_histogram(p, (hipStream_t)hip_stream);
+    if (e != hipSuccess) return hip_fail(e, "histogram kernel launch");
+    return JPEGENC_OK;
+}
+
+void jpegenc_rgb_to_ycbcr(uint8_t r8, uint8_t g8, uint8_t b8, uint8_t out[3]) {   // image_buffer.rs:9-31
+    const int32_t r = r8, g = g8, b = b8;
+    out[0] = (uint8_t)((19595 * r + 38470 * g + 7471 * b + 0x7FFF) >> 16);
+    out[1] = (uint8_t)((-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 0x7FFF) >> 16);
+    out[2] = (uint8_t)((32768 * r - 27439 * g - 5329 * b + (128 << 16) + 0x7FFF) >> 16);
+}
+
+void jpegenc_cmyk_to_ycck(uint8_t c, uint8_t m, uint8_t y, uint8_t k, uint8_t out[4]) {   // image_buffer.rs:33-38
+    jpegenc_rgb_to_ycbcr(c, m, y, out);
+    out[3] = (uint8_t)(255 - k);
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// host_common.h — internals shared by the C-ABI translation units (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/jpegenc_mi355x.h"
+#include "device_params.h"
+
+namespace jpegenc {
+
+void set_last_error(const std::string &msg);
+int fail(int status, const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+#define JPEGENC_HIP(call)                                        \
+    do {                                                         \
+        hipError_t e__ = (call);                                 \
+        if (e__ != hipSuccess) return jpegenc::hip_fail(e__, #call); \
+    } while (0)
+
+// init_components (encoder.rs:569-631) for a JpegColorType.
+int components_for(int jpeg_color_type, int hs, int vs, jpegenc_layout *L);
+int jpeg_color_type_of(int color_type);
+
+// Fill the kernel parameter block for interleaved pixel input.
+int build_block_params(BlockKernelParams *p, const jpegenc_layout &L, int width, int height,
+                       int color_type, const jpegenc_qtable tables[2], int order);
+// Same for planar, already-converted input (user ImageBuffer path).
+int build_block_params_planes(BlockKernelParams *p, const jpegenc_layout &L, int width, int height,
+                              const jpegenc_qtable tables[2], int order);
+
+// block_kernels.hip
+hipError_t launch_blocks_generic(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream);
+hipError_t launch_histogram(const HistKernelParams &p, hipStream_t stream);
+// fast_kernels.hip: returns false when the configuration has no specialised kernel
+bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream,
+                        hipError_t *err);
+
+int ensure_device_ready(int device);
+
+}  // namespace jpegenc

@@ -1,0 +1,838 @@
+// host_encoder.cpp — the Encoder-shaped half of the C ABI: mirrors `struct Encoder`
+// (src/encoder.rs:213-515) and keeps on the host exactly what the north star keeps there — scan
+// orchestration (encoder.rs:517-975), Huffman tables (huffman.rs) and the JFIF bit writer
+// (writer.rs) — while every pixel -> coefficient step runs in the HIP kernels.
+//
+// Entropy coding is inherently serial per scan; it is written for throughput (64-bit accumulator,
+// word-at-a-time 0xFF stuffing test like writer.rs:169-184, zero-run skipping through a
+// non-zero bitmask) and frames of a batch are coded by one host thread per in-flight frame.
+#include <string.h>
+
+#include <atomic>
+#include <memory>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "host_common.h"
+#include "tables_data.inc"
+
+namespace jpegenc {
+
+// T.81 Figure A.6 (writer.rs:64-68)
+static const uint8_t kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ---------------------------------------------------------------------------------------------
+// Huffman tables (huffman.rs)
+struct HuffTable {
+    uint8_t bits[16];
+    uint8_t vals[256];
+    int nvals = 0;
+    uint32_t code[256];   // right-aligned code
+    uint8_t size[256];
+
+    void assign(const uint8_t b[16], const uint8_t *v, int n) {
+        memcpy(bits, b, 16);
+        memcpy(vals, v, (size_t)n);
+        nvals = n;
+        memset(code, 0, sizeof code);
+        memset(size, 0, sizeof size);
+        // Figures C.1-C.3 (huffman.rs:240-288): canonical codes in order of increasing length
+        unsigned next = 0;
+        int k = 0;
+        for (int len = 1; len <= 16; len++) {
+            for (int i = 0; i < bits[len - 1]; i++, k++) {
+                code[vals[k]] = next++;
+                size[vals[k]] = (uint8_t)len;
+            }
+            next <<= 1;
+        }
+    }
+
+    // Annex K.2 as HuffmanTable::new_optimized implements it (huffman.rs:99-221), including its
+    // tie rule (`<=`: among equal least frequencies the LARGEST symbol wins) — that rule decides
+    // the emitted DHT bytes, so it is part of the drop-in contract.
+    void assign_optimized(const uint32_t freq_in[257]) {
+        uint32_t freq[257];
+        int others[257], codesize[257];
+        memcpy(freq, freq_in, sizeof freq);
+        for (int i = 0; i < 257; i++) { others[i] = -1; codesize[i] = 0; }
+        for (;;) {
+            int v1 = -1, v2 = -1;
+            uint32_t least = UINT32_MAX;
+            for (int i = 0; i < 257; i++)
+                if (freq[i] && freq[i] <= least) { least = freq[i]; v1 = i; }
+            if (v1 < 0) break;
+            least = UINT32_MAX;
+            for (int i = 0; i < 257; i++)
+                if (freq[i] && freq[i] <= least && i != v1) { least = freq[i]; v2 = i; }
+            if (v2 < 0) break;
+            freq[v1] += freq[v2];
+            freq[v2] = 0;
+            for (codesize[v1]++; others[v1] >= 0;) { v1 = others[v1]; codesize[v1]++; }
+            others[v1] = v2;
+            for (codesize[v2]++; others[v2] >= 0;) { v2 = others[v2]; codesize[v2]++; }
+        }
+        int count[33] = {0};
+        for (int i = 0; i < 257; i++)
+            if (codesize[i]) count[codesize[i]]++;
+        int i = 32;
+        for (; i > 16; i--) {                       // Figure K.3: fold lengths > 16 back
+            while (count[i] > 0) {
+                int j = i - 2;
+                while (count[j] == 0) j--;
+                count[i] -= 2; count[i - 1]++; count[j + 1] += 2; count[j]--;
+            }
+        }
+        while (count[i] == 0) i--;
+        count[i]--;                                 // the reserved all-ones code point (symbol 256)
+        uint8_t v[256], b[16];
+        int n = 0;
+        for (int s = 1; s <= 32; s++)               // Figure K.4
+            for (int sym = 0; sym < 256; sym++)
+                if (codesize[sym] == s) v[n++] = (uint8_t)sym;
+        for (int s = 0; s < 16; s++) b[s] = (uint8_t)count[s + 1];
+        assign(b, v, n);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Output: segments + entropy-coded data into one growing buffer, handed to the sink in large pieces
+// (the reference may call write_all with 1-byte slices, writer.rs:129-131; the byte stream is
+// what is contractual).
+struct Out {
+    std::vector<uint8_t> buf;
+    jpegenc_write_fn sink = nullptr;
+    void *user = nullptr;
+    bool failed = false;
+    uint64_t acc = 0;
+    int nbits = 0;
+
+    void u8(unsigned v) { buf.push_back((uint8_t)v); }
+    void u16(unsigned v) { u8(v >> 8); u8(v & 0xFF); }
+    void marker(unsigned m) { u8(0xFF); u8(m); }
+    void bytes(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; buf.insert(buf.end(), b, b + n); }
+    void segment(unsigned m, const uint8_t *d, size_t n) { marker(m); u16((unsigned)((n + 2) & 0xFFFF)); bytes(d, n); }
+    void drain(bool force) {
+        if (!sink || failed) return;
+        if (force || buf.size() >= (1u << 20)) {
+            if (!buf.empty() && sink(user, buf.data(), buf.size()) != 0) failed = true;
+            buf.clear();
+        }
+    }
+
+    // entropy-coded segment writer -----------------------------------------------------------
+    uint8_t *cur = nullptr, *lim = nullptr;
+    void begin_bits() { acc = 0; nbits = 0; }
+    void reserve_bits(size_t n) {
+        const size_t used = buf.size();
+        (void)used;
+        if ((size_t)(lim - cur) < n) {
+            const size_t off = cur ? (size_t)(cur - buf.data()) : buf.size();
+            buf.resize(off + n + (1u << 16));
+            cur = buf.data() + off;
+            lim = buf.data() + buf.size();
+        }
+    }
+    void open_bits() { cur = nullptr; lim = nullptr; reserve_bits(1 << 16); }
+    void close_bits() { buf.resize((size_t)(cur - buf.data())); cur = lim = nullptr; }
+
+    inline void put(uint32_t code, int size) {              // write_bits, writer.rs:186-202
+        acc = (acc << size) | code;
+        nbits += size;
+        if (nbits >= 32) {
+            const uint32_t w = (uint32_t)(acc >> (nbits - 32));
+            nbits -= 32;
+            if ((w & 0x80808080u & ~(w + 0x01010101u)) != 0) {   // some byte is 0xFF: stuff
+                for (int s = 24; s >= 0; s -= 8) {
+                    const uint8_t b = (uint8_t)(w >> s);
+                    *cur++ = b;
+                    if (b == 0xFF) *cur++ = 0;
+                }
+            } else {
+                cur[0] = (uint8_t)(w >> 24); cur[1] = (uint8_t)(w >> 16); cur[2] = (uint8_t)(w >> 8); cur[3] = (uint8_t)w;
+                cur += 4;
+            }
+        }
+    }
+    void finalize_bits() {                                   // finalize_bit_buffer, writer.rs:138-154
+        put(0x7F, 7);
+        while (nbits >= 8) {
+            const uint8_t b = (uint8_t)(acc >> (nbits - 8));
+            *cur++ = b;
+            if (b == 0xFF) *cur++ = 0;
+            nbits -= 8;
+        }
+        acc = 0; nbits = 0;
+    }
+};
+
+static inline int bit_length(unsigned a) { return a ? 32 - __builtin_clz(a) : 0; }
+
+static inline void put_dc(Out &o, int16_t value, int16_t prev, const HuffTable &dc) {   // write_dc, writer.rs:342-354
+    const int diff = (int16_t)(value - prev);
+    const int nb = bit_length((unsigned)(diff < 0 ? -diff : diff));                     // get_code :455-470
+    const uint32_t mag = (uint32_t)(diff - (diff < 0)) & ((1u << nb) - 1u);
+    o.put((dc.code[nb] << nb) | mag, dc.size[nb] + nb);
+}
+
+static inline void put_ac(Out &o, const int16_t *b, int start, int end, const HuffTable &ac) {   // write_ac_block :356-388
+    uint64_t nz = 0;
+    for (int k = 0; k < 64; k++) nz |= (uint64_t)(b[k] != 0) << k;
+    nz &= (end == 64 ? ~0ull : ((1ull << end) - 1)) & ~((1ull << start) - 1);
+    int next = start;
+    while (nz) {
+        const int pos = __builtin_ctzll(nz);
+        nz &= nz - 1;
+        int run = pos - next;
+        for (; run > 15; run -= 16) o.put(ac.code[0xF0], ac.size[0xF0]);
+        const int v = b[pos];
+        const int nb = bit_length((unsigned)(v < 0 ? -v : v));
+        const uint32_t mag = (uint32_t)(v - (v < 0)) & ((1u << nb) - 1u);
+        const int sym = (run << 4) | nb;
+        o.put((ac.code[sym] << nb) | mag, ac.size[sym] + nb);
+        next = pos + 1;
+    }
+    if (next < end) o.put(ac.code[0], ac.size[0]);           // trailing zeros -> EOB
+}
+
+// restart bookkeeping of every scan loop (encoder.rs:748-757 + 793-800 and the three copies below)
+struct Restart {
+    int interval, restarts = 0, to_go;
+    explicit Restart(int iv) : interval(iv), to_go(iv) {}
+    bool before(Out &o) {
+        if (interval > 0 && to_go == 0) {
+            o.finalize_bits();
+            *o.cur++ = 0xFF; *o.cur++ = (uint8_t)(0xD0 + restarts % 8);
+            return true;
+        }
+        return false;
+    }
+    void after() {
+        if (interval > 0) {
+            if (to_go == 0) { to_go = interval; restarts = (restarts + 1) & 7; }
+            to_go--;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+struct DeviceCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void *d_pixels = nullptr, *d_coeffs = nullptr, *d_freq = nullptr;
+    size_t d_pixels_cap = 0, d_coeffs_cap = 0;
+    int16_t *h_coeffs = nullptr;
+    size_t h_coeffs_cap = 0;
+    uint8_t *h_pixels = nullptr;
+    size_t h_pixels_cap = 0;
+    uint32_t *h_freq = nullptr;
+    static constexpr int kChunks = 8;
+    hipEvent_t chunk_done[kChunks] = {};
+
+    int open(int dev) {
+        if (device == dev && stream) return JPEGENC_OK;
+        close();
+        int rc = ensure_device_ready(dev);
+        if (rc) return rc;
+        device = dev;
+        JPEGENC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto &e : chunk_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        JPEGENC_HIP(hipMalloc(&d_freq, sizeof(uint32_t) * 2 * 2 * 257));
+        JPEGENC_HIP(hipHostMalloc((void **)&h_freq, sizeof(uint32_t) * 2 * 2 * 257, hipHostMallocDefault));
+        return JPEGENC_OK;
+    }
+    int reserve(size_t pixel_bytes, size_t coeff_bytes, bool pinned_pixels) {
+        JPEGENC_HIP(hipSetDevice(device));
+        if (pixel_bytes > d_pixels_cap) {
+            if (d_pixels) (void)hipFree(d_pixels);
+            d_pixels = nullptr; d_pixels_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_pixels, pixel_bytes));
+            d_pixels_cap = pixel_bytes;
+        }
+        if (coeff_bytes > d_coeffs_cap) {
+            if (d_coeffs) (void)hipFree(d_coeffs);
+            d_coeffs = nullptr; d_coeffs_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_coeffs, coeff_bytes));
+            d_coeffs_cap = coeff_bytes;
+        }
+        if (coeff_bytes > h_coeffs_cap) {
+            if (h_coeffs) (void)hipHostFree(h_coeffs);
+            h_coeffs = nullptr; h_coeffs_cap = 0;
+            JPEGENC_HIP(hipHostMalloc((void **)&h_coeffs, coeff_bytes, hipHostMallocDefault));
+            h_coeffs_cap = coeff_bytes;
+        }
+        if (pinned_pixels && pixel_bytes > h_pixels_cap) {
+            if (h_pixels) (void)hipHostFree(h_pixels);
+            h_pixels = nullptr; h_pixels_cap = 0;
+            JPEGENC_HIP(hipHostMalloc((void **)&h_pixels, pixel_bytes, hipHostMallocDefault));
+            h_pixels_cap = pixel_bytes;
+        }
+        return JPEGENC_OK;
+    }
+    void close() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        for (auto &e : chunk_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (d_pixels) (void)hipFree(d_pixels);
+        if (d_coeffs) (void)hipFree(d_coeffs);
+        if (d_freq) (void)hipFree(d_freq);
+        if (h_coeffs) (void)hipHostFree(h_coeffs);
+        if (h_pixels) (void)hipHostFree(h_pixels);
+        if (h_freq) (void)hipHostFree(h_freq);
+        *this = DeviceCtx();
+    }
+    ~DeviceCtx() { close(); }
+    DeviceCtx() = default;
+    DeviceCtx(const DeviceCtx &) = delete;
+    DeviceCtx &operator=(DeviceCtx &&o) = default;
+};
+
+struct Config {                      // the fields of struct Encoder, encoder.rs:213-231
+    int quality = 0;
+    int density_unit = JPEGENC_DENSITY_PIXEL_ASPECT_RATIO;   // PixelDensity::default, writer.rs:37-45
+    uint16_t density_x = 1, density_y = 1;
+    int sampling = JPEGENC_F_1_1;
+    int qtype[2] = {JPEGENC_Q_DEFAULT, JPEGENC_Q_DEFAULT};
+    uint16_t qcustom[2][64] = {};
+    int progressive_scans = 0;       // Option<u8>
+    int restart_interval = 0;        // Option<u16>
+    bool optimize = false;
+    int fdct_variant = JPEGENC_FDCT_SCALAR;
+    std::vector<std::pair<uint8_t, std::vector<uint8_t>>> app_segments;
+};
+
+}  // namespace jpegenc
+
+using namespace jpegenc;
+
+struct jpegenc_encoder {
+    Config cfg;
+    int device = 0;
+    DeviceCtx ctx;
+};
+
+namespace jpegenc {
+
+static void sampling_hv(int sf, int *h, int *v) { *h = (sf >> 4) & 0x07; *v = sf & 0x0F; }   // encoder.rs:173-176
+
+static bool known_sampling(int sf) {
+    switch (sf) {
+    case JPEGENC_F_1_1: case JPEGENC_F_2_1: case JPEGENC_F_1_2: case JPEGENC_F_2_2: case JPEGENC_F_4_1:
+    case JPEGENC_F_4_2: case JPEGENC_F_1_4: case JPEGENC_F_2_4: case JPEGENC_R_4_4_4: case JPEGENC_R_4_4_0:
+    case JPEGENC_R_4_4_1: case JPEGENC_R_4_2_2: case JPEGENC_R_4_2_0: case JPEGENC_R_4_2_1: case JPEGENC_R_4_1_1:
+    case JPEGENC_R_4_1_0: return true;
+    }
+    return false;
+}
+
+struct Tables {
+    jpegenc_qtable q[2];
+    HuffTable h[2][2];               // [destination][0 = DC, 1 = AC]
+};
+
+static void default_huffman(Tables &t) {                      // Encoder::new, encoder.rs:240-249
+    t.h[0][0].assign(k_k3_luma_dc_bits, k_k3_luma_dc_vals, 12);
+    t.h[0][1].assign(k_k3_luma_ac_bits, k_k3_luma_ac_vals, 162);
+    t.h[1][0].assign(k_k3_chroma_dc_bits, k_k3_chroma_dc_vals, 12);
+    t.h[1][1].assign(k_k3_chroma_ac_bits, k_k3_chroma_ac_vals, 162);
+}
+
+// SOI .. user APPn (encode_image_internal, encoder.rs:536-554)
+static void write_prologue(Out &o, const Config &c, int jct) {
+    o.marker(0xD8);
+    o.marker(0xE0); o.u16(16);                                // write_header, writer.rs:216-239
+    o.bytes("JFIF\0", 5);
+    o.u8(0x01); o.u8(0x02);
+    o.u8((unsigned)c.density_unit);
+    o.u16(c.density_x); o.u16(c.density_y);
+    o.u8(0); o.u8(0);
+    if (jct == JPEGENC_J_CMYK || jct == JPEGENC_J_YCCK) {     // Adobe APP14, transform 0 / 2
+        uint8_t adobe[12] = {'A', 'd', 'o', 'b', 'e', 0, 0, 0, 0, 0, 0, 0};
+        adobe[11] = jct == JPEGENC_J_YCCK ? 2 : 0;
+        o.segment(0xEE, adobe, 12);
+    }
+    for (const auto &s : c.app_segments) o.segment(0xE0u + s.first, s.second.data(), s.second.size());
+}
+
+// write_frame_header (encoder.rs:633-667): SOF, DQT x2, DHT x2|4, DRI
+static void write_frame_header(Out &o, const Config &c, int width, int height, const jpegenc_layout &L, const Tables &t) {
+    o.marker(c.progressive_scans ? 0xC2 : 0xC0);              // writer.rs:390-422
+    o.u16((unsigned)(2 + 1 + 2 + 2 + 1 + L.num_components * 3));
+    o.u8(8); o.u16((unsigned)height); o.u16((unsigned)width); o.u8((unsigned)L.num_components);
+    for (int i = 0; i < L.num_components; i++) {
+        o.u8((unsigned)i); o.u8((unsigned)((L.h[i] << 4) | L.v[i])); o.u8((unsigned)L.table[i]);
+    }
+    for (int d = 0; d < 2; d++) {                             // writer.rs:283-300
+        o.marker(0xDB); o.u16(2 + 1 + 64); o.u8((unsigned)d);
+        for (int i = 0; i < 64; i++) o.u8((uint8_t)(t.q[d].table[kZZ[i]] >> 3));
+    }
+    const int ndest = L.num_components >= 3 ? 2 : 1;
+    for (int d = 0; d < ndest; d++)
+        for (int cls = 0; cls < 2; cls++) {                   // writer.rs:253-269
+            const HuffTable &h = t.h[d][cls];
+            o.marker(0xC4); o.u16((unsigned)(2 + 1 + 16 + h.nvals)); o.u8((unsigned)((cls << 4) | d));
+            o.bytes(h.bits, 16); o.bytes(h.vals, (size_t)h.nvals);
+        }
+    if (c.restart_interval) { o.marker(0xDD); o.u16(4); o.u16((unsigned)c.restart_interval); }   // :302-306
+}
+
+static void write_scan_header(Out &o, const jpegenc_layout &L, int first, int n, int ss, int se) {   // writer.rs:424-452
+    o.marker(0xDA); o.u16((unsigned)(2 + 1 + n * 2 + 3)); o.u8((unsigned)n);
+    for (int i = first; i < first + n; i++) { o.u8((unsigned)i); o.u8((unsigned)((L.table[i] << 4) | L.table[i])); }
+    o.u8((unsigned)ss); o.u8((unsigned)se); o.u8(0);
+}
+
+enum Mode { MODE_INTERLEAVED, MODE_SEQUENTIAL, MODE_PROGRESSIVE };
+
+static Mode select_mode(const Config &c) {                    // encoder.rs:556-562
+    int h, v;
+    sampling_hv(c.sampling, &h, &v);
+    if (c.progressive_scans) return MODE_PROGRESSIVE;
+    const bool interleavable = (h == 1 || h == 2) && (v == 1 || v == 2);   // supports_interleaved :178-187
+    return (c.optimize || !interleavable) ? MODE_SEQUENTIAL : MODE_INTERLEAVED;
+}
+
+// Entropy-code MCUs [m0, m1) of an interleaved scan (the inner loops of encoder.rs:747-801).
+struct InterleavedState {
+    int16_t prev_dc[4] = {0, 0, 0, 0};
+    Restart rst;
+    explicit InterleavedState(int interval) : rst(interval) {}
+};
+
+static void code_mcus(Out &o, const jpegenc_layout &L, const Tables &t, const int16_t *blocks, uint64_t m0, uint64_t m1,
+                      uint32_t bpm, InterleavedState &st) {
+    const int16_t *b = blocks + m0 * bpm * 64;
+    for (uint64_t m = m0; m < m1; m++) {
+        o.reserve_bits(bpm * 512 + 64);
+        if (st.rst.before(o)) st.prev_dc[0] = st.prev_dc[1] = st.prev_dc[2] = st.prev_dc[3] = 0;
+        for (int i = 0; i < L.num_components; i++) {
+            const HuffTable &dc = t.h[L.table[i]][0], &ac = t.h[L.table[i]][1];
+            for (int k = 0; k < L.h[i] * L.v[i]; k++, b += 64) {
+                put_dc(o, b[0], st.prev_dc[i], dc);           // write_block, writer.rs:331-340
+                put_ac(o, b, 1, 64, ac);
+                st.prev_dc[i] = b[0];
+            }
+        }
+        st.rst.after();
+    }
+}
+
+// One non-interleaved scan over a component's blocks: sequential (encoder.rs:823-861), the DC pass
+// (:885-922) or one AC band (:938-971) of progressive mode.
+static void code_component_scan(Out &o, const Config &c, const HuffTable &dc, const HuffTable &ac, const int16_t *blocks,
+                                uint64_t n, bool with_dc, int start, int end) {
+    Restart rst(c.restart_interval);
+    int16_t prev_dc = 0;
+    o.open_bits();
+    o.begin_bits();
+    for (uint64_t k = 0; k < n; k++) {
+        const int16_t *b = blocks + k * 64;
+        o.reserve_bits(1024);
+        if (rst.before(o)) prev_dc = 0;
+        if (with_dc) { put_dc(o, b[0], prev_dc, dc); prev_dc = b[0]; }
+        if (end > start) put_ac(o, b, start, end, ac);
+        rst.after();
+    }
+    o.finalize_bits();
+    o.close_bits();
+}
+
+static int validate_image(size_t len, int width, int height, int color_type) {
+    const int bpp = jpegenc_bytes_per_pixel(color_type);
+    if (!bpp) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");
+    if (width < 0 || height < 0 || width > 65535 || height > 65535)
+        return fail(JPEGENC_ERR_INVALID_ARGUMENT, "width/height must fit u16");
+    const size_t required = (size_t)width * (size_t)height * (size_t)bpp;
+    if (len < required)                                        // encoder.rs:447-454
+        return fail(JPEGENC_ERR_BAD_IMAGE_DATA, "Image data too small for dimensions and color_type: " +
+                    std::to_string(len) + " need at least " + std::to_string(required));
+    if (width == 0 || height == 0)                             // encoder.rs:521-526
+        return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "Image dimensions must be non zero: " +
+                    std::to_string(width) + "x" + std::to_string(height));
+    return JPEGENC_OK;
+}
+
+// The whole of encode_image_internal for one frame whose pixels are described by `p` (device
+// pointers not yet set).  `upload` copies the source into ctx.d_pixels on ctx.stream.
+template <class Upload>
+static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes,
+                        size_t pixel_bytes, Upload upload, jpegenc_write_fn sink, void *user) {
+    Tables t;
+    int rc = jpegenc_qtable_init(&t.q[0], c.qtype[0], c.qcustom[0], c.quality, 1);   // encoder.rs:528-531
+    if (rc) return rc;
+    rc = jpegenc_qtable_init(&t.q[1], c.qtype[1], c.qcustom[1], c.quality, 0);
+    if (rc) return rc;
+    default_huffman(t);
+    int hs, vs;
+    sampling_hv(c.sampling, &hs, &vs);
+    const Mode mode = select_mode(c);
+    const int order = mode == MODE_INTERLEAVED ? JPEGENC_ORDER_MCU : JPEGENC_ORDER_PLANAR;
+    jpegenc_layout L;
+    rc = jpegenc_layout_init(&L, width, height, color_type_or_planes, hs, vs, order);
+    if (rc) return rc;
+
+    // ---- device: upload, fused kernel, [histogram], download ---------------------------------
+    const size_t coeff_bytes = (size_t)L.total_blocks * 128;
+    rc = ctx.reserve(pixel_bytes, coeff_bytes, color_type_or_planes >= 100);
+    if (rc) return rc;
+    rc = upload(ctx);
+    if (rc) return rc;
+    BlockKernelParams p;
+    if (color_type_or_planes >= 100) rc = build_block_params_planes(&p, L, width, height, t.q, order);
+    else rc = build_block_params(&p, L, width, height, color_type_or_planes, t.q, order);
+    if (rc) return rc;
+    p.pixels = (const uint8_t *)ctx.d_pixels;
+    p.coeffs = ctx.d_coeffs;
+    p.pixel_frame_stride = pixel_bytes;
+    p.coeff_frame_stride = L.total_blocks;
+    hipError_t err = hipSuccess;
+    if (!launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, 1, c.fdct_variant, ctx.stream);
+    if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+    const bool optimize = c.optimize && mode != MODE_INTERLEAVED;
+    if (optimize) {
+        rc = jpegenc_histogram_device(ctx.d_coeffs, &L, c.progressive_scans, ctx.d_freq, ctx.stream);
+        if (rc) return rc;
+        JPEGENC_HIP(hipMemcpyAsync(ctx.h_freq, ctx.d_freq, sizeof(uint32_t) * 2 * 2 * 257, hipMemcpyDeviceToHost, ctx.stream));
+    }
+    // coefficient tiles come back in kChunks pieces so that entropy coding of tile k overlaps the
+    // copy of tile k+1 (interleaved mode consumes them in order; the other modes need them all)
+    const uint32_t bpm = (uint32_t)(L.total_blocks / (L.mcus ? L.mcus : 1));
+    uint64_t chunk_end_mcu[DeviceCtx::kChunks];
+    int nchunks = 1;
+    if (mode == MODE_INTERLEAVED) {
+        nchunks = (int)(L.mcus < (uint64_t)DeviceCtx::kChunks ? L.mcus : (uint64_t)DeviceCtx::kChunks);
+        uint64_t prev = 0;
+        for (int k = 0; k < nchunks; k++) {
+            const uint64_t end = L.mcus * (uint64_t)(k + 1) / (uint64_t)nchunks;
+            JPEGENC_HIP(hipMemcpyAsync((uint8_t *)ctx.h_coeffs + prev * bpm * 128, (const uint8_t *)ctx.d_coeffs + prev * bpm * 128,
+                                       (end - prev) * bpm * 128, hipMemcpyDeviceToHost, ctx.stream));
+            JPEGENC_HIP(hipEventRecord(ctx.chunk_done[k], ctx.stream));
+            chunk_end_mcu[k] = end;
+            prev = end;
+        }
+    } else {
+        JPEGENC_HIP(hipMemcpyAsync(ctx.h_coeffs, ctx.d_coeffs, coeff_bytes, hipMemcpyDeviceToHost, ctx.stream));
+        JPEGENC_HIP(hipEventRecord(ctx.chunk_done[0], ctx.stream));
+    }
+
+    // ---- host: headers + entropy coding -------------------------------------------------------
+    Out o;
+    o.sink = sink; o.user = user;
+    o.buf.reserve((size_t)1 << 20);
+    write_prologue(o, c, jct);
+    if (mode == MODE_INTERLEAVED) {                          // encode_image_interleaved, encoder.rs:699-807
+        write_frame_header(o, c, width, height, L, t);
+        write_scan_header(o, L, 0, L.num_components, 0, 63);
+        InterleavedState st(c.restart_interval);
+        o.open_bits();
+        o.begin_bits();
+        uint64_t m0 = 0;
+        for (int k = 0; k < nchunks; k++) {
+            JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[k]));
+            code_mcus(o, L, t, ctx.h_coeffs, m0, chunk_end_mcu[k], bpm, st);
+            m0 = chunk_end_mcu[k];
+        }
+        o.reserve_bits(64);
+        o.finalize_bits();
+        o.close_bits();
+    } else {
+        JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[0]));
+        if (optimize) {                                      // optimize_huffman_table, encoder.rs:1086-1200
+            const int max_tables = L.num_components < 2 ? L.num_components : 2;
+            for (int d = 0; d < max_tables; d++)
+                for (int k = 0; k < 2; k++) t.h[d][k].assign_optimized(ctx.h_freq + (d * 2 + k) * 257);
+        }
+        write_frame_header(o, c, width, height, L, t);       // after the tables are final (:821, :881)
+        if (mode == MODE_SEQUENTIAL) {                       // encode_image_sequential, encoder.rs:810-864
+            const int16_t *comp = ctx.h_coeffs;
+            for (int i = 0; i < L.num_components; comp += L.blocks[i] * 64, i++) {
+                write_scan_header(o, L, i, 1, 0, 63);
+                code_component_scan(o, c, t.h[L.table[i]][0], t.h[L.table[i]][1], comp, L.blocks[i], true, 1, 64);
+                o.drain(false);
+            }
+        } else {                                             // encode_image_progressive, encoder.rs:869-975
+            const int16_t *comp = ctx.h_coeffs;
+            for (int i = 0; i < L.num_components; comp += L.blocks[i] * 64, i++) {
+                write_scan_header(o, L, i, 1, 0, 0);
+                code_component_scan(o, c, t.h[L.table[i]][0], t.h[L.table[i]][1], comp, L.blocks[i], true, 0, 0);
+            }
+            const int scans = c.progressive_scans - 1, per = 64 / scans;
+            for (int s = 0; s < scans; s++) {
+                const int start = s * per < 1 ? 1 : s * per;
+                const int end = s == scans - 1 ? 64 : (s + 1) * per;
+                comp = ctx.h_coeffs;
+                for (int i = 0; i < L.num_components; comp += L.blocks[i] * 64, i++) {
+                    write_scan_header(o, L, i, 1, start, end - 1);
+                    code_component_scan(o, c, t.h[L.table[i]][0], t.h[L.table[i]][1], comp, L.blocks[i], false, start, end);
+                    o.drain(false);
+                }
+            }
+        }
+    }
+    o.marker(0xD9);                                          // EOI, encoder.rs:564
+    o.drain(true);
+    if (o.failed) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
+    return JPEGENC_OK;
+}
+
+static int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *data, size_t len, int width,
+                         int height, int color_type, jpegenc_write_fn sink, void *user) {
+    int rc = validate_image(len, width, height, color_type);      // before any device work
+    if (rc) return rc;
+    if (!sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null sink");
+    rc = ctx.open(device);
+    if (rc) return rc;
+    const size_t bytes = (size_t)width * (size_t)height * (size_t)jpegenc_bytes_per_pixel(color_type);
+    auto upload = [&](DeviceCtx &cx) -> int {
+        JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
+        return JPEGENC_OK;
+    };
+    return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user);
+}
+
+struct BufferSink {
+    uint8_t *out;
+    size_t cap, len;
+};
+static int buffer_sink(void *user, const uint8_t *data, size_t n) {
+    BufferSink *b = (BufferSink *)user;
+    if (b->len + n <= b->cap) memcpy(b->out + b->len, data, n);
+    b->len += n;
+    return 0;
+}
+
+}  // namespace jpegenc
+
+extern "C" {
+
+jpegenc_encoder *jpegenc_encoder_new(int quality) {           // Encoder::new, encoder.rs:239-275
+    jpegenc_encoder *e = new (std::nothrow) jpegenc_encoder();
+    if (!e) return nullptr;
+    e->cfg.quality = quality;
+    e->cfg.sampling = quality < 90 ? JPEGENC_F_2_2 : JPEGENC_F_1_1;
+    return e;
+}
+
+void jpegenc_encoder_free(jpegenc_encoder *e) { delete e; }
+
+#define REQUIRE(e) do { if (!(e)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null encoder"); } while (0)
+
+int jpegenc_encoder_set_device(jpegenc_encoder *e, int device) {
+    REQUIRE(e);
+    if (device < 0) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "negative device index");
+    e->device = device;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_set_fdct_variant(jpegenc_encoder *e, int variant) {
+    REQUIRE(e);
+    if (variant != JPEGENC_FDCT_SCALAR && variant != JPEGENC_FDCT_SIMD) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown FDCT variant");
+    e->cfg.fdct_variant = variant;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_set_density(jpegenc_encoder *e, int unit, uint16_t x, uint16_t y) {
+    REQUIRE(e);
+    if (unit < 0 || unit > 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown density unit");
+    e->cfg.density_unit = unit; e->cfg.density_x = x; e->cfg.density_y = y;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_density(const jpegenc_encoder *e, int *unit, uint16_t *x, uint16_t *y) {
+    REQUIRE(e);
+    if (unit) *unit = e->cfg.density_unit;
+    if (x) *x = e->cfg.density_x;
+    if (y) *y = e->cfg.density_y;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_set_sampling_factor(jpegenc_encoder *e, int sf) {
+    REQUIRE(e);
+    if (!known_sampling(sf)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown SamplingFactor");
+    e->cfg.sampling = sf;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_sampling_factor(const jpegenc_encoder *e) { return e ? e->cfg.sampling : -1; }
+
+int jpegenc_encoder_set_quantization_tables(jpegenc_encoder *e, int luma_type, const uint16_t luma_custom[64],
+                                            int chroma_type, const uint16_t chroma_custom[64]) {
+    REQUIRE(e);
+    const int types[2] = {luma_type, chroma_type};
+    const uint16_t *customs[2] = {luma_custom, chroma_custom};
+    for (int i = 0; i < 2; i++) {
+        if (types[i] < 0 || types[i] > JPEGENC_Q_CUSTOM) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown quantisation table type");
+        if (types[i] == JPEGENC_Q_CUSTOM && !customs[i]) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "custom table requires 64 values");
+    }
+    for (int i = 0; i < 2; i++) {
+        e->cfg.qtype[i] = types[i];
+        if (types[i] == JPEGENC_Q_CUSTOM) memcpy(e->cfg.qcustom[i], customs[i], sizeof(uint16_t) * 64);
+    }
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_quantization_tables(const jpegenc_encoder *e, int types[2]) {
+    REQUIRE(e);
+    if (!types) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null output");
+    types[0] = e->cfg.qtype[0]; types[1] = e->cfg.qtype[1];
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_set_progressive(jpegenc_encoder *e, int progressive) {   // encoder.rs:317-319
+    REQUIRE(e);
+    e->cfg.progressive_scans = progressive ? 4 : 0;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_set_progressive_scans(jpegenc_encoder *e, int scans) {   // panics upstream, encoder.rs:328-335
+    REQUIRE(e);
+    if (scans < 2 || scans > 64) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "Invalid number of scans: " + std::to_string(scans));
+    e->cfg.progressive_scans = scans;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_progressive_scans(const jpegenc_encoder *e) { return e ? e->cfg.progressive_scans : -1; }
+
+int jpegenc_encoder_set_restart_interval(jpegenc_encoder *e, uint16_t interval) {   // encoder.rs:345-347
+    REQUIRE(e);
+    e->cfg.restart_interval = interval;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_restart_interval(const jpegenc_encoder *e) { return e ? e->cfg.restart_interval : -1; }
+
+int jpegenc_encoder_set_optimized_huffman_tables(jpegenc_encoder *e, int optimize) {
+    REQUIRE(e);
+    e->cfg.optimize = optimize != 0;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_optimized_huffman_tables(const jpegenc_encoder *e) { return e ? (int)e->cfg.optimize : -1; }
+
+int jpegenc_encoder_add_app_segment(jpegenc_encoder *e, int nr, const uint8_t *data, size_t len) {   // encoder.rs:374-383
+    REQUIRE(e);
+    if (nr <= 0 || nr > 15) return fail(JPEGENC_ERR_INVALID_APP_SEGMENT, "Invalid app segment number: " + std::to_string(nr));
+    if (len > 65533) return fail(JPEGENC_ERR_APP_SEGMENT_TOO_LARGE, "App segment exceeds maximum allowed data length of 65533: " + std::to_string(len));
+    if (len && !data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null data");
+    e->cfg.app_segments.emplace_back((uint8_t)nr, std::vector<uint8_t>(data, data + len));
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_add_icc_profile(jpegenc_encoder *e, const uint8_t *data, size_t len) {   // encoder.rs:392-417
+    REQUIRE(e);
+    if (len && !data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null data");
+    static const char kMarker[12] = {'I', 'C', 'C', '_', 'P', 'R', 'O', 'F', 'I', 'L', 'E', 0};
+    const size_t max_chunk = 65535 - 2 - 12 - 2;
+    const size_t num_chunks = (len + max_chunk - 1) / max_chunk;
+    if (num_chunks >= 255) return fail(JPEGENC_ERR_ICC_TOO_LARGE, "ICC profile exceeds maximum allowed data length: " + std::to_string(len));
+    for (size_t i = 0; i < num_chunks; i++) {
+        const size_t n = len - i * max_chunk < max_chunk ? len - i * max_chunk : max_chunk;
+        std::vector<uint8_t> chunk;
+        chunk.reserve(14 + n);
+        chunk.insert(chunk.end(), kMarker, kMarker + 12);
+        chunk.push_back((uint8_t)(i + 1));
+        chunk.push_back((uint8_t)num_chunks);
+        chunk.insert(chunk.end(), data + i * max_chunk, data + i * max_chunk + n);
+        int rc = jpegenc_encoder_add_app_segment(e, 2, chunk.data(), chunk.size());
+        if (rc) return rc;
+    }
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_add_exif_metadata(jpegenc_encoder *e, const uint8_t *data, size_t len) {   // encoder.rs:426-435
+    REQUIRE(e);
+    if (len && !data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null data");
+    std::vector<uint8_t> seg = {0x45, 0x78, 0x69, 0x66, 0x00, 0x00};
+    seg.insert(seg.end(), data, data + len);
+    return jpegenc_encoder_add_app_segment(e, 1, seg.data(), seg.size());
+}
+
+int jpegenc_encoder_encode(jpegenc_encoder *e, const uint8_t *data, size_t len, int width, int height, int color_type,
+                           jpegenc_write_fn sink, void *user) {
+    REQUIRE(e);
+    if (len && !data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null data");
+    return encode_pixels(e->cfg, e->ctx, e->device, data, len, width, height, color_type, sink, user);
+}
+
+int jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len, int width, int height,
+                                     int color_type, uint8_t *out, size_t cap, size_t *out_len) {
+    REQUIRE(e);
+    BufferSink b = {out, out ? cap : 0, 0};
+    int rc = jpegenc_encoder_encode(e, data, len, width, height, color_type, buffer_sink, &b);
+    if (out_len) *out_len = b.len;
+    if (rc) return rc;
+    if (b.len > b.cap) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "output needs " + std::to_string(b.len) + " bytes");
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_encode_image(jpegenc_encoder *e, int jct, int width, int height, jpegenc_fill_row_fn fill_row,
+                                 void *image_user, jpegenc_write_fn sink, void *sink_user) {
+    REQUIRE(e);
+    if (!fill_row || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null callback");
+    if (jct < JPEGENC_J_LUMA || jct > JPEGENC_J_YCCK) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown JPEG colour type");
+    if (width < 0 || height < 0 || width > 65535 || height > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "width/height must fit u16");
+    if (width == 0 || height == 0) return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "Image dimensions must be non zero");
+    int rc = e->ctx.open(e->device);
+    if (rc) return rc;
+    const int ncomp = jct == JPEGENC_J_LUMA ? 1 : jct == JPEGENC_J_YCBCR ? 3 : 4;
+    const size_t plane = (size_t)width * (size_t)height, bytes = plane * (size_t)ncomp;
+    auto upload = [&](DeviceCtx &cx) -> int {
+        // the user's fill_buffers runs on the host, one call per image row, straight into pinned memory
+        for (int y = 0; y < height; y++) {
+            uint8_t *rows[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int cidx = 0; cidx < ncomp; cidx++) rows[cidx] = cx.h_pixels + (size_t)cidx * plane + (size_t)y * (size_t)width;
+            fill_row(image_user, (uint16_t)y, rows);
+        }
+        JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, cx.h_pixels, bytes, hipMemcpyHostToDevice, cx.stream));
+        return JPEGENC_OK;
+    };
+    return encode_frame(e->cfg, e->ctx, jct, width, height, 100 + jct, bytes, upload, sink, sink_user);
+}
+
+int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len, int num_frames,
+                                 int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
+    REQUIRE(e);
+    if (num_frames < 0 || (num_frames && (!frames || !users)) || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
+    int rc = validate_image(frame_len, width, height, color_type);
+    if (rc) return rc;
+    rc = ensure_device_ready(e->device);
+    if (rc) return rc;
+    // one host worker per in-flight frame; each owns a stream + buffers, so H2D / kernel / D2H of
+    // one frame overlap the entropy coding of the others
+    unsigned hw = std::thread::hardware_concurrency();
+    int workers = (int)(hw ? hw : 4);
+    if (workers > 16) workers = 16;
+    if (workers > num_frames) workers = num_frames;
+    std::atomic<int> next(0), status(JPEGENC_OK);
+    std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
+    auto body = [&](int w) {
+        DeviceCtx ctx;
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= num_frames || status.load() != JPEGENC_OK) break;
+            int r = frames[i] ? encode_pixels(e->cfg, ctx, e->device, frames[i], frame_len, width, height, color_type, sink, users[i])
+                              : fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
+            if (r != JPEGENC_OK) {
+                int expected = JPEGENC_OK;
+                if (status.compare_exchange_strong(expected, r)) messages[(size_t)w] = jpegenc_last_error();
+                break;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < workers; w++) pool.emplace_back(body, w);
+    if (workers > 0) body(0);
+    for (auto &th : pool) th.join();
+    if (status.load() != JPEGENC_OK) {
+        for (const auto &m : messages) if (!m.empty()) { set_last_error(m); break; }
+        return status.load();
+    }
+    return JPEGENC_OK;
+}
+
+}  // extern "C"

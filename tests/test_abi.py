@@ -1,0 +1,167 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a
+GPU, exports every symbol include/jpegenc_mi355x.h declares, and its host-side logic (tables,
+geometry, validation, configuration) matches the oracle.  No compute calls here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def binding(pkg):
+    import importlib
+    b = importlib.import_module("jpeg_encoder_amd.binding")
+    if not os.path.exists(b.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return b
+
+
+def test_header_symbols_are_exported(binding):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "jpegenc_mi355x.h")).read()
+    declared = set(re.findall(r"\b(jpegenc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"jpegenc_write_fn", "jpegenc_fill_row_fn"}
+    assert declared == set(binding.ABI_SYMBOLS)
+    lib = binding.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert lib.jpegenc_abi_version() == 1
+
+
+def test_qtable_matches_oracle(binding, oracle):
+    rng = np.random.default_rng(0)
+    for quality in (1, 10, 49, 50, 75, 80, 90, 95, 100, 0, 255):
+        for preset in range(9):
+            got = binding.qtables(quality, (preset, preset))
+            want = oracle.qtables(quality, (preset, preset))
+            for i in range(2):
+                assert list(got[i].table) == list(want[i].table)
+                assert list(got[i].reciprocals) == list(want[i].recip)
+                assert list(got[i].corrections) == list(want[i].corr)
+    custom = [int(v) for v in rng.integers(0, 70000, 64) % 65536]
+    got = binding.qtables(33, (binding.Q_CUSTOM, binding.Q_CUSTOM), (custom, custom))
+    want = oracle.qtables(33, (oracle.Q_CUSTOM, oracle.Q_CUSTOM), (custom, custom))
+    assert list(got[1].table) == list(want[1].table) and list(got[1].reciprocals) == list(want[1].recip)
+
+
+def test_layout_matches_oracle(binding, oracle):
+    for ct in range(9):
+        for hs, vs in [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 2), (1, 4), (2, 4)]:
+            for w, h in [(1, 1), (8, 8), (9, 17), (258, 128), (37, 21), (1920, 1080)]:
+                for order in (0, 1):
+                    L = binding.layout(w, h, ct, hs, vs, order)
+                    total, per = oracle.block_counts(w, h, ct, hs, vs, order)
+                    assert L.total_blocks == total
+                    assert list(L.blocks)[:L.num_components] == per
+
+
+def test_survey_geometry(binding):
+    """SURVEY.md §8 geometry table."""
+    assert binding.layout(256, 256, binding.RGB, 1, 1, 0).total_blocks == 3072
+    L = binding.layout(3840, 2160, binding.RGB, 2, 2, 0)
+    assert (L.mcus, L.total_blocks) == (32400, 194400)
+    L = binding.layout(1920, 1080, binding.RGB, 2, 2, 0)
+    assert (L.mcus, L.total_blocks) == (8160, 48960)
+    assert binding.layout(7680, 4320, binding.CMYK, 1, 1, 0).total_blocks == 2073600
+    assert binding.layout(3840, 2160, binding.RGB, 1, 1, 1).total_blocks == 388800
+    assert list(binding.layout(258, 128, binding.RGB, 2, 2, 0).blocks)[:3] == [17 * 8 * 4, 17 * 8, 17 * 8]
+    assert list(binding.layout(258, 128, binding.RGB, 2, 2, 1).blocks)[:3] == [33 * 16, 17 * 8, 17 * 8]
+
+
+def test_encoder_configuration_api(binding):
+    """Encoder::new defaults and setters (src/encoder.rs:239-364, tests :1323-1331)."""
+    e = binding.Encoder(100)
+    assert e.sampling_factor() == binding.F_1_1
+    assert binding.Encoder(89).sampling_factor() == binding.F_2_2
+    assert binding.Encoder(90).sampling_factor() == binding.F_1_1
+    assert e.progressive_scans() is None
+    e.set_progressive(True)
+    assert e.progressive_scans() == 4                 # test_set_progressive
+    e.set_progressive(False)
+    assert e.progressive_scans() is None
+    e.set_progressive_scans(64)
+    assert e.progressive_scans() == 64
+    for bad in (0, 1, 65):
+        with pytest.raises(binding.JpegEncError) as err:   # the reference panics here
+            e.set_progressive_scans(bad)
+        assert err.value.status == binding.ERR_INVALID_ARGUMENT
+    assert e.restart_interval() is None
+    e.set_restart_interval(32)
+    assert e.restart_interval() == 32
+    e.set_restart_interval(0)
+    assert e.restart_interval() is None
+    assert e.optimized_huffman_tables() is False
+    e.set_optimized_huffman_tables(True)
+    assert e.optimized_huffman_tables() is True
+    assert e.density() == (binding.DENSITY_PIXEL_ASPECT_RATIO, 1, 1)
+    e.set_density(binding.DENSITY_INCHES, 300, 300)
+    assert e.density() == (binding.DENSITY_INCHES, 300, 300)
+    assert e.quantization_tables() == (binding.Q_DEFAULT, binding.Q_DEFAULT)
+    e.set_quantization_tables(binding.Q_FLAT, binding.Q_CUSTOM, chroma_custom=[3] * 64)
+    assert e.quantization_tables() == (binding.Q_FLAT, binding.Q_CUSTOM)
+    e.set_sampling_factor(0x80 | 0x22)                # R_4_2_0 alias
+    assert e.sampling_factor() == 0xA2
+    with pytest.raises(binding.JpegEncError):
+        e.set_sampling_factor(0x44)
+
+
+def test_encoder_segment_validation(binding):
+    """add_app_segment / add_icc_profile limits (src/encoder.rs:374-417)."""
+    e = binding.Encoder(90)
+    for nr in (0, 16):
+        with pytest.raises(binding.JpegEncError) as err:
+            e.add_app_segment(nr, b"x")
+        assert err.value.status == binding.ERR_INVALID_APP_SEGMENT
+    with pytest.raises(binding.JpegEncError) as err:
+        e.add_app_segment(1, b"x" * 65534)
+    assert err.value.status == binding.ERR_APP_SEGMENT_TOO_LARGE
+    e.add_app_segment(15, b"x" * 65533)
+    with pytest.raises(binding.JpegEncError) as err:
+        e.add_icc_profile(b"\0" * (65519 * 255))
+    assert err.value.status == binding.ERR_ICC_TOO_LARGE
+    e.add_icc_profile(b"\0" * (65519 * 3))
+    e.add_exif_metadata(b"MM\0*")
+
+
+def test_validation_precedes_device_work(binding, synth):
+    """BadImageData / ZeroImageDimensions are reported without touching the GPU
+    (src/encoder.rs:447-454, 521-526) — these must hold even on a box with no device."""
+    px = synth.test_img_rgb()
+    e = binding.Encoder(90)
+    with pytest.raises(binding.JpegEncError) as err:
+        e.encode(px.reshape(-1)[:-1], 258, 128, binding.RGB)
+    assert err.value.status == binding.ERR_BAD_IMAGE_DATA
+    assert "need at least 99072" in str(err.value)
+    with pytest.raises(binding.JpegEncError) as err:
+        e.encode(px, 0, 128, binding.RGB)
+    assert err.value.status == binding.ERR_ZERO_IMAGE_DIMENSIONS
+    with pytest.raises(binding.JpegEncError) as err:
+        binding.blocks_host(px.reshape(-1)[:100], 258, 128, binding.RGB, 2, 2, 90)
+    assert err.value.status == binding.ERR_BAD_IMAGE_DATA
+
+
+def test_no_cpu_fallback(binding, synth):
+    """Without a GPU every compute entry point must fail loudly, never compute on the host."""
+    if binding.device_count() > 0:
+        pytest.skip("a GPU is present")
+    px = synth.test_img_rgb()
+    with pytest.raises(binding.JpegEncError) as err:
+        binding.blocks_host(px, 258, 128, binding.RGB, 2, 2, 90)
+    assert err.value.status == binding.ERR_NO_DEVICE
+    with pytest.raises(binding.JpegEncError) as err:
+        binding.Encoder(90).encode(px, 258, 128, binding.RGB)
+    assert err.value.status == binding.ERR_NO_DEVICE
+
+
+def test_free_functions(binding, oracle):
+    """rgb_to_ycbcr / cmyk_to_ycck re-exports (src/lib.rs:45-49)."""
+    import ctypes as C
+    out = (C.c_uint8 * 4)()
+    rng = np.random.default_rng(5)
+    for r, g, b, k in rng.integers(0, 256, (200, 4)):
+        binding.lib().jpegenc_rgb_to_ycbcr(int(r), int(g), int(b), out)
+        assert tuple(out)[:3] == oracle.rgb_to_ycbcr(int(r), int(g), int(b))
+        binding.lib().jpegenc_cmyk_to_ycck(int(r), int(g), int(b), int(k), out)
+        assert tuple(out) == oracle.cmyk_to_ycck(int(r), int(g), int(b), int(k))
