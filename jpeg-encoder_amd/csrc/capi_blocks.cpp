@@ -67,14 +67,20 @@ static bool valid_sampling(int hs, int vs) {   // SamplingFactor::from_factors, 
     return (hs == 1 || hs == 2 || hs == 4) && (vs == 1 || vs == 2 || vs == 4) && !(hs == 4 && vs == 4);
 }
 
-static void fill_quant(QuantDev *d, const jpegenc_qtable &t) {
+static int fill_quant(QuantDev *d, const jpegenc_qtable &t) {
     for (int i = 0; i < 64; i++) {
-        d->r2[i] = 2u * (uint32_t)t.reciprocals[i];
-        d->c2[i] = 2u * (uint32_t)t.corrections[i] * (uint32_t)t.reciprocals[i];
+        const int64_t r = t.reciprocals[i], c = t.corrections[i];
+        const int64_t two_r = 2 * r, neg_two_d = 4 * c * r - 2 * 32767, acc = 2 * c * r;
+        if (two_r < 0 || two_r > 32767 || neg_two_d < -32768 || neg_two_d > 32767 || acc > 0x3FFFFFFF)
+            return fail(JPEGENC_ERR_INVALID_ARGUMENT, "quantisation table outside the range the kernel supports");
+        const int k = i >> 3, x = i & 7;          // natural index i = k*8 + x
+        d->qc[(x * 8 + k) * 2] = (uint32_t)(two_r & 0xFFFF) | ((uint32_t)(neg_two_d & 0xFFFF) << 16);
+        d->qc[(x * 8 + k) * 2 + 1] = (uint32_t)acc;
     }
+    return JPEGENC_OK;
 }
 
-static void fill_geometry(BlockKernelParams *p, const jpegenc_layout &L, int width, int height, int order,
+static int fill_geometry(BlockKernelParams *p, const jpegenc_layout &L, int width, int height, int order,
                           const jpegenc_qtable tables[2]) {
     p->width = width; p->height = height;
     p->ncomp = L.num_components; p->hmax = L.max_h; p->vmax = L.max_v; p->order = order;
@@ -95,14 +101,16 @@ static void fill_geometry(BlockKernelParams *p, const jpegenc_layout &L, int wid
     p->bpm = first;
     p->wave_start[L.num_components] = waves;
     p->task_start[L.num_components] = tasks;
-    fill_quant(&p->q[0], tables[0]);
-    fill_quant(&p->q[1], tables[1]);
+    int rc = fill_quant(&p->q[0], tables[0]);
+    if (rc) return rc;
+    return fill_quant(&p->q[1], tables[1]);
 }
 
 int build_block_params(BlockKernelParams *p, const jpegenc_layout &L, int width, int height,
                        int color_type, const jpegenc_qtable tables[2], int order) {
     memset(p, 0, sizeof *p);
-    fill_geometry(p, L, width, height, order, tables);
+    int rc = fill_geometry(p, L, width, height, order, tables);
+    if (rc) return rc;
     p->bpp = jpegenc_bytes_per_pixel(color_type);
     p->o[0] = 0; p->o[1] = 1; p->o[2] = 2;
     switch (color_type) {
@@ -120,7 +128,8 @@ int build_block_params(BlockKernelParams *p, const jpegenc_layout &L, int width,
 int build_block_params_planes(BlockKernelParams *p, const jpegenc_layout &L, int width, int height,
                               const jpegenc_qtable tables[2], int order) {
     memset(p, 0, sizeof *p);
-    fill_geometry(p, L, width, height, order, tables);
+    int rc = fill_geometry(p, L, width, height, order, tables);
+    if (rc) return rc;
     p->bpp = 1;
     p->xform = XF_PLANES;
     p->plane_stride = (uint64_t)width * (uint64_t)height;

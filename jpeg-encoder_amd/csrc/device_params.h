@@ -14,12 +14,16 @@ enum Xform : int32_t {
     XF_PLANES = 5        // user ImageBuffer: already-converted planar rows (image_buffer.rs:86-98)
 };
 
-// Quantiser constants in the form the kernel consumes (natural order):
-//   q = sign(v) * ((|v| * r2 + c2) >> 16),  r2 = 2*reciprocal, c2 = 2*correction*reciprocal
-// which equals ((|v| + correction) * reciprocal) >> 15 of quantization.rs:291-307.
+// Quantiser constants in the form the kernel consumes (natural order).  With r = reciprocal,
+// c = correction (quantization.rs:187-207) and D = 32767 - 2*c*r:
+//   kq = (2r, -2D) as a packed i16 pair, aq = 2*c*r
+//   q  = (v*2r + [v<0]*2D + aq) >> 16  ==  sign(v) * (((|v| + c) * r) >> 15)   (quantization.rs:291-307)
+// (derivation in fdct_quant.hip.h).  Both halves of kq fit i16 for every divisor 8..16384.
+// Stored in the order the kernel consumes them — pass 2 finishes one COLUMN x at a time, rows k =
+// 0..7 — so each column's 16 constants are one contiguous scalar load:
+//   qc[(x * 8 + k) * 2 + 0] = kq of natural coefficient k*8+x,  qc[.. + 1] = its aq.
 struct QuantDev {
-    uint32_t r2[64];
-    uint32_t c2[64];
+    uint32_t qc[128];
 };
 
 struct BlockKernelParams {
