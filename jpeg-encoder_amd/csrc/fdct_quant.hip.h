@@ -73,8 +73,32 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b)));
 }
-__device__ __forceinline__ int odd(uint32_t d01, uint32_t d32, Lin4 c, int acc) {
-    return dot2(d01, pk(c.d0, c.d1), dot2(d32, pk(c.d3, c.d2), acc));
+// First dot2 of a chain: VOP3P form with the pair constant in a VGPR and the rounding constant as an
+// SGPR accumulator.  hipcc otherwise picks v_dot2c (VOP2: literal pair, accumulate in place), which
+// costs one extra v_mov per chain to preload the rounding constant — 128 per block.
+__device__ __forceinline__ int dot2_first(uint32_t a, uint32_t k_vgpr, int round_sgpr) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(k_vgpr), "s"(round_sgpr));
+    return d;
+}
+// pair constants that start a chain; kept in VGPRs for the whole block
+struct ChainConsts {
+    uint32_t k2, k6, o1, o3, o5, o7, p1_0, p1_4, p2_0, p2_4;
+};
+__device__ __forceinline__ ChainConsts chain_consts() {
+    ChainConsts c;
+    c.k2 = pk(F_0_541 + F_0_765, F_0_541);       // out2 = tmp13*(.541+.765) + tmp12*.541
+    c.k6 = pk(F_0_541, F_0_541 - F_1_847);       // out6 = tmp13*.541 + tmp12*(.541-1.847)
+    c.o1 = pk(ODD1.d3, ODD1.d2); c.o3 = pk(ODD3.d3, ODD3.d2);
+    c.o5 = pk(ODD5.d3, ODD5.d2); c.o7 = pk(ODD7.d3, ODD7.d2);
+    c.p1_0 = pk(4, 4); c.p1_4 = pk(4, -4); c.p2_0 = pk(1, 1); c.p2_4 = pk(1, -1);
+    // keep them materialised (one v_mov each, once per block) instead of re-created per use
+    asm volatile("" : "+v"(c.k2), "+v"(c.k6), "+v"(c.o1), "+v"(c.o3), "+v"(c.o5), "+v"(c.o7));
+    asm volatile("" : "+v"(c.p1_0), "+v"(c.p1_4), "+v"(c.p2_0), "+v"(c.p2_4));
+    return c;
+}
+__device__ __forceinline__ int odd(uint32_t d01, uint32_t d32, Lin4 c, uint32_t k32_vgpr, int acc) {
+    return dot2(d01, pk(c.d0, c.d1), dot2_first(d32, k32_vgpr, acc));
 }
 // low halves of two ints -> one packed pair (lo = a, hi = b)
 __device__ __forceinline__ uint32_t pack_lo(int a, int b) {
@@ -95,34 +119,33 @@ __device__ constexpr uint8_t kZigzag[64] = {
 // out[k]: the pass's k-th output after its rounding shift (not yet truncated to i16).
 // PASS 1 takes unsigned samples 0..255 and folds get_block's "-128" into output 0.
 template <int PASS, bool SIMD_ODD_LANE>
-__device__ __forceinline__ void islow_pass(uint32_t a, uint32_t b, uint32_t c, uint32_t d, int out[8]) {
+__device__ __forceinline__ void islow_pass(uint32_t a, uint32_t b, uint32_t c, uint32_t d, const ChainConsts &K,
+                                           int out[8]) {
     const uint32_t s01 = pk_add(a, c), s32 = pk_add(b, d);
     const uint32_t d01 = pk_sub(a, c), d32 = pk_sub(b, d);
     const uint32_t ta = pk_add(s01, s32);      // (tmp10, tmp11)
     const uint32_t ts = pk_sub(s01, s32);      // (tmp13, tmp12)
-    constexpr uint32_t k2 = pk(F_0_541 + F_0_765, F_0_541);      // out2 = tmp13*(.541+.765) + tmp12*.541
-    constexpr uint32_t k6 = pk(F_0_541, F_0_541 - F_1_847);      // out6 = tmp13*.541 + tmp12*(.541-1.847)
     if (PASS == 1) {
         constexpr int n = CONST_BITS - PASS1_BITS, r = 1 << (n - 1);
-        out[0] = dot2(ta, pk(4, 4), -4096);    // fdct.rs:137: (tmp10 + tmp11) << 2, minus 8*128*4
-        out[4] = dot2(ta, pk(4, -4), 0);       // fdct.rs:138
-        out[2] = dot2(ts, k2, r) >> n;
-        out[6] = dot2(ts, k6, r) >> n;
-        out[1] = odd(d01, d32, ODD1, r) >> n;
-        out[3] = odd(d01, d32, ODD3, r) >> n;
-        out[5] = odd(d01, d32, ODD5, r) >> n;
-        out[7] = odd(d01, d32, ODD7, r) >> n;
+        out[0] = dot2_first(ta, K.p1_0, -4096);   // fdct.rs:137: (tmp10 + tmp11) << 2, minus 8*128*4
+        out[4] = dot2_first(ta, K.p1_4, 0);       // fdct.rs:138
+        out[2] = dot2_first(ts, K.k2, r) >> n;
+        out[6] = dot2_first(ts, K.k6, r) >> n;
+        out[1] = odd(d01, d32, ODD1, K.o1, r) >> n;
+        out[3] = odd(d01, d32, ODD3, K.o3, r) >> n;
+        out[5] = odd(d01, d32, ODD5, K.o5, r) >> n;
+        out[7] = odd(d01, d32, ODD7, K.o7, r) >> n;
     } else {
         constexpr int n = CONST_BITS + PASS1_BITS, r = 1 << (n - 1);
         constexpr int r2 = SIMD_ODD_LANE ? 0 : (1 << (PASS1_BITS - 1));   // avx2/fdct.rs:196-209,:291
-        out[0] = dot2(ta, pk(1, 1), r2) >> PASS1_BITS;                     // fdct.rs:197
-        out[4] = dot2(ta, pk(1, -1), r2) >> PASS1_BITS;                    // fdct.rs:198
-        out[2] = dot2(ts, k2, r) >> n;
-        out[6] = dot2(ts, k6, r) >> n;
-        out[1] = odd(d01, d32, ODD1, r) >> n;
-        out[3] = odd(d01, d32, ODD3, r) >> n;
-        out[5] = odd(d01, d32, ODD5, r) >> n;
-        out[7] = odd(d01, d32, ODD7, r) >> n;
+        out[0] = dot2_first(ta, K.p2_0, r2) >> PASS1_BITS;                 // fdct.rs:197
+        out[4] = dot2_first(ta, K.p2_4, r2) >> PASS1_BITS;                 // fdct.rs:198
+        out[2] = dot2_first(ts, K.k2, r) >> n;
+        out[6] = dot2_first(ts, K.k6, r) >> n;
+        out[1] = odd(d01, d32, ODD1, K.o1, r) >> n;
+        out[3] = odd(d01, d32, ODD3, K.o3, r) >> n;
+        out[5] = odd(d01, d32, ODD5, K.o5, r) >> n;
+        out[7] = odd(d01, d32, ODD7, K.o7, r) >> n;
     }
 }
 
@@ -134,9 +157,10 @@ __device__ __forceinline__ void islow_pass(uint32_t a, uint32_t b, uint32_t c, u
 template <int VARIANT>
 __device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], const QuantDev (&q)[2],
                                                  bool chroma_table, uint32_t out[32]) {
+    const ChainConsts K = chain_consts();
     int mid[8][8];
 #pragma unroll
-    for (int y = 0; y < 8; y++) islow_pass<1, false>(rows[y][0], rows[y][1], rows[y][2], rows[y][3], mid[y]);
+    for (int y = 0; y < 8; y++) islow_pass<1, false>(rows[y][0], rows[y][1], rows[y][2], rows[y][3], K, mid[y]);
 
     int prod[64];   // 2 * quantiser product of natural coefficient n; its high half is the result
 #pragma unroll
@@ -144,8 +168,8 @@ __device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], cons
         const uint32_t a = pack_lo(mid[0][x], mid[1][x]), b = pack_lo(mid[3][x], mid[2][x]);
         const uint32_t c = pack_lo(mid[7][x], mid[6][x]), d = pack_lo(mid[4][x], mid[5][x]);
         int col[8];
-        if (VARIANT == 1 && (x & 1)) islow_pass<2, true>(a, b, c, d, col);
-        else islow_pass<2, false>(a, b, c, d, col);
+        if (VARIANT == 1 && (x & 1)) islow_pass<2, true>(a, b, c, d, K, col);
+        else islow_pass<2, false>(a, b, c, d, K, col);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int i = (x * 8 + k) * 2;

@@ -79,7 +79,10 @@ __device__ __forceinline__ WaveTask decode_task(const BlockKernelParams &p, uint
 
 // Wave-private, bank-conflict-free transposition of 64 lanes x 128 B into whole-line stores.
 // Lane L deposits its block's 16-B chunk j at slot L, position j ^ (L & 7); the read side walks the
-// area linearly (chunk g = t*64 + lane), so 8 consecutive lanes emit one block = one 128-B line.
+// area linearly (chunk g = it*64 + lane), so 8 consecutive lanes emit one block = one 128-B line.
+// The destination of slot s needs no division: in MCU order slot -> (MCU first + s / hv, k = s % hv)
+// with hv in {1,2,4,8}, and consecutive iterations advance the slot by 8, i.e. the block index by a
+// wave-uniform step; in planar order blocks are simply consecutive.
 __device__ __forceinline__ void stage_and_store(const BlockKernelParams &p, const WaveTask &t, uint8_t *stage,
                                                 uint32_t lane, const uint32_t packed[32], uint4 *frame_out) {
 #pragma unroll
@@ -91,12 +94,32 @@ __device__ __forceinline__ void stage_and_store(const BlockKernelParams &p, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const uint32_t slot0 = lane >> 3, j = lane & 7u;
+    uint32_t unit, unit_step, unit_limit;     // "unit" = MCU (MCU order) or block (planar)
+    uint64_t index;                           // output block index of slot0
+    uint32_t index_step;
+    if (p.order == 0) {
+        const uint32_t lg = 31u - (uint32_t)__builtin_clz(t.per_mcu);          // hv is a power of two
+        unit = t.first + (slot0 >> lg);
+        unit_step = 8u >> lg;
+        unit_limit = p.total_mcus;
+        index = (uint64_t)unit * p.bpm + p.comp_first[t.comp] + (slot0 & (t.per_mcu - 1u));
+        index_step = unit_step * p.bpm;
+        if (t.per_mcu > 8u) { unit_step = 0; index_step = 0; }                 // not reachable (hv <= 8)
+    } else {
+        unit = t.first + slot0;
+        unit_step = 8u;
+        unit_limit = p.nblocks[t.comp];
+        index = p.comp_off[t.comp] + unit;
+        index_step = 8u;
+    }
+    const uint8_t *src = stage + slot0 * 128u + ((j ^ (slot0 & 7u)) << 4);     // (slot0 + 8*it) & 7 == slot0 & 7
+    uint4 *dst = frame_out + index * 8u + j;
 #pragma unroll
     for (int it = 0; it < 8; it++) {
-        const uint32_t g = (uint32_t)it * 64u + lane, slot = g >> 3, j = g & 7u;
-        const uint4 v = *reinterpret_cast<const uint4 *>(stage + slot * 128u + ((j ^ (slot & 7u)) << 4));
-        const BlockRef r = locate(p, t, slot);
-        if (r.valid) frame_out[r.out_index * 8u + j] = v;
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + it * 1024);
+        if (unit + (uint32_t)it * unit_step < unit_limit) dst[(size_t)it * index_step * 8u] = v;
     }
 }
 
