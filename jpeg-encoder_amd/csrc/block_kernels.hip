@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(640) k_blocks_generic(const BlockKernelParams 
         rows[y][3] = s[4] | (s[5] << 16);
     }
     uint32_t packed[32];
-    fdct_quant_block<VARIANT>(rows, p.q, p.qsel[c] != 0, packed);
+    fdct_quant_block<VARIANT>(rows, quant_table(p.qsel[c]), packed);
     stage_and_store(p, t, smem + wave * kStageBytes, lane, packed, frame_out);
 }
 

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(384) k_blocks_rgb(const BlockKernelParams p, c
     const BlockRef me = locate(p, t, lane);
     const int c = t.comp;
     const int hlim = p.height - 1;
-    const size_t pitch = (size_t)p.width * BPP;
+    const uint32_t pitch = (uint32_t)p.width * BPP;                 // frame bytes < 2^31 (checked by the launcher)
     const bool aligned4 = (((uintptr_t)frame | pitch) & 3u) == 0;   // wave-uniform
     uint32_t rows[8][4];
 
@@ -108,11 +108,13 @@ __global__ void __launch_bounds__(384) k_blocks_rgb(const BlockKernelParams p, c
         constexpr int N = BPP * 8 / 4;
         const bool interior = me.x0 + 8 <= p.width;
         if (interior) {
-            const uint8_t *base = frame + (size_t)me.x0 * BPP;
+            // byte offset of row y = min(first + y*pitch, last): bottom-edge rows repeat row h-1
+            const uint32_t first = (uint32_t)me.y0 * pitch + (uint32_t)me.x0 * BPP;
+            const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * BPP;
 #pragma unroll
             for (int y = 0; y < 8; y++) {
                 uint32_t d[N], v[8];
-                load_row<N>(base + (size_t)min(me.y0 + y, hlim) * pitch, aligned4, d);
+                load_row<N>(frame + min(first + (uint32_t)y * pitch, last), aligned4, d);
 #pragma unroll
                 for (int x = 0; x < 8; x++) v[x] = luma16(pixel_word<BPP, 1, N>(d, x), k);
                 rows[y][0] = __builtin_amdgcn_perm(v[1], v[0], 0x0C050C01u);
@@ -128,11 +130,12 @@ __global__ void __launch_bounds__(384) k_blocks_rgb(const BlockKernelParams p, c
         const uint32_t sh = c == 1 ? k.sh_b : k.sh_r;
         const bool interior = me.x0 + 8 * SX <= p.width;
         if (interior) {
-            const uint8_t *base = frame + (size_t)me.x0 * BPP;
+            const uint32_t first = (uint32_t)me.y0 * pitch + (uint32_t)me.x0 * BPP;
+            const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * BPP;
 #pragma unroll
             for (int y = 0; y < 8; y++) {
                 uint32_t d[N], v[8];
-                load_row<N>(base + (size_t)min(me.y0 + y * SY, hlim) * pitch, aligned4, d);
+                load_row<N>(frame + min(first + (uint32_t)(y * SY) * pitch, last), aligned4, d);
 #pragma unroll
                 for (int x = 0; x < 8; x++) v[x] = chroma32(pixel_word<BPP, SX, N>(d, x), sel, kk, sh);
                 rows[y][0] = __builtin_amdgcn_perm(v[1], v[0], 0x0C060C02u);
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(384) k_blocks_rgb(const BlockKernelParams p, c
         }
     }
     uint32_t packed[32];
-    fdct_quant_block<VARIANT>(rows, p.q, c != 0, packed);
+    fdct_quant_block<VARIANT>(rows, quant_table(c != 0), packed);
     stage_and_store(p, t, smem + wave * kStageBytes, lane, packed, frame_out);
 }
 
@@ -202,6 +205,7 @@ static hipError_t launch_rgb(const BlockKernelParams &p, int num_frames, int var
 
 bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream, hipError_t *err) {
     if (p.xform != XF_RGB2YCC || p.ncomp != 3) return false;
+    if ((uint64_t)p.width * (uint64_t)p.height * (uint64_t)p.bpp >= (1ull << 31)) return false;   // 32-bit row offsets
     const int sx = p.sx[1], sy = p.sy[1];
     if (p.sx[0] != 1 || p.sy[0] != 1 || sx > 2 || sy > 2 || p.sx[2] != sx || p.sy[2] != sy) return false;
 #define JPEGENC_CASE(B, X, Y) if (p.bpp == B && sx == X && sy == Y) { *err = launch_rgb<B, X, Y>(p, num_frames, variant, stream); return true; }

@@ -149,14 +149,23 @@ __device__ __forceinline__ void islow_pass(uint32_t a, uint32_t b, uint32_t c, u
     }
 }
 
+typedef const uint32_t __attribute__((address_space(4))) *qconst_ptr;
+
+// The quantiser table of destination `table` as a wave-uniform pointer into kernarg memory
+// (BlockKernelParams must be the kernel's FIRST argument).  Going through the kernarg segment
+// pointer keeps every constant an immediate-offset scalar load from one base; indexing the by-value
+// argument with a run-time table number makes hipcc build 128 separate 64-bit addresses and spill.
+__device__ __forceinline__ qconst_ptr quant_table(int table) {
+    const char __attribute__((address_space(4))) *args =
+        (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    return (qconst_ptr)(args + __builtin_offsetof(BlockKernelParams, q) + (size_t)table * sizeof(QuantDev));
+}
+
 // rows[y] = {(x0,x1),(x3,x2),(x7,x6),(x4,x5)} of UNSIGNED samples of block row y.
-// `chroma_table` must be wave-uniform: both tables are read from kernarg memory with
-// immediate-offset scalar loads and the wanted constant is picked with s_cselect (indexing the
-// by-value argument with a run-time table number makes hipcc materialise 128 separate 64-bit
-// addresses and spill them).  out[j] = zig-zag coefficients (2j, 2j+1) packed as little-endian i16.
+// qc = quant_table(t), wave-uniform.  out[j] = zig-zag coefficients (2j, 2j+1) packed as
+// little-endian i16.
 template <int VARIANT>
-__device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], const QuantDev (&q)[2],
-                                                 bool chroma_table, uint32_t out[32]) {
+__device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], qconst_ptr qc, uint32_t out[32]) {
     const ChainConsts K = chain_consts();
     int mid[8][8];
 #pragma unroll
@@ -173,9 +182,7 @@ __device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], cons
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int i = (x * 8 + k) * 2;
-            const uint32_t kq = chroma_table ? q[1].qc[i] : q[0].qc[i];
-            const uint32_t aq = chroma_table ? q[1].qc[i + 1] : q[0].qc[i + 1];
-            prod[k * 8 + x] = dot2((uint32_t)col[k], kq, (int)aq);
+            prod[k * 8 + x] = dot2((uint32_t)col[k], qc[i], (int)qc[i + 1]);
         }
     }
 #pragma unroll

@@ -119,7 +119,14 @@ __device__ __forceinline__ void stage_and_store(const BlockKernelParams &p, cons
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + it * 1024);
-        if (unit + (uint32_t)it * unit_step < unit_limit) dst[(size_t)it * index_step * 8u] = v;
+        if (unit + (uint32_t)it * unit_step < unit_limit) {
+#ifndef JPEGENC_PLAIN_STORE   // streaming stores: +1.6 % on the 4K bench (nothing re-reads the coefficients)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(&dst[(size_t)it * index_step * 8u]));
+#else
+            dst[(size_t)it * index_step * 8u] = v;
+#endif
+        }
     }
 }
 
