@@ -160,6 +160,33 @@ int jpegenc_blocks_host(int device, const uint8_t *pixels, size_t pixels_len, in
 int jpegenc_histogram_device(const void *d_coeffs_planar, const jpegenc_layout *layout,
                              int progressive_scans, void *d_freq, void *hip_stream);
 
+/* ---- entropy coding of a baseline interleaved scan on the device --------- */
+/* One Huffman table as a DHT segment carries it (huffman.rs:66-70): counts per code length and
+ * the symbol values in code order. */
+typedef struct jpegenc_huffman_spec {
+    uint8_t bits[16];
+    uint8_t values[256];
+    int32_t num_values;
+} jpegenc_huffman_spec;
+
+/* Bytes of device scratch jpegenc_scan_device needs for `num_frames` frames of this MCU-order
+ * layout; 0 if the geometry is not supported on the device (then code the scan on the host). */
+size_t jpegenc_scan_workspace_size(const jpegenc_layout *layout, int num_frames);
+/* Worst-case bytes of one frame's entropy-coded segment (use it as out_frame_stride). */
+size_t jpegenc_scan_max_bytes(const jpegenc_layout *layout);
+
+/* Replaces the write_block calls of encode_image_interleaved plus the closing
+ * finalize_bit_buffer (encoder.rs:781-788, :804; writer.rs:138-202, 331-388) for scans without
+ * restart markers: MCU-order coefficient blocks in HBM -> the scan's entropy-coded bytes (0xFF
+ * stuffed, 1-padded) in HBM, byte-identical to the reference's.  tables[d][0] = DC, [d][1] = AC
+ * of destination d; NULL selects the Annex K.3 defaults of Encoder::new (encoder.rs:240-249).
+ * d_out receives each frame's segment at f * out_frame_stride, d_out_lengths[f] its length.
+ * Asynchronous on hip_stream. */
+int jpegenc_scan_device(const void *d_coeffs_mcu, size_t coeff_frame_stride, int num_frames,
+                        const jpegenc_layout *layout, const jpegenc_huffman_spec (*tables)[2],
+                        void *d_out, size_t out_frame_stride, uint32_t *d_out_lengths,
+                        void *d_workspace, size_t workspace_bytes, void *hip_stream);
+
 /* ---- Encoder-shaped API (struct Encoder, src/encoder.rs:213-515) ------------------------ */
 typedef struct jpegenc_encoder jpegenc_encoder;
 
@@ -171,6 +198,10 @@ jpegenc_encoder *jpegenc_encoder_new(int quality);                       /* Enco
 void jpegenc_encoder_free(jpegenc_encoder *e);
 int  jpegenc_encoder_set_device(jpegenc_encoder *e, int device);         /* GPU this handle drives */
 int  jpegenc_encoder_set_fdct_variant(jpegenc_encoder *e, int variant);  /* default SCALAR */
+/* 1 (default): baseline interleaved scans without restart markers are entropy-coded on the GPU
+ * and only compressed bytes cross PCIe; 0: coefficients come back and the host codes them.  The
+ * emitted bytes are identical either way. */
+int  jpegenc_encoder_set_device_entropy(jpegenc_encoder *e, int enable);
 
 int  jpegenc_encoder_set_density(jpegenc_encoder *e, int unit, uint16_t x, uint16_t y);   /* :280 */
 int  jpegenc_encoder_density(const jpegenc_encoder *e, int *unit, uint16_t *x, uint16_t *y);

@@ -38,6 +38,8 @@ ABI_SYMBOLS = [
     "jpegenc_abi_version", "jpegenc_device_count", "jpegenc_last_error", "jpegenc_status_string",
     "jpegenc_qtable_init", "jpegenc_bytes_per_pixel", "jpegenc_layout_init",
     "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_histogram_device",
+    "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
+    "jpegenc_encoder_set_device_entropy",
     "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
     "jpegenc_encoder_set_fdct_variant", "jpegenc_encoder_set_density", "jpegenc_encoder_density",
     "jpegenc_encoder_set_sampling_factor", "jpegenc_encoder_sampling_factor",
@@ -107,7 +109,13 @@ def lib():
         l.jpegenc_encoder_new.argtypes = [C.c_int]
         l.jpegenc_encoder_free.argtypes = [C.c_void_p]
         l.jpegenc_encoder_free.restype = None
-        for name in ("set_device", "set_fdct_variant", "set_sampling_factor", "set_progressive",
+        l.jpegenc_scan_workspace_size.restype = C.c_size_t
+        l.jpegenc_scan_workspace_size.argtypes = [C.POINTER(Layout), C.c_int]
+        l.jpegenc_scan_max_bytes.restype = C.c_size_t
+        l.jpegenc_scan_max_bytes.argtypes = [C.POINTER(Layout)]
+        l.jpegenc_scan_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Layout), C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        for name in ("set_device", "set_device_entropy", "set_fdct_variant", "set_sampling_factor", "set_progressive",
                      "set_progressive_scans", "set_optimized_huffman_tables"):
             getattr(l, "jpegenc_encoder_" + name).argtypes = [C.c_void_p, C.c_int]
         for name in ("sampling_factor", "progressive_scans", "restart_interval", "optimized_huffman_tables"):
@@ -182,6 +190,21 @@ def blocks_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, c
     """Raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous on `stream_ptr`."""
     check(lib().jpegenc_blocks_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, color_type,
                                       hs, vs, q, order, variant, d_coeffs_ptr, coeff_frame_stride, stream_ptr))
+
+
+def scan_device(d_coeffs_ptr, coeff_frame_stride, num_frames, L, d_out_ptr, out_frame_stride, d_lengths_ptr,
+                d_workspace_ptr, workspace_bytes, stream_ptr=0, tables=None):
+    """Device entropy coding of an interleaved scan; tables=None -> Annex K.3 defaults."""
+    check(lib().jpegenc_scan_device(d_coeffs_ptr, coeff_frame_stride, num_frames, C.byref(L), tables, d_out_ptr,
+                                    out_frame_stride, d_lengths_ptr, d_workspace_ptr, workspace_bytes, stream_ptr))
+
+
+def scan_workspace_size(L, num_frames):
+    return lib().jpegenc_scan_workspace_size(C.byref(L), num_frames)
+
+
+def scan_max_bytes(L):
+    return lib().jpegenc_scan_max_bytes(C.byref(L))
 
 
 def histogram_device(d_coeffs_ptr, L, progressive_scans, d_freq_ptr, stream_ptr=0):
@@ -261,6 +284,9 @@ class Encoder:
 
     def optimized_huffman_tables(self):
         return bool(lib().jpegenc_encoder_optimized_huffman_tables(self._h))
+
+    def set_device_entropy(self, enable):
+        check(lib().jpegenc_encoder_set_device_entropy(self._h, 1 if enable else 0))
 
     def set_fdct_variant(self, variant):
         check(lib().jpegenc_encoder_set_fdct_variant(self._h, variant))

@@ -7,7 +7,7 @@ out="${here}/../libjpegenc_mi355x.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-const-variable -Wno-unused-function
        -I"${here}/../../include")
-srcs=("${here}"/block_kernels.hip "${here}"/fast_kernels.hip "${here}"/capi_blocks.cpp "${here}"/host_encoder.cpp)
+srcs=("${here}"/block_kernels.hip "${here}"/fast_kernels.hip "${here}"/entropy_kernels.hip "${here}"/capi_entropy.hip "${here}"/capi_blocks.cpp "${here}"/host_encoder.cpp)
 objs=()
 mkdir -p "${here}/build"
 for s in "${srcs[@]}"; do

@@ -1,0 +1,305 @@
+// entropy_kernels.hip — baseline Huffman entropy coding of an interleaved scan ON THE DEVICE
+// (SURVEY.md §8f rank 1).  Produces, byte for byte, what JfifWriter::write_block + write_bits +
+// finalize_bit_buffer emit for the scan (writer.rs:138-202, 331-388), so the host only has to add
+// headers and EOI and only compressed bytes cross PCIe.
+//
+// Variable-length coding is serial in the reference; here it is five data-parallel steps:
+//   1. k_block_bits   one lane per block: exact bit length of the block's code
+//                     (DC category + Huffman codes of every (run,size) symbol, ZRLs, EOB)
+//   2. scan           exclusive prefix sum -> bit offset of every block (3 small kernels)
+//   3. k_block_pack   one lane per block re-walks its coefficients and writes its bits at that
+//                     offset (64-bit accumulator, whole 32-bit words stored plainly, the two
+//                     boundary words OR-ed atomically into the zeroed buffer); the last block adds
+//                     the 1-padding of finalize_bit_buffer
+//   4. k_count_ff + scan   0xFF bytes per 16-byte chunk and their prefix sum
+//   5. k_stuff        scatter with 0xFF -> 0xFF 0x00 stuffing
+// DC prediction needs no scan: the predecessor of a block is a fixed earlier block of the same
+// component in MCU order, read straight from the coefficient array.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "entropy_params.h"
+#include "host_common.h"
+
+namespace jpegenc {
+
+constexpr int kScanTile = 4096;      // elements per workgroup in the scans (256 threads x 16)
+
+// ---- generic exclusive scan of uint32 (per frame: blockIdx.y) ---------------------------------
+// n is read from device memory when n_dev != nullptr (data-dependent sizes never visit the host).
+__device__ __forceinline__ uint32_t frame_n(const uint32_t *n_dev, uint32_t n_const, uint32_t frame) {
+    return n_dev ? n_dev[frame] : n_const;
+}
+
+__global__ void __launch_bounds__(256) k_scan_reduce(const uint32_t *in, uint64_t in_stride, uint32_t *partials,
+                                                     uint32_t max_tiles, const uint32_t *n_dev, uint32_t n_const) {
+    const uint32_t f = blockIdx.y, n = frame_n(n_dev, n_const, f);
+    const uint32_t tile = blockIdx.x;
+    if ((uint64_t)tile * kScanTile >= n) return;
+    const uint32_t *src = in + (size_t)f * in_stride;
+    uint32_t sum = 0;
+    for (int i = 0; i < 16; i++) {
+        const uint32_t idx = tile * kScanTile + i * 256 + threadIdx.x;
+        if (idx < n) sum += src[idx];
+    }
+    __shared__ uint32_t red[256];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[(size_t)f * max_tiles + tile] = red[0];
+}
+
+__global__ void __launch_bounds__(256) k_scan_partials(uint32_t *partials, uint32_t max_tiles, uint32_t *totals,
+                                                       const uint32_t *n_dev, uint32_t n_const) {
+    const uint32_t f = blockIdx.x, n = frame_n(n_dev, n_const, f);
+    const uint32_t tiles = (uint32_t)(((uint64_t)n + kScanTile - 1) / kScanTile);
+    uint32_t *p = partials + (size_t)f * max_tiles;
+    __shared__ uint32_t buf[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < tiles; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < tiles ? p[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < 256; s <<= 1) {          // Hillis-Steele inclusive scan
+            const uint32_t t = (int)threadIdx.x >= s ? buf[threadIdx.x - s] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < tiles) p[i] = carry + buf[threadIdx.x] - v;      // exclusive
+        __syncthreads();
+        if (threadIdx.x == 255) carry += buf[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[f] = carry;
+}
+
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *in, uint64_t in_stride, uint32_t *out,
+                                                    uint64_t out_stride, const uint32_t *partials, uint32_t max_tiles,
+                                                    const uint32_t *n_dev, uint32_t n_const) {
+    const uint32_t f = blockIdx.y, n = frame_n(n_dev, n_const, f);
+    const uint32_t tile = blockIdx.x;
+    if ((uint64_t)tile * kScanTile >= n) return;
+    const uint32_t *src = in + (size_t)f * in_stride;
+    uint32_t *dst = out + (size_t)f * out_stride;
+    // each thread owns 16 consecutive elements
+    const uint32_t first = tile * kScanTile + threadIdx.x * 16;
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { v[i] = first + i < n ? src[first + i] : 0; sum += v[i]; }
+    __shared__ uint32_t buf[256];
+    buf[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+        const uint32_t t = (int)threadIdx.x >= s ? buf[threadIdx.x - s] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = partials[(size_t)f * max_tiles + tile] + buf[threadIdx.x] - sum;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (first + i < n) dst[first + i] = run;
+        run += v[i];
+    }
+}
+
+// ---- walking one block's symbols ----------------------------------------------------------------
+__device__ __forceinline__ uint32_t bit_size(int v) {          // get_code().0 / get_num_bits (writer.rs:455-470)
+    const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    return a ? 32u - (uint32_t)__builtin_clz(a) : 0u;
+}
+
+struct BitSink {          // k_block_pack: bits go to memory; k_block_bits: only counted
+    uint32_t *words;      // word pointer of the next flush
+    uint64_t acc;
+    uint32_t nacc;
+    bool first;
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void put_bits(BitSink &s, uint32_t &total, uint32_t code, uint32_t len) {
+    total += len;
+    if (EMIT) {
+        s.acc = (s.acc << len) | code;
+        s.nacc += len;
+        if (s.nacc >= 32) {
+            const uint32_t w = __builtin_bswap32((uint32_t)(s.acc >> (s.nacc - 32)));   // MSB-first byte stream
+            if (s.first) atomicOr(s.words, w); else *s.words = w;
+            s.first = false;
+            s.words++;
+            s.nacc -= 32;
+        }
+    }
+}
+
+// lut: [table][0 = DC, 1 = AC][256] of (size << 16 | code), in LDS
+template <bool EMIT>
+__device__ __forceinline__ uint32_t walk_block(const EntropyParams &p, const uint32_t *lut, const int16_t *frame_coeffs,
+                                               uint32_t b, BitSink &s) {
+    const uint32_t mcu = b / p.bpm, pos = b - mcu * p.bpm;
+    const uint32_t table = p.pos_table[pos];
+    const uint32_t *dc_lut = lut + table * 512, *ac_lut = dc_lut + 256;
+    const uint4 *src = reinterpret_cast<const uint4 *>(frame_coeffs + (size_t)b * 64);
+    uint32_t c[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint4 u = src[i];
+        c[4 * i] = u.x; c[4 * i + 1] = u.y; c[4 * i + 2] = u.z; c[4 * i + 3] = u.w;
+    }
+    // DC: predecessor = previous block of the same component (write_dc, writer.rs:342-354;
+    // predictors reset at the start of the scan and at restart boundaries, encoder.rs:748-757)
+    int prev = 0;
+    const int delta = p.pos_prev_delta[pos];              // blocks back inside the MCU, or 0
+    if (delta) {
+        prev = frame_coeffs[(size_t)(b - delta) * 64];
+    } else {
+        const bool restart_here = p.restart_interval && (mcu % p.restart_interval) == 0;
+        if (mcu > 0 && !restart_here) prev = frame_coeffs[((size_t)(mcu - 1) * p.bpm + p.pos_last_of_comp[pos]) * 64];
+    }
+    uint32_t total = 0;
+    {
+        const int dc = (int16_t)(c[0] & 0xFFFFu);
+        const int diff = (int16_t)(dc - prev);
+        const uint32_t n = bit_size(diff);
+        const uint32_t e = dc_lut[n];
+        const uint32_t mag = (uint32_t)(diff - (diff < 0)) & ((1u << n) - 1u);
+        put_bits<EMIT>(s, total, ((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
+    }
+    // AC: write_ac_block (writer.rs:356-388)
+    uint32_t run = 0;
+    const uint32_t zrl = ac_lut[0xF0];
+#pragma unroll
+    for (int k = 1; k < 64; k++) {
+        const int v = (k & 1) ? (int)c[k >> 1] >> 16 : (int)(int16_t)(c[k >> 1] & 0xFFFFu);
+        if (v != 0) {
+            while (run > 15) { put_bits<EMIT>(s, total, zrl & 0xFFFFu, zrl >> 16); run -= 16; }
+            const uint32_t n = bit_size(v);
+            const uint32_t e = ac_lut[(run << 4) | n];
+            const uint32_t mag = (uint32_t)(v - (v < 0)) & ((1u << n) - 1u);
+            put_bits<EMIT>(s, total, ((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
+            run = 0;
+        } else {
+            run++;
+        }
+    }
+    if (run > 0) { const uint32_t e = ac_lut[0]; put_bits<EMIT>(s, total, e & 0xFFFFu, e >> 16); }
+    return total;
+}
+
+__device__ __forceinline__ void load_lut(const EntropyParams &p, uint32_t *lut) {
+    for (uint32_t i = threadIdx.x; i < 4 * 256; i += blockDim.x) lut[i] = p.lut[i];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_block_bits(const EntropyParams p) {
+    __shared__ uint32_t lut[4 * 256];
+    load_lut(p, lut);
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (b >= p.nblocks) return;
+    BitSink s = {nullptr, 0, 0, false};
+    const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
+    p.bits[(size_t)f * p.nblocks + b] = walk_block<false>(p, lut, frame, b, s);
+}
+
+__global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
+    __shared__ uint32_t lut[4 * 256];
+    load_lut(p, lut);
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (b >= p.nblocks) return;
+    const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
+    const uint32_t off = p.bitoff[(size_t)f * p.nblocks + b];
+    uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
+    BitSink s = {stream + (off >> 5), 0, off & 31u, true};
+    walk_block<true>(p, lut, frame, b, s);
+    if (b == p.nblocks - 1) {
+        // finalize_bit_buffer (writer.rs:138-154): seven 1-bits, then only whole bytes are kept
+        const uint32_t total = p.total_bits[f], pad = (8u - (total & 7u)) & 7u;
+        if (pad) {
+            s.acc = (s.acc << pad) | ((1u << pad) - 1u);
+            s.nacc += pad;
+            if (s.nacc >= 32) {
+                const uint32_t w = __builtin_bswap32((uint32_t)(s.acc >> (s.nacc - 32)));
+                if (s.first) atomicOr(s.words, w); else *s.words = w;
+                s.first = false; s.words++; s.nacc -= 32;
+            }
+        }
+        p.raw_bytes[f] = (total + pad) >> 3;
+        p.raw_chunks[f] = (((total + pad) >> 3) + 15u) >> 4;
+    }
+    if (s.nacc) atomicOr(s.words, __builtin_bswap32((uint32_t)(s.acc << (32 - s.nacc))));
+}
+
+// ---- byte stuffing --------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ff_count4(uint32_t w) {           // number of 0xFF bytes in a dword
+    const uint32_t t = w & (w >> 4);                                    // both nibbles all-ones <=> byte 0xFF
+    const uint32_t u = t & (t >> 2);
+    const uint32_t m = u & (u >> 1) & 0x01010101u;
+    return (m * 0x01010101u) >> 24;
+}
+
+__global__ void __launch_bounds__(256) k_count_ff(const EntropyParams p) {
+    const uint32_t f = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.raw_chunks[f]) return;
+    const uint4 v = reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride)[q];
+    // bytes beyond raw_bytes are still zero (the buffer is cleared per encode), so they never count
+    p.ffcount[(size_t)f * p.max_chunks + q] = ff_count4(v.x) + ff_count4(v.y) + ff_count4(v.z) + ff_count4(v.w);
+}
+
+__global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
+    const uint32_t f = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nbytes = p.raw_bytes[f];
+    if (q >= p.raw_chunks[f]) return;
+    const uint8_t *src = p.raw + (size_t)f * p.raw_stride + (size_t)q * 16;
+    uint8_t *dst = p.out + (size_t)f * p.out_stride + (size_t)q * 16 + p.ffprefix[(size_t)f * p.max_chunks + q];
+    const uint4 v = *reinterpret_cast<const uint4 *>(src);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t valid = nbytes - q * 16 < 16 ? nbytes - q * 16 : 16;
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if ((uint32_t)i < valid) {
+            const uint8_t byte = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+            dst[o++] = byte;
+            if (byte == 0xFF) dst[o++] = 0;              // flush_byte_from_bit_buffer, writer.rs:157-167
+        }
+    }
+    if (q + 1 == p.raw_chunks[f]) p.out_bytes[f] = q * 16 + p.ffprefix[(size_t)f * p.max_chunks + q] + o;
+}
+
+// ---- launcher ----------------------------------------------------------------------------------------
+static hipError_t scan(const uint32_t *in, uint64_t in_stride, uint32_t *out, uint64_t out_stride, uint32_t *partials,
+                       uint32_t max_tiles, uint32_t *totals, const uint32_t *n_dev, uint32_t n_max, int frames,
+                       hipStream_t st) {
+    const uint32_t tiles = (n_max + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles, frames), dim3(256), 0, st, in, in_stride, partials, max_tiles, n_dev, n_max);
+    hipLaunchKernelGGL(k_scan_partials, dim3(frames), dim3(256), 0, st, partials, max_tiles, totals, n_dev, n_max);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles, frames), dim3(256), 0, st, in, in_stride, out, out_stride, partials,
+                       max_tiles, n_dev, n_max);
+    return hipGetLastError();
+}
+
+hipError_t launch_entropy_interleaved(const EntropyParams &p, int frames, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(p.raw, 0, (size_t)frames * p.raw_stride, st);
+    if (e != hipSuccess) return e;
+    const uint32_t bgrid = (p.nblocks + 255u) / 256u;
+    hipLaunchKernelGGL(k_block_bits, dim3(bgrid, frames), dim3(256), 0, st, p);
+    e = scan(p.bits, p.nblocks, p.bitoff, p.nblocks, p.partials, p.max_tiles, p.total_bits, nullptr, p.nblocks, frames, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_block_pack, dim3(bgrid, frames), dim3(256), 0, st, p);
+    const uint32_t cgrid = (p.max_chunks + 255u) / 256u;
+    hipLaunchKernelGGL(k_count_ff, dim3(cgrid, frames), dim3(256), 0, st, p);
+    e = scan(p.ffcount, p.max_chunks, p.ffprefix, p.max_chunks, p.partials, p.max_tiles, p.total_ff, p.raw_chunks,
+             p.max_chunks, frames, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_stuff, dim3(cgrid, frames), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace jpegenc

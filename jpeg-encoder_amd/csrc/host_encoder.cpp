@@ -230,6 +230,12 @@ struct DeviceCtx {
     uint8_t *h_pixels = nullptr;
     size_t h_pixels_cap = 0;
     uint32_t *h_freq = nullptr;
+    // device entropy coding (interleaved scans): scratch, coded segment, its length
+    void *d_scan_ws = nullptr, *d_scan_out = nullptr;
+    size_t d_scan_ws_cap = 0, d_scan_out_cap = 0;
+    uint32_t *d_scan_len = nullptr, *h_scan_len = nullptr;
+    uint8_t *h_scan_out = nullptr;
+    size_t h_scan_out_cap = 0;
     static constexpr int kChunks = 8;
     hipEvent_t chunk_done[kChunks] = {};
 
@@ -243,6 +249,33 @@ struct DeviceCtx {
         for (auto &e : chunk_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         JPEGENC_HIP(hipMalloc(&d_freq, sizeof(uint32_t) * 2 * 2 * 257));
         JPEGENC_HIP(hipHostMalloc((void **)&h_freq, sizeof(uint32_t) * 2 * 2 * 257, hipHostMallocDefault));
+        JPEGENC_HIP(hipMalloc((void **)&d_scan_len, sizeof(uint32_t)));
+        JPEGENC_HIP(hipHostMalloc((void **)&h_scan_len, sizeof(uint32_t), hipHostMallocDefault));
+        return JPEGENC_OK;
+    }
+    int reserve_scan(size_t ws_bytes, size_t out_bytes) {
+        if (ws_bytes > d_scan_ws_cap) {
+            if (d_scan_ws) (void)hipFree(d_scan_ws);
+            d_scan_ws = nullptr; d_scan_ws_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_scan_ws, ws_bytes));
+            d_scan_ws_cap = ws_bytes;
+        }
+        if (out_bytes > d_scan_out_cap) {
+            if (d_scan_out) (void)hipFree(d_scan_out);
+            d_scan_out = nullptr; d_scan_out_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_scan_out, out_bytes));
+            d_scan_out_cap = out_bytes;
+        }
+        return JPEGENC_OK;
+    }
+    int reserve_scan_host(size_t bytes) {
+        if (bytes > h_scan_out_cap) {
+            if (h_scan_out) (void)hipHostFree(h_scan_out);
+            h_scan_out = nullptr; h_scan_out_cap = 0;
+            const size_t cap = bytes + bytes / 2 + (1u << 20);
+            JPEGENC_HIP(hipHostMalloc((void **)&h_scan_out, cap, hipHostMallocDefault));
+            h_scan_out_cap = cap;
+        }
         return JPEGENC_OK;
     }
     int reserve(size_t pixel_bytes, size_t coeff_bytes, bool pinned_pixels) {
@@ -284,6 +317,11 @@ struct DeviceCtx {
         if (h_coeffs) (void)hipHostFree(h_coeffs);
         if (h_pixels) (void)hipHostFree(h_pixels);
         if (h_freq) (void)hipHostFree(h_freq);
+        if (d_scan_ws) (void)hipFree(d_scan_ws);
+        if (d_scan_out) (void)hipFree(d_scan_out);
+        if (d_scan_len) (void)hipFree(d_scan_len);
+        if (h_scan_len) (void)hipHostFree(h_scan_len);
+        if (h_scan_out) (void)hipHostFree(h_scan_out);
         *this = DeviceCtx();
     }
     ~DeviceCtx() { close(); }
@@ -303,6 +341,7 @@ struct Config {                      // the fields of struct Encoder, encoder.rs
     int restart_interval = 0;        // Option<u16>
     bool optimize = false;
     int fdct_variant = JPEGENC_FDCT_SCALAR;
+    bool device_entropy = true;      // GPU Huffman coding of interleaved scans (same bytes as the host path)
     std::vector<std::pair<uint8_t, std::vector<uint8_t>>> app_segments;
 };
 
@@ -499,6 +538,44 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         if (rc) return rc;
         JPEGENC_HIP(hipMemcpyAsync(ctx.h_freq, ctx.d_freq, sizeof(uint32_t) * 2 * 2 * 257, hipMemcpyDeviceToHost, ctx.stream));
     }
+    // ---- interleaved scan without restart markers: entropy-code on the device, fetch bytes only ---
+    if (mode == MODE_INTERLEAVED && c.device_entropy && c.restart_interval == 0) {
+        const size_t ws = scan_workspace_size(L, 1), cap = scan_max_bytes(L);
+        if (ws && cap) {
+            rc = ctx.reserve_scan(ws, cap);
+            if (rc) return rc;
+            jpegenc_huffman_spec specs[2][2];
+            for (int d = 0; d < 2; d++)
+                for (int k = 0; k < 2; k++) {
+                    memset(&specs[d][k], 0, sizeof specs[d][k]);
+                    memcpy(specs[d][k].bits, t.h[d][k].bits, 16);
+                    memcpy(specs[d][k].values, t.h[d][k].vals, (size_t)t.h[d][k].nvals);
+                    specs[d][k].num_values = t.h[d][k].nvals;
+                }
+            rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, specs, 0, ctx.d_scan_out, cap, ctx.d_scan_len,
+                             ctx.d_scan_ws, ws, ctx.stream);
+            if (rc) return rc;
+            JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_len, ctx.d_scan_len, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
+            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            const size_t nbytes = *ctx.h_scan_len;
+            rc = ctx.reserve_scan_host(nbytes);
+            if (rc) return rc;
+            JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out, ctx.d_scan_out, nbytes, hipMemcpyDeviceToHost, ctx.stream));
+            Out o;
+            o.sink = sink; o.user = user;
+            write_prologue(o, c, jct);
+            write_frame_header(o, c, width, height, L, t);
+            write_scan_header(o, L, 0, L.num_components, 0, 63);
+            o.drain(true);                                           // headers go out while the copy runs
+            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            if (sink(user, ctx.h_scan_out, nbytes) != 0) o.failed = true;
+            o.marker(0xD9);
+            o.drain(true);
+            if (o.failed) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
+            return JPEGENC_OK;
+        }
+    }
+
     // coefficient tiles come back in kChunks pieces so that entropy coding of tile k overlaps the
     // copy of tile k+1 (interleaved mode consumes them in order; the other modes need them all)
     const uint32_t bpm = (uint32_t)(L.total_blocks / (L.mcus ? L.mcus : 1));
@@ -626,6 +703,12 @@ int jpegenc_encoder_set_device(jpegenc_encoder *e, int device) {
     REQUIRE(e);
     if (device < 0) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "negative device index");
     e->device = device;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_set_device_entropy(jpegenc_encoder *e, int enable) {
+    REQUIRE(e);
+    e->cfg.device_entropy = enable != 0;
     return JPEGENC_OK;
 }
 

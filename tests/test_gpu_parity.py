@@ -415,3 +415,72 @@ def test_config5_progressive_optimized_4k(binding, oracle, synth):
     got = e.encode(px, w, h, binding.RGB)
     want = oracle.encode_jpeg(px, w, h, oracle.RGB, 90, progressive_scans=4, optimize=True)
     assert got == want
+
+
+# ------------------------------------------------------------------------------------------
+# Device entropy coding: the interleaved scan coded on the GPU must equal the host
+# coder and the oracle byte for byte.
+
+@pytest.mark.parametrize("ct,samp,q,w,h", [
+    (1, (2, 2), 90, 258, 128), (1, (1, 1), 100, 258, 128), (1, (2, 1), 35, 515, 77), (1, (1, 2), 75, 64, 515),
+    (0, (1, 1), 80, 258, 128), (6, (1, 1), 95, 258, 192), (8, (2, 2), 60, 258, 192), (7, (2, 1), 85, 130, 70),
+    (2, (2, 2), 1, 40, 40), (1, (2, 2), 100, 1, 1), (1, (1, 1), 100, 8, 8)])
+def test_device_entropy_matches_host_and_oracle(binding, oracle, synth, ct, samp, q, w, h):
+    px = _image(synth, ct, w, h, 17)
+    files = []
+    for on in (True, False):
+        e = binding.Encoder(q)
+        e.set_sampling_factor(binding.sampling_factor(*samp))
+        e.set_device_entropy(on)
+        files.append(e.encode(px, w, h, ct))
+    want = oracle.encode_jpeg(px, w, h, ct, q, sampling=samp)
+    assert files[0] == want, "device entropy coder differs from the oracle"
+    assert files[1] == want, "host entropy coder differs from the oracle"
+
+
+def test_device_entropy_dense_ff_and_custom_tables(binding, oracle, synth):
+    """Noise at q=100 with all-ones tables: long codes, many 0xFF bytes to stuff."""
+    px = synth.noise_image(320, 240, 3, 99)
+    e = binding.Encoder(100)
+    e.set_quantization_tables(binding.Q_CUSTOM, binding.Q_CUSTOM, [1] * 64, [1] * 64)
+    got = e.encode(px, 320, 240, binding.RGB)
+    want = oracle.encode_jpeg(px, 320, 240, oracle.RGB, 100, qpresets=(oracle.Q_CUSTOM, oracle.Q_CUSTOM),
+                              qcustoms=([1] * 64, [1] * 64))
+    assert got == want
+    assert got.count(b"\xFF\x00") > 100
+
+
+def test_scan_device_batch_api(binding, oracle, synth):
+    """jpegenc_scan_device on HBM-resident coefficients of several frames."""
+    import torch
+    dev = torch.device("cuda:0")
+    w, h, n = 200, 120, 4
+    L = binding.layout(w, h, binding.RGB, 2, 2, 0)
+    nblk = int(L.total_blocks)
+    frames = [synth.noise_image(w, h, 3, 70 + k) for k in range(n)]
+    co = np.stack([binding.blocks_host(f, w, h, binding.RGB, 2, 2, 90, 0) for f in frames])
+    d_co = torch.from_numpy(co).to(dev)
+    cap = binding.scan_max_bytes(L)
+    ws = binding.scan_workspace_size(L, n)
+    assert cap > 0 and ws > 0
+    d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_ws = torch.empty(ws, dtype=torch.uint8, device=dev)
+    binding.scan_device(d_co.data_ptr(), nblk, n, L, d_out.data_ptr(), cap, d_len.data_ptr(), d_ws.data_ptr(), ws, 0)
+    torch.cuda.synchronize()
+    lens = d_len.cpu().numpy()
+    out = d_out.cpu().numpy()
+    for k, f in enumerate(frames):
+        full = oracle.encode_jpeg(f, w, h, oracle.RGB, 90, sampling=(2, 2))
+        sos = full.index(b"\xFF\xDA")
+        scan = full[sos + 2 + 12:-2]          # after the 12-byte SOS segment, before EOI
+        assert bytes(out[k, :lens[k]]) == scan
+
+
+def test_config2_4k_full_file(binding, oracle, synth):
+    """BASELINE config 2 end to end: 4K RGB q=90 4:2:0 -> JPEG bytes (device entropy) == oracle."""
+    w, h = 3840, 2160
+    for px in (synth.criterion_pattern(w, h), synth.noise_image(w, h, 3, 5)):
+        e = binding.Encoder(90)
+        e.set_sampling_factor(binding.F_2_2)
+        assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, 90, sampling=(2, 2))
