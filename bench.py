@@ -188,14 +188,28 @@ def main():
             frames = [np.ascontiguousarray(np.roll(base, 16 * i, axis=1)) for i in range(args.e2e_frames)]
             enc = binding.Encoder(QUALITY, device=local_rank)
             enc.set_sampling_factor(binding.F_2_2)
-            enc.encode_batch(frames[:2], W, H, binding.RGB)          # warm-up
+            cap = 16 << 20
+            arrs = [f.reshape(-1) for f in frames]
+            outs = [np.empty(cap, dtype=np.uint8) for _ in frames]
+            import ctypes as C
+            n = len(frames)
+            ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+            optrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+            caps = (C.c_size_t * n)(*([cap] * n))
+            lens = (C.c_size_t * n)()
+
+            def run():
+                binding.check(binding.lib().jpegenc_encoder_encode_batch_to_buffers(
+                    enc._h, ptrs, arrs[0].size, n, W, H, binding.RGB, optrs, caps, lens))
+            run()                                                    # warm-up: buffers, page faults
             t1 = time.perf_counter()
-            outs = enc.encode_batch(frames, W, H, binding.RGB)
+            run()
             dt = time.perf_counter() - t1
-            result["end_to_end"] = {"value": round(len(frames) * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
-                                    "what": "pageable host RGB (Criterion pattern) -> JPEG bytes (PCIe + kernel + host Huffman), "
-                                            f"{len(frames)} frames, {os.cpu_count()} host threads available",
-                                    "jpeg_bytes_per_frame": int(sum(len(o) for o in outs) / len(outs))}
+            result["end_to_end"] = {"value": round(n * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
+                                    "what": "pageable host RGB (Criterion pattern) -> JPEG bytes in host buffers: "
+                                            "H2D + fused kernel + device entropy coding + D2H of compressed bytes, "
+                                            f"{n} frames, one GPU, up to 16 host threads of {os.cpu_count()}",
+                                    "jpeg_bytes_per_frame": int(sum(lens) / n)}
     if rank == 0:
         print(json.dumps(result))
     if distributed:

@@ -244,6 +244,13 @@ int  jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *fram
                                   int num_frames, int width, int height, int color_type,
                                   jpegenc_write_fn sink, void *const *users);
 
+/* Same batch, each frame into its own caller buffer (no callbacks): outs[i] has capacities[i]
+ * bytes, lengths[i] receives the size frame i needs; a frame that does not fit makes the call
+ * return JPEGENC_ERR_BUFFER_TOO_SMALL after all frames have been attempted. */
+int  jpegenc_encoder_encode_batch_to_buffers(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len,
+                                             int num_frames, int width, int height, int color_type,
+                                             uint8_t *const *outs, const size_t *capacities, size_t *lengths);
+
 /* free functions re-exported by the crate (src/lib.rs:45-49) — host arithmetic, for callers that
  * implement their own ImageBuffer. */
 void jpegenc_rgb_to_ycbcr(uint8_t r, uint8_t g, uint8_t b, uint8_t out[3]);

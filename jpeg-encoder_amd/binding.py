@@ -50,7 +50,8 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_optimized_huffman_tables", "jpegenc_encoder_add_app_segment",
     "jpegenc_encoder_add_icc_profile", "jpegenc_encoder_add_exif_metadata",
     "jpegenc_encoder_encode", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_image",
-    "jpegenc_encoder_encode_batch", "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
+    "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
+    "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
 ]
 
 
@@ -138,6 +139,9 @@ def lib():
                                                    C.c_void_p, WRITE_FN, C.c_void_p]
         l.jpegenc_encoder_encode_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_int,
                                                    C.c_int, C.c_int, C.c_int, WRITE_FN, C.POINTER(C.c_void_p)]
+        l.jpegenc_encoder_encode_batch_to_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_int,
+                                                              C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                                              C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         l.jpegenc_rgb_to_ycbcr.argtypes = [C.c_uint8] * 3 + [C.POINTER(C.c_uint8)]
         l.jpegenc_cmyk_to_ycck.argtypes = [C.c_uint8] * 4 + [C.POINTER(C.c_uint8)]
         _lib = l
@@ -330,6 +334,20 @@ class Encoder:
         cb, fb = WRITE_FN(sink), FILL_ROW_FN(fill)
         check(lib().jpegenc_encoder_encode_image(self._h, jpeg_color_type, width, height, fb, None, cb, None))
         return b"".join(chunks)
+
+    def encode_batch_to_buffers(self, frames, width, height, color_type, capacity):
+        """Batch encode with no Python in the inner loop: returns a list of bytes objects."""
+        arrs = [np.ascontiguousarray(f, dtype=np.uint8).reshape(-1) for f in frames]
+        n = len(arrs)
+        outs = [np.empty(capacity, dtype=np.uint8) for _ in range(n)]
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        optrs = (C.c_void_p * max(n, 1))(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * max(n, 1))(*([capacity] * n))
+        lens = (C.c_size_t * max(n, 1))()
+        flen = arrs[0].size if n else 0
+        check(lib().jpegenc_encoder_encode_batch_to_buffers(self._h, ptrs, flen, n, width, height, color_type,
+                                                           optrs, caps, lens))
+        return [outs[i][:lens[i]].tobytes() for i in range(n)], outs, list(lens)
 
     def encode_batch(self, frames, width, height, color_type):
         """frames: list of equally sized uint8 arrays -> list of bytes (frame-parallel on one GPU)."""

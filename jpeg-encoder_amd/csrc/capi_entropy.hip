@@ -12,11 +12,12 @@ namespace jpegenc {
 struct LutSpecs { jpegenc_huffman_spec t[2][2]; };
 
 __global__ void k_build_lut(const LutSpecs specs, uint32_t *lut) {
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) lut[i] = 0;
+    __syncthreads();
     const int id = threadIdx.x;                       // 0..3 = [destination][class]
     if (id >= 4) return;
     const jpegenc_huffman_spec &s = specs.t[id >> 1][id & 1];
     uint32_t *out = lut + id * 256;
-    for (int i = 0; i < 256; i++) out[i] = 0;
     uint32_t code = 0;
     int k = 0;
     for (int len = 1; len <= 16; len++) {
@@ -120,7 +121,7 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
     p.out = (uint8_t *)d_out;
     p.out_stride = out_frame_stride;
     p.out_bytes = d_out_lengths;
-    hipLaunchKernelGGL(k_build_lut, dim3(1), dim3(64), 0, st, specs, (uint32_t *)(ws + pl.off_lut));
+    hipLaunchKernelGGL(k_build_lut, dim3(1), dim3(256), 0, st, specs, (uint32_t *)(ws + pl.off_lut));
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = launch_entropy_interleaved(p, frames, st);
     if (e != hipSuccess) return hip_fail(e, "entropy kernels");

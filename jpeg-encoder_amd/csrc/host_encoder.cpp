@@ -6,9 +6,12 @@
 // Entropy coding is inherently serial per scan; it is written for throughput (64-bit accumulator,
 // word-at-a-time 0xFF stuffing test like writer.rs:169-184, zero-run skipping through a
 // non-zero bitmask) and frames of a batch are coded by one host thread per in-flight frame.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <string>
 #include <thread>
@@ -253,6 +256,15 @@ struct DeviceCtx {
         JPEGENC_HIP(hipHostMalloc((void **)&h_scan_len, sizeof(uint32_t), hipHostMallocDefault));
         return JPEGENC_OK;
     }
+    int reserve_host_coeffs(size_t coeff_bytes) {      // only the host entropy path needs the coefficients
+        if (coeff_bytes > h_coeffs_cap) {
+            if (h_coeffs) (void)hipHostFree(h_coeffs);
+            h_coeffs = nullptr; h_coeffs_cap = 0;
+            JPEGENC_HIP(hipHostMalloc((void **)&h_coeffs, coeff_bytes, hipHostMallocDefault));
+            h_coeffs_cap = coeff_bytes;
+        }
+        return JPEGENC_OK;
+    }
     int reserve_scan(size_t ws_bytes, size_t out_bytes) {
         if (ws_bytes > d_scan_ws_cap) {
             if (d_scan_ws) (void)hipFree(d_scan_ws);
@@ -291,12 +303,6 @@ struct DeviceCtx {
             d_coeffs = nullptr; d_coeffs_cap = 0;
             JPEGENC_HIP(hipMalloc(&d_coeffs, coeff_bytes));
             d_coeffs_cap = coeff_bytes;
-        }
-        if (coeff_bytes > h_coeffs_cap) {
-            if (h_coeffs) (void)hipHostFree(h_coeffs);
-            h_coeffs = nullptr; h_coeffs_cap = 0;
-            JPEGENC_HIP(hipHostMalloc((void **)&h_coeffs, coeff_bytes, hipHostMallocDefault));
-            h_coeffs_cap = coeff_bytes;
         }
         if (pinned_pixels && pixel_bytes > h_pixels_cap) {
             if (h_pixels) (void)hipHostFree(h_pixels);
@@ -353,6 +359,7 @@ struct jpegenc_encoder {
     Config cfg;
     int device = 0;
     DeviceCtx ctx;
+    std::vector<std::unique_ptr<DeviceCtx>> workers;   // batch API: one per in-flight frame, kept across calls
 };
 
 namespace jpegenc {
@@ -539,6 +546,11 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         JPEGENC_HIP(hipMemcpyAsync(ctx.h_freq, ctx.d_freq, sizeof(uint32_t) * 2 * 2 * 257, hipMemcpyDeviceToHost, ctx.stream));
     }
     // ---- interleaved scan without restart markers: entropy-code on the device, fetch bytes only ---
+    static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    const auto t_begin = now();
     if (mode == MODE_INTERLEAVED && c.device_entropy && c.restart_interval == 0) {
         const size_t ws = scan_workspace_size(L, 1), cap = scan_max_bytes(L);
         if (ws && cap) {
@@ -555,8 +567,10 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, specs, 0, ctx.d_scan_out, cap, ctx.d_scan_len,
                              ctx.d_scan_ws, ws, ctx.stream);
             if (rc) return rc;
+            const auto t_launched = now();
             JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_len, ctx.d_scan_len, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
             JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            const auto t_len = now();
             const size_t nbytes = *ctx.h_scan_len;
             rc = ctx.reserve_scan_host(nbytes);
             if (rc) return rc;
@@ -568,9 +582,12 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             write_scan_header(o, L, 0, L.num_components, 0, 63);
             o.drain(true);                                           // headers go out while the copy runs
             JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            const auto t_copied = now();
             if (sink(user, ctx.h_scan_out, nbytes) != 0) o.failed = true;
             o.marker(0xD9);
             o.drain(true);
+            if (trace) fprintf(stderr, "[jpegenc] frame: launch %ld us, wait-len %ld us, d2h %ld us, sink %ld us, bytes %zu\n",
+                               us(t_begin, t_launched), us(t_launched, t_len), us(t_len, t_copied), us(t_copied, now()), nbytes);
             if (o.failed) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
             return JPEGENC_OK;
         }
@@ -578,6 +595,8 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
 
     // coefficient tiles come back in kChunks pieces so that entropy coding of tile k overlaps the
     // copy of tile k+1 (interleaved mode consumes them in order; the other modes need them all)
+    rc = ctx.reserve_host_coeffs(coeff_bytes);
+    if (rc) return rc;
     const uint32_t bpm = (uint32_t)(L.total_blocks / (L.mcus ? L.mcus : 1));
     uint64_t chunk_end_mcu[DeviceCtx::kChunks];
     int nchunks = 1;
@@ -658,7 +677,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
 }
 
 static int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *data, size_t len, int width,
-                         int height, int color_type, jpegenc_write_fn sink, void *user) {
+                         int height, int color_type, jpegenc_write_fn sink, void *user, bool staged = false) {
     int rc = validate_image(len, width, height, color_type);      // before any device work
     if (rc) return rc;
     if (!sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null sink");
@@ -666,7 +685,18 @@ static int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint
     if (rc) return rc;
     const size_t bytes = (size_t)width * (size_t)height * (size_t)jpegenc_bytes_per_pixel(color_type);
     auto upload = [&](DeviceCtx &cx) -> int {
-        JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
+        if (staged) {       // batch workers: copy into this worker's pinned buffer, then a true async DMA
+            if (bytes > cx.h_pixels_cap) {
+                if (cx.h_pixels) (void)hipHostFree(cx.h_pixels);
+                cx.h_pixels = nullptr; cx.h_pixels_cap = 0;
+                JPEGENC_HIP(hipHostMalloc((void **)&cx.h_pixels, bytes, hipHostMallocDefault));
+                cx.h_pixels_cap = bytes;
+            }
+            memcpy(cx.h_pixels, data, bytes);
+            JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, cx.h_pixels, bytes, hipMemcpyHostToDevice, cx.stream));
+        } else {
+            JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
+        }
         return JPEGENC_OK;
     };
     return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user);
@@ -893,12 +923,14 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     if (workers > num_frames) workers = num_frames;
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
+    while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
+    const bool staged = getenv("JPEGENC_BATCH_PAGEABLE_H2D") == nullptr;
     auto body = [&](int w) {
-        DeviceCtx ctx;
+        DeviceCtx &ctx = *e->workers[(size_t)w];
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= num_frames || status.load() != JPEGENC_OK) break;
-            int r = frames[i] ? encode_pixels(e->cfg, ctx, e->device, frames[i], frame_len, width, height, color_type, sink, users[i])
+            int r = frames[i] ? encode_pixels(e->cfg, ctx, e->device, frames[i], frame_len, width, height, color_type, sink, users[i], staged)
                               : fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
             if (r != JPEGENC_OK) {
                 int expected = JPEGENC_OK;
@@ -916,6 +948,27 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
         return status.load();
     }
     return JPEGENC_OK;
+}
+
+int jpegenc_encoder_encode_batch_to_buffers(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len,
+                                            int num_frames, int width, int height, int color_type,
+                                            uint8_t *const *outs, const size_t *capacities, size_t *lengths) {
+    REQUIRE(e);
+    if (num_frames < 0 || (num_frames && (!outs || !capacities || !lengths))) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
+    std::vector<BufferSink> sinks((size_t)num_frames);
+    std::vector<void *> users((size_t)num_frames);
+    for (int i = 0; i < num_frames; i++) {
+        sinks[(size_t)i] = BufferSink{outs[i], outs[i] ? capacities[i] : 0, 0};
+        users[(size_t)i] = &sinks[(size_t)i];
+    }
+    int rc = jpegenc_encoder_encode_batch(e, frames, frame_len, num_frames, width, height, color_type, buffer_sink, users.data());
+    bool fits = true;
+    for (int i = 0; i < num_frames; i++) {
+        lengths[i] = sinks[(size_t)i].len;
+        if (sinks[(size_t)i].len > sinks[(size_t)i].cap) fits = false;
+    }
+    if (rc) return rc;
+    return fits ? JPEGENC_OK : fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "at least one output buffer is too small");
 }
 
 }  // extern "C"

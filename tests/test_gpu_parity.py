@@ -484,3 +484,13 @@ def test_config2_4k_full_file(binding, oracle, synth):
         e = binding.Encoder(90)
         e.set_sampling_factor(binding.F_2_2)
         assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, 90, sampling=(2, 2))
+
+
+def test_encode_batch_to_buffers(binding, oracle, synth):
+    frames = [synth.lcg_image(320, 200, 3, 7 + k) for k in range(9)]
+    outs, _, lens = binding.Encoder(85).encode_batch_to_buffers(frames, 320, 200, binding.RGB, 1 << 20)
+    for f, o in zip(frames, outs):
+        assert o == oracle.encode_jpeg(f, 320, 200, oracle.RGB, 85)
+    with pytest.raises(binding.JpegEncError) as err:
+        binding.Encoder(85).encode_batch_to_buffers(frames, 320, 200, binding.RGB, 100)
+    assert err.value.status == binding.ERR_BUFFER_TOO_SMALL
