@@ -1,0 +1,225 @@
+// fast_kernel_impl.hip.h — tuned block-encode kernels for every built-in ColorType at sampling factors
+// 1 and 2 (the paths all five BASELINE configs take): the RGB family (Rgb / Rgba / Bgr / Bgra ->
+// YCbCr, and CmykAsYcck's C,M,Y -> YCC) and the "byte-plane" formats whose component is one byte of
+// the pixel, optionally inverted (Luma, Ycbcr, Ycck, Cmyk = 255 - v, the K of CmykAsYcck, and the
+// planar rows of a user ImageBuffer).
+//
+// Same decomposition as the generic kernel (wave_tasks.hip.h); what changes is how a lane gets its
+// 64 samples:
+//   * a block row is fetched with ONE or TWO wide vector loads per lane (24 / 32 / 48 / 64 bytes),
+//     straight from HBM into registers — adjacent lanes own adjacent blocks, so a wave's load covers
+//     a dense span of the image row; there is no LDS round trip and no barrier on the input side;
+//   * each pixel is isolated as one dword W = [c0 c1 c2 x] with v_alignbyte_b32 (3-byte pixels) or
+//     is already one (4-byte pixels);
+//   * Y  = (19595 r + 38470 g + 7471 b + 0x7FFF) >> 16 (image_buffer.rs:22-26) is evaluated with the
+//     8-bit dot product unit: coefficients split into high and low bytes,
+//         t = udot4(W, LO, 0x7FFF) >> 8;   Y = byte1(udot4(W, HI, t))
+//     which is exact because floor((256*HI + LO') / 65536) = floor((HI + floor(LO'/256)) / 256);
+//   * Cb / Cr (image_buffer.rs:23-28) use one v_dot2_i32_i16 on the zero-extended (r,g) or (g,b)
+//     pair with the 32768*b / 32768*r term and the rounding bias in the accumulator;
+//   * only the samples get_block would read (encoder.rs:1232-1237) are ever converted: for 4:2:0 a
+//     chroma lane converts 64 of the 256 pixels it covers;
+//   * results are packed by v_perm_b32 directly into the 16-bit pair order the FDCT consumes.
+// Channel order (RGB vs BGR) is data: byte-coefficient vectors, permute selectors and shift amounts
+// are wave-uniform scalars.  Blocks that touch the right image edge take a per-sample clamped path
+// (the reference's edge replication, encoder.rs:738-744); bottom-edge rows are clamped row indices.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fdct_quant.hip.h"
+#include "host_common.h"
+#include "wave_tasks.hip.h"
+
+namespace jpegenc {
+
+enum Role : int32_t { ROLE_Y = 0, ROLE_CB = 1, ROLE_CR = 2, ROLE_BYTE = 3 };
+
+struct ColourConsts {
+    uint32_t y_lo, y_hi;        // udot4 byte coefficients of Y, in memory byte order
+    uint32_t sel_cb, sel_cr;    // v_perm selectors building the zero-extended (r,g) / (g,b) u16 pair
+    uint32_t k_cb, k_cr;        // sdot2 constants (-11059,-21709) / (-27439,-5329)
+    uint32_t sh_b, sh_r;        // bit offset of the blue / red byte inside W
+    int32_t o_r, o_g, o_b;      // byte offsets (edge path)
+    int32_t role[4];            // what each component is made of
+    int32_t byte_index[4];      // ROLE_BYTE: which byte of the pixel
+    int32_t invert[4];          // ROLE_BYTE: sample = 255 - byte (CmykImage, image_buffer.rs:251-254)
+    uint64_t plane_offset[4];   // XF_PLANES: start of the component's plane inside the frame
+};
+
+constexpr int kBias = (128 << 16) + 0x7FFF;   // image_buffer.rs:23-28
+
+template <int N>
+struct __attribute__((packed, aligned(4))) Raw4 { uint32_t v[N]; };
+template <int N>
+struct __attribute__((packed, aligned(1))) Raw1 { uint32_t v[N]; };
+
+template <int N>
+__device__ __forceinline__ void load_row(const uint8_t *p, bool aligned4, uint32_t (&d)[N]) {
+    if (aligned4) {
+        const Raw4<N> r = *reinterpret_cast<const Raw4<N> *>(p);
+#pragma unroll
+        for (int i = 0; i < N; i++) d[i] = r.v[i];
+    } else {
+        const Raw1<N> r = *reinterpret_cast<const Raw1<N> *>(p);
+#pragma unroll
+        for (int i = 0; i < N; i++) d[i] = r.v[i];
+    }
+}
+
+// dword holding pixel `p` of a row of STRIDE-spaced pixels (bytes [c0 c1 c2 x]).
+template <int BPP, int STEP, int N>
+__device__ __forceinline__ uint32_t pixel_word(const uint32_t (&d)[N], int p) {
+    const int byte = p * STEP * BPP;
+    const int w = byte >> 2, s = byte & 3;
+    if (s == 0) return d[w];
+    if (w + 1 < N) return __builtin_amdgcn_alignbyte(d[w + 1], d[w], (uint32_t)s);
+    return d[w] >> (8 * s);                       // last pixel: its 3 bytes sit in the top of the last dword
+}
+
+__device__ __forceinline__ uint32_t luma16(uint32_t w, const ColourConsts &k) {
+    const uint32_t t = __builtin_amdgcn_udot4(w, k.y_lo, 0x7FFFu, false) >> 8;
+    return __builtin_amdgcn_udot4(w, k.y_hi, t, false);          // Y in bits 8..15
+}
+__device__ __forceinline__ uint32_t chroma32(uint32_t w, uint32_t sel, uint32_t kk, uint32_t sh) {
+    const uint32_t pair = __builtin_amdgcn_perm(0u, w, sel);
+    const int acc = (int)((((w >> sh) & 0xFFu) << 15) + (uint32_t)kBias);
+    return (uint32_t)dot2(pair, kk, acc);                        // Cb/Cr in bits 16..23
+}
+
+// scalar arithmetic for the clamped edge path (identical results by construction)
+__device__ __forceinline__ uint32_t edge_sample(const uint8_t *px, int role, int c, const ColourConsts &k) {
+    if (role == ROLE_BYTE) {
+        const uint32_t v = px[k.byte_index[c]];
+        return k.invert[c] ? 255u - v : v;
+    }
+    const int r = px[k.o_r], g = px[k.o_g], b = px[k.o_b];
+    if (role == ROLE_Y) return (uint32_t)((19595 * r + 38470 * g + 7471 * b + 0x7FFF) >> 16);
+    if (role == ROLE_CB) return (uint32_t)((-11059 * r - 21709 * g + 32768 * b + kBias) >> 16);
+    return (uint32_t)((32768 * r - 27439 * g - 5329 * b + kBias) >> 16);
+}
+
+
+// ---- fetching the 64 samples of a block ----------------------------------------------------------
+struct LumaConv {          // Y of an RGB-order pixel word
+    const ColourConsts &k;
+    static constexpr uint32_t kPack = 0x0C050C01u;            // byte 1 of each result
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return luma16(w, k); }
+};
+struct ChromaConv {        // Cb or Cr
+    uint32_t sel, kk, sh;
+    static constexpr uint32_t kPack = 0x0C060C02u;            // byte 2 of each result
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return chroma32(w, sel, kk, sh); }
+};
+
+// rows[y] = {(x0,x1),(x3,x2),(x7,x6),(x4,x5)}; `pack` selects the result byte of each converted word.
+template <int BPP, int STEPX, int STEPY, class Conv>
+__device__ __forceinline__ void fetch_rows(const uint8_t *frame, bool aligned4, uint32_t first, uint32_t last,
+                                           uint32_t pitch, uint32_t pack, const Conv &conv, uint32_t (&rows)[8][4]) {
+    constexpr int N = (BPP * 8 * STEPX + 3) / 4;
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+        uint32_t d[N], v[8];
+        // byte offset of row y = min(first + y*pitch, last): bottom-edge rows repeat row h-1
+        load_row<N>(frame + min(first + (uint32_t)(y * STEPY) * pitch, last), aligned4, d);
+#pragma unroll
+        for (int x = 0; x < 8; x++) v[x] = conv(pixel_word<BPP, STEPX, N>(d, x));
+        rows[y][0] = __builtin_amdgcn_perm(v[1], v[0], pack);
+        rows[y][1] = __builtin_amdgcn_perm(v[2], v[3], pack);
+        rows[y][2] = __builtin_amdgcn_perm(v[6], v[7], pack);
+        rows[y][3] = __builtin_amdgcn_perm(v[5], v[4], pack);
+    }
+}
+struct ByteConv {          // the sample is a byte of the pixel word itself
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w; }
+};
+
+// CONV = the kernel carries the RGB -> YCbCr roles (RGB family, CmykAsYcck); otherwise byte planes only.
+// 3-byte RGB has at most 6 waves per 64-MCU group; CmykAsYcck / 4-component layouts up to 10.
+template <int BPP, int SX, int SY, int VARIANT, bool CONV>
+__global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t per_group = p.order == 0 ? p.wave_start[p.ncomp] : 4u;
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wave;
+    const WaveTask t = decode_task(p, gw % per_group, gw / per_group);
+    const int c = t.comp;
+    const uint8_t *frame = p.pixels + (size_t)blockIdx.y * p.pixel_frame_stride + k.plane_offset[c];
+    uint4 *frame_out = reinterpret_cast<uint4 *>(p.coeffs) + (size_t)blockIdx.y * p.coeff_frame_stride * 8u;
+
+    const BlockRef me = locate(p, t, lane);
+    const int role = k.role[c];
+    const bool sub = p.sx[c] > 1 || p.sy[c] > 1;                    // this component is decimated by (SX, SY)
+    const int sxc = sub ? SX : 1, syc = sub ? SY : 1;
+    const int hlim = p.height - 1;
+    const uint32_t pitch = (uint32_t)p.width * BPP;                 // frame bytes < 2^31 (checked by the launcher)
+    const bool aligned4 = (((uintptr_t)frame | pitch) & 3u) == 0;   // wave-uniform
+    const uint32_t first = (uint32_t)me.y0 * pitch + (uint32_t)me.x0 * BPP;
+    const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * BPP;
+    uint32_t rows[8][4];
+
+    if (me.x0 + 8 * sxc <= p.width) {
+        if (CONV && role == ROLE_Y) {
+            fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, LumaConv::kPack, LumaConv{k}, rows);
+        } else if (CONV && role != ROLE_BYTE) {
+            const ChromaConv cc = {role == ROLE_CB ? k.sel_cb : k.sel_cr, role == ROLE_CB ? k.k_cb : k.k_cr,
+                                   role == ROLE_CB ? k.sh_b : k.sh_r};
+            fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, ChromaConv::kPack, cc, rows);
+        } else if (!CONV || BPP == 4) {
+            // byte b of each pixel word -> zero-extended 16-bit pair; `255 - v` as one packed subtract.
+            // In the conversion kernels only CmykAsYcck's K plane (4-byte pixels, never decimated) gets here.
+            const uint32_t b = (uint32_t)k.byte_index[c];
+            const uint32_t pack = 0x0C040C00u | b | (b << 16);
+            if (!CONV && sub && (SX > 1 || SY > 1)) fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
+            else fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
+            if (k.invert[c]) {
+#pragma unroll
+                for (int y = 0; y < 8; y++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) rows[y][i] = pk_sub(0x00FF00FFu, rows[y][i]);
+            }
+        }
+    } else {
+        // right-edge blocks: per-sample clamped reads = the reference's replicated last column
+        // (encoder.rs:738-744); one shared copy for all roles, taken by a handful of lanes
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+            const uint8_t *row = frame + (size_t)min(me.y0 + y * syc, hlim) * pitch;
+            uint32_t v[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) v[x] = edge_sample(row + (size_t)min(me.x0 + x * sxc, p.width - 1) * BPP, role, c, k);
+            rows[y][0] = v[0] | (v[1] << 16); rows[y][1] = v[3] | (v[2] << 16);
+            rows[y][2] = v[7] | (v[6] << 16); rows[y][3] = v[4] | (v[5] << 16);
+        }
+    }
+    uint32_t packed[32];
+    fdct_quant_block<VARIANT>(rows, quant_table(p.qsel[c]), packed);
+    stage_and_store(p, t, smem + wave * kStageBytes, lane, packed, frame_out);
+}
+
+template <int BPP, int SX, int SY, bool CONV>
+static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k, int num_frames, int variant,
+                              hipStream_t stream) {
+    dim3 grid, block;
+    size_t lds;
+    if (p.order == 0) {
+        const uint32_t waves = p.wave_start[p.ncomp];               // <= 10 for sampling factors 1 and 2
+        grid = dim3((p.total_mcus + 63u) / 64u, (unsigned)num_frames);
+        block = dim3(waves * 64u);
+        lds = (size_t)waves * kStageBytes;
+    } else {
+        grid = dim3((p.task_start[p.ncomp] + 3u) / 4u, (unsigned)num_frames);
+        block = dim3(256);
+        lds = 4 * kStageBytes;
+    }
+    if (variant == 1) hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 1, CONV>), grid, block, lds, stream, p, k);
+    else hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 0, CONV>), grid, block, lds, stream, p, k);
+    return hipGetLastError();
+}
+
+// fast_kernels_bytes.hip
+bool launch_bytes_family(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant,
+                         hipStream_t stream, hipError_t *err);
+
+}  // namespace jpegenc
