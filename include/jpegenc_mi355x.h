@@ -160,7 +160,7 @@ int jpegenc_blocks_host(int device, const uint8_t *pixels, size_t pixels_len, in
 int jpegenc_histogram_device(const void *d_coeffs_planar, const jpegenc_layout *layout,
                              int progressive_scans, void *d_freq, void *hip_stream);
 
-/* ---- entropy coding of a baseline interleaved scan on the device --------- */
+/* ---- entropy coding of a scan on the device ------------------------------ */
 /* One Huffman table as a DHT segment carries it (huffman.rs:66-70): counts per code length and
  * the symbol values in code order. */
 typedef struct jpegenc_huffman_spec {
@@ -169,21 +169,32 @@ typedef struct jpegenc_huffman_spec {
     int32_t num_values;
 } jpegenc_huffman_spec;
 
-/* Bytes of device scratch jpegenc_scan_device needs for `num_frames` frames of this MCU-order
- * layout; 0 if the geometry is not supported on the device (then code the scan on the host). */
-size_t jpegenc_scan_workspace_size(const jpegenc_layout *layout, int num_frames);
-/* Worst-case bytes of one frame's entropy-coded segment (use it as out_frame_stride). */
-size_t jpegenc_scan_max_bytes(const jpegenc_layout *layout);
+/* One scan = one entropy-coded segment. */
+typedef struct jpegenc_scan {
+    int32_t component;        /* -1: all components interleaved, layout must be ORDER_MCU
+                                 (encode_image_interleaved, encoder.rs:747-790);
+                                 >= 0: that component of an ORDER_PLANAR layout (encoder.rs:823-861, 885-972) */
+    int32_t with_dc;          /* code DC differences (baseline scans and progressive DC scans) */
+    int32_t ac_start, ac_end; /* zig-zag band [ac_start, ac_end): 1,64 for baseline; equal = no AC */
+    int32_t restart_interval; /* MCUs between RSTn markers, 0 = none (encoder.rs:345-347) */
+} jpegenc_scan;
 
-/* Replaces the write_block calls of encode_image_interleaved plus the closing
- * finalize_bit_buffer (encoder.rs:781-788, :804; writer.rs:138-202, 331-388) for scans without
- * restart markers: MCU-order coefficient blocks in HBM -> the scan's entropy-coded bytes (0xFF
- * stuffed, 1-padded) in HBM, byte-identical to the reference's.  tables[d][0] = DC, [d][1] = AC
- * of destination d; NULL selects the Annex K.3 defaults of Encoder::new (encoder.rs:240-249).
- * d_out receives each frame's segment at f * out_frame_stride, d_out_lengths[f] its length.
- * Asynchronous on hip_stream. */
-int jpegenc_scan_device(const void *d_coeffs_mcu, size_t coeff_frame_stride, int num_frames,
-                        const jpegenc_layout *layout, const jpegenc_huffman_spec (*tables)[2],
+/* Bytes of device scratch jpegenc_scan_device needs; 0 if the scan is not supported on the device
+ * (then code it on the host). */
+size_t jpegenc_scan_workspace_size(const jpegenc_layout *layout, const jpegenc_scan *scan, int num_frames);
+/* Worst-case bytes of one frame's segment (use it as out_frame_stride). */
+size_t jpegenc_scan_max_bytes(const jpegenc_layout *layout, const jpegenc_scan *scan);
+
+/* Replaces the write_block / write_dc / write_ac_block calls of a scan together with its RSTn
+ * bookkeeping and the closing finalize_bit_buffer (encoder.rs:747-804, 823-861, 885-972;
+ * writer.rs:138-202, 331-388): coefficient blocks in HBM -> the scan's entropy-coded bytes (0xFF
+ * stuffed, 1-padded, RSTn markers included) in HBM, byte-identical to the reference's.
+ * tables[d][0] = DC, [d][1] = AC of destination d; NULL selects the Annex K.3 defaults of
+ * Encoder::new (encoder.rs:240-249).  d_out receives each frame's segment at f * out_frame_stride,
+ * d_out_lengths[f] its length.  Asynchronous on hip_stream. */
+int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num_frames,
+                        const jpegenc_layout *layout, const jpegenc_scan *scan,
+                        const jpegenc_huffman_spec (*tables)[2],
                         void *d_out, size_t out_frame_stride, uint32_t *d_out_lengths,
                         void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
@@ -198,9 +209,8 @@ jpegenc_encoder *jpegenc_encoder_new(int quality);                       /* Enco
 void jpegenc_encoder_free(jpegenc_encoder *e);
 int  jpegenc_encoder_set_device(jpegenc_encoder *e, int device);         /* GPU this handle drives */
 int  jpegenc_encoder_set_fdct_variant(jpegenc_encoder *e, int variant);  /* default SCALAR */
-/* 1 (default): baseline interleaved scans without restart markers are entropy-coded on the GPU
- * and only compressed bytes cross PCIe; 0: coefficients come back and the host codes them.  The
- * emitted bytes are identical either way. */
+/* 1 (default): every scan is entropy-coded on the GPU and only compressed bytes cross PCIe;
+ * 0: coefficients come back and the host codes them.  The emitted bytes are identical either way. */
 int  jpegenc_encoder_set_device_entropy(jpegenc_encoder *e, int enable);
 
 int  jpegenc_encoder_set_density(jpegenc_encoder *e, int unit, uint16_t x, uint16_t y);   /* :280 */

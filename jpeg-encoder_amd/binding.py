@@ -65,6 +65,11 @@ class Layout(C.Structure):
                 ("blocks", C.c_uint64 * 4), ("total_blocks", C.c_uint64), ("mcus", C.c_uint64)]
 
 
+class Scan(C.Structure):
+    _fields_ = [("component", C.c_int32), ("with_dc", C.c_int32), ("ac_start", C.c_int32), ("ac_end", C.c_int32),
+                ("restart_interval", C.c_int32)]
+
+
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 FILL_ROW_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint16, C.POINTER(C.POINTER(C.c_uint8)))
 
@@ -111,11 +116,12 @@ def lib():
         l.jpegenc_encoder_free.argtypes = [C.c_void_p]
         l.jpegenc_encoder_free.restype = None
         l.jpegenc_scan_workspace_size.restype = C.c_size_t
-        l.jpegenc_scan_workspace_size.argtypes = [C.POINTER(Layout), C.c_int]
+        l.jpegenc_scan_workspace_size.argtypes = [C.POINTER(Layout), C.POINTER(Scan), C.c_int]
         l.jpegenc_scan_max_bytes.restype = C.c_size_t
-        l.jpegenc_scan_max_bytes.argtypes = [C.POINTER(Layout)]
-        l.jpegenc_scan_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Layout), C.c_void_p,
-                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        l.jpegenc_scan_max_bytes.argtypes = [C.POINTER(Layout), C.POINTER(Scan)]
+        l.jpegenc_scan_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Layout), C.POINTER(Scan),
+                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_void_p]
         for name in ("set_device", "set_device_entropy", "set_fdct_variant", "set_sampling_factor", "set_progressive",
                      "set_progressive_scans", "set_optimized_huffman_tables"):
             getattr(l, "jpegenc_encoder_" + name).argtypes = [C.c_void_p, C.c_int]
@@ -196,19 +202,24 @@ def blocks_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, c
                                       hs, vs, q, order, variant, d_coeffs_ptr, coeff_frame_stride, stream_ptr))
 
 
-def scan_device(d_coeffs_ptr, coeff_frame_stride, num_frames, L, d_out_ptr, out_frame_stride, d_lengths_ptr,
+def baseline_scan(component=-1, restart_interval=0):
+    return Scan(component, 1, 1, 64, restart_interval)
+
+
+def scan_device(d_coeffs_ptr, coeff_frame_stride, num_frames, L, scan, d_out_ptr, out_frame_stride, d_lengths_ptr,
                 d_workspace_ptr, workspace_bytes, stream_ptr=0, tables=None):
-    """Device entropy coding of an interleaved scan; tables=None -> Annex K.3 defaults."""
-    check(lib().jpegenc_scan_device(d_coeffs_ptr, coeff_frame_stride, num_frames, C.byref(L), tables, d_out_ptr,
-                                    out_frame_stride, d_lengths_ptr, d_workspace_ptr, workspace_bytes, stream_ptr))
+    """Device entropy coding of one scan; tables=None -> Annex K.3 defaults."""
+    check(lib().jpegenc_scan_device(d_coeffs_ptr, coeff_frame_stride, num_frames, C.byref(L), C.byref(scan), tables,
+                                    d_out_ptr, out_frame_stride, d_lengths_ptr, d_workspace_ptr, workspace_bytes,
+                                    stream_ptr))
 
 
-def scan_workspace_size(L, num_frames):
-    return lib().jpegenc_scan_workspace_size(C.byref(L), num_frames)
+def scan_workspace_size(L, scan, num_frames):
+    return lib().jpegenc_scan_workspace_size(C.byref(L), C.byref(scan), num_frames)
 
 
-def scan_max_bytes(L):
-    return lib().jpegenc_scan_max_bytes(C.byref(L))
+def scan_max_bytes(L, scan):
+    return lib().jpegenc_scan_max_bytes(C.byref(L), C.byref(scan))
 
 
 def histogram_device(d_coeffs_ptr, L, progressive_scans, d_freq_ptr, stream_ptr=0):

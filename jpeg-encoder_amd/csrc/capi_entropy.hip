@@ -27,35 +27,56 @@ __global__ void k_build_lut(const LutSpecs specs, uint32_t *lut) {
 }
 
 struct ScanPlan {
-    uint32_t nblocks, bpm, max_chunks, max_tiles;
+    uint32_t max_blocks, max_chunks, max_tiles;
     uint64_t raw_stride;
-    size_t off_lut, off_bits, off_bitoff, off_partials, off_scalars, off_raw, off_ffcount, off_ffprefix, total;
+    size_t off_lut, off_bits, off_bitoff, off_partials, off_scalars, off_intervals, off_raw, off_ffcount, off_ffprefix, total;
 };
 
-static bool plan_scan(const jpegenc_layout &L, int frames, ScanPlan *pl) {
-    if (L.mcus == 0 || L.total_blocks == 0 || frames <= 0) return false;
-    const uint64_t bpm = L.total_blocks / L.mcus;
-    if (bpm * L.mcus != L.total_blocks || bpm > 10) return false;            // MCU-order layouts only
-    if (L.total_blocks * 1728ull >= (1ull << 32)) return false;              // 32-bit bit offsets
-    pl->nblocks = (uint32_t)L.total_blocks;
-    pl->bpm = (uint32_t)bpm;
-    pl->raw_stride = ((uint64_t)pl->nblocks * 224 + 64 + 15) & ~15ull;      // <= 216 B of code per block
+// Worst-case code bytes of one block of a scan: DC <= 16 + 11 bits, each AC coefficient <= 16 + 11,
+// EOB <= 16, plus the interval's 16-byte alignment slack when every MCU is its own interval.
+static uint64_t block_bound(const jpegenc_scan &sc) {
+    const uint64_t bits = (sc.with_dc ? 27u : 0u) + (sc.ac_end > sc.ac_start ? (uint64_t)(sc.ac_end - sc.ac_start) * 27u + 16u : 0u);
+    return (bits + 7) / 8 + 1;
+}
+
+static uint64_t scan_blocks(const jpegenc_layout &L, const jpegenc_scan &sc) {
+    return sc.component < 0 ? L.total_blocks : L.blocks[sc.component];
+}
+
+static bool valid_scan(const jpegenc_layout &L, const jpegenc_scan &sc) {
+    if (sc.component >= L.num_components) return false;
+    if (sc.ac_start < 1 || sc.ac_end > 64 || sc.ac_end < sc.ac_start) return false;
+    if (sc.restart_interval < 0 || sc.restart_interval > 65535) return false;
+    if (sc.component < 0) {
+        if (L.mcus == 0 || L.total_blocks % L.mcus != 0 || L.total_blocks / L.mcus > 10) return false;
+        uint64_t bpm = 0;
+        for (int c = 0; c < L.num_components; c++) bpm += (uint64_t)(L.h[c] * L.v[c]);
+        if (bpm * L.mcus != L.total_blocks) return false;                      // not an MCU-order layout
+    }
+    const uint64_t n = scan_blocks(L, sc);
+    return n > 0 && n * block_bound(sc) * 8ull < (1ull << 32);                // 32-bit bit offsets
+}
+
+// Workspace for scans of up to `max_blocks` blocks with up to `bound` code bytes per block.
+static void plan_scan(uint64_t max_blocks, uint64_t bound, int frames, ScanPlan *pl) {
+    pl->max_blocks = (uint32_t)max_blocks;
+    pl->raw_stride = (max_blocks * (bound + 16) + 64 + 15) & ~15ull;
     pl->max_chunks = (uint32_t)(pl->raw_stride / 16);
-    const uint32_t big = pl->max_chunks > pl->nblocks ? pl->max_chunks : pl->nblocks;
+    const uint32_t big = pl->max_chunks > pl->max_blocks ? pl->max_chunks : pl->max_blocks;
     pl->max_tiles = (big + 4095) / 4096 + 1;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     const size_t F = (size_t)frames;
     pl->off_lut = take(4 * 256 * 4);
-    pl->off_bits = take(F * pl->nblocks * 4);
-    pl->off_bitoff = take(F * pl->nblocks * 4);
+    pl->off_bits = take(F * pl->max_blocks * 4);
+    pl->off_bitoff = take(F * pl->max_blocks * 4);
     pl->off_partials = take(F * pl->max_tiles * 4);
     pl->off_scalars = take(F * 4 * 4);
+    pl->off_intervals = take(F * (size_t)pl->max_blocks * 4 * 4);
     pl->off_raw = take(F * pl->raw_stride);
     pl->off_ffcount = take(F * (size_t)pl->max_chunks * 4);
     pl->off_ffprefix = take(F * (size_t)pl->max_chunks * 4);
     pl->total = o;
-    return true;
 }
 
 static void default_spec(jpegenc_huffman_spec *s, const uint8_t *bits, const uint8_t *vals, int n) {
@@ -65,14 +86,20 @@ static void default_spec(jpegenc_huffman_spec *s, const uint8_t *bits, const uin
     s->num_values = n;
 }
 
-int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
-                const jpegenc_huffman_spec (*tables)[2], uint32_t restart_interval, void *d_out,
-                size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st) {
+size_t scan_workspace_size(const jpegenc_layout &L, const jpegenc_scan &sc, int frames) {
+    if (!valid_scan(L, sc) || frames <= 0) return 0;
     ScanPlan pl;
-    if (!plan_scan(L, frames, &pl)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan geometry not supported on the device");
-    if (ws_bytes < pl.total) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "scan workspace too small");
-    if (out_frame_stride < 2 * pl.raw_stride) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "out_frame_stride < jpegenc_scan_max_bytes");
-    if (coeff_frame_stride < L.total_blocks) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "coeff_frame_stride < total_blocks");
+    plan_scan(scan_blocks(L, sc), block_bound(sc), frames, &pl);
+    return pl.total;
+}
+size_t scan_max_bytes(const jpegenc_layout &L, const jpegenc_scan &sc) {
+    if (!valid_scan(L, sc)) return 0;
+    ScanPlan pl;
+    plan_scan(scan_blocks(L, sc), block_bound(sc), 1, &pl);
+    return (size_t)(2 * pl.raw_stride);                     // every byte stuffed + markers
+}
+
+int upload_huffman_luts(const jpegenc_huffman_spec (*tables)[2], void *d_lut, hipStream_t st) {
     LutSpecs specs;
     if (tables) {
         for (int d = 0; d < 2; d++)
@@ -86,24 +113,55 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
         default_spec(&specs.t[1][0], k_k3_chroma_dc_bits, k_k3_chroma_dc_vals, 12);
         default_spec(&specs.t[1][1], k_k3_chroma_ac_bits, k_k3_chroma_ac_vals, 162);
     }
+    hipLaunchKernelGGL(k_build_lut, dim3(1), dim3(256), 0, st, specs, (uint32_t *)d_lut);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_build_lut");
+    return JPEGENC_OK;
+}
+
+// d_lut == nullptr: build the tables into the workspace first.
+int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
+                const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
+                size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st) {
+    if (!valid_scan(L, sc)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan not supported on the device");
+    if (frames <= 0) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "num_frames must be positive");
+    const uint64_t nblocks = scan_blocks(L, sc);
+    // the workspace may have been sized for a larger scan of the same frame: lay it out for what fits
+    ScanPlan need;
+    plan_scan(nblocks, block_bound(sc), frames, &need);
+    if (ws_bytes < need.total) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "scan workspace too small");
+    if (out_frame_stride < 2 * need.raw_stride) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "out_frame_stride < jpegenc_scan_max_bytes");
+    if (coeff_frame_stride < L.total_blocks) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "coeff_frame_stride < total_blocks");
+    const ScanPlan &pl = need;
     uint8_t *ws = (uint8_t *)d_ws;
     EntropyParams p;
     memset(&p, 0, sizeof p);
-    p.coeffs = (const int16_t *)d_coeffs;
-    p.coeff_frame_stride = coeff_frame_stride;
-    p.nblocks = pl.nblocks;
-    p.bpm = pl.bpm;
-    p.restart_interval = restart_interval;
-    uint32_t pos = 0;
-    for (int c = 0; c < L.num_components; c++) {
-        const uint32_t hv = (uint32_t)(L.h[c] * L.v[c]);
-        for (uint32_t k = 0; k < hv; k++, pos++) {
-            p.pos_table[pos] = (uint32_t)L.table[c];
-            p.pos_prev_delta[pos] = k > 0 ? 1u : 0u;
-            p.pos_last_of_comp[pos] = pos - k + hv - 1;
+    uint64_t first_block = 0;
+    if (sc.component < 0) {
+        p.bpm = (uint32_t)(L.total_blocks / L.mcus);
+        uint32_t pos = 0;
+        for (int c = 0; c < L.num_components; c++) {
+            const uint32_t hv = (uint32_t)(L.h[c] * L.v[c]);
+            for (uint32_t k = 0; k < hv; k++, pos++) {
+                p.pos_table[pos] = (uint32_t)L.table[c];
+                p.pos_prev_delta[pos] = k > 0 ? 1u : 0u;
+                p.pos_last_of_comp[pos] = pos - k + hv - 1;
+            }
         }
+    } else {
+        p.bpm = 1;
+        p.pos_table[0] = (uint32_t)L.table[sc.component];
+        for (int c = 0; c < sc.component; c++) first_block += L.blocks[c];
     }
-    p.lut = (const uint32_t *)(ws + pl.off_lut);
+    p.coeffs = (const int16_t *)d_coeffs + first_block * 64;
+    p.coeff_frame_stride = coeff_frame_stride;
+    p.nblocks = (uint32_t)nblocks;
+    p.with_dc = sc.with_dc ? 1u : 0u;
+    p.ac_start = (uint32_t)sc.ac_start;
+    p.ac_end = (uint32_t)sc.ac_end;
+    p.interval_blocks = sc.restart_interval ? (uint32_t)sc.restart_interval * p.bpm : p.nblocks;
+    if (p.interval_blocks > p.nblocks) p.interval_blocks = p.nblocks;
+    p.nintervals = (p.nblocks + p.interval_blocks - 1) / p.interval_blocks;
     p.bits = (uint32_t *)(ws + pl.off_bits);
     p.bitoff = (uint32_t *)(ws + pl.off_bitoff);
     p.partials = (uint32_t *)(ws + pl.off_partials);
@@ -113,6 +171,9 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
     p.raw_bytes = scalars + frames;
     p.raw_chunks = scalars + 2 * frames;
     p.total_ff = scalars + 3 * frames;
+    uint32_t *iv = (uint32_t *)(ws + pl.off_intervals);
+    const size_t ivn = (size_t)frames * p.nintervals;
+    p.ilen = iv; p.ichunks = iv + ivn; p.iexact = iv + 2 * ivn; p.ichunk = iv + 3 * ivn;
     p.raw = ws + pl.off_raw;
     p.raw_stride = pl.raw_stride;
     p.max_chunks = pl.max_chunks;
@@ -121,20 +182,17 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
     p.out = (uint8_t *)d_out;
     p.out_stride = out_frame_stride;
     p.out_bytes = d_out_lengths;
-    hipLaunchKernelGGL(k_build_lut, dim3(1), dim3(256), 0, st, specs, (uint32_t *)(ws + pl.off_lut));
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = launch_entropy_interleaved(p, frames, st);
+    if (d_lut) {
+        p.lut = (const uint32_t *)d_lut;
+    } else {
+        int rc = upload_huffman_luts(tables, ws + pl.off_lut, st);
+        if (rc) return rc;
+        p.lut = (const uint32_t *)(ws + pl.off_lut);
+    }
+    hipError_t e = hipMemsetAsync(d_out_lengths, 0, sizeof(uint32_t) * (size_t)frames, st);   // empty scans stay 0
+    if (e == hipSuccess) e = launch_entropy_scan(p, frames, st);
     if (e != hipSuccess) return hip_fail(e, "entropy kernels");
     return JPEGENC_OK;
-}
-
-size_t scan_workspace_size(const jpegenc_layout &L, int frames) {
-    ScanPlan pl;
-    return plan_scan(L, frames, &pl) ? pl.total : 0;
-}
-size_t scan_max_bytes(const jpegenc_layout &L) {
-    ScanPlan pl;
-    return plan_scan(L, 1, &pl) ? (size_t)(2 * pl.raw_stride) : 0;
 }
 
 }  // namespace jpegenc
@@ -143,17 +201,20 @@ using namespace jpegenc;
 
 extern "C" {
 
-size_t jpegenc_scan_workspace_size(const jpegenc_layout *layout, int num_frames) {
-    return layout ? scan_workspace_size(*layout, num_frames) : 0;
+size_t jpegenc_scan_workspace_size(const jpegenc_layout *layout, const jpegenc_scan *scan, int num_frames) {
+    return layout && scan ? scan_workspace_size(*layout, *scan, num_frames) : 0;
 }
 
-size_t jpegenc_scan_max_bytes(const jpegenc_layout *layout) { return layout ? scan_max_bytes(*layout) : 0; }
+size_t jpegenc_scan_max_bytes(const jpegenc_layout *layout, const jpegenc_scan *scan) {
+    return layout && scan ? scan_max_bytes(*layout, *scan) : 0;
+}
 
-int jpegenc_scan_device(const void *d_coeffs_mcu, size_t coeff_frame_stride, int num_frames, const jpegenc_layout *layout,
-                        const jpegenc_huffman_spec (*tables)[2], void *d_out, size_t out_frame_stride,
-                        uint32_t *d_out_lengths, void *d_workspace, size_t workspace_bytes, void *hip_stream) {
-    if (!d_coeffs_mcu || !layout || !d_out || !d_out_lengths || !d_workspace) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
-    return scan_device(d_coeffs_mcu, coeff_frame_stride, num_frames, *layout, tables, 0, d_out, out_frame_stride,
+int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num_frames, const jpegenc_layout *layout,
+                        const jpegenc_scan *scan, const jpegenc_huffman_spec (*tables)[2], void *d_out,
+                        size_t out_frame_stride, uint32_t *d_out_lengths, void *d_workspace, size_t workspace_bytes,
+                        void *hip_stream) {
+    if (!d_coeffs || !layout || !scan || !d_out || !d_out_lengths || !d_workspace) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    return scan_device(d_coeffs, coeff_frame_stride, num_frames, *layout, *scan, tables, nullptr, d_out, out_frame_stride,
                        d_out_lengths, d_workspace, workspace_bytes, (hipStream_t)hip_stream);
 }
 

@@ -1,18 +1,22 @@
-// entropy_kernels.hip — baseline Huffman entropy coding of an interleaved scan ON THE DEVICE
-// (SURVEY.md §8f rank 1).  Produces, byte for byte, what JfifWriter::write_block + write_bits +
-// finalize_bit_buffer emit for the scan (writer.rs:138-202, 331-388), so the host only has to add
-// headers and EOI and only compressed bytes cross PCIe.
+// entropy_kernels.hip — Huffman entropy coding of one scan ON THE DEVICE.
+// Produces, byte for byte, what JfifWriter::write_block / write_dc / write_ac_block + write_bits +
+// finalize_bit_buffer + the RSTn bookkeeping emit for the scan (writer.rs:138-202, 331-388;
+// encoder.rs:747-801, 823-861, 885-972), so the host only adds headers and only compressed bytes
+// cross PCIe.  Covers interleaved baseline scans and the per-component scans of sequential and
+// progressive (spectral selection) mode, with or without restart intervals, any Huffman tables.
 //
-// Variable-length coding is serial in the reference; here it is five data-parallel steps:
-//   1. k_block_bits   one lane per block: exact bit length of the block's code
-//                     (DC category + Huffman codes of every (run,size) symbol, ZRLs, EOB)
-//   2. scan           exclusive prefix sum -> bit offset of every block (3 small kernels)
-//   3. k_block_pack   one lane per block re-walks its coefficients and writes its bits at that
-//                     offset (64-bit accumulator, whole 32-bit words stored plainly, the two
-//                     boundary words OR-ed atomically into the zeroed buffer); the last block adds
-//                     the 1-padding of finalize_bit_buffer
-//   4. k_count_ff + scan   0xFF bytes per 16-byte chunk and their prefix sum
-//   5. k_stuff        scatter with 0xFF -> 0xFF 0x00 stuffing
+// Variable-length coding is serial in the reference; here it is data-parallel steps:
+//   1. k_block_bits     one lane per block: exact bit length of the block's code
+//                       (DC category + Huffman codes of every (run,size) symbol, ZRLs, EOB)
+//   2. scan             exclusive prefix sum -> bit offset of every block (3 small kernels)
+//   3. k_interval_len   bytes of every restart interval (1-padded to a byte); two more scans give
+//                       each interval a 16-byte aligned place in the raw buffer and its exact offset
+//   4. k_block_pack     one lane per block re-walks its coefficients and writes its bits at its
+//                       offset (64-bit accumulator, whole 32-bit words stored plainly, the boundary
+//                       words OR-ed atomically into the zeroed buffer); the last block of an interval
+//                       adds the 1-padding of finalize_bit_buffer
+//   5. k_count_ff+scan  0xFF bytes per 16-byte chunk and their prefix sum
+//   6. k_stuff          scatter with 0xFF -> 0xFF 0x00 stuffing, RSTn markers between intervals
 // DC prediction needs no scan: the predecessor of a block is a fixed earlier block of the same
 // component in MCU order, read straight from the coefficient array.
 #include <hip/hip_runtime.h>
@@ -153,18 +157,17 @@ __device__ __forceinline__ uint32_t walk_block(const EntropyParams &p, const uin
         const uint4 u = src[i];
         c[4 * i] = u.x; c[4 * i + 1] = u.y; c[4 * i + 2] = u.z; c[4 * i + 3] = u.w;
     }
-    // DC: predecessor = previous block of the same component (write_dc, writer.rs:342-354;
-    // predictors reset at the start of the scan and at restart boundaries, encoder.rs:748-757)
-    int prev = 0;
-    const int delta = p.pos_prev_delta[pos];              // blocks back inside the MCU, or 0
-    if (delta) {
-        prev = frame_coeffs[(size_t)(b - delta) * 64];
-    } else {
-        const bool restart_here = p.restart_interval && (mcu % p.restart_interval) == 0;
-        if (mcu > 0 && !restart_here) prev = frame_coeffs[((size_t)(mcu - 1) * p.bpm + p.pos_last_of_comp[pos]) * 64];
-    }
     uint32_t total = 0;
-    {
+    if (p.with_dc) {
+        // DC: predecessor = previous block of the same component (write_dc, writer.rs:342-354;
+        // predictors reset at the start of the scan and at restart boundaries, encoder.rs:748-757)
+        int prev = 0;
+        if (p.pos_prev_delta[pos]) {
+            prev = frame_coeffs[(size_t)(b - 1) * 64];
+        } else {
+            const bool interval_start = (b - pos) % p.interval_blocks == 0;
+            if (!interval_start) prev = frame_coeffs[((size_t)(mcu - 1) * p.bpm + p.pos_last_of_comp[pos]) * 64];
+        }
         const int dc = (int16_t)(c[0] & 0xFFFFu);
         const int diff = (int16_t)(dc - prev);
         const uint32_t n = bit_size(diff);
@@ -172,12 +175,14 @@ __device__ __forceinline__ uint32_t walk_block(const EntropyParams &p, const uin
         const uint32_t mag = (uint32_t)(diff - (diff < 0)) & ((1u << n) - 1u);
         put_bits<EMIT>(s, total, ((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
     }
-    // AC: write_ac_block (writer.rs:356-388)
+    // AC: write_ac_block(block, start, end) (writer.rs:356-388)
+    if (p.ac_end <= p.ac_start) return total;
     uint32_t run = 0;
     const uint32_t zrl = ac_lut[0xF0];
 #pragma unroll
     for (int k = 1; k < 64; k++) {
         const int v = (k & 1) ? (int)c[k >> 1] >> 16 : (int)(int16_t)(c[k >> 1] & 0xFFFFu);
+        if ((uint32_t)k < p.ac_start || (uint32_t)k >= p.ac_end) continue;
         if (v != 0) {
             while (run > 15) { put_bits<EMIT>(s, total, zrl & 0xFFFFu, zrl >> 16); run -= 16; }
             const uint32_t n = bit_size(v);
@@ -214,13 +219,17 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     if (b >= p.nblocks) return;
     const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
-    const uint32_t off = p.bitoff[(size_t)f * p.nblocks + b];
-    uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
-    BitSink s = {stream + (off >> 5), 0, off & 31u, true};
-    walk_block<true>(p, lut, frame, b, s);
-    if (b == p.nblocks - 1) {
+    const uint32_t *G = p.bitoff + (size_t)f * p.nblocks;
+    const uint32_t iv = b / p.interval_blocks, iv_first = iv * p.interval_blocks;
+    const uint32_t in_iv = G[b] - G[iv_first];                                   // bits before b in its interval
+    uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride) +
+                       (size_t)p.ichunk[(size_t)f * p.nintervals + iv] * 4;      // interval base, 16-byte aligned
+    BitSink s = {stream + (in_iv >> 5), 0, in_iv & 31u, true};
+    const uint32_t mine = walk_block<true>(p, lut, frame, b, s);
+    const uint32_t iv_last = min(iv_first + p.interval_blocks, p.nblocks) - 1;
+    if (b == iv_last) {
         // finalize_bit_buffer (writer.rs:138-154): seven 1-bits, then only whole bytes are kept
-        const uint32_t total = p.total_bits[f], pad = (8u - (total & 7u)) & 7u;
+        const uint32_t total = in_iv + mine, pad = (8u - (total & 7u)) & 7u;
         if (pad) {
             s.acc = (s.acc << pad) | ((1u << pad) - 1u);
             s.nacc += pad;
@@ -230,10 +239,20 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
                 s.first = false; s.words++; s.nacc -= 32;
             }
         }
-        p.raw_bytes[f] = (total + pad) >> 3;
-        p.raw_chunks[f] = (((total + pad) >> 3) + 15u) >> 4;
     }
     if (s.nacc) atomicOr(s.words, __builtin_bswap32((uint32_t)(s.acc << (32 - s.nacc))));
+}
+
+// bytes of every restart interval after 1-padding (finalize_bit_buffer keeps whole bytes only)
+__global__ void __launch_bounds__(256) k_interval_len(const EntropyParams p) {
+    const uint32_t f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.nintervals) return;
+    const uint32_t *G = p.bitoff + (size_t)f * p.nblocks;
+    const uint32_t first = i * p.interval_blocks, end = min(first + p.interval_blocks, p.nblocks);
+    const uint32_t bits = (end == p.nblocks ? p.total_bits[f] : G[end]) - G[first];
+    const uint32_t bytes = (bits + 7u) >> 3;
+    p.ilen[(size_t)f * p.nintervals + i] = bytes;
+    p.ichunks[(size_t)f * p.nintervals + i] = (bytes + 15u) >> 4;
 }
 
 // ---- byte stuffing --------------------------------------------------------------------------------
@@ -254,13 +273,23 @@ __global__ void __launch_bounds__(256) k_count_ff(const EntropyParams p) {
 
 __global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
     const uint32_t f = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nbytes = p.raw_bytes[f];
     if (q >= p.raw_chunks[f]) return;
+    // interval of this chunk: the last i with ichunk[i] <= q among intervals that own chunks
+    const uint32_t *ichunk = p.ichunk + (size_t)f * p.nintervals;
+    uint32_t lo = 0, hi = p.nintervals;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ichunk[mid] <= q) lo = mid; else hi = mid;
+    }
+    const uint32_t iv = lo, j = q - ichunk[iv];
+    const uint32_t ilen = p.ilen[(size_t)f * p.nintervals + iv], nchunks = p.ichunks[(size_t)f * p.nintervals + iv];
     const uint8_t *src = p.raw + (size_t)f * p.raw_stride + (size_t)q * 16;
-    uint8_t *dst = p.out + (size_t)f * p.out_stride + (size_t)q * 16 + p.ffprefix[(size_t)f * p.max_chunks + q];
+    // raw bytes of earlier intervals + this interval's earlier bytes + stuffed zeros + 2-byte markers so far
+    uint8_t *dst = p.out + (size_t)f * p.out_stride + p.iexact[(size_t)f * p.nintervals + iv] + (size_t)j * 16 +
+                   p.ffprefix[(size_t)f * p.max_chunks + q] + 2u * iv;
     const uint4 v = *reinterpret_cast<const uint4 *>(src);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    const uint32_t valid = nbytes - q * 16 < 16 ? nbytes - q * 16 : 16;
+    const uint32_t valid = ilen - j * 16 < 16 ? ilen - j * 16 : 16;
     uint32_t o = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -270,7 +299,14 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
             if (byte == 0xFF) dst[o++] = 0;              // flush_byte_from_bit_buffer, writer.rs:157-167
         }
     }
-    if (q + 1 == p.raw_chunks[f]) p.out_bytes[f] = q * 16 + p.ffprefix[(size_t)f * p.max_chunks + q] + o;
+    if (j + 1 == nchunks) {
+        if (iv + 1 < p.nintervals) {          // RSTn between intervals (encoder.rs:748-752): n = interval index mod 8
+            dst[o++] = 0xFF;
+            dst[o++] = (uint8_t)(0xD0 + (iv & 7u));
+        } else {
+            p.out_bytes[f] = (uint32_t)(dst + o - (p.out + (size_t)f * p.out_stride));
+        }
+    }
 }
 
 // ---- launcher ----------------------------------------------------------------------------------------
@@ -285,12 +321,17 @@ static hipError_t scan(const uint32_t *in, uint64_t in_stride, uint32_t *out, ui
     return hipGetLastError();
 }
 
-hipError_t launch_entropy_interleaved(const EntropyParams &p, int frames, hipStream_t st) {
+hipError_t launch_entropy_scan(const EntropyParams &p, int frames, hipStream_t st) {
     hipError_t e = hipMemsetAsync(p.raw, 0, (size_t)frames * p.raw_stride, st);
     if (e != hipSuccess) return e;
     const uint32_t bgrid = (p.nblocks + 255u) / 256u;
     hipLaunchKernelGGL(k_block_bits, dim3(bgrid, frames), dim3(256), 0, st, p);
     e = scan(p.bits, p.nblocks, p.bitoff, p.nblocks, p.partials, p.max_tiles, p.total_bits, nullptr, p.nblocks, frames, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_interval_len, dim3((p.nintervals + 255u) / 256u, frames), dim3(256), 0, st, p);
+    e = scan(p.ilen, p.nintervals, p.iexact, p.nintervals, p.partials, p.max_tiles, p.raw_bytes, nullptr, p.nintervals, frames, st);
+    if (e != hipSuccess) return e;
+    e = scan(p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, p.nintervals, frames, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_block_pack, dim3(bgrid, frames), dim3(256), 0, st, p);
     const uint32_t cgrid = (p.max_chunks + 255u) / 256u;

@@ -4,33 +4,42 @@
 
 namespace jpegenc {
 
+// One scan = one entropy-coded segment: either all components interleaved (blocks in MCU order,
+// encode_image_interleaved, encoder.rs:747-790) or one component's blocks in planar order
+// (sequential / progressive scans, encoder.rs:823-861, 885-972).
 struct EntropyParams {
-    // scan geometry: blocks of a frame in MCU order (encode_image_interleaved, encoder.rs:747-790)
-    const int16_t *coeffs;
+    const int16_t *coeffs;           // frame 0, first block of the scan
     uint64_t coeff_frame_stride;     // blocks between frames
     uint32_t nblocks;                // blocks per frame in the scan
-    uint32_t bpm;                    // blocks per MCU
-    uint32_t restart_interval;       // MCUs (0 = none); intervals themselves are coded by the host path
+    uint32_t bpm;                    // blocks per MCU of this scan (1 for a single-component scan)
+    uint32_t with_dc;                // code DC differences (baseline / DC scan)
+    uint32_t ac_start, ac_end;       // zig-zag band [ac_start, ac_end), ac_start >= 1; empty = no AC
+    uint32_t interval_blocks;        // restart interval in blocks (R * bpm), = nblocks when there is none
+    uint32_t nintervals;
     uint32_t pos_table[10];          // Huffman table destination of each block position in the MCU
     uint32_t pos_prev_delta[10];     // 1 when the previous block of the MCU has the same component
     uint32_t pos_last_of_comp[10];   // position of the component's last block inside an MCU
     // Huffman code tables: [destination][0 = DC, 1 = AC][symbol] = size << 16 | code
     const uint32_t *lut;
     // workspace (device), per frame
-    uint32_t *bits;                  // [frames][nblocks]   code length of each block
-    uint32_t *bitoff;                // [frames][nblocks]   exclusive prefix sum
-    uint32_t *partials;              // [frames][max_tiles] scan scratch
+    uint32_t *bits;                  // [frames][nblocks]      code length of each block
+    uint32_t *bitoff;                // [frames][nblocks]      exclusive prefix sum over the scan
+    uint32_t *partials;              // [frames][max_tiles]    scan scratch
     uint32_t max_tiles;
     uint32_t *total_bits;            // [frames]
-    uint8_t *raw;                    // [frames][raw_stride] unstuffed bit stream (zeroed per call)
+    uint32_t *ilen;                  // [frames][nintervals]   bytes of each interval (1-padded, unstuffed)
+    uint32_t *ichunks;               // [frames][nintervals]   ceil(ilen / 16)
+    uint32_t *iexact;                // [frames][nintervals]   exclusive prefix of ilen
+    uint32_t *ichunk;                // [frames][nintervals]   exclusive prefix of ichunks
+    uint32_t *raw_bytes;             // [frames] sum of ilen
+    uint32_t *raw_chunks;            // [frames] sum of ichunks
+    uint8_t *raw;                    // [frames][raw_stride]   unstuffed bits, every interval 16-byte aligned
     uint64_t raw_stride;             // bytes, multiple of 16
     uint32_t max_chunks;             // raw_stride / 16
-    uint32_t *raw_bytes;             // [frames] bytes of unstuffed stream (after 1-padding)
-    uint32_t *raw_chunks;            // [frames] ceil(raw_bytes / 16)
     uint32_t *ffcount;               // [frames][max_chunks]
     uint32_t *ffprefix;              // [frames][max_chunks]
     uint32_t *total_ff;              // [frames]
-    uint8_t *out;                    // [frames][out_stride] stuffed entropy-coded segment
+    uint8_t *out;                    // [frames][out_stride]   stuffed segment incl. RSTn markers
     uint64_t out_stride;
     uint32_t *out_bytes;             // [frames] its length
 };

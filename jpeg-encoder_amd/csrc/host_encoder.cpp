@@ -236,7 +236,9 @@ struct DeviceCtx {
     // device entropy coding (interleaved scans): scratch, coded segment, its length
     void *d_scan_ws = nullptr, *d_scan_out = nullptr;
     size_t d_scan_ws_cap = 0, d_scan_out_cap = 0;
-    uint32_t *d_scan_len = nullptr, *h_scan_len = nullptr;
+    uint32_t *d_scan_len = nullptr, *h_scan_len = nullptr;     // kMaxScans entries
+    void *d_lut = nullptr;
+    static constexpr int kMaxScans = 4 * 64;
     uint8_t *h_scan_out = nullptr;
     size_t h_scan_out_cap = 0;
     static constexpr int kChunks = 8;
@@ -252,8 +254,9 @@ struct DeviceCtx {
         for (auto &e : chunk_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         JPEGENC_HIP(hipMalloc(&d_freq, sizeof(uint32_t) * 2 * 2 * 257));
         JPEGENC_HIP(hipHostMalloc((void **)&h_freq, sizeof(uint32_t) * 2 * 2 * 257, hipHostMallocDefault));
-        JPEGENC_HIP(hipMalloc((void **)&d_scan_len, sizeof(uint32_t)));
-        JPEGENC_HIP(hipHostMalloc((void **)&h_scan_len, sizeof(uint32_t), hipHostMallocDefault));
+        JPEGENC_HIP(hipMalloc((void **)&d_scan_len, sizeof(uint32_t) * kMaxScans));
+        JPEGENC_HIP(hipHostMalloc((void **)&h_scan_len, sizeof(uint32_t) * kMaxScans, hipHostMallocDefault));
+        JPEGENC_HIP(hipMalloc(&d_lut, 4 * 256 * sizeof(uint32_t)));
         return JPEGENC_OK;
     }
     int reserve_host_coeffs(size_t coeff_bytes) {      // only the host entropy path needs the coefficients
@@ -326,6 +329,7 @@ struct DeviceCtx {
         if (d_scan_ws) (void)hipFree(d_scan_ws);
         if (d_scan_out) (void)hipFree(d_scan_out);
         if (d_scan_len) (void)hipFree(d_scan_len);
+        if (d_lut) (void)hipFree(d_lut);
         if (h_scan_len) (void)hipHostFree(h_scan_len);
         if (h_scan_out) (void)hipHostFree(h_scan_out);
         *this = DeviceCtx();
@@ -545,17 +549,54 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         if (rc) return rc;
         JPEGENC_HIP(hipMemcpyAsync(ctx.h_freq, ctx.d_freq, sizeof(uint32_t) * 2 * 2 * 257, hipMemcpyDeviceToHost, ctx.stream));
     }
-    // ---- interleaved scan without restart markers: entropy-code on the device, fetch bytes only ---
+    // ---- entropy-code every scan on the device and fetch only the compressed bytes ----------------
     static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
     const auto t_begin = now();
-    if (mode == MODE_INTERLEAVED && c.device_entropy && c.restart_interval == 0) {
-        const size_t ws = scan_workspace_size(L, 1), cap = scan_max_bytes(L);
-        if (ws && cap) {
-            rc = ctx.reserve_scan(ws, cap);
+    if (c.device_entropy) {
+        struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap; };
+        std::vector<Job> jobs;
+        auto add = [&](int comp, int with_dc, int s0, int s1, int first, int n, int ss, int se) {
+            Job j;
+            j.sc = jpegenc_scan{comp, with_dc, s0, s1, c.restart_interval};
+            j.first = first; j.n = n; j.ss = ss; j.se = se; j.off = 0; j.cap = 0;
+            jobs.push_back(j);
+        };
+        if (mode == MODE_INTERLEAVED) {
+            add(-1, 1, 1, 64, 0, L.num_components, 0, 63);
+        } else if (mode == MODE_SEQUENTIAL) {                               // encoder.rs:823-861
+            for (int i = 0; i < L.num_components; i++) add(i, 1, 1, 64, i, 1, 0, 63);
+        } else {                                                            // encoder.rs:885-972
+            for (int i = 0; i < L.num_components; i++) add(i, 1, 1, 1, i, 1, 0, 0);
+            const int scans = c.progressive_scans - 1, per = 64 / scans;
+            for (int sidx = 0; sidx < scans; sidx++) {
+                const int start = sidx * per < 1 ? 1 : sidx * per;
+                const int end = sidx == scans - 1 ? 64 : (sidx + 1) * per;
+                for (int i = 0; i < L.num_components; i++) add(i, 0, start, end, i, 1, start, end - 1);
+            }
+        }
+        bool supported = (int)jobs.size() <= DeviceCtx::kMaxScans;
+        size_t ws = 0, out_total = 0;
+        for (auto &j : jobs) {
+            if (!j.sc.with_dc && j.sc.ac_end == j.sc.ac_start) continue;       // empty band: nothing to code
+            j.cap = scan_max_bytes(L, j.sc);
+            const size_t w = scan_workspace_size(L, j.sc, 1);
+            if (!j.cap || !w) { supported = false; break; }
+            j.off = out_total;
+            out_total += j.cap;
+            if (w > ws) ws = w;
+        }
+        if (supported) {
+            rc = ctx.reserve_scan(ws, out_total);
             if (rc) return rc;
+            if (optimize) {                                  // optimize_huffman_table, encoder.rs:1086-1200
+                JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+                const int max_tables = L.num_components < 2 ? L.num_components : 2;
+                for (int d = 0; d < max_tables; d++)
+                    for (int k = 0; k < 2; k++) t.h[d][k].assign_optimized(ctx.h_freq + (d * 2 + k) * 257);
+            }
             jpegenc_huffman_spec specs[2][2];
             for (int d = 0; d < 2; d++)
                 for (int k = 0; k < 2; k++) {
@@ -564,30 +605,57 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                     memcpy(specs[d][k].values, t.h[d][k].vals, (size_t)t.h[d][k].nvals);
                     specs[d][k].num_values = t.h[d][k].nvals;
                 }
-            rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, specs, 0, ctx.d_scan_out, cap, ctx.d_scan_len,
-                             ctx.d_scan_ws, ws, ctx.stream);
+            rc = upload_huffman_luts(specs, ctx.d_lut, ctx.stream);
             if (rc) return rc;
+            JPEGENC_HIP(hipMemsetAsync(ctx.d_scan_len, 0, sizeof(uint32_t) * jobs.size(), ctx.stream));
+            for (size_t k = 0; k < jobs.size(); k++) {
+                Job &j = jobs[k];
+                if (!j.cap) continue;
+                rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)ctx.d_scan_out + j.off,
+                                 j.cap, ctx.d_scan_len + k, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream);
+                if (rc) return rc;
+            }
             const auto t_launched = now();
-            JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_len, ctx.d_scan_len, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
+            JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_len, ctx.d_scan_len, sizeof(uint32_t) * jobs.size(), hipMemcpyDeviceToHost, ctx.stream));
             JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
             const auto t_len = now();
-            const size_t nbytes = *ctx.h_scan_len;
+            size_t nbytes = 0;
+            for (size_t k = 0; k < jobs.size(); k++) nbytes += ctx.h_scan_len[k];
             rc = ctx.reserve_scan_host(nbytes);
             if (rc) return rc;
-            JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out, ctx.d_scan_out, nbytes, hipMemcpyDeviceToHost, ctx.stream));
+            size_t at = 0;
+            for (size_t k = 0; k < jobs.size(); k++) {
+                const size_t n = ctx.h_scan_len[k];
+                if (n) JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out + at, (const uint8_t *)ctx.d_scan_out + jobs[k].off, n, hipMemcpyDeviceToHost, ctx.stream));
+                at += n;
+            }
             Out o;
             o.sink = sink; o.user = user;
             write_prologue(o, c, jct);
-            write_frame_header(o, c, width, height, L, t);
-            write_scan_header(o, L, 0, L.num_components, 0, 63);
-            o.drain(true);                                           // headers go out while the copy runs
+            write_frame_header(o, c, width, height, L, t);          // after the tables are final (:821, :881)
             JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
             const auto t_copied = now();
-            if (sink(user, ctx.h_scan_out, nbytes) != 0) o.failed = true;
+            at = 0;
+            for (size_t k = 0; k < jobs.size(); k++) {
+                const Job &j = jobs[k];
+                write_scan_header(o, L, j.first, j.n, j.ss, j.se);
+                if (j.cap) {
+                    o.bytes(ctx.h_scan_out + at, ctx.h_scan_len[k]);
+                    at += ctx.h_scan_len[k];
+                } else if (c.restart_interval) {
+                    // empty band (progressive with > 33 scans, encoder.rs:927-944): no bits at all, but the
+                    // restart bookkeeping still emits its markers (encoder.rs:947-951)
+                    const uint64_t n = L.blocks[j.sc.component];
+                    for (uint64_t b = (uint64_t)c.restart_interval, r = 0; b < n; b += (uint64_t)c.restart_interval, r++) {
+                        o.u8(0xFF); o.u8(0xD0 + (unsigned)(r & 7));
+                    }
+                }
+                o.drain(false);
+            }
             o.marker(0xD9);
             o.drain(true);
-            if (trace) fprintf(stderr, "[jpegenc] frame: launch %ld us, wait-len %ld us, d2h %ld us, sink %ld us, bytes %zu\n",
-                               us(t_begin, t_launched), us(t_launched, t_len), us(t_len, t_copied), us(t_copied, now()), nbytes);
+            if (trace) fprintf(stderr, "[jpegenc] frame: launch %ld us, wait-len %ld us, d2h %ld us, emit %ld us, bytes %zu, scans %zu\n",
+                               us(t_begin, t_launched), us(t_launched, t_len), us(t_len, t_copied), us(t_copied, now()), nbytes, jobs.size());
             if (o.failed) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
             return JPEGENC_OK;
         }

@@ -237,8 +237,9 @@ FILE_CASES = {
 }
 
 
-def _encoder(binding, kw):
+def _encoder(binding, kw, device_entropy=True):
     e = binding.Encoder(kw["quality"])
+    e.set_device_entropy(device_entropy)
     if "sampling" in kw:
         e.set_sampling_factor(binding.sampling_factor(*kw["sampling"]))
     if kw.get("progressive_scans"):
@@ -260,12 +261,14 @@ def _encoder(binding, kw):
 REFERENCE_UNDECODABLE = {"rgb_progressive_64", "restart_optimized"}
 
 
+@pytest.mark.parametrize("device_entropy", [True, False], ids=["gpu-entropy", "host-entropy"])
 @pytest.mark.parametrize("name", sorted(FILE_CASES))
-def test_encoder_files_match_oracle(binding, oracle, synth, name):
+def test_encoder_files_match_oracle(binding, oracle, synth, name, device_entropy):
+    """Every mode, with the scans entropy-coded on the GPU and on the host: same bytes as the oracle."""
     from PIL import Image
     kw = FILE_CASES[name]
     px = synth.test_img_rgb()
-    got = _encoder(binding, kw).encode(px, 258, 128, binding.RGB)
+    got = _encoder(binding, kw, device_entropy).encode(px, 258, 128, binding.RGB)
     want = oracle.encode_jpeg(px, 258, 128, oracle.RGB, **kw)
     assert got == want, f"{name}: {len(got)} vs {len(want)} bytes"
     if name in REFERENCE_UNDECODABLE:
@@ -460,13 +463,14 @@ def test_scan_device_batch_api(binding, oracle, synth):
     frames = [synth.noise_image(w, h, 3, 70 + k) for k in range(n)]
     co = np.stack([binding.blocks_host(f, w, h, binding.RGB, 2, 2, 90, 0) for f in frames])
     d_co = torch.from_numpy(co).to(dev)
-    cap = binding.scan_max_bytes(L)
-    ws = binding.scan_workspace_size(L, n)
+    scan = binding.baseline_scan()
+    cap = binding.scan_max_bytes(L, scan)
+    ws = binding.scan_workspace_size(L, scan, n)
     assert cap > 0 and ws > 0
     d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
     d_len = torch.zeros(n, dtype=torch.int32, device=dev)
     d_ws = torch.empty(ws, dtype=torch.uint8, device=dev)
-    binding.scan_device(d_co.data_ptr(), nblk, n, L, d_out.data_ptr(), cap, d_len.data_ptr(), d_ws.data_ptr(), ws, 0)
+    binding.scan_device(d_co.data_ptr(), nblk, n, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(), d_ws.data_ptr(), ws, 0)
     torch.cuda.synchronize()
     lens = d_len.cpu().numpy()
     out = d_out.cpu().numpy()
@@ -494,3 +498,31 @@ def test_encode_batch_to_buffers(binding, oracle, synth):
     with pytest.raises(binding.JpegEncError) as err:
         binding.Encoder(85).encode_batch_to_buffers(frames, 320, 200, binding.RGB, 100)
     assert err.value.status == binding.ERR_BUFFER_TOO_SMALL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(quality=90, sampling=(2, 2), restart_interval=1), dict(quality=90, sampling=(2, 2), restart_interval=7),
+    dict(quality=75, sampling=(1, 1), restart_interval=33), dict(quality=75, sampling=(4, 1), restart_interval=5),
+    dict(quality=60, progressive_scans=3, restart_interval=4), dict(quality=95, sampling=(2, 1), progressive_scans=9),
+    dict(quality=60, progressive_scans=64, restart_interval=3), dict(quality=80, sampling=(1, 2), optimize=True),
+    dict(quality=30, optimize=True, progressive_scans=5)])
+def test_device_entropy_all_scan_kinds(binding, oracle, synth, kw):
+    """Restart intervals, per-component scans, DC-only and AC-band scans, optimised tables — coded on
+    the GPU, on noisy data (many ZRLs / stuffed bytes) and ragged sizes."""
+    for w, h in [(131, 77), (320, 200)]:
+        px = synth.noise_image(w, h, 3, w)
+        for on in (True, False):
+            got = _encoder(binding, kw, on).encode(px, w, h, binding.RGB)
+            assert got == oracle.encode_jpeg(px, w, h, oracle.RGB, **kw), (kw, w, h, on)
+
+
+def test_config4_8k_cmyk_restart_full_file(binding, oracle, synth):
+    """BASELINE config 4 end to end at full size: 7680x4320 CMYK q=95 4:4:4, restart interval = one
+    MCU row (960), entropy-coded on the GPU."""
+    w, h = 7680, 4320
+    px = synth.criterion_pattern(w, h)
+    px = np.concatenate([px, (255 - px[..., :1])], axis=-1)
+    e = binding.Encoder(95)
+    e.set_restart_interval(960)
+    got = e.encode(px, w, h, binding.CMYK)
+    assert got == oracle.encode_jpeg(px, w, h, oracle.CMYK, 95, restart_interval=960)
