@@ -181,6 +181,40 @@ def main():
     }
     if rank == 0 and world == 1:
         result["cpu_baseline"] = cpu_baseline(args.cpu_seconds, synth)
+        # side figure (never `value`): pixels in HBM -> complete entropy-coded scan bytes in HBM
+        # (fused block kernel + device Huffman coding), same frames, HIP-event timed
+        try:
+            Fd = min(F, 16)
+            scan = binding.baseline_scan()
+            cap = binding.scan_max_bytes(L, scan)
+            wsz = binding.scan_workspace_size(L, scan, Fd)
+            d_out = torch.empty((Fd, cap), dtype=torch.uint8, device=dev)
+            d_len = torch.zeros(Fd, dtype=torch.int32, device=dev)
+            d_ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+
+            def full():
+                binding.blocks_device(d_px.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, HS, VS, q, binding.ORDER_MCU,
+                                      binding.FDCT_SCALAR, d_co.data_ptr(), nblk, stream.cuda_stream)
+                binding.scan_device(d_co.data_ptr(), nblk, Fd, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(),
+                                    d_ws.data_ptr(), wsz, stream.cuda_stream)
+            for _ in range(2):
+                full()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(5):
+                full()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            result["device_resident_full_encode"] = {
+                "value": round(Fd * W * H / ms / 1e3, 1), "unit": "Mpixels/s",
+                "what": f"{Fd} 4K frames in HBM -> entropy-coded scan bytes in HBM (block kernel + device Huffman, "
+                        "noise frames = worst case for entropy coding)",
+                "scan_bytes_per_frame": int(d_len.float().mean().item())}
+            del d_out, d_ws
+        except Exception as exc:                                   # side figure only
+            result["device_resident_full_encode"] = {"error": str(exc)}
         if args.e2e_frames > 0:
             # side figure (never `value`): host frames -> JPEG bytes through the Encoder batch API
             # (H2D + kernel + D2H + host Huffman, one host thread per in-flight frame)
