@@ -526,3 +526,40 @@ def test_config4_8k_cmyk_restart_full_file(binding, oracle, synth):
     e.set_restart_interval(960)
     got = e.encode(px, w, h, binding.CMYK)
     assert got == oracle.encode_jpeg(px, w, h, oracle.CMYK, 95, restart_interval=960)
+
+
+def test_randomised_configurations(binding, oracle, synth):
+    """Fuzz-style sweep (the reference's fuzz targets only ask 'does not panic'; here every random
+    configuration must also be byte-identical to the oracle): size, ColorType, sampling factor,
+    quality, scan mode, restart interval, custom tables, FDCT build, entropy coder."""
+    rng = np.random.default_rng(20261002)
+    samplings = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 2), (1, 4), (2, 4)]
+    for trial in range(60):
+        ct = int(rng.integers(0, 9))
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        px = rng.integers(0, 256, (h, w, binding.BPP[ct]), dtype=np.uint8)
+        if trial % 3 == 0:                                   # smooth content: long zero runs, EOBs
+            px = (np.add.outer(np.arange(h), np.arange(w))[..., None] // 3 + np.arange(binding.BPP[ct])).astype(np.uint8)
+        kw = dict(quality=int(rng.integers(1, 101)), sampling=samplings[int(rng.integers(0, 8))])
+        mode = int(rng.integers(0, 4))
+        if mode == 1:
+            kw["progressive_scans"] = int(rng.integers(2, 20))
+        elif mode == 2:
+            kw["optimize"] = True
+        elif mode == 3:
+            kw["progressive_scans"] = int(rng.integers(2, 8))
+            kw["optimize"] = True
+        if rng.integers(0, 3) == 0 and not kw.get("optimize"):
+            kw["restart_interval"] = int(rng.integers(1, 40))
+        variant = int(rng.integers(0, 2))
+        e = _encoder(binding, kw, device_entropy=bool(rng.integers(0, 2)))
+        e.set_fdct_variant(variant)
+        okw = dict(kw)
+        if rng.integers(0, 4) == 0:
+            cust = [int(v) for v in rng.integers(1, 300, 64)]
+            e.set_quantization_tables(binding.Q_CUSTOM, int(rng.integers(0, 9)), cust, None)
+            okw["qpresets"] = (oracle.Q_CUSTOM, e.quantization_tables()[1])
+            okw["qcustoms"] = (cust, None)
+        got = e.encode(px, w, h, ct)
+        want = oracle.encode_jpeg(px, w, h, ct, variant=variant, **okw)
+        assert got == want, (trial, ct, w, h, kw, variant)
