@@ -47,6 +47,11 @@ RATE_KERNEL(k_sub, "v_sub_u32 %0, %1, %0")
 RATE_KERNEL(k_max, "v_max_i32 %0, %0, %1")
 RATE_KERNEL(k_pkmul, "v_pk_mul_lo_u16 %0, %0, %1")
 RATE_KERNEL(k_pkmad, "v_pk_mad_i16 %0, %0, %1, %2")
+RATE_KERNEL(k_sdwa_shift, "v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD")
+RATE_KERNEL(k_sdwa_mov, "v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0")
+RATE_KERNEL(k_mov, "v_mov_b32 %0, %1")
+RATE_KERNEL(k_bfi, "v_bfi_b32 %0, %1, %2, %0")
+RATE_KERNEL(k_lshlor, "v_lshl_or_b32 %0, %1, 16, %0")
 
 __global__ void __launch_bounds__(256) k_copy(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
@@ -110,6 +115,11 @@ int main() {
     run_rate("bfe_u32", k_bfe, d_out, w, &clk);
     run_rate("alignbyte", k_alignbyte, d_out, w, &clk);
     run_rate("cndmask", k_cndmask, d_out, w, &clk);
+    run_rate("sdwa_ashr_w1", k_sdwa_shift, d_out, w, &clk);
+    run_rate("sdwa_mov_w1", k_sdwa_mov, d_out, w, &clk);
+    run_rate("mov_b32", k_mov, d_out, w, &clk);
+    run_rate("bfi_b32", k_bfi, d_out, w, &clk);
+    run_rate("lshl_or_b32", k_lshlor, d_out, w, &clk);
 
     // streaming copy: the practical HBM ceiling for a read-N-write-N kernel
     const size_t bytes = (size_t)1 << 30;

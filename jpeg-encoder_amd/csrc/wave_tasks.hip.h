@@ -31,26 +31,49 @@ struct BlockRef {
     int x0, y0;          // sample origin in full-resolution plane coordinates
 };
 
+// Division of a wave-uniform value on the scalar unit (one readfirstlane'd VALU sequence per wave
+// instead of one per lane would still be VALU; hipcc lowers uniform u32 division to SALU code).
 __device__ __forceinline__ BlockRef locate(const BlockKernelParams &p, const WaveTask &t, uint32_t slot) {
     BlockRef r;
     const int c = t.comp;
     if (p.order == 0) {   // encode_image_interleaved geometry, encoder.rs:713-717, 759-769
-        const uint32_t mcu = t.first + slot / t.per_mcu, k = slot % t.per_mcu;
+        const uint32_t lg = 31u - (uint32_t)__builtin_clz(t.per_mcu);          // h*v is a power of two
+        const uint32_t dm = slot >> lg, k = slot & (t.per_mcu - 1u);
+        const uint32_t mcu = t.first + dm;
         r.valid = mcu < p.total_mcus;
-        const uint32_t m = r.valid ? mcu : 0;
-        const uint32_t mx = m % p.mcus_x, my = m / p.mcus_x;
-        const uint32_t h_off = k % (uint32_t)p.h[c], v_off = k / (uint32_t)p.h[c];
+        // (mx, my) of the wave's first MCU by uniform arithmetic; lanes add their offset and wrap
+        const uint32_t first = __builtin_amdgcn_readfirstlane(t.first < p.total_mcus ? t.first : 0u);
+        const uint32_t my0 = first / p.mcus_x, mx0 = first - my0 * p.mcus_x;
+        uint32_t mx = mx0 + dm, my = my0;
+        if (p.mcus_x >= 64u) {                 // at most one wrap: dm < 64 <= mcus_x
+            if (mx >= p.mcus_x) { mx -= p.mcus_x; my++; }
+        } else {
+            const uint32_t q = mx / p.mcus_x;
+            my += q; mx -= q * p.mcus_x;
+        }
+        if (!r.valid) { mx = 0; my = 0; }
+        const uint32_t hc = (uint32_t)p.h[c], lh = 31u - (uint32_t)__builtin_clz(hc);
+        const uint32_t h_off = k & (hc - 1u), v_off = k >> lh;                  // h is 1, 2 or 4
         r.x0 = (int)(mx * 8u * (uint32_t)p.hmax + h_off * 8u);
         r.y0 = (int)(my * 8u * (uint32_t)p.vmax + v_off * 8u);
-        r.out_index = (uint64_t)m * p.bpm + p.comp_first[c] + k;
+        r.out_index = (uint64_t)(r.valid ? mcu : 0u) * p.bpm + p.comp_first[c] + k;
     } else {              // encode_blocks geometry, encoder.rs:1012-1039
         const uint32_t b = t.first + slot;
         r.valid = b < p.nblocks[c];
-        const uint32_t bb = r.valid ? b : 0;
-        const uint32_t bx = bb % p.cols[c], by = bb / p.cols[c];
+        const uint32_t cols = p.cols[c];
+        const uint32_t first = __builtin_amdgcn_readfirstlane(t.first < p.nblocks[c] ? t.first : 0u);
+        const uint32_t by0 = first / cols, bx0 = first - by0 * cols;
+        uint32_t bx = bx0 + slot, by = by0;
+        if (cols >= 64u) {
+            if (bx >= cols) { bx -= cols; by++; }
+        } else {
+            const uint32_t q = bx / cols;
+            by += q; bx -= q * cols;
+        }
+        if (!r.valid) { bx = 0; by = 0; }
         r.x0 = (int)(bx * 8u * (uint32_t)p.sx[c]);
         r.y0 = (int)(by * 8u * (uint32_t)p.sy[c]);
-        r.out_index = p.comp_off[c] + bb;
+        r.out_index = p.comp_off[c] + (r.valid ? b : 0u);
     }
     return r;
 }
