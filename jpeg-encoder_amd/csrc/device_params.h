@@ -45,6 +45,7 @@ struct BlockKernelParams {
     uint32_t nblocks[4];
     uint64_t comp_off[4];             // first output block of each component
     uint32_t task_start[5];           // prefix sums of ceil(nblocks/64)
+    uint32_t wave_groups;             // != 0: single-wave workgroups, XCD-aware id -> (group, wave) map
     QuantDev q[2];
 };
 

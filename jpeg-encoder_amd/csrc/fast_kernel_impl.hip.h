@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fdct_quant.hip.h"
 #include "host_common.h"
@@ -142,9 +143,11 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t per_group = p.order == 0 ? p.wave_start[p.ncomp] : 4u;
-    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wave;
-    const WaveTask t = decode_task(p, gw % per_group, gw / per_group);
+    uint32_t group, wave_in_group;
+    wave_identity(p, per_group, &group, &wave_in_group);
+    const WaveTask t = decode_task(p, wave_in_group, group);
     const int c = t.comp;
+    if (t.first >= (p.order == 0 ? p.total_mcus : p.nblocks[c])) return;      // padding wave: nothing to do
     const uint8_t *frame = p.pixels + (size_t)blockIdx.y * p.pixel_frame_stride + k.plane_offset[c];
     uint4 *frame_out = reinterpret_cast<uint4 *>(p.coeffs) + (size_t)blockIdx.y * p.coeff_frame_stride * 8u;
 
@@ -203,18 +206,23 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
                               hipStream_t stream) {
     dim3 grid, block;
     size_t lds;
-    if (p.order == 0) {
-        const uint32_t waves = p.wave_start[p.ncomp];               // <= 10 for sampling factors 1 and 2
-        grid = dim3((p.total_mcus + 63u) / 64u, (unsigned)num_frames);
-        block = dim3(waves * 64u);
-        lds = (size_t)waves * kStageBytes;
+    BlockKernelParams q = p;
+    // measured: no gain over one workgroup per group (profiles/README.md), so it stays opt-in
+    static const bool per_wave = getenv("JPEGENC_WAVE_WORKGROUPS") != nullptr;
+    const uint32_t per_group = p.order == 0 ? p.wave_start[p.ncomp] : 4u;      // <= 10 for sampling factors 1 and 2
+    const uint32_t groups = p.order == 0 ? (p.total_mcus + 63u) / 64u : (p.task_start[p.ncomp] + 3u) / 4u;
+    if (per_wave) {
+        q.wave_groups = groups;
+        grid = dim3(((groups + 7u) / 8u) * 8u * per_group, (unsigned)num_frames);
+        block = dim3(64);
+        lds = kStageBytes;
     } else {
-        grid = dim3((p.task_start[p.ncomp] + 3u) / 4u, (unsigned)num_frames);
-        block = dim3(256);
-        lds = 4 * kStageBytes;
+        grid = dim3(groups, (unsigned)num_frames);
+        block = dim3(per_group * 64u);
+        lds = (size_t)per_group * kStageBytes;
     }
-    if (variant == 1) hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 1, CONV>), grid, block, lds, stream, p, k);
-    else hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 0, CONV>), grid, block, lds, stream, p, k);
+    if (variant == 1) hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 1, CONV>), grid, block, lds, stream, q, k);
+    else hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 0, CONV>), grid, block, lds, stream, q, k);
     return hipGetLastError();
 }
 

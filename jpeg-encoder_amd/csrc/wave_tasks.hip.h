@@ -78,6 +78,26 @@ __device__ __forceinline__ BlockRef locate(const BlockKernelParams &p, const Wav
     return r;
 }
 
+// Which (group, wave-in-group) a hardware wave works on.  Default: a workgroup holds all waves of one
+// group.  With p.wave_groups != 0 every wave is its own 64-thread workgroup (LDS and wave slots are
+// recycled per wave instead of per 6-wave group, which matters because luma and chroma waves finish
+// at different times) and the id is remapped so that the waves of one group - which read the same
+// pixels - still land on one XCD and share its L2: workgroup ids are dealt round-robin over the 8
+// XCDs (observed, speed only - never correctness), so id = xcd + 8 * (slot) puts slots of equal
+// id % 8 together.
+__device__ __forceinline__ void wave_identity(const BlockKernelParams &p, uint32_t per_group, uint32_t *group,
+                                              uint32_t *wave_in_group) {
+    if (p.wave_groups) {
+        const uint32_t w = blockIdx.x, xcd = w & 7u, j = w >> 3;
+        *group = (j / per_group) * 8u + xcd;          // >= wave_groups for the padding ids: no valid block
+        *wave_in_group = j % per_group;
+    } else {
+        const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        *group = gw / per_group;
+        *wave_in_group = gw % per_group;
+    }
+}
+
 __device__ __forceinline__ WaveTask decode_task(const BlockKernelParams &p, uint32_t wave_in_group,
                                                 uint32_t group) {
     WaveTask t;
