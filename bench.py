@@ -90,9 +90,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("JPEGENC_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank self-test of the RCCL path
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the block-encode path has no CPU fallback")
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:

@@ -164,6 +164,8 @@ __device__ __forceinline__ qconst_ptr quant_table(int table) {
 // rows[y] = {(x0,x1),(x3,x2),(x7,x6),(x4,x5)} of UNSIGNED samples of block row y.
 // qc = quant_table(t), wave-uniform.  out[j] = zig-zag coefficients (2j, 2j+1) packed as
 // little-endian i16.
+// (Tried and rejected on hardware: feeding (kq, aq) through broadcast LDS reads to avoid the 64
+// SGPR->VGPR accumulator moves made the 4K bench 8 % slower.)
 template <int VARIANT>
 __device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], qconst_ptr qc, uint32_t out[32]) {
     const ChainConsts K = chain_consts();
