@@ -1,11 +1,14 @@
 // host_encoder.cpp — the Encoder-shaped half of the C ABI: mirrors `struct Encoder`
-// (src/encoder.rs:213-515) and keeps on the host exactly what the north star keeps there — scan
-// orchestration (encoder.rs:517-975), Huffman tables (huffman.rs) and the JFIF bit writer
-// (writer.rs) — while every pixel -> coefficient step runs in the HIP kernels.
+// (src/encoder.rs:213-515) and keeps on the host what the north star keeps there — scan
+// orchestration (encoder.rs:517-975), Huffman table construction (huffman.rs) and JFIF marker
+// emission (writer.rs) — while every pixel -> coefficient step runs in the HIP kernels.
 //
-// Entropy coding is inherently serial per scan; it is written for throughput (64-bit accumulator,
-// word-at-a-time 0xFF stuffing test like writer.rs:169-184, zero-run skipping through a
-// non-zero bitmask) and frames of a batch are coded by one host thread per in-flight frame.
+// Scans are entropy-coded on the device by default (entropy_kernels.hip) and only compressed bytes
+// come back.  The host entropy coder below is the alternative path (jpegenc_encoder_set_device_entropy
+// (e, 0), or geometries the device coder declines): coefficient tiles arrive through pinned
+// hipMemcpyAsync copies and are coded as they land, with a 64-bit accumulator, word-at-a-time 0xFF
+// stuffing test (like writer.rs:169-184) and zero-run skipping through a non-zero bitmask.  Frames
+// of a batch are driven by one host thread per in-flight frame.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
