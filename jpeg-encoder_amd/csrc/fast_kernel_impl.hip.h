@@ -105,12 +105,20 @@ __device__ __forceinline__ uint32_t edge_sample(const uint8_t *px, int role, int
 struct LumaConv {          // Y of an RGB-order pixel word
     const ColourConsts &k;
     static constexpr uint32_t kPack = 0x0C050C01u;            // byte 1 of each result
+#ifdef JPEGENC_PROBE_MEMORY_ONLY
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w; }
+#else
     __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return luma16(w, k); }
+#endif
 };
 struct ChromaConv {        // Cb or Cr
     uint32_t sel, kk, sh;
     static constexpr uint32_t kPack = 0x0C060C02u;            // byte 2 of each result
+#ifdef JPEGENC_PROBE_MEMORY_ONLY
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w + sel; }
+#else
     __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return chroma32(w, sel, kk, sh); }
+#endif
 };
 
 // rows[y] = {(x0,x1),(x3,x2),(x7,x6),(x4,x5)}; `pack` selects the result byte of each converted word.
@@ -197,7 +205,12 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
         }
     }
     uint32_t packed[32];
+#ifdef JPEGENC_PROBE_MEMORY_ONLY   // diagnostic build: same loads and stores, no block math
+#pragma unroll
+    for (int j = 0; j < 32; j++) packed[j] = rows[j >> 2][j & 3];
+#else
     fdct_quant_block<VARIANT>(rows, quant_table(p.qsel[c]), packed);
+#endif
     stage_and_store(p, t, smem + wave * kStageBytes, lane, packed, frame_out);
 }
 

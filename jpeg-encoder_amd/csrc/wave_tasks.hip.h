@@ -22,7 +22,8 @@ constexpr int kStageBytes = kWave * 128;   // one wave's coefficient staging are
 struct WaveTask {
     int comp;            // component of every block in the wave
     uint32_t first;      // MCU order: first MCU of the wave; planar: first block of the wave
-    uint32_t per_mcu;    // MCU order: blocks of this component per MCU (h*v)
+    uint32_t per_mcu;    // MCU order: blocks of this component per MCU THAT THIS WAVE HANDLES (power of two)
+    uint32_t k_base;     // MCU order: index (v_off * h + h_off) of the first of them
 };
 
 struct BlockRef {
@@ -37,8 +38,8 @@ __device__ __forceinline__ BlockRef locate(const BlockKernelParams &p, const Wav
     BlockRef r;
     const int c = t.comp;
     if (p.order == 0) {   // encode_image_interleaved geometry, encoder.rs:713-717, 759-769
-        const uint32_t lg = 31u - (uint32_t)__builtin_clz(t.per_mcu);          // h*v is a power of two
-        const uint32_t dm = slot >> lg, k = slot & (t.per_mcu - 1u);
+        const uint32_t lg = 31u - (uint32_t)__builtin_clz(t.per_mcu);          // a power of two
+        const uint32_t dm = slot >> lg, k = t.k_base + (slot & (t.per_mcu - 1u));
         const uint32_t mcu = t.first + dm;
         r.valid = mcu < p.total_mcus;
         // (mx, my) of the wave's first MCU by uniform arithmetic; lanes add their offset and wrap
@@ -105,15 +106,23 @@ __device__ __forceinline__ WaveTask decode_task(const BlockKernelParams &p, uint
         int c = 0;
         while (c + 1 < p.ncomp && wave_in_group >= p.wave_start[c + 1]) c++;
         t.comp = c;
-        t.per_mcu = (uint32_t)(p.h[c] * p.v[c]);
+        const uint32_t hv = (uint32_t)(p.h[c] * p.v[c]);
         const uint32_t w = wave_in_group - p.wave_start[c];      // 0 .. h*v-1
-        t.first = group * 64u + w * (64u / t.per_mcu);
+        // A wave takes ONE row of the component's blocks inside the MCU (h of them) from 64/h MCUs:
+        // it then reads 8 image rows in segments of up to 1.5-3 KB instead of 16 rows in 768-B
+        // segments.  The component's h*v waves = h MCU ranges x v block-rows.
+        (void)hv;
+        t.per_mcu = (uint32_t)p.h[c];
+        const uint32_t range = w % t.per_mcu, vrow = w / t.per_mcu;          // vrow < v
+        t.k_base = vrow * t.per_mcu;
+        t.first = group * 64u + range * (64u / t.per_mcu);
     } else {
         const uint32_t task = group * 4u + wave_in_group;
         int c = 0;
         while (c + 1 < p.ncomp && task >= p.task_start[c + 1]) c++;
         t.comp = c;
         t.per_mcu = 1;
+        t.k_base = 0;
         t.first = (task - p.task_start[c]) * 64u;
         if (task >= p.task_start[p.ncomp]) t.first = 0xFFFFFFC0u;   // past the end: nothing valid
     }
@@ -147,7 +156,7 @@ __device__ __forceinline__ void stage_and_store(const BlockKernelParams &p, cons
         unit = t.first + (slot0 >> lg);
         unit_step = 8u >> lg;
         unit_limit = p.total_mcus;
-        index = (uint64_t)unit * p.bpm + p.comp_first[t.comp] + (slot0 & (t.per_mcu - 1u));
+        index = (uint64_t)unit * p.bpm + p.comp_first[t.comp] + t.k_base + (slot0 & (t.per_mcu - 1u));
         index_step = unit_step * p.bpm;
         if (t.per_mcu > 8u) { unit_step = 0; index_step = 0; }                 // not reachable (hv <= 8)
     } else {
