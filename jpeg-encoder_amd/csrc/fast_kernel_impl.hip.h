@@ -170,6 +170,15 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
     const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * BPP;
     uint32_t rows[8][4];
 
+#if defined(JPEGENC_PROBE_MEMORY_ONLY) && JPEGENC_PROBE_MEMORY_ONLY == 5   // stores only
+    {
+#pragma unroll
+        for (int y = 0; y < 8; y++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) rows[y][i] = lane * 33u + y * 4u + i;
+    }
+    if (false)
+#endif
     if (me.x0 + 8 * sxc <= p.width) {
         if (CONV && role == ROLE_Y) {
             fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, LumaConv::kPack, LumaConv{k}, rows);
@@ -211,7 +220,14 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
 #else
     fdct_quant_block<VARIANT>(rows, quant_table(p.qsel[c]), packed);
 #endif
+#if defined(JPEGENC_PROBE_MEMORY_ONLY) && JPEGENC_PROBE_MEMORY_ONLY == 4       // loads only
+    uint32_t x = 0;
+#pragma unroll
+    for (int j = 0; j < 32; j++) x ^= packed[j];
+    if (x == 0x12345u) frame_out[lane].x = x;
+#else
     stage_and_store(p, t, smem + wave * kStageBytes, lane, packed, frame_out);
+#endif
 }
 
 template <int BPP, int SX, int SY, bool CONV>
