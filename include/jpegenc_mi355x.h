@@ -237,6 +237,11 @@ int  jpegenc_encoder_add_exif_metadata(jpegenc_encoder *e, const uint8_t *data, 
  * the same configuration can encode further images.  Output goes to `sink` in order. */
 int  jpegenc_encoder_encode(jpegenc_encoder *e, const uint8_t *data, size_t len, int width,
                             int height, int color_type, jpegenc_write_fn sink, void *user);
+/* Same for an image that already lives in this handle's device memory (a decoder or camera
+ * pipeline's output): no host-to-device copy; the kernels read `d_pixels` directly (it must stay
+ * valid and unmodified until the call returns). */
+int  jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int width, int height,
+                                   int color_type, jpegenc_write_fn sink, void *user);
 /* Same, into a caller buffer; *out_len is always set to the size the file needs. */
 int  jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len,
                                       int width, int height, int color_type, uint8_t *out,

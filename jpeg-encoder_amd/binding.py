@@ -49,7 +49,8 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_restart_interval", "jpegenc_encoder_set_optimized_huffman_tables",
     "jpegenc_encoder_optimized_huffman_tables", "jpegenc_encoder_add_app_segment",
     "jpegenc_encoder_add_icc_profile", "jpegenc_encoder_add_exif_metadata",
-    "jpegenc_encoder_encode", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_image",
+    "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_to_buffer",
+    "jpegenc_encoder_encode_image",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
 ]
@@ -139,6 +140,7 @@ def lib():
         l.jpegenc_encoder_add_exif_metadata.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         l.jpegenc_encoder_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                              WRITE_FN, C.c_void_p]
+        l.jpegenc_encoder_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, WRITE_FN, C.c_void_p]
         l.jpegenc_encoder_encode_to_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                                        C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         l.jpegenc_encoder_encode_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, FILL_ROW_FN,
@@ -326,6 +328,18 @@ class Encoder:
 
         cb = WRITE_FN(sink)
         check(lib().jpegenc_encoder_encode(self._h, px.ctypes.data, px.size, width, height, color_type, cb, None))
+        return b"".join(chunks)
+
+    def encode_device(self, d_pixels_ptr, width, height, color_type):
+        """Encode an image that is already in device memory (raw pointer, e.g. torch data_ptr())."""
+        chunks = []
+
+        def sink(_user, ptr, n):
+            chunks.append(C.string_at(ptr, n))
+            return 0
+
+        cb = WRITE_FN(sink)
+        check(lib().jpegenc_encoder_encode_device(self._h, d_pixels_ptr, width, height, color_type, cb, None))
         return b"".join(chunks)
 
     def encode_image(self, jpeg_color_type, width, height, fill_buffers):

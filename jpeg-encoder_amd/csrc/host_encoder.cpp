@@ -230,6 +230,7 @@ struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;
     void *d_pixels = nullptr, *d_coeffs = nullptr, *d_freq = nullptr;
+    const void *external_pixels = nullptr;   // device-resident input: use the caller's buffer, no upload
     size_t d_pixels_cap = 0, d_coeffs_cap = 0;
     int16_t *h_coeffs = nullptr;
     size_t h_coeffs_cap = 0;
@@ -531,7 +532,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
 
     // ---- device: upload, fused kernel, [histogram], download ---------------------------------
     const size_t coeff_bytes = (size_t)L.total_blocks * 128;
-    rc = ctx.reserve(pixel_bytes, coeff_bytes, color_type_or_planes >= 100);
+    rc = ctx.reserve(ctx.external_pixels ? 0 : pixel_bytes, coeff_bytes, color_type_or_planes >= 100);
     if (rc) return rc;
     rc = upload(ctx);
     if (rc) return rc;
@@ -539,7 +540,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     if (color_type_or_planes >= 100) rc = build_block_params_planes(&p, L, width, height, t.q, order);
     else rc = build_block_params(&p, L, width, height, color_type_or_planes, t.q, order);
     if (rc) return rc;
-    p.pixels = (const uint8_t *)ctx.d_pixels;
+    p.pixels = (const uint8_t *)(ctx.external_pixels ? ctx.external_pixels : ctx.d_pixels);
     p.coeffs = ctx.d_coeffs;
     p.pixel_frame_stride = pixel_bytes;
     p.coeff_frame_stride = L.total_blocks;
@@ -941,6 +942,24 @@ int jpegenc_encoder_encode(jpegenc_encoder *e, const uint8_t *data, size_t len, 
     REQUIRE(e);
     if (len && !data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null data");
     return encode_pixels(e->cfg, e->ctx, e->device, data, len, width, height, color_type, sink, user);
+}
+
+int jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int width, int height, int color_type,
+                                  jpegenc_write_fn sink, void *user) {
+    REQUIRE(e);
+    if (!d_pixels || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    const int bpp = jpegenc_bytes_per_pixel(color_type);
+    if (!bpp) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");
+    if (width < 0 || height < 0 || width > 65535 || height > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "width/height must fit u16");
+    if (width == 0 || height == 0) return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "Image dimensions must be non zero");
+    int rc = e->ctx.open(e->device);
+    if (rc) return rc;
+    const size_t bytes = (size_t)width * (size_t)height * (size_t)bpp;
+    e->ctx.external_pixels = d_pixels;
+    auto upload = [&](DeviceCtx &) -> int { return JPEGENC_OK; };
+    rc = encode_frame(e->cfg, e->ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user);
+    e->ctx.external_pixels = nullptr;
+    return rc;
 }
 
 int jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len, int width, int height,

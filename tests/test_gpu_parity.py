@@ -563,3 +563,15 @@ def test_randomised_configurations(binding, oracle, synth):
         got = e.encode(px, w, h, ct)
         want = oracle.encode_jpeg(px, w, h, ct, variant=variant, **okw)
         assert got == want, (trial, ct, w, h, kw, variant)
+
+
+def test_encode_device_resident_input(binding, oracle, synth):
+    """jpegenc_encoder_encode_device: pixels already in HBM, all scan modes."""
+    import torch
+    px = synth.lcg_image(300, 170, 3, 77)
+    d = torch.from_numpy(px.copy()).to("cuda:0")
+    for kw in (dict(quality=90), dict(quality=70, progressive_scans=4, optimize=True), dict(quality=85, restart_interval=9)):
+        for on in (True, False):
+            e = _encoder(binding, kw, on)
+            assert e.encode_device(d.data_ptr(), 300, 170, binding.RGB) == oracle.encode_jpeg(px, 300, 170, oracle.RGB, **kw)
+    assert bytes(d.cpu().numpy().reshape(-1)) == px.tobytes()          # input untouched
