@@ -213,23 +213,54 @@ __global__ void __launch_bounds__(256) k_block_bits(const EntropyParams p) {
     p.bits[(size_t)f * p.nblocks + b] = walk_block<false>(p, lut, frame, b, s);
 }
 
+// Bit packing.  A wave's 64 blocks occupy one contiguous run of the raw stream (plus the alignment
+// gaps between restart intervals), so the wave assembles that run in a private LDS window - lanes OR
+// their first/last partial words in, store whole words plainly - and then writes the window to HBM
+// with coalesced stores; only the two words it may share with neighbouring waves go out as atomic
+// ORs into the zeroed buffer.  Runs longer than the window (pathological content) are written
+// straight to HBM with the same code.
+constexpr uint32_t kPackWindowWords = 2048;      // 8 KiB per wave
+
 __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
     __shared__ uint32_t lut[4 * 256];
+    __shared__ uint32_t window[4][kPackWindowWords];
     load_lut(p, lut);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    if (b >= p.nblocks) return;
+    const bool valid = b < p.nblocks;
+    const uint64_t vmask = __ballot(valid);
+    if (vmask == 0) return;                                                      // whole wave past the end
     const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
     const uint32_t *G = p.bitoff + (size_t)f * p.nblocks;
-    const uint32_t iv = b / p.interval_blocks, iv_first = iv * p.interval_blocks;
-    const uint32_t in_iv = G[b] - G[iv_first];                                   // bits before b in its interval
-    uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride) +
-                       (size_t)p.ichunk[(size_t)f * p.nintervals + iv] * 4;      // interval base, 16-byte aligned
-    BitSink s = {stream + (in_iv >> 5), 0, in_iv & 31u, true};
-    const uint32_t mine = walk_block<true>(p, lut, frame, b, s);
-    const uint32_t iv_last = min(iv_first + p.interval_blocks, p.nblocks) - 1;
-    if (b == iv_last) {
+    uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
+
+    uint32_t in_iv = 0, first_word = 0, last_word = 0, pad = 0, iv_last = 0;
+    if (valid) {
+        const uint32_t iv = b / p.interval_blocks, iv_first = iv * p.interval_blocks;
+        iv_last = min(iv_first + p.interval_blocks, p.nblocks) - 1;
+        in_iv = G[b] - G[iv_first];                                              // bits before b in its interval
+        const uint32_t base = p.ichunk[(size_t)f * p.nintervals + iv] * 4u;      // interval base (words), 16-B aligned
+        const uint32_t mine = p.bits[(size_t)f * p.nblocks + b];
         // finalize_bit_buffer (writer.rs:138-154): seven 1-bits, then only whole bytes are kept
-        const uint32_t total = in_iv + mine, pad = (8u - (total & 7u)) & 7u;
+        if (b == iv_last) pad = (8u - ((in_iv + mine) & 7u)) & 7u;
+        const uint32_t end = in_iv + mine + pad;
+        first_word = base + (in_iv >> 5);
+        last_word = base + ((end ? end - 1u : 0u) >> 5);
+    }
+    const uint32_t nvalid = (uint32_t)__popcll(vmask);
+    const uint32_t w0 = (uint32_t)__shfl((int)first_word, 0), w1 = (uint32_t)__shfl((int)last_word, (int)nvalid - 1);
+    const uint32_t nwords = w1 - w0 + 1u;
+    const bool staged = nwords <= kPackWindowWords;                              // wave-uniform
+    uint32_t *win = window[wave];
+    if (staged) {
+        for (uint32_t i = lane; i < nwords; i += 64u) win[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (valid) {
+        BitSink s = {staged ? win + (first_word - w0) : stream + first_word, 0, in_iv & 31u, true};
+        walk_block<true>(p, lut, frame, b, s);
         if (pad) {
             s.acc = (s.acc << pad) | ((1u << pad) - 1u);
             s.nacc += pad;
@@ -239,8 +270,25 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
                 s.first = false; s.words++; s.nacc -= 32;
             }
         }
+        if (s.nacc) atomicOr(s.words, __builtin_bswap32((uint32_t)(s.acc << (32 - s.nacc))));
     }
-    if (s.nacc) atomicOr(s.words, __builtin_bswap32((uint32_t)(s.acc << (32 - s.nacc))));
+    if (staged) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = lane; i < nwords; i += 64u) {
+            const uint32_t v = win[i];
+            if (i == 0 || i + 1 == nwords) { if (v) atomicOr(stream + w0 + i, v); }
+            else stream[w0 + i] = v;
+        }
+    }
+}
+
+// Clear the part of the raw buffer this frame's scan will use (its size is only known on the device).
+__global__ void __launch_bounds__(256) k_zero_raw(const EntropyParams p) {
+    const uint32_t f = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > p.raw_chunks[f] || q >= p.max_chunks) return;
+    reinterpret_cast<uint4 *>(p.raw + (size_t)f * p.raw_stride)[q] = make_uint4(0, 0, 0, 0);
 }
 
 // bytes of every restart interval after 1-padding (finalize_bit_buffer keeps whole bytes only)
@@ -322,8 +370,7 @@ static hipError_t scan(const uint32_t *in, uint64_t in_stride, uint32_t *out, ui
 }
 
 hipError_t launch_entropy_scan(const EntropyParams &p, int frames, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(p.raw, 0, (size_t)frames * p.raw_stride, st);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
     const uint32_t bgrid = (p.nblocks + 255u) / 256u;
     hipLaunchKernelGGL(k_block_bits, dim3(bgrid, frames), dim3(256), 0, st, p);
     e = scan(p.bits, p.nblocks, p.bitoff, p.nblocks, p.partials, p.max_tiles, p.total_bits, nullptr, p.nblocks, frames, st);
@@ -333,8 +380,9 @@ hipError_t launch_entropy_scan(const EntropyParams &p, int frames, hipStream_t s
     if (e != hipSuccess) return e;
     e = scan(p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, p.nintervals, frames, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_block_pack, dim3(bgrid, frames), dim3(256), 0, st, p);
     const uint32_t cgrid = (p.max_chunks + 255u) / 256u;
+    hipLaunchKernelGGL(k_zero_raw, dim3(cgrid, frames), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_block_pack, dim3(bgrid, frames), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_count_ff, dim3(cgrid, frames), dim3(256), 0, st, p);
     e = scan(p.ffcount, p.max_chunks, p.ffprefix, p.max_chunks, p.partials, p.max_tiles, p.total_ff, p.raw_chunks,
              p.max_chunks, frames, st);
