@@ -286,9 +286,9 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
 
 // Clear the part of the raw buffer this frame's scan will use (its size is only known on the device).
 __global__ void __launch_bounds__(256) k_zero_raw(const EntropyParams p) {
-    const uint32_t f = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > p.raw_chunks[f] || q >= p.max_chunks) return;
-    reinterpret_cast<uint4 *>(p.raw + (size_t)f * p.raw_stride)[q] = make_uint4(0, 0, 0, 0);
+    const uint32_t f = blockIdx.y, n = min(p.raw_chunks[f] + 1u, p.max_chunks);
+    uint4 *raw = reinterpret_cast<uint4 *>(p.raw + (size_t)f * p.raw_stride);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) raw[q] = make_uint4(0, 0, 0, 0);
 }
 
 // bytes of every restart interval after 1-padding (finalize_bit_buffer keeps whole bytes only)
@@ -301,6 +301,10 @@ __global__ void __launch_bounds__(256) k_interval_len(const EntropyParams p) {
     const uint32_t bytes = (bits + 7u) >> 3;
     p.ilen[(size_t)f * p.nintervals + i] = bytes;
     p.ichunks[(size_t)f * p.nintervals + i] = (bytes + 15u) >> 4;
+    if (p.nintervals == 1) {                       // no restart markers: the two interval scans are trivial
+        p.iexact[f] = 0; p.ichunk[f] = 0;
+        p.raw_bytes[f] = bytes; p.raw_chunks[f] = (bytes + 15u) >> 4;
+    }
 }
 
 // ---- byte stuffing --------------------------------------------------------------------------------
@@ -311,49 +315,89 @@ __device__ __forceinline__ uint32_t ff_count4(uint32_t w) {           // number 
     return (m * 0x01010101u) >> 24;
 }
 
+// The chunk kernels run over a data-dependent number of 16-byte chunks (raw_chunks[f], known only on
+// the device): a bounded grid walks them with a stride instead of launching the worst case.
+constexpr uint32_t kChunkGrid = 1024;
+
 __global__ void __launch_bounds__(256) k_count_ff(const EntropyParams p) {
-    const uint32_t f = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= p.raw_chunks[f]) return;
-    const uint4 v = reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride)[q];
-    // bytes beyond raw_bytes are still zero (the buffer is cleared per encode), so they never count
-    p.ffcount[(size_t)f * p.max_chunks + q] = ff_count4(v.x) + ff_count4(v.y) + ff_count4(v.z) + ff_count4(v.w);
+    const uint32_t f = blockIdx.y, n = p.raw_chunks[f];
+    const uint4 *raw = reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const uint4 v = raw[q];
+        // bytes beyond an interval's length are zero (k_zero_raw), so they never count
+        p.ffcount[(size_t)f * p.max_chunks + q] = ff_count4(v.x) + ff_count4(v.y) + ff_count4(v.z) + ff_count4(v.w);
+    }
 }
 
+// Stuffing scatter.  A workgroup takes 256 consecutive chunks; their output is one contiguous byte
+// range, so the bytes (with the inserted 0x00 and the RSTn markers) are laid out in LDS first -
+// phase-aligned with the destination - and then copied out as whole dwords; only the partial words
+// at the two ends, which neighbouring workgroups also touch, are written byte by byte.
 __global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
-    const uint32_t f = blockIdx.y, q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= p.raw_chunks[f]) return;
-    // interval of this chunk: the last i with ichunk[i] <= q among intervals that own chunks
+    __shared__ __attribute__((aligned(16))) uint8_t stage[256 * 34 + 32];
+    __shared__ uint32_t tile_begin, tile_end;
+    const uint32_t f = blockIdx.y, n = p.raw_chunks[f];
     const uint32_t *ichunk = p.ichunk + (size_t)f * p.nintervals;
-    uint32_t lo = 0, hi = p.nintervals;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (ichunk[mid] <= q) lo = mid; else hi = mid;
-    }
-    const uint32_t iv = lo, j = q - ichunk[iv];
-    const uint32_t ilen = p.ilen[(size_t)f * p.nintervals + iv], nchunks = p.ichunks[(size_t)f * p.nintervals + iv];
-    const uint8_t *src = p.raw + (size_t)f * p.raw_stride + (size_t)q * 16;
-    // raw bytes of earlier intervals + this interval's earlier bytes + stuffed zeros + 2-byte markers so far
-    uint8_t *dst = p.out + (size_t)f * p.out_stride + p.iexact[(size_t)f * p.nintervals + iv] + (size_t)j * 16 +
-                   p.ffprefix[(size_t)f * p.max_chunks + q] + 2u * iv;
-    const uint4 v = *reinterpret_cast<const uint4 *>(src);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    const uint32_t valid = ilen - j * 16 < 16 ? ilen - j * 16 : 16;
-    uint32_t o = 0;
+    uint8_t *out = p.out + (size_t)f * p.out_stride;
+    for (uint32_t tile = blockIdx.x; tile * 256u < n; tile += gridDim.x) {
+        const uint32_t q = tile * 256u + threadIdx.x;
+        const bool active = q < n;
+        uint32_t pos = 0, o = 0, iv = 0, j = 0, ilen = 0, nchunks = 0;
+        if (active) {
+            // interval of this chunk: the last i with ichunk[i] <= q
+            uint32_t lo = 0, hi = p.nintervals;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ichunk[mid] <= q) lo = mid; else hi = mid;
+            }
+            iv = lo; j = q - ichunk[iv];
+            ilen = p.ilen[(size_t)f * p.nintervals + iv]; nchunks = p.ichunks[(size_t)f * p.nintervals + iv];
+            // raw bytes of earlier intervals + this interval's earlier bytes + stuffed zeros + 2-byte markers so far
+            pos = p.iexact[(size_t)f * p.nintervals + iv] + j * 16u + p.ffprefix[(size_t)f * p.max_chunks + q] + 2u * iv;
+        }
+        if (threadIdx.x == 0) tile_begin = pos;
+        __syncthreads();
+        const uint32_t begin = tile_begin;
+        const uint32_t phase = (uint32_t)((uintptr_t)(out + begin) & 3u);          // LDS image shares the destination's alignment
+        if (active) {
+            uint8_t *dst = stage + phase + (pos - begin);
+            const uint4 v = reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride)[q];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t valid = ilen - j * 16u < 16u ? ilen - j * 16u : 16u;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if ((uint32_t)i < valid) {
-            const uint8_t byte = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
-            dst[o++] = byte;
-            if (byte == 0xFF) dst[o++] = 0;              // flush_byte_from_bit_buffer, writer.rs:157-167
+            for (int i = 0; i < 16; i++) {
+                if ((uint32_t)i < valid) {
+                    const uint8_t byte = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+                    dst[o++] = byte;
+                    if (byte == 0xFF) dst[o++] = 0;          // flush_byte_from_bit_buffer, writer.rs:157-167
+                }
+            }
+            if (j + 1 == nchunks) {
+                if (iv + 1 < p.nintervals) {      // RSTn between intervals (encoder.rs:748-752): n = interval index mod 8
+                    dst[o++] = 0xFF;
+                    dst[o++] = (uint8_t)(0xD0 + (iv & 7u));
+                } else {
+                    p.out_bytes[f] = pos + o;
+                }
+            }
         }
-    }
-    if (j + 1 == nchunks) {
-        if (iv + 1 < p.nintervals) {          // RSTn between intervals (encoder.rs:748-752): n = interval index mod 8
-            dst[o++] = 0xFF;
-            dst[o++] = (uint8_t)(0xD0 + (iv & 7u));
-        } else {
-            p.out_bytes[f] = (uint32_t)(dst + o - (p.out + (size_t)f * p.out_stride));
+        const uint32_t last = min(n - tile * 256u, 256u) - 1u;
+        if (threadIdx.x == last) tile_end = pos + o;
+        __syncthreads();
+        const uint32_t end = tile_end;
+        const uint32_t len = end - begin;
+        uint8_t *gdst = out + begin - phase;                                     // 4-byte aligned
+        const uint32_t total = phase + len;
+        for (uint32_t wd = threadIdx.x; wd * 4u < total; wd += 256u) {
+            const uint32_t b0 = wd * 4u;
+            if (b0 >= phase && b0 + 4u <= total) {
+                *reinterpret_cast<uint32_t *>(gdst + b0) = *reinterpret_cast<const uint32_t *>(stage + b0);
+            } else {
+                for (uint32_t k = 0; k < 4u; k++)
+                    if (b0 + k >= phase && b0 + k < total) gdst[b0 + k] = stage[b0 + k];
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -376,11 +420,13 @@ hipError_t launch_entropy_scan(const EntropyParams &p, int frames, hipStream_t s
     e = scan(p.bits, p.nblocks, p.bitoff, p.nblocks, p.partials, p.max_tiles, p.total_bits, nullptr, p.nblocks, frames, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_interval_len, dim3((p.nintervals + 255u) / 256u, frames), dim3(256), 0, st, p);
-    e = scan(p.ilen, p.nintervals, p.iexact, p.nintervals, p.partials, p.max_tiles, p.raw_bytes, nullptr, p.nintervals, frames, st);
-    if (e != hipSuccess) return e;
-    e = scan(p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, p.nintervals, frames, st);
-    if (e != hipSuccess) return e;
-    const uint32_t cgrid = (p.max_chunks + 255u) / 256u;
+    if (p.nintervals > 1) {
+        e = scan(p.ilen, p.nintervals, p.iexact, p.nintervals, p.partials, p.max_tiles, p.raw_bytes, nullptr, p.nintervals, frames, st);
+        if (e != hipSuccess) return e;
+        e = scan(p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, p.nintervals, frames, st);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t cgrid = min((p.max_chunks + 255u) / 256u, kChunkGrid);
     hipLaunchKernelGGL(k_zero_raw, dim3(cgrid, frames), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_block_pack, dim3(bgrid, frames), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_count_ff, dim3(cgrid, frames), dim3(256), 0, st, p);
