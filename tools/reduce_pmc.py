@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Reduce separate `rocprofv3 --pmc` passes over bench.py into profiles/pmc_traffic.json.
+
+Each pass is one directory written by
+    rocprofv3 --pmc <counters> --output-format csv -d gpurun_out/<dir> -- python3 bench.py --steps 20 --warmup 5 \
+        --settle-ms 0 --cpu-seconds 0.2 --headline-only
+(--pmc never combined with a trace option).  Counter rows of the dominant kernel are summed over the
+XCD/SE instances rocprofv3 reports per dispatch and averaged over dispatches.
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and
+WRITE_SIZE are in KiB-like units of 1 KB; on gfx950 FETCH_SIZE counts 64 B for each 128-B request of a
+16-byte-per-lane stream, so it is doubled; WRITE_SIZE is exact.
+
+usage: tools/reduce_pmc.py --kernel k_blocks_fast --alg-bytes N --out profiles/pmc_traffic.json DIR [DIR...]
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+
+
+def reduce_dir(path, kernel_substr):
+    per_counter = collections.defaultdict(lambda: collections.defaultdict(float))
+    name = None
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if kernel_substr not in row["Kernel_Name"]:
+                    continue
+                name = row["Kernel_Name"]
+                per_counter[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+    out = {}
+    for counter, by_dispatch in per_counter.items():
+        vals = list(by_dispatch.values())
+        out[counter] = sum(vals) / len(vals)
+    return name, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel", default="k_blocks_fast")
+    ap.add_argument("--alg-bytes", type=int, required=True, help="algorithmic bytes per launch (DESIGN.md)")
+    ap.add_argument("--workload", default="32 frames 3840x2160 RGB q=90 4:2:0 per launch (bench.py)")
+    ap.add_argument("--out", default="profiles/pmc_traffic.json")
+    ap.add_argument("dirs", nargs="+")
+    a = ap.parse_args()
+
+    counters, kname = {}, None
+    for d in a.dirs:
+        n, c = reduce_dir(d, a.kernel)
+        kname = kname or n
+        counters.update(c)
+    if "FETCH_SIZE" not in counters or "WRITE_SIZE" not in counters:
+        raise SystemExit("need FETCH_SIZE and WRITE_SIZE passes; got " + ", ".join(sorted(counters)))
+    rd = int(round(counters["FETCH_SIZE"] * 1024 * 2))
+    wr = int(round(counters["WRITE_SIZE"] * 1024))
+    doc = {
+        "kernel": kname,
+        "workload": a.workload,
+        "counters_mean_per_launch": counters,
+        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on 16-B/lane streams -> doubled "
+                      "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; both in KB",
+        "hbm_read_bytes_per_launch": rd,
+        "hbm_write_bytes_per_launch": wr,
+        "hbm_bytes_per_launch": rd + wr,
+        "algorithmic_bytes_per_launch": a.alg_bytes,
+        "traffic_over_algorithmic": (rd + wr) / a.alg_bytes,
+        "collected": "separate rocprofv3 --pmc passes (one directory each: " + ", ".join(os.path.basename(os.path.normpath(d)) for d in a.dirs)
+                     + "), each: rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --steps 20 --warmup 5 --settle-ms 0 --cpu-seconds 0.2 --headline-only; reduced by tools/reduce_pmc.py",
+    }
+    d = {}
+    if "SQ_WAVES" in counters and counters["SQ_WAVES"]:
+        w = counters["SQ_WAVES"]
+        if "SQ_INSTS_VALU" in counters:
+            d["valu_instr_per_wave"] = counters["SQ_INSTS_VALU"] / w
+        if "SQ_INSTS_SALU" in counters:
+            d["salu_instr_per_wave"] = counters["SQ_INSTS_SALU"] / w
+    if "GRBM_GUI_ACTIVE" in counters and counters["GRBM_GUI_ACTIVE"]:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_* cycle counters tick once per 4 clocks and are
+        # summed over the 256 CUs x 4 SIMDs
+        cyc = counters["GRBM_GUI_ACTIVE"] / 8.0
+        d["kernel_cycles_per_xcd"] = cyc
+        if "SQ_ACTIVE_INST_VALU" in counters:
+            d["valu_busy_fraction"] = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0)
+        if "SQ_WAVE_CYCLES" in counters:
+            d["mean_waves_per_simd"] = counters["SQ_WAVE_CYCLES"] * 4.0 / (cyc * 1024.0)
+    if d:
+        doc["derived"] = d
+    with open(a.out, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print(json.dumps({k: doc[k] for k in ("kernel", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}))
+
+
+if __name__ == "__main__":
+    main()
