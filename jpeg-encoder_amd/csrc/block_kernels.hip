@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(640) k_blocks_generic(const BlockKernelParams 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // a workgroup normally holds every wave of one group; launch_blocks_generic falls back to
     // single-wave workgroups when a group would exceed the block-size limit
-    const uint32_t per_group = p.order == 0 ? p.wave_start[p.ncomp] : 4u;
+    const uint32_t per_group = p.per_group;
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + wave;
     const WaveTask t = decode_task(p, gw % per_group, gw / per_group);
     const uint8_t *frame = p.pixels + (size_t)blockIdx.y * p.pixel_frame_stride;
@@ -168,8 +168,8 @@ __global__ void __launch_bounds__(256) k_histogram(const HistKernelParams p) {
 hipError_t launch_blocks_generic(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream) {
     dim3 grid, block;
     size_t lds;
-    if (p.order == 0) {
-        const uint32_t waves = p.wave_start[p.ncomp], groups = (p.total_mcus + 63u) / 64u;
+    {
+        const uint32_t waves = p.per_group, groups = p.groups;
         if (waves * 64u <= 640u) {
             grid = dim3(groups, (unsigned)num_frames);
             block = dim3(waves * 64u);
@@ -179,11 +179,6 @@ hipError_t launch_blocks_generic(const BlockKernelParams &p, int num_frames, int
             block = dim3(64);
             lds = kStageBytes;
         }
-    } else {
-        const uint32_t tasks = p.task_start[p.ncomp];
-        grid = dim3((tasks + 3u) / 4u, (unsigned)num_frames);
-        block = dim3(256);
-        lds = 4 * kStageBytes;
     }
     if (variant == 1) hipLaunchKernelGGL(k_blocks_generic<1>, grid, block, lds, stream, p);
     else hipLaunchKernelGGL(k_blocks_generic<0>, grid, block, lds, stream, p);

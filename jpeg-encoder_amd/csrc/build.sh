@@ -3,16 +3,17 @@
 # Python binding so that it travels with the tree.
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="${here}/../libjpegenc_mi355x.so"
+out="${JPEGENC_OUT:-${here}/../libjpegenc_mi355x.so}"        # JPEGENC_OUT / JPEGENC_BUILD_DIR: diagnostic variant builds
+bdir="${JPEGENC_BUILD_DIR:-${here}/build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-const-variable -Wno-unused-function
        -I"${here}/../../include")
 srcs=("${here}"/block_kernels.hip "${here}"/fast_kernels.hip "${here}"/fast_kernels_bytes.hip "${here}"/entropy_kernels.hip "${here}"/capi_entropy.hip "${here}"/capi_blocks.cpp "${here}"/host_encoder.cpp)
 objs=()
-mkdir -p "${here}/build"
+mkdir -p "${bdir}"
 pids=()
 for s in "${srcs[@]}"; do
-  o="${here}/build/$(basename "${s}").o"
+  o="${bdir}/$(basename "${s}").o"
   if [[ ! -f "${o}" || "${s}" -nt "${o}" || -n "$(find "${here}" -maxdepth 1 \( -name '*.h' -o -name '*.inc' \) -newer "${o}" -print -quit)" || "${here}/../../include/jpegenc_mi355x.h" -nt "${o}" ]]; then
     "${HIPCC}" "${FLAGS[@]}" -x hip -c "${s}" -o "${o}" ${EXTRA_HIPCC_FLAGS:-} &
     pids+=($!)

@@ -101,6 +101,21 @@ static int fill_geometry(BlockKernelParams *p, const jpegenc_layout &L, int widt
     p->bpm = first;
     p->wave_start[L.num_components] = waves;
     p->task_start[L.num_components] = tasks;
+    if (order == 0) {
+        p->per_group = waves;
+        p->groups = (uint32_t)cdiv(L.mcus, 64);
+    } else if (waves <= 10u) {
+        p->planar_round = p->per_group = waves;
+        uint32_t groups = 0;
+        for (int c = 0; c < L.num_components; c++) {
+            const uint32_t g = (uint32_t)cdiv(cdiv(L.blocks[c], 64), (uint64_t)(L.h[c] * L.v[c]));
+            if (g > groups) groups = g;
+        }
+        p->groups = groups;
+    } else {
+        p->per_group = 4;
+        p->groups = (tasks + 3u) / 4u;
+    }
     int rc = fill_quant(&p->q[0], tables[0]);
     if (rc) return rc;
     return fill_quant(&p->q[1], tables[1]);

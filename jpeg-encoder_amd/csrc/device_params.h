@@ -46,6 +46,11 @@ struct BlockKernelParams {
     uint64_t comp_off[4];             // first output block of each component
     uint32_t task_start[5];           // prefix sums of ceil(nblocks/64)
     uint32_t wave_groups;             // != 0: single-wave workgroups, XCD-aware id -> (group, wave) map
+    uint32_t per_group;               // waves per group (= workgroup): MCU order sum(h*v); planar see planar_round
+    uint32_t planar_round;            // planar order: != 0 -> a group holds h*v consecutive 64-block tasks of EVERY
+                                      // component (they cover the same pixels, read from HBM once); 0 -> 4 tasks in
+                                      // component-major sequence (more than 10 waves per round)
+    uint32_t groups;                  // groups per frame
     QuantDev q[2];
 };
 

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t per_group = p.order == 0 ? p.wave_start[p.ncomp] : 4u;
+    const uint32_t per_group = p.per_group;
     uint32_t group, wave_in_group;
     wave_identity(p, per_group, &group, &wave_in_group);
     const WaveTask t = decode_task(p, wave_in_group, group);
@@ -238,8 +238,7 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
     BlockKernelParams q = p;
     // measured: no gain over one workgroup per group (profiles/README.md), so it stays opt-in
     static const bool per_wave = getenv("JPEGENC_WAVE_WORKGROUPS") != nullptr;
-    const uint32_t per_group = p.order == 0 ? p.wave_start[p.ncomp] : 4u;      // <= 10 for sampling factors 1 and 2
-    const uint32_t groups = p.order == 0 ? (p.total_mcus + 63u) / 64u : (p.task_start[p.ncomp] + 3u) / 4u;
+    const uint32_t per_group = p.per_group, groups = p.groups;                 // <= 10 waves for sampling factors 1 and 2
     if (per_wave) {
         q.wave_groups = groups;
         grid = dim3(((groups + 7u) / 8u) * 8u * per_group, (unsigned)num_frames);

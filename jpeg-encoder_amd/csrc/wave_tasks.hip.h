@@ -4,7 +4,8 @@
 //     and the colour constants are wave-uniform); one LANE owns one block;
 //   * MCU order: a group is 64 MCUs and holds h*v waves per component (slot -> MCU, h_off, v_off as
 //     encode_image_interleaved walks them, encoder.rs:747-769); planar order: a task is 64
-//     consecutive blocks of a component in encode_blocks order (encoder.rs:1020-1054);
+//     consecutive blocks of a component in encode_blocks order (encoder.rs:1020-1054) and a group
+//     holds h*v tasks of every component, i.e. the tasks that read the same pixel rows;
 //   * waves never synchronise with each other.  A wave stages its 64 x 128 B of output in a
 //     private, XOR-swizzled 8 KiB LDS region so that every global store instruction writes whole
 //     128-B lines (16 B per lane, 8 consecutive lanes per block).
@@ -116,6 +117,16 @@ __device__ __forceinline__ WaveTask decode_task(const BlockKernelParams &p, uint
         const uint32_t range = w % t.per_mcu, vrow = w / t.per_mcu;          // vrow < v
         t.k_base = vrow * t.per_mcu;
         t.first = group * 64u + range * (64u / t.per_mcu);
+    } else if (p.planar_round) {
+        // the h*v tasks of component c in round `group`: every component advances through the image at
+        // the same pace, so the waves of a workgroup read the same pixel rows (one HBM read, L2 hits after)
+        int c = 0;
+        while (c + 1 < p.ncomp && wave_in_group >= p.wave_start[c + 1]) c++;
+        t.comp = c;
+        t.per_mcu = 1;
+        t.k_base = 0;
+        const uint32_t task = group * (uint32_t)(p.h[c] * p.v[c]) + (wave_in_group - p.wave_start[c]);
+        t.first = task < (p.task_start[c + 1] - p.task_start[c]) ? task * 64u : 0xFFFFFFC0u;
     } else {
         const uint32_t task = group * 4u + wave_in_group;
         int c = 0;

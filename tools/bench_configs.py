@@ -15,7 +15,7 @@ ge.load_package()
 b = importlib.import_module("jpeg_encoder_amd.binding")
 
 
-def time_blocks(name, w, h, ct, hs, vs, q, order, frames, reps=20):
+def time_blocks(name, w, h, ct, hs, vs, q, order, frames, reps=100):
     dev = torch.device("cuda:0")
     bpp = b.BPP[ct]
     fb = w * h * bpp
@@ -30,9 +30,12 @@ def time_blocks(name, w, h, ct, hs, vs, q, order, frames, reps=20):
 
     def run():
         b.blocks_device(d_px.data_ptr(), fb, frames, w, h, ct, hs, vs, qt, order, 0, d_co.data_ptr(), nblk, st.cuda_stream)
-    for _ in range(5):
-        run()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()                      # run-in: see profiles/r01_g_step_series.txt
+    while time.perf_counter() - t0 < 0.15:
+        for _ in range(8):
+            run()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(reps):
