@@ -51,6 +51,8 @@ struct BlockKernelParams {
                                       // component (they cover the same pixels, read from HBM once); 0 -> 4 tasks in
                                       // component-major sequence (more than 10 waves per round)
     uint32_t groups;                  // groups per frame
+    uint32_t xcd_chunk;               // diagnostic (JPEGENC_XCD_CONTIGUOUS): != 0 -> workgroup id x works on group
+                                      // (x % 8) * xcd_chunk + x / 8, i.e. each XCD walks one contiguous eighth
     QuantDev q[2];
 };
 

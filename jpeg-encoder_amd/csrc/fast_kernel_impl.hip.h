@@ -41,6 +41,13 @@ struct ColourConsts {
     uint32_t sel_cb, sel_cr;    // v_perm selectors building the zero-extended (r,g) / (g,b) u16 pair
     uint32_t k_cb, k_cr;        // sdot2 constants (-11059,-21709) / (-27439,-5329)
     uint32_t sh_b, sh_r;        // bit offset of the blue / red byte inside W
+    // Cb and Cr with non-negative coefficients only (so that they are udot4s like Y):
+    //   Cb = (11059 (255-r) + 21709 (255-g) + 32768 b + 65535) >> 16
+    //   Cr = (32768 r + 27439 (255-g) + 5329 (255-b) + 65535) >> 16
+    // are identical to image_buffer.rs:24-28 because 255 * 32768 + 65535 = (128 << 16) + 0x7FFF;
+    // `*_xor` complements the two negated channels of the pixel word.
+    uint32_t cb_lo, cb_hi, cb_xor;
+    uint32_t cr_lo, cr_hi, cr_xor;
     int32_t o_r, o_g, o_b;      // byte offsets (edge path)
     int32_t role[4];            // what each component is made of
     int32_t byte_index[4];      // ROLE_BYTE: which byte of the pixel
@@ -87,6 +94,11 @@ __device__ __forceinline__ uint32_t chroma32(uint32_t w, uint32_t sel, uint32_t 
     const int acc = (int)((((w >> sh) & 0xFFu) << 15) + (uint32_t)kBias);
     return (uint32_t)dot2(pair, kk, acc);                        // Cb/Cr in bits 16..23
 }
+__device__ __forceinline__ uint32_t chroma16(uint32_t w, uint32_t lo, uint32_t hi, uint32_t x) {
+    const uint32_t u = w ^ x;
+    const uint32_t t = __builtin_amdgcn_udot4(u, lo, 0xFFFFu, false) >> 8;
+    return __builtin_amdgcn_udot4(u, hi, t, false);              // Cb/Cr in bits 8..15
+}
 
 // scalar arithmetic for the clamped edge path (identical results by construction)
 __device__ __forceinline__ uint32_t edge_sample(const uint8_t *px, int role, int c, const ColourConsts &k) {
@@ -111,13 +123,26 @@ struct LumaConv {          // Y of an RGB-order pixel word
     __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return luma16(w, k); }
 #endif
 };
-struct ChromaConv {        // Cb or Cr
+// Two exact forms of Cb / Cr.  The udot4 form is 4 instructions per sample instead of 6 and wins where
+// chroma is full resolution (4:4:4: +4 %); with decimated chroma the perm + sdot2 form measures 1.5 %
+// faster on the 4K bench although it issues more (profiles/README.md), so each instantiation takes
+// the one that is faster for it.
+struct ChromaConvDot2 {    // Cb or Cr = sdot2 of a (c0, c1) pair + the third channel shifted into place
     uint32_t sel, kk, sh;
     static constexpr uint32_t kPack = 0x0C060C02u;            // byte 2 of each result
 #ifdef JPEGENC_PROBE_MEMORY_ONLY
     __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w + sel; }
 #else
     __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return chroma32(w, sel, kk, sh); }
+#endif
+};
+struct ChromaConv {        // Cb or Cr = two udot4 of the pixel word with two channels complemented
+    uint32_t lo, hi, x;
+    static constexpr uint32_t kPack = 0x0C050C01u;            // byte 1 of each result
+#ifdef JPEGENC_PROBE_MEMORY_ONLY
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w + lo; }
+#else
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return chroma16(w, lo, hi, x); }
 #endif
 };
 
@@ -183,9 +208,15 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
         if (CONV && role == ROLE_Y) {
             fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, LumaConv::kPack, LumaConv{k}, rows);
         } else if (CONV && role != ROLE_BYTE) {
-            const ChromaConv cc = {role == ROLE_CB ? k.sel_cb : k.sel_cr, role == ROLE_CB ? k.k_cb : k.k_cr,
-                                   role == ROLE_CB ? k.sh_b : k.sh_r};
-            fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, ChromaConv::kPack, cc, rows);
+            if (SX * SY == 1) {
+                const ChromaConv cc = {role == ROLE_CB ? k.cb_lo : k.cr_lo, role == ROLE_CB ? k.cb_hi : k.cr_hi,
+                                       role == ROLE_CB ? k.cb_xor : k.cr_xor};
+                fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, ChromaConv::kPack, cc, rows);
+            } else {
+                const ChromaConvDot2 cc = {role == ROLE_CB ? k.sel_cb : k.sel_cr, role == ROLE_CB ? k.k_cb : k.k_cr,
+                                           role == ROLE_CB ? k.sh_b : k.sh_r};
+                fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, ChromaConvDot2::kPack, cc, rows);
+            }
         } else if (!CONV || BPP == 4) {
             // byte b of each pixel word -> zero-extended 16-bit pair; `255 - v` as one packed subtract.
             // In the conversion kernels only CmykAsYcck's K plane (4-byte pixels, never decimated) gets here.
@@ -245,10 +276,16 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
         block = dim3(64);
         lds = kStageBytes;
     } else {
-        grid = dim3(groups, (unsigned)num_frames);
+        static const bool xcd_contig = getenv("JPEGENC_XCD_CONTIGUOUS") != nullptr;
+        uint32_t gx = groups;
+        if (xcd_contig) { q.xcd_chunk = (groups + 7u) / 8u; gx = q.xcd_chunk * 8u; }
+        grid = dim3(gx, (unsigned)num_frames);
         block = dim3(per_group * 64u);
         lds = (size_t)per_group * kStageBytes;
     }
+    // diagnostic: extra dynamic LDS per workgroup lowers the number of resident workgroups per CU
+    static const char *pad_env = getenv("JPEGENC_LDS_PAD_KB");
+    if (pad_env) lds += (size_t)atoi(pad_env) * 1024u;
     if (variant == 1) hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 1, CONV>), grid, block, lds, stream, q, k);
     else hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 0, CONV>), grid, block, lds, stream, q, k);
     return hipGetLastError();

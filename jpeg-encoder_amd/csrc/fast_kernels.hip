@@ -20,6 +20,12 @@ static bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx
     k.k_cr = pk(-27439, -5329);
     k.sh_b = 8u * (uint32_t)o_b;
     k.sh_r = 8u * (uint32_t)o_r;
+    k.cb_lo = bytes3(11059 & 255, 21709 & 255, 32768 & 255);
+    k.cb_hi = bytes3(11059 >> 8, 21709 >> 8, 32768 >> 8);
+    k.cb_xor = bytes3(255, 255, 0);
+    k.cr_lo = bytes3(32768 & 255, 27439 & 255, 5329 & 255);
+    k.cr_hi = bytes3(32768 >> 8, 27439 >> 8, 5329 >> 8);
+    k.cr_xor = bytes3(0, 255, 255);
     k.o_r = o_r; k.o_g = o_g; k.o_b = o_b;
     for (int c = 0; c < p.ncomp; c++) {
         k.role[c] = ROLE_BYTE; k.byte_index[c] = c; k.invert[c] = 0; k.plane_offset[c] = 0;

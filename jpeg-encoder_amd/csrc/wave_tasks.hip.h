@@ -94,7 +94,12 @@ __device__ __forceinline__ void wave_identity(const BlockKernelParams &p, uint32
         *group = (j / per_group) * 8u + xcd;          // >= wave_groups for the padding ids: no valid block
         *wave_in_group = j % per_group;
     } else {
-        const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        uint32_t bx = blockIdx.x;
+        if (p.xcd_chunk) {
+            bx = (bx & 7u) * p.xcd_chunk + (bx >> 3);
+            if ((blockIdx.x >> 3) >= p.xcd_chunk || bx >= p.groups) bx = 0x00FFFFFFu;     // padding id: no valid block
+        }
+        const uint32_t gw = bx * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         *group = gw / per_group;
         *wave_in_group = gw % per_group;
     }
