@@ -95,8 +95,9 @@ __global__ void __launch_bounds__(640) k_blocks_generic(const BlockKernelParams 
 }
 
 // ---- symbol statistics for optimised Huffman tables (encoder.rs:1086-1200) -------------------
-// One lane per block; per-workgroup LDS histograms (4 x 257 counters of the two tables), one
-// global atomic per non-zero counter at the end.  DC differences chain through the whole
+// One lane per block; per-workgroup LDS histograms (4 x 257 counters of the two tables) kept in 16
+// interleaved copies - lane l counts in copy l % 16, so the few hot symbols do not serialise a
+// wave's LDS atomics on one address - and one global atomic per non-zero counter at the end.  DC differences chain through the whole
 // component with no restart reset (encoder.rs:1104-1116): lane b reads block b-1's DC.
 __device__ __forceinline__ uint32_t nbits(int v) {      // get_num_bits, encoder.rs:1244-1257
     const uint32_t a = (uint32_t)(v < 0 ? -v : v);
@@ -104,9 +105,11 @@ __device__ __forceinline__ uint32_t nbits(int v) {      // get_num_bits, encoder
 }
 
 __global__ void __launch_bounds__(256) k_histogram(const HistKernelParams p) {
-    __shared__ uint32_t h[2][2][257];
-    for (uint32_t i = threadIdx.x; i < 2 * 2 * 257; i += blockDim.x) (&h[0][0][0])[i] = 0;
+    constexpr uint32_t kCopies = 16;
+    __shared__ uint32_t h[2 * 2 * 257 * kCopies];
+    for (uint32_t i = threadIdx.x; i < 2 * 2 * 257 * kCopies; i += blockDim.x) h[i] = 0;
     __syncthreads();
+    const uint32_t copy = threadIdx.x & (kCopies - 1u);
     uint64_t total = 0;
     for (int c = 0; c < p.ncomp; c++) total += p.nblocks[c];
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < total;
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(256) k_histogram(const HistKernelParams p) {
         uint64_t local = b;
         while (local >= p.nblocks[c]) { local -= p.nblocks[c]; c++; }
         const int16_t *blk = p.coeffs + (p.comp_off[c] + local) * 64u;
-        uint32_t *dc = h[p.table[c]][0], *ac = h[p.table[c]][1];
+        uint32_t *dc = h + (uint32_t)p.table[c] * (2u * 257u * kCopies) + copy, *ac = dc + 257u * kCopies;
         // 64 coefficients as 8 x 16-byte loads
         int16_t v[64];
         const uint4 *src = reinterpret_cast<const uint4 *>(blk);
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256) k_histogram(const HistKernelParams p) {
             }
         }
         const int prev = local == 0 ? 0 : (int)blk[-64];
-        atomicAdd(&dc[nbits((int16_t)(v[0] - prev))], 1u);
+        atomicAdd(&dc[nbits((int16_t)(v[0] - prev)) * kCopies], 1u);
         int scans = 1, per = 64;
         if (p.progressive_scans) { scans = p.progressive_scans - 1; per = 64 / scans; }
         int band_end = p.progressive_scans ? (scans == 1 ? 64 : per) : 64;
@@ -147,8 +150,8 @@ __global__ void __launch_bounds__(256) k_histogram(const HistKernelParams p) {
             if (value == 0) {
                 zero_run++;
             } else {
-                while (zero_run > 15) { atomicAdd(&ac[0xF0], 1u); zero_run -= 16; }
-                atomicAdd(&ac[(zero_run << 4) | (int)nbits(value)], 1u);
+                while (zero_run > 15) { atomicAdd(&ac[0xF0u * kCopies], 1u); zero_run -= 16; }
+                atomicAdd(&ac[(uint32_t)((zero_run << 4) | (int)nbits(value)) * kCopies], 1u);
                 zero_run = 0;
             }
         }
@@ -156,7 +159,9 @@ __global__ void __launch_bounds__(256) k_histogram(const HistKernelParams p) {
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 2 * 2 * 257; i += blockDim.x) {
-        const uint32_t n = (&h[0][0][0])[i];
+        uint32_t n = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kCopies; k++) n += h[i * kCopies + ((k + threadIdx.x) & (kCopies - 1u))];
         if (n) atomicAdd(&p.freq[i], n);
     }
     // dc_freq[256] = ac_freq[256] = 1 for every table that is built (encoder.rs:1089-1095)
@@ -191,7 +196,7 @@ hipError_t launch_histogram(const HistKernelParams &p, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(p.freq, 0, sizeof(uint32_t) * 2 * 2 * 257, stream);
     if (e != hipSuccess) return e;
     unsigned blocks = (unsigned)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;          // 2 resident workgroups per CU (66 KB of LDS each): amortises zeroing + reduction
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_histogram, dim3(blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
