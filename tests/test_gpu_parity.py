@@ -147,6 +147,26 @@ def test_blocks_device_batch_with_strides(binding, oracle, synth):
         assert (out[k, L.total_blocks:] == -7).all()      # padding blocks untouched
 
 
+@pytest.mark.parametrize("w,h", [(65535, 9), (9, 65535)])
+def test_blocks_maximum_dimensions(binding, oracle, synth, w, h):
+    """u16::MAX wide / tall (Encoder::encode takes u16 dimensions, encoder.rs:440-446)."""
+    px = synth.noise_image(w, h, 3, 5)
+    for hs, vs, order in [(2, 2, 0), (1, 1, 1), (2, 1, 1)]:
+        _same(binding.blocks_host(px, w, h, binding.RGB, hs, vs, 85, order),
+              oracle.encode_blocks(px, w, h, oracle.RGB, hs, vs, 85, order))
+
+
+def test_blocks_frame_beyond_2gib(binding, oracle, synth):
+    """A frame of 2^31 bytes or more leaves the 32-bit row offsets of the tuned kernels and takes the
+    generic kernel (launch_blocks_fast declines it): same results."""
+    w, h = 32768, 21846                       # 32768 * 21846 * 3 = 2 147 549 184 B
+    px = synth.noise_image(w, h, 3, 11)
+    assert px.size >= 1 << 31
+    got = binding.blocks_host(px, w, h, binding.RGB, 2, 2, 90, 0)
+    want = oracle.encode_blocks(px, w, h, oracle.RGB, 2, 2, 90, 0)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_config2_4k_420_full_size(binding, oracle, synth):
     """BASELINE config 2: 3840x2160 RGB q=90 4:2:0 — full compare plus size-independent checks."""
     w, h = 3840, 2160
@@ -278,6 +298,17 @@ def test_encoder_files_match_oracle(binding, oracle, synth, name, device_entropy
     assert im.size == (258, 128) and im.mode == "RGB"
     if kw["quality"] >= 80:
         assert np.abs(np.asarray(im).astype(np.int16) - px.astype(np.int16)).max() < 20   # lib.rs:176-185
+
+
+@pytest.mark.parametrize("w,h", [(65535, 8), (8, 65535)])
+@pytest.mark.parametrize("device_entropy", [True, False], ids=["gpu-entropy", "host-entropy"])
+def test_encoder_maximum_dimensions_file(binding, oracle, synth, w, h, device_entropy):
+    """Whole files at u16::MAX width / height: baseline, and restart + optimised + progressive."""
+    px = synth.noise_image(w, h, 3, 21)
+    for kw in (dict(quality=80), dict(quality=92, progressive_scans=5, optimize=True, restart_interval=7, sampling=(2, 1))):
+        got = _encoder(binding, kw, device_entropy).encode(px, w, h, binding.RGB)
+        want = oracle.encode_jpeg(px, w, h, oracle.RGB, **kw)
+        assert got == want, f"{kw}: {len(got)} vs {len(want)} bytes"
 
 
 def test_encoder_file_anchors(binding, synth):
@@ -575,3 +606,32 @@ def test_encode_device_resident_input(binding, oracle, synth):
             e = _encoder(binding, kw, on)
             assert e.encode_device(d.data_ptr(), 300, 170, binding.RGB) == oracle.encode_jpeg(px, 300, 170, oracle.RGB, **kw)
     assert bytes(d.cpu().numpy().reshape(-1)) == px.tobytes()          # input untouched
+
+
+def test_handles_are_independent_across_threads(binding, oracle, synth):
+    """Boundary contract (threading): one handle per thread, the library is re-entrant
+    across handles.  Eight threads encode different images with different settings at once."""
+    import threading
+    jobs = []
+    for i in range(8):
+        w, h = 97 + 31 * i, 61 + 17 * i
+        kw = [dict(quality=90), dict(quality=75, sampling=(2, 2)), dict(quality=60, progressive_scans=4),
+              dict(quality=85, optimize=True), dict(quality=95, restart_interval=3)][i % 5]
+        jobs.append((synth.lcg_image(w, h, 3, 100 + i), w, h, kw))
+    out, errs = [None] * len(jobs), []
+
+    def run(i):
+        try:
+            px, w, h, kw = jobs[i]
+            for _ in range(3):
+                out[i] = _encoder(binding, kw, device_entropy=bool(i & 1)).encode(px, w, h, binding.RGB)
+        except Exception as exc:                                  # surfaced below
+            errs.append((i, exc))
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i, (px, w, h, kw) in enumerate(jobs):
+        assert out[i] == oracle.encode_jpeg(px, w, h, oracle.RGB, **kw), i
