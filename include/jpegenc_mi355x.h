@@ -146,6 +146,21 @@ int jpegenc_blocks_device(const void *d_pixels, size_t pixel_frame_stride, int n
                           const jpegenc_qtable tables[2], int order, int fdct_variant,
                           void *d_coeffs, size_t coeff_frame_stride, void *hip_stream);
 
+/* Streaming pipeline of coefficient tiles: what the north star describes and what a host Huffman coder
+ * (JfifWriter::write_block over a frame's blocks, writer.rs:331-388) is fed from.  `frames[i]` are host
+ * images of identical geometry (`frame_len` >= w*h*bpp bytes each, validated like Encoder::encode).
+ * Frame i goes host -> device -> fused kernel -> pinned host tile; `callback(user, i, coeffs,
+ * num_blocks)` is invoked on the calling thread, in frame order, with the frame's layout.total_blocks
+ * blocks (64 zig-zag i16 each, `order` as in jpegenc_blocks_device); the tile is valid until the
+ * callback returns; a non-zero return aborts with JPEGENC_ERR_WRITE.  Copies of neighbouring frames
+ * overlap the kernel (one stream per direction).  Pinned frames (hipHostMalloc / hipHostRegister)
+ * are uploaded in place; pageable frames are staged through internal pinned buffers by this thread. */
+typedef int (*jpegenc_tile_callback)(void *user, int frame_index, const int16_t *coeffs, size_t num_blocks);
+int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame_len, int num_frames,
+                          int width, int height, int color_type, int h_sampling, int v_sampling,
+                          const jpegenc_qtable tables[2], int order, int fdct_variant,
+                          jpegenc_tile_callback callback, void *user);
+
 /* Host-resident convenience: H2D + kernel + D2H + synchronise on `device`.  `pixels_len` is
  * validated like Encoder::encode (encoder.rs:447-454); `coeffs_capacity` is in i16 values. */
 int jpegenc_blocks_host(int device, const uint8_t *pixels, size_t pixels_len, int width, int height,

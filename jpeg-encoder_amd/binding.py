@@ -37,7 +37,7 @@ F_4_1, F_4_2, F_1_4, F_2_4 = 0x41, 0x42, 0x14, 0x24
 ABI_SYMBOLS = [
     "jpegenc_abi_version", "jpegenc_device_count", "jpegenc_last_error", "jpegenc_status_string",
     "jpegenc_qtable_init", "jpegenc_bytes_per_pixel", "jpegenc_layout_init",
-    "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_histogram_device",
+    "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_histogram_device",
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
     "jpegenc_encoder_set_device_entropy",
     "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
@@ -111,6 +111,8 @@ def lib():
                                             C.c_void_p, C.c_size_t, C.c_void_p]
         l.jpegenc_blocks_host.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.POINTER(QTable), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        l.jpegenc_blocks_stream.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.POINTER(QTable), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         l.jpegenc_histogram_device.argtypes = [C.c_void_p, C.POINTER(Layout), C.c_int, C.c_void_p, C.c_void_p]
         l.jpegenc_encoder_new.restype = C.c_void_p
         l.jpegenc_encoder_new.argtypes = [C.c_int]
@@ -195,6 +197,33 @@ def blocks_host(pixels, width, height, color_type, hs, vs, quality=None, order=O
     check(lib().jpegenc_blocks_host(device, px.ctypes.data, px.size, width, height, color_type, hs, vs, q,
                                     order, variant, out.ctypes.data, out.size))
     return out[:total]
+
+
+TILE_CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int16), C.c_size_t)
+
+
+def blocks_stream(frame_ptrs, frame_len, width, height, color_type, hs, vs, q, on_tile, order=ORDER_MCU,
+                  variant=FDCT_SCALAR, device=0):
+    """jpegenc_blocks_stream: host frames (addresses in `frame_ptrs`) -> on_tile(index, ndarray view) per
+    frame, in order, with uploads / kernel / downloads of neighbouring frames overlapped.  The view is
+    only valid inside the callback; a non-zero / raising callback aborts the stream."""
+    n = len(frame_ptrs)
+    ptrs = (C.c_void_p * max(n, 1))(*frame_ptrs)
+    err = []
+
+    def trampoline(_user, index, coeffs, num_blocks):
+        try:
+            view = np.ctypeslib.as_array(coeffs, shape=(num_blocks, 64))
+            return int(on_tile(index, view) or 0)
+        except BaseException as exc:          # never unwind through C
+            err.append(exc)
+            return -1
+    cb = TILE_CALLBACK(trampoline)
+    rc = lib().jpegenc_blocks_stream(device, ptrs, frame_len, n, width, height, color_type, hs, vs, q, order,
+                                     variant, cb, None)
+    if err:
+        raise err[0]
+    check(rc)
 
 
 def blocks_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, color_type, hs, vs, q,

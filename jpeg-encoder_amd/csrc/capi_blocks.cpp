@@ -319,6 +319,128 @@ int jpegenc_blocks_host(int device, const uint8_t *pixels, size_t pixels_len, in
     return JPEGENC_OK;
 }
 
+// ---- streaming pipeline of coefficient tiles (the north-star data path) --------------------------
+// host frames -> H2D -> fused kernel -> D2H of the frame's coefficient tile into pinned memory ->
+// callback (where the caller's Huffman coder runs).  One stream per copy direction and one for the
+// kernel keep both DMA engines and the compute queue busy; the dependencies between the streams are
+// resolved by this thread (hipEventSynchronize before enqueueing the dependent operation): GPU-side
+// cross-stream waits serialise the two copy queues on this stack and halve the rate.
+namespace {
+struct StreamSlot {
+    void *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+    hipEvent_t up = nullptr, kernel = nullptr, down = nullptr;
+};
+struct StreamPipe {
+    static constexpr int kSlots = 4;
+    StreamSlot slot[kSlots];
+    hipStream_t s_up = nullptr, s_k = nullptr, s_dn = nullptr;
+    ~StreamPipe() {
+        if (s_up) (void)hipStreamSynchronize(s_up);
+        if (s_k) (void)hipStreamSynchronize(s_k);
+        if (s_dn) (void)hipStreamSynchronize(s_dn);
+        for (auto &x : slot) {
+            if (x.h_in) (void)hipHostFree(x.h_in);
+            if (x.h_out) (void)hipHostFree(x.h_out);
+            if (x.d_in) (void)hipFree(x.d_in);
+            if (x.d_out) (void)hipFree(x.d_out);
+            if (x.up) (void)hipEventDestroy(x.up);
+            if (x.kernel) (void)hipEventDestroy(x.kernel);
+            if (x.down) (void)hipEventDestroy(x.down);
+        }
+        if (s_up) (void)hipStreamDestroy(s_up);
+        if (s_k) (void)hipStreamDestroy(s_k);
+        if (s_dn) (void)hipStreamDestroy(s_dn);
+    }
+};
+bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+
+int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame_len, int num_frames,
+                          int width, int height, int color_type, int hs, int vs, const jpegenc_qtable tables[2],
+                          int order, int fdct_variant, jpegenc_tile_callback callback, void *user) {
+    const int bpp = jpegenc_bytes_per_pixel(color_type);
+    if (!bpp) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");
+    if (width < 0 || height < 0 || width > 65535 || height > 65535)
+        return fail(JPEGENC_ERR_INVALID_ARGUMENT, "image dimensions must fit u16");
+    const size_t required = (size_t)width * (size_t)height * (size_t)bpp;
+    if (frame_len < required)                                          // encoder.rs:447-454
+        return fail(JPEGENC_ERR_BAD_IMAGE_DATA, "Image data too small for dimensions and color_type: " +
+                    std::to_string(frame_len) + " need at least " + std::to_string(required));
+    if (width == 0 || height == 0) return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "Image dimensions must be non zero");
+    if (num_frames < 0 || (num_frames > 0 && !frames) || !callback || !tables) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    for (int i = 0; i < num_frames; i++)
+        if (!frames[i]) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame pointer");
+    jpegenc_layout L;
+    int rc = jpegenc_layout_init(&L, width, height, color_type, hs, vs, order);
+    if (rc) return rc;
+    if (num_frames == 0) return JPEGENC_OK;
+    rc = ensure_device_ready(device);
+    if (rc) return rc;
+
+    const size_t tile_bytes = (size_t)L.total_blocks * 128;
+    StreamPipe pipe;
+    const int slots = num_frames < StreamPipe::kSlots ? num_frames : StreamPipe::kSlots;
+    JPEGENC_HIP(hipStreamCreateWithFlags(&pipe.s_up, hipStreamNonBlocking));
+    JPEGENC_HIP(hipStreamCreateWithFlags(&pipe.s_k, hipStreamNonBlocking));
+    JPEGENC_HIP(hipStreamCreateWithFlags(&pipe.s_dn, hipStreamNonBlocking));
+    bool all_pinned = true;
+    for (int i = 0; i < num_frames && all_pinned; i++) all_pinned = is_pinned_host(frames[i]);
+    for (int j = 0; j < slots; j++) {
+        StreamSlot &x = pipe.slot[j];
+        if (!all_pinned) JPEGENC_HIP(hipHostMalloc(&x.h_in, required, hipHostMallocDefault));
+        JPEGENC_HIP(hipHostMalloc(&x.h_out, tile_bytes, hipHostMallocDefault));
+        JPEGENC_HIP(hipMalloc(&x.d_in, required));
+        JPEGENC_HIP(hipMalloc(&x.d_out, tile_bytes));
+        JPEGENC_HIP(hipEventCreateWithFlags(&x.up, hipEventDisableTiming));
+        JPEGENC_HIP(hipEventCreateWithFlags(&x.kernel, hipEventDisableTiming));
+        JPEGENC_HIP(hipEventCreateWithFlags(&x.down, hipEventDisableTiming));
+    }
+    // An event that was never recorded counts as complete, so the first round needs no special case.
+    auto upload = [&](int i) -> int {
+        StreamSlot &x = pipe.slot[i % slots];
+        JPEGENC_HIP(hipEventSynchronize(x.kernel));                    // the kernel of frame i - slots has read d_in
+        const void *src = frames[i];
+        if (!all_pinned) {
+            JPEGENC_HIP(hipEventSynchronize(x.up));                    // the previous upload from h_in has left
+            memcpy(x.h_in, frames[i], required);
+            src = x.h_in;
+        }
+        JPEGENC_HIP(hipMemcpyAsync(x.d_in, src, required, hipMemcpyHostToDevice, pipe.s_up));
+        JPEGENC_HIP(hipEventRecord(x.up, pipe.s_up));
+        return JPEGENC_OK;
+    };
+    auto deliver = [&](int i) -> int {
+        StreamSlot &x = pipe.slot[i % slots];
+        JPEGENC_HIP(hipEventSynchronize(x.down));
+        const int cb = callback(user, i, (const int16_t *)x.h_out, (size_t)L.total_blocks);
+        if (cb != 0) return fail(JPEGENC_ERR_WRITE, "tile callback returned " + std::to_string(cb));
+        return JPEGENC_OK;
+    };
+    const int ahead = slots > 2 ? 2 : 1;
+    for (int i = 0; i < ahead && i < num_frames; i++)
+        if ((rc = upload(i))) return rc;
+    for (int i = 0; i < num_frames; i++) {
+        StreamSlot &x = pipe.slot[i % slots];
+        if (i + ahead < num_frames && (rc = upload(i + ahead))) return rc;
+        if (i >= slots && (rc = deliver(i - slots))) return rc;       // frees h_out of this slot (in frame order)
+        JPEGENC_HIP(hipEventSynchronize(x.up));
+        rc = jpegenc_blocks_device(x.d_in, required, 1, width, height, color_type, hs, vs, tables, order, fdct_variant,
+                                   x.d_out, L.total_blocks, pipe.s_k);
+        if (rc) return rc;
+        JPEGENC_HIP(hipEventRecord(x.kernel, pipe.s_k));
+        JPEGENC_HIP(hipEventSynchronize(x.kernel));
+        JPEGENC_HIP(hipMemcpyAsync(x.h_out, x.d_out, tile_bytes, hipMemcpyDeviceToHost, pipe.s_dn));
+        JPEGENC_HIP(hipEventRecord(x.down, pipe.s_dn));
+    }
+    for (int i = num_frames > slots ? num_frames - slots : 0; i < num_frames; i++)
+        if ((rc = deliver(i))) return rc;
+    return JPEGENC_OK;
+}
+
 int jpegenc_histogram_device(const void *d_coeffs_planar, const jpegenc_layout *L, int progressive_scans,
                              void *d_freq, void *hip_stream) {
     if (!d_coeffs_planar || !L || !d_freq) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");

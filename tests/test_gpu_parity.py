@@ -635,3 +635,42 @@ def test_handles_are_independent_across_threads(binding, oracle, synth):
     assert not errs, errs
     for i, (px, w, h, kw) in enumerate(jobs):
         assert out[i] == oracle.encode_jpeg(px, w, h, oracle.RGB, **kw), i
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned"])
+def test_blocks_stream_tiles_in_order(binding, oracle, synth, pinned):
+    """jpegenc_blocks_stream: eleven frames through the upload / kernel / download pipeline (more frames
+    than pipeline slots), tiles delivered in frame order and equal to the oracle's."""
+    import torch
+    w, h, n = 333, 211, 11
+    frames = [np.ascontiguousarray(synth.lcg_image(w, h, 3, 900 + i)) for i in range(n)]
+    keep = frames
+    if pinned:
+        keep = [torch.from_numpy(f.copy()).pin_memory() for f in frames]
+        ptrs = [t.data_ptr() for t in keep]
+    else:
+        ptrs = [f.ctypes.data for f in frames]
+    q = binding.qtables(77)
+    seen = []
+
+    def on_tile(index, tile):
+        seen.append((index, tile.copy()))
+    binding.blocks_stream(ptrs, frames[0].size, w, h, binding.RGB, 2, 2, q, on_tile)
+    assert [i for i, _ in seen] == list(range(n))
+    for i, tile in seen:
+        _same(tile, oracle.encode_blocks(frames[i], w, h, oracle.RGB, 2, 2, 77, 0))
+    del keep
+
+
+def test_blocks_stream_errors_and_abort(binding, synth):
+    w, h = 64, 48
+    f = np.ascontiguousarray(synth.lcg_image(w, h, 3, 1))
+    q = binding.qtables(80)
+    with pytest.raises(binding.JpegEncError) as e:
+        binding.blocks_stream([f.ctypes.data], f.size - 1, w, h, binding.RGB, 1, 1, q, lambda i, t: 0)
+    assert e.value.status == binding.ERR_BAD_IMAGE_DATA
+    calls = []
+    with pytest.raises(binding.JpegEncError) as e:
+        binding.blocks_stream([f.ctypes.data] * 6, f.size, w, h, binding.RGB, 1, 1, q, lambda i, t: calls.append(i) or (7 if i == 2 else 0))
+    assert e.value.status == binding.ERR_WRITE and calls == [0, 1, 2]
+    binding.blocks_stream([], f.size, w, h, binding.RGB, 1, 1, q, lambda i, t: 0)      # empty batch is fine
