@@ -326,13 +326,16 @@ def main():
                 binding.check(binding.lib().jpegenc_encoder_encode_batch_to_buffers(
                     enc._h, ptrs, arrs[0].size, n, W, H, binding.RGB, optrs, caps, lens))
             run()                                                    # warm-up: buffers, page faults
-            t1 = time.perf_counter()
-            run()
-            dt = time.perf_counter() - t1
+            times = []
+            for _ in range(5):
+                t1 = time.perf_counter()
+                run()
+                times.append(time.perf_counter() - t1)
+            dt = sorted(times)[len(times) // 2]                      # median of 5 batches
             result["end_to_end"] = {"value": round(n * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
                                     "what": "pageable host RGB (Criterion pattern) -> JPEG bytes in host buffers: "
                                             "H2D + fused kernel + device entropy coding + D2H of compressed bytes, "
-                                            f"{n} frames, one GPU, up to 16 host threads of {os.cpu_count()}",
+                                            f"{n} frames per batch (median of 5 batches), one GPU, up to 16 host threads of {os.cpu_count()}",
                                     "jpeg_bytes_per_frame": int(sum(lens) / n)}
     if rank == 0:
         print(json.dumps(result))
