@@ -563,9 +563,10 @@ def test_randomised_configurations(binding, oracle, synth):
     """Fuzz-style sweep (the reference's fuzz targets only ask 'does not panic'; here every random
     configuration must also be byte-identical to the oracle): size, ColorType, sampling factor,
     quality, scan mode, restart interval, custom tables, FDCT build, entropy coder."""
-    rng = np.random.default_rng(20261002)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("JPEGENC_FUZZ_SEED", "20261002")))
     samplings = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 2), (1, 4), (2, 4)]
-    for trial in range(60):
+    for trial in range(int(os.environ.get("JPEGENC_FUZZ_TRIALS", "60"))):     # longer soaks: set the two variables
         ct = int(rng.integers(0, 9))
         w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
         px = rng.integers(0, 256, (h, w, binding.BPP[ct]), dtype=np.uint8)
