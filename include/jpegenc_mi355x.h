@@ -261,6 +261,11 @@ int  jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int
 int  jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len,
                                       int width, int height, int color_type, uint8_t *out,
                                       size_t out_capacity, size_t *out_len);
+/* Encoder::new_file(path, quality) + encode (encoder.rs:1204-1219): the file is created (truncated)
+ * first, like File::create at construction time, so it exists - possibly empty - even when the image
+ * is then rejected; creation or write failures are JPEGENC_ERR_WRITE (IoError). */
+int  jpegenc_encoder_encode_to_file(jpegenc_encoder *e, const char *path, const uint8_t *data,
+                                    size_t len, int width, int height, int color_type);
 /* Encoder::encode_image with a user ImageBuffer (image_buffer.rs:86-98): `fill_row(user, y,
  * planes)` must append `width` already-converted samples of row y to each of the
  * jpeg_color_type's planes (1, 3 or 4 pointers, each `width` bytes). */

@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_restart_interval", "jpegenc_encoder_set_optimized_huffman_tables",
     "jpegenc_encoder_optimized_huffman_tables", "jpegenc_encoder_add_app_segment",
     "jpegenc_encoder_add_icc_profile", "jpegenc_encoder_add_exif_metadata",
-    "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_to_buffer",
+    "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_to_file",
     "jpegenc_encoder_encode_image",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
@@ -358,6 +358,12 @@ class Encoder:
         cb = WRITE_FN(sink)
         check(lib().jpegenc_encoder_encode(self._h, px.ctypes.data, px.size, width, height, color_type, cb, None))
         return b"".join(chunks)
+
+    def encode_to_file(self, path, pixels, width, height, color_type):
+        """Encoder::new_file(path, q) + encode: the file is created first, then written."""
+        px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
+        lib().jpegenc_encoder_encode_to_file.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        check(lib().jpegenc_encoder_encode_to_file(self._h, os.fsencode(path), px.ctypes.data, px.size, width, height, color_type))
 
     def encode_device(self, d_pixels_ptr, width, height, color_type):
         """Encode an image that is already in device memory (raw pointer, e.g. torch data_ptr())."""

@@ -973,6 +973,21 @@ int jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, si
     return JPEGENC_OK;
 }
 
+static int file_sink(void *user, const uint8_t *data, size_t n) {
+    return fwrite(data, 1, n, (FILE *)user) == n ? 0 : 1;
+}
+
+int jpegenc_encoder_encode_to_file(jpegenc_encoder *e, const char *path, const uint8_t *data, size_t len, int width,
+                                   int height, int color_type) {
+    REQUIRE(e);
+    if (!path) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null path");
+    FILE *f = fopen(path, "wb");                                      // File::create, encoder.rs:1216
+    if (!f) return fail(JPEGENC_ERR_WRITE, std::string("cannot create ") + path);
+    int rc = jpegenc_encoder_encode(e, data, len, width, height, color_type, file_sink, f);
+    if (fclose(f) != 0 && rc == JPEGENC_OK) rc = fail(JPEGENC_ERR_WRITE, std::string("cannot write ") + path);
+    return rc;
+}
+
 int jpegenc_encoder_encode_image(jpegenc_encoder *e, int jct, int width, int height, jpegenc_fill_row_fn fill_row,
                                  void *image_user, jpegenc_write_fn sink, void *sink_user) {
     REQUIRE(e);

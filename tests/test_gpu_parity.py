@@ -675,3 +675,18 @@ def test_blocks_stream_errors_and_abort(binding, synth):
         binding.blocks_stream([f.ctypes.data] * 6, f.size, w, h, binding.RGB, 1, 1, q, lambda i, t: calls.append(i) or (7 if i == 2 else 0))
     assert e.value.status == binding.ERR_WRITE and calls == [0, 1, 2]
     binding.blocks_stream([], f.size, w, h, binding.RGB, 1, 1, q, lambda i, t: 0)      # empty batch is fine
+
+
+def test_encode_to_file_like_new_file(binding, oracle, synth, tmp_path):
+    """Encoder::new_file (encoder.rs:1204-1219): file created first, IoError when it cannot be."""
+    px = synth.test_img_rgb()
+    out = tmp_path / "a.jpg"
+    binding.Encoder(85).encode_to_file(str(out), px, 258, 128, binding.RGB)
+    assert out.read_bytes() == oracle.encode_jpeg(px, 258, 128, oracle.RGB, 85)
+    with pytest.raises(binding.JpegEncError) as e:
+        binding.Encoder(85).encode_to_file(str(tmp_path / "no_such_dir" / "b.jpg"), px, 258, 128, binding.RGB)
+    assert e.value.status == binding.ERR_WRITE
+    short = tmp_path / "c.jpg"
+    with pytest.raises(binding.JpegEncError) as e:
+        binding.Encoder(85).encode_to_file(str(short), px.reshape(-1)[:-1], 258, 128, binding.RGB)
+    assert e.value.status == binding.ERR_BAD_IMAGE_DATA and short.exists() and short.stat().st_size == 0
