@@ -128,6 +128,9 @@ const char *jpegenc_status_string(int status);
  * JPEGENC_Q_CUSTOM (values clamped to 1..=2048, not quality-scaled, :250-259). */
 int jpegenc_qtable_init(jpegenc_qtable *out, int table_type, const uint16_t custom[64],
                         int quality, int luma);
+/* SamplingFactor::from_factors (encoder.rs:157-171): the enum value, or -1 where the reference
+ * returns None. */
+int jpegenc_sampling_factor_from_factors(int horizontal, int vertical);
 /* ColorType::get_bytes_per_pixel (encoder.rs:101-111); 0 for an unknown type. */
 int jpegenc_bytes_per_pixel(int color_type);
 /* init_components + block-count rules of both drivers (encoder.rs:569-631, 713-717, 1012-1025). */

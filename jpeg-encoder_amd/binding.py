@@ -36,7 +36,7 @@ F_4_1, F_4_2, F_1_4, F_2_4 = 0x41, 0x42, 0x14, 0x24
 # every symbol include/jpegenc_mi355x.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "jpegenc_abi_version", "jpegenc_device_count", "jpegenc_last_error", "jpegenc_status_string",
-    "jpegenc_qtable_init", "jpegenc_bytes_per_pixel", "jpegenc_layout_init",
+    "jpegenc_qtable_init", "jpegenc_bytes_per_pixel", "jpegenc_sampling_factor_from_factors", "jpegenc_layout_init",
     "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_histogram_device",
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
     "jpegenc_encoder_set_device_entropy",

@@ -283,6 +283,13 @@ int jpegenc_blocks_device(const void *d_pixels, size_t pixel_frame_stride, int n
     return JPEGENC_OK;
 }
 
+int jpegenc_sampling_factor_from_factors(int horizontal, int vertical) {      // encoder.rs:157-171
+    static const int ok[8][2] = {{1, 1}, {1, 2}, {1, 4}, {2, 1}, {2, 2}, {2, 4}, {4, 1}, {4, 2}};
+    for (const auto &f : ok)
+        if (f[0] == horizontal && f[1] == vertical) return (horizontal << 4) | vertical;
+    return -1;
+}
+
 int jpegenc_blocks_host(int device, const uint8_t *pixels, size_t pixels_len, int width, int height, int color_type,
                         int hs, int vs, const jpegenc_qtable tables[2], int order, int fdct_variant,
                         int16_t *coeffs, size_t coeffs_capacity) {

@@ -165,3 +165,14 @@ def test_free_functions(binding, oracle):
         assert tuple(out)[:3] == oracle.rgb_to_ycbcr(int(r), int(g), int(b))
         binding.lib().jpegenc_cmyk_to_ycck(int(r), int(g), int(b), int(k), out)
         assert tuple(out) == oracle.cmyk_to_ycck(int(r), int(g), int(b), int(k))
+
+
+def test_sampling_factor_from_factors(binding):
+    """SamplingFactor::from_factors (encoder.rs:157-171) and the table test at :1302-1321."""
+    f = binding.lib().jpegenc_sampling_factor_from_factors
+    valid = {(1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2)}
+    for h in range(0, 6):
+        for v in range(0, 6):
+            want = (h << 4) | v if (h, v) in valid else -1
+            assert f(h, v) == want
+    assert f(2, 2) == binding.F_2_2 and f(4, 1) == binding.F_4_1
