@@ -45,6 +45,7 @@ struct BlockKernelParams {
     uint32_t nblocks[4];
     uint64_t comp_off[4];             // first output block of each component
     uint32_t task_start[5];           // prefix sums of ceil(nblocks/64)
+    unsigned long long *timing;       // diagnostic build (-DJPEGENC_WAVE_TIMING): [role][phase] cycle sums + wave counts
     uint32_t wave_groups;             // != 0: single-wave workgroups, XCD-aware id -> (group, wave) map
     uint32_t per_group;               // waves per group (= workgroup): MCU order sum(h*v); planar see planar_round
     uint32_t planar_round;            // planar order: != 0 -> a group holds h*v consecutive 64-block tasks of EVERY

@@ -173,6 +173,9 @@ struct ByteConv {          // the sample is a byte of the pixel word itself
 template <int BPP, int SX, int SY, int VARIANT, bool CONV>
 __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef JPEGENC_WAVE_TIMING
+    const uint64_t tm0 = __builtin_readcyclecounter();
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t per_group = p.per_group;
@@ -194,6 +197,11 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
     const uint32_t first = (uint32_t)me.y0 * pitch + (uint32_t)me.x0 * BPP;
     const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * BPP;
     uint32_t rows[8][4];
+#ifdef JPEGENC_WAVE_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t tm1 = __builtin_readcyclecounter();        // prologue done: block origin and row offsets known
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 
 #if defined(JPEGENC_PROBE_MEMORY_ONLY) && JPEGENC_PROBE_MEMORY_ONLY == 5   // stores only
     {
@@ -244,6 +252,12 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
             rows[y][2] = v[7] | (v[6] << 16); rows[y][3] = v[4] | (v[5] << 16);
         }
     }
+#ifdef JPEGENC_WAVE_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" :: "v"(rows[7][3]), "v"(rows[0][0]));
+    const uint64_t tm2 = __builtin_readcyclecounter();        // rows loaded and converted
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     uint32_t packed[32];
 #ifdef JPEGENC_PROBE_MEMORY_ONLY   // diagnostic build: same loads and stores, no block math
 #pragma unroll
@@ -257,9 +271,31 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
     for (int j = 0; j < 32; j++) x ^= packed[j];
     if (x == 0x12345u) frame_out[lane].x = x;
 #else
+#ifdef JPEGENC_WAVE_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" :: "v"(packed[0]), "v"(packed[31]));
+    const uint64_t tm3 = __builtin_readcyclecounter();        // FDCT + quantiser done
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     stage_and_store(p, t, smem + wave * kStageBytes, lane, packed, frame_out);
 #endif
+#ifdef JPEGENC_WAVE_TIMING
+    __builtin_amdgcn_s_waitcnt(0);                             // stores retired (vmcnt 0): end of the wave's life
+    const uint64_t tm4 = __builtin_readcyclecounter();
+    if (p.timing && lane == 0) {       // one 32-byte record per wave, no atomics (they would dominate the kernel)
+        const size_t id = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave;
+        if (id < (1u << 20)) {
+            uint32_t *tq = reinterpret_cast<uint32_t *>(p.timing) + id * 8;
+            tq[0] = (uint32_t)(tm1 - tm0); tq[1] = (uint32_t)(tm2 - tm1); tq[2] = (uint32_t)(tm3 - tm2); tq[3] = (uint32_t)(tm4 - tm3);
+            tq[4] = 1u + (uint32_t)(role == ROLE_Y || role == ROLE_BYTE ? 0 : 1);
+        }
+    }
+#endif
 }
+
+#ifdef JPEGENC_WAVE_TIMING
+unsigned long long *wave_timing_buffer();      // fast_kernels.hip
+#endif
 
 template <int BPP, int SX, int SY, bool CONV>
 static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k, int num_frames, int variant,
@@ -284,6 +320,9 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
         lds = (size_t)per_group * kStageBytes;
     }
     // diagnostic: extra dynamic LDS per workgroup lowers the number of resident workgroups per CU
+#ifdef JPEGENC_WAVE_TIMING
+    q.timing = wave_timing_buffer();
+#endif
     static const char *pad_env = getenv("JPEGENC_LDS_PAD_KB");
     if (pad_env) lds += (size_t)atoi(pad_env) * 1024u;
     if (variant == 1) hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 1, CONV>), grid, block, lds, stream, q, k);

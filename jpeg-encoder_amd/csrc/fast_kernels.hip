@@ -1,5 +1,6 @@
 // fast_kernels.hip — dispatcher of the tuned block-encode kernels + the instantiations that carry
 // RGB -> YCbCr conversion (see fast_kernel_impl.hip.h for the design notes).
+#include <stdlib.h>
 #include <string.h>
 
 #include "fast_kernel_impl.hip.h"
@@ -76,4 +77,37 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
     return false;
 }
 
+#ifdef JPEGENC_WAVE_TIMING
+unsigned long long *wave_timing_buffer() {
+    static unsigned long long *buf = nullptr;
+    if (!buf) {
+        if (hipMalloc((void **)&buf, (size_t)32 << 20) != hipSuccess) return nullptr;      // 2^20 waves x 32 B
+        (void)hipMemset(buf, 0, (size_t)32 << 20);
+    }
+    return buf;
+}
+#endif
+
 }  // namespace jpegenc
+
+#ifdef JPEGENC_WAVE_TIMING
+// diagnostic builds only: copies [luma/byte waves, chroma waves] x {prologue, fetch+convert, FDCT+quant,
+// stage+store, waves} cycle sums to the host and clears them
+extern "C" int jpegenc_debug_wave_timing(unsigned long long out[16]) {
+    unsigned long long *b = jpegenc::wave_timing_buffer();
+    if (!b) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    static uint32_t *host = (uint32_t *)malloc((size_t)32 << 20);
+    if (hipMemcpy(host, b, (size_t)32 << 20, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+    (void)hipMemset(b, 0, (size_t)32 << 20);
+    for (int i = 0; i < 16; i++) out[i] = 0;
+    for (size_t w = 0; w < ((size_t)1 << 20); w++) {       // records of the LAST launch
+        const uint32_t *r = host + w * 8;
+        if (!r[4]) continue;
+        unsigned long long *o = out + (r[4] - 1) * 8;
+        for (int i = 0; i < 4; i++) o[i] += r[i];
+        o[4]++;
+    }
+    return 0;
+}
+#endif

@@ -99,9 +99,9 @@ __device__ __forceinline__ void wave_identity(const BlockKernelParams &p, uint32
             bx = (bx & 7u) * p.xcd_chunk + (bx >> 3);
             if ((blockIdx.x >> 3) >= p.xcd_chunk || bx >= p.groups) bx = 0x00FFFFFFu;     // padding id: no valid block
         }
-        const uint32_t gw = bx * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        *group = gw / per_group;
-        *wave_in_group = gw % per_group;
+        // the workgroup holds exactly the per_group waves of one group (launchers): no division
+        *group = bx;
+        *wave_in_group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     }
 }
 
