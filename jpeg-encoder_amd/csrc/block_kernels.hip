@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(640) k_blocks_generic(const BlockKernelParams 
     }
     uint32_t packed[32];
     fdct_quant_block<VARIANT>(rows, quant_table(p.qsel[c]), packed);
-    stage_and_store(p, t, smem + wave * kStageBytes, lane, packed, frame_out);
+    stage_and_store(store_map(p, t), smem + wave * kStageBytes, lane, packed, frame_out);
 }
 
 // ---- symbol statistics for optimised Huffman tables (encoder.rs:1086-1200) -------------------

@@ -26,6 +26,41 @@ struct QuantDev {
     uint32_t qc[128];
 };
 
+// What a wave of the tuned kernels needs before its first pixel load, laid out so that it arrives in
+// two wide scalar loads (one s_load_dwordx16 each) instead of ~20 dependent single-dword loads
+// scattered over the prologue's control flow (which took 16 % of a wave's life, tools/diag/wave_timing.py).
+struct alignas(64) FastHeader {
+    uint64_t pixels, coeffs;
+    uint64_t pixel_frame_stride;      // bytes
+    uint64_t coeff_frame_stride;      // blocks
+    uint32_t width, height, pitch, order;
+    uint32_t bpm;                     // blocks per MCU (MCU order)
+    uint32_t mcu_w, mcu_h;            // 8 * hmax, 8 * vmax: MCU size in full-resolution samples
+    uint32_t reserved;
+};
+struct alignas(64) FastWave {         // one per wave of a group, indexed by the wave's number in the workgroup
+    uint32_t bits;                    // see FW_* below
+    uint32_t first_off;               // MCU order: first MCU = group * 64 + first_off; planar: task = group * hv + first_off
+    uint32_t hv;                      // planar: tasks of this component per round
+    uint32_t units_x;                 // MCUs (MCU order) / blocks of this component (planar) per row
+    uint32_t limit;                   // MCUs of the frame / blocks of this component
+    uint32_t magic, shift;            // n / units_x == (n * magic) >> shift for every n < 2^26
+    uint32_t out_base_lo, out_base_hi;   // MCU order: index of the wave's first block inside an MCU; planar: component offset
+    uint32_t conv[3];                 // the role's conversion constants (luma / chroma udot4: lo, hi, xor; chroma sdot2: sel, k, shift)
+    uint32_t byte_pack;               // ROLE_BYTE: v_perm selector of the sample byte
+    uint32_t invert;                  // ROLE_BYTE: sample = 255 - byte
+    uint32_t plane_lo, plane_hi;      // XF_PLANES: byte offset of the component's plane
+};
+enum : uint32_t {                     // FastWave::bits
+    FW_COMP_SHIFT = 0,                // 2 bits
+    FW_ROLE_SHIFT = 2,                // 2 bits
+    FW_QSEL_SHIFT = 4,                // 1 bit
+    FW_SUB_SHIFT = 5,                 // 1 bit: decimated by the kernel's (SX, SY)
+    FW_LG_SHIFT = 6,                  // 2 bits: log2 of the component's blocks per MCU row that this wave handles (= log2 h)
+    FW_VROW_SHIFT = 8,                // 3 bits: which block row inside the MCU
+    FW_VALID_SHIFT = 11,              // 1 bit: wave has work (padding waves of short groups exit)
+};
+
 struct BlockKernelParams {
     const uint8_t *pixels;
     void *coeffs;
@@ -46,15 +81,14 @@ struct BlockKernelParams {
     uint64_t comp_off[4];             // first output block of each component
     uint32_t task_start[5];           // prefix sums of ceil(nblocks/64)
     unsigned long long *timing;       // diagnostic build (-DJPEGENC_WAVE_TIMING): [role][phase] cycle sums + wave counts
-    uint32_t wave_groups;             // != 0: single-wave workgroups, XCD-aware id -> (group, wave) map
     uint32_t per_group;               // waves per group (= workgroup): MCU order sum(h*v); planar see planar_round
     uint32_t planar_round;            // planar order: != 0 -> a group holds h*v consecutive 64-block tasks of EVERY
                                       // component (they cover the same pixels, read from HBM once); 0 -> 4 tasks in
                                       // component-major sequence (more than 10 waves per round)
     uint32_t groups;                  // groups per frame
-    uint32_t xcd_chunk;               // diagnostic (JPEGENC_XCD_CONTIGUOUS): != 0 -> workgroup id x works on group
-                                      // (x % 8) * xcd_chunk + x / 8, i.e. each XCD walks one contiguous eighth
     QuantDev q[2];
+    FastHeader fast_hdr;
+    FastWave fast_wave[10];
 };
 
 struct HistKernelParams {

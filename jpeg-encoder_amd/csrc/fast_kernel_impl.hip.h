@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "fdct_quant.hip.h"
 #include "host_common.h"
@@ -85,9 +86,17 @@ __device__ __forceinline__ uint32_t pixel_word(const uint32_t (&d)[N], int p) {
     return d[w] >> (8 * s);                       // last pixel: its 3 bytes sit in the top of the last dword
 }
 
-__device__ __forceinline__ uint32_t luma16(uint32_t w, const ColourConsts &k) {
-    const uint32_t t = __builtin_amdgcn_udot4(w, k.y_lo, 0x7FFFu, false) >> 8;
-    return __builtin_amdgcn_udot4(w, k.y_hi, t, false);          // Y in bits 8..15
+__device__ __forceinline__ uint32_t luma16(uint32_t w, uint32_t lo, uint32_t hi) {
+    const uint32_t t = __builtin_amdgcn_udot4(w, lo, 0x7FFFu, false) >> 8;
+    return __builtin_amdgcn_udot4(w, hi, t, false);              // Y in bits 8..15
+}
+
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+// 64 bytes of the kernel argument block as one s_load_dwordx16 (BlockKernelParams is the first argument).
+__device__ __forceinline__ u32x16 kernarg16(size_t byte_offset) {
+    const char __attribute__((address_space(4))) *args =
+        (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    return *reinterpret_cast<const u32x16 __attribute__((address_space(4))) *>(args + byte_offset);
 }
 __device__ __forceinline__ uint32_t chroma32(uint32_t w, uint32_t sel, uint32_t kk, uint32_t sh) {
     const uint32_t pair = __builtin_amdgcn_perm(0u, w, sel);
@@ -115,12 +124,12 @@ __device__ __forceinline__ uint32_t edge_sample(const uint8_t *px, int role, int
 
 // ---- fetching the 64 samples of a block ----------------------------------------------------------
 struct LumaConv {          // Y of an RGB-order pixel word
-    const ColourConsts &k;
+    uint32_t lo, hi;
     static constexpr uint32_t kPack = 0x0C050C01u;            // byte 1 of each result
 #ifdef JPEGENC_PROBE_MEMORY_ONLY
     __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w; }
 #else
-    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return luma16(w, k); }
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return luma16(w, lo, hi); }
 #endif
 };
 // Two exact forms of Cb / Cr.  The udot4 form is 4 instructions per sample instead of 6 and wins where
@@ -178,21 +187,42 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
 #endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t per_group = p.per_group;
-    uint32_t group, wave_in_group;
-    wave_identity(p, per_group, &group, &wave_in_group);
-    const WaveTask t = decode_task(p, wave_in_group, group);
-    const int c = t.comp;
-    if (t.first >= (p.order == 0 ? p.total_mcus : p.nblocks[c])) return;      // padding wave: nothing to do
-    const uint8_t *frame = p.pixels + (size_t)blockIdx.y * p.pixel_frame_stride + k.plane_offset[c];
-    uint4 *frame_out = reinterpret_cast<uint4 *>(p.coeffs) + (size_t)blockIdx.y * p.coeff_frame_stride * 8u;
-
-    const BlockRef me = locate(p, t, lane);
-    const int role = k.role[c];
-    const bool sub = p.sx[c] > 1 || p.sy[c] > 1;                    // this component is decimated by (SX, SY)
+    // Two wide scalar loads bring everything the prologue needs (device_params.h: FastHeader, FastWave);
+    // the workgroup holds exactly the waves of one group, so group = blockIdx.x and the wave's number
+    // selects its FastWave record.
+    const u32x16 H = kernarg16(__builtin_offsetof(BlockKernelParams, fast_hdr));
+    const u32x16 Wv = kernarg16(__builtin_offsetof(BlockKernelParams, fast_wave) + (size_t)wave * sizeof(FastWave));
+    const uint32_t bits = Wv[0];
+    const int c = (int)((bits >> FW_COMP_SHIFT) & 3u);
+    const int role = (int)((bits >> FW_ROLE_SHIFT) & 3u);
+    const int qsel = (int)((bits >> FW_QSEL_SHIFT) & 1u);
+    const bool sub = (bits >> FW_SUB_SHIFT) & 1u;                   // this component is decimated by (SX, SY)
+    const uint32_t lg = (bits >> FW_LG_SHIFT) & 3u, vrow = (bits >> FW_VROW_SHIFT) & 7u;
+    const uint32_t order = H[11], units_x = Wv[3], limit = Wv[4], magic = Wv[5], shift = Wv[6];
+    const uint32_t first_unit = order == 0 ? blockIdx.x * 64u + Wv[1] : (blockIdx.x * Wv[2] + Wv[1]) * 64u;
+    if (first_unit >= limit) return;                                // padding wave of the last group: nothing to do
+    const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0], co_base = ((uint64_t)H[3] << 32) | H[2];
+    const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4], co_stride = ((uint64_t)H[7] << 32) | H[6];
+    const uint8_t *frame = reinterpret_cast<const uint8_t *>(px_base) + (size_t)blockIdx.y * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]);
+    uint4 *frame_out = reinterpret_cast<uint4 *>(co_base) + (size_t)blockIdx.y * co_stride * 8u;
+    const int width = (int)H[8], hlim = (int)H[9] - 1;
+    const uint32_t pitch = H[10];                                   // frame bytes < 2^31 (checked by the launcher)
     const int sxc = sub ? SX : 1, syc = sub ? SY : 1;
-    const int hlim = p.height - 1;
-    const uint32_t pitch = (uint32_t)p.width * BPP;                 // frame bytes < 2^31 (checked by the launcher)
+
+    // this lane's block: (ux, uy) = MCU (MCU order) or block of the component (planar) in the frame
+    const uint32_t row0 = (uint32_t)(((uint64_t)first_unit * magic) >> shift), col0 = first_unit - row0 * units_x;   // wave-uniform
+    const uint32_t dm = order == 0 ? lane >> lg : lane, sub_k = order == 0 ? lane & ((1u << lg) - 1u) : 0u;
+    uint32_t ux = col0 + dm, uy = row0;
+    if (units_x >= 64u) {                      // at most one wrap: dm < 64 <= units_x
+        if (ux >= units_x) { ux -= units_x; uy++; }
+    } else {
+        const uint32_t q = (uint32_t)(((uint64_t)ux * magic) >> shift);
+        uy += q; ux -= q * units_x;
+    }
+    if (first_unit + dm >= limit) { ux = 0; uy = 0; }               // slots past the end read block 0 and store nothing
+    BlockRef me;
+    me.x0 = order == 0 ? (int)(ux * H[13] + sub_k * 8u) : (int)(ux * 8u * (uint32_t)sxc);
+    me.y0 = order == 0 ? (int)(uy * H[14] + vrow * 8u) : (int)(uy * 8u * (uint32_t)syc);
     const bool aligned4 = (((uintptr_t)frame | pitch) & 3u) == 0;   // wave-uniform
     const uint32_t first = (uint32_t)me.y0 * pitch + (uint32_t)me.x0 * BPP;
     const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * BPP;
@@ -212,27 +242,24 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
     }
     if (false)
 #endif
-    if (me.x0 + 8 * sxc <= p.width) {
+    if (me.x0 + 8 * sxc <= width) {
         if (CONV && role == ROLE_Y) {
-            fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, LumaConv::kPack, LumaConv{k}, rows);
+            fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, LumaConv::kPack, LumaConv{Wv[9], Wv[10]}, rows);
         } else if (CONV && role != ROLE_BYTE) {
             if (SX * SY == 1) {
-                const ChromaConv cc = {role == ROLE_CB ? k.cb_lo : k.cr_lo, role == ROLE_CB ? k.cb_hi : k.cr_hi,
-                                       role == ROLE_CB ? k.cb_xor : k.cr_xor};
+                const ChromaConv cc = {Wv[9], Wv[10], Wv[11]};
                 fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, ChromaConv::kPack, cc, rows);
             } else {
-                const ChromaConvDot2 cc = {role == ROLE_CB ? k.sel_cb : k.sel_cr, role == ROLE_CB ? k.k_cb : k.k_cr,
-                                           role == ROLE_CB ? k.sh_b : k.sh_r};
+                const ChromaConvDot2 cc = {Wv[9], Wv[10], Wv[11]};
                 fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, ChromaConvDot2::kPack, cc, rows);
             }
         } else if (!CONV || BPP == 4) {
             // byte b of each pixel word -> zero-extended 16-bit pair; `255 - v` as one packed subtract.
             // In the conversion kernels only CmykAsYcck's K plane (4-byte pixels, never decimated) gets here.
-            const uint32_t b = (uint32_t)k.byte_index[c];
-            const uint32_t pack = 0x0C040C00u | b | (b << 16);
+            const uint32_t pack = Wv[12];
             if (!CONV && sub && (SX > 1 || SY > 1)) fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
             else fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
-            if (k.invert[c]) {
+            if (Wv[13]) {
 #pragma unroll
                 for (int y = 0; y < 8; y++)
 #pragma unroll
@@ -247,7 +274,7 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
             const uint8_t *row = frame + (size_t)min(me.y0 + y * syc, hlim) * pitch;
             uint32_t v[8];
 #pragma unroll
-            for (int x = 0; x < 8; x++) v[x] = edge_sample(row + (size_t)min(me.x0 + x * sxc, p.width - 1) * BPP, role, c, k);
+            for (int x = 0; x < 8; x++) v[x] = edge_sample(row + (size_t)min(me.x0 + x * sxc, width - 1) * BPP, role, c, k);
             rows[y][0] = v[0] | (v[1] << 16); rows[y][1] = v[3] | (v[2] << 16);
             rows[y][2] = v[7] | (v[6] << 16); rows[y][3] = v[4] | (v[5] << 16);
         }
@@ -263,7 +290,7 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
 #pragma unroll
     for (int j = 0; j < 32; j++) packed[j] = rows[j >> 2][j & 3];
 #else
-    fdct_quant_block<VARIANT>(rows, quant_table(p.qsel[c]), packed);
+    fdct_quant_block<VARIANT>(rows, quant_table(qsel), packed);
 #endif
 #if defined(JPEGENC_PROBE_MEMORY_ONLY) && JPEGENC_PROBE_MEMORY_ONLY == 4       // loads only
     uint32_t x = 0;
@@ -277,7 +304,10 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
     const uint64_t tm3 = __builtin_readcyclecounter();        // FDCT + quantiser done
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    stage_and_store(p, t, smem + wave * kStageBytes, lane, packed, frame_out);
+    StoreMap sm;
+    sm.order = order; sm.lg = lg; sm.first = first_unit; sm.limit = limit; sm.bpm = H[12];
+    sm.out_base = ((uint64_t)Wv[8] << 32) | Wv[7];
+    stage_and_store(sm, smem + wave * kStageBytes, lane, packed, frame_out);
 #endif
 #ifdef JPEGENC_WAVE_TIMING
     __builtin_amdgcn_s_waitcnt(0);                             // stores retired (vmcnt 0): end of the wave's life
@@ -297,32 +327,72 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
 unsigned long long *wave_timing_buffer();      // fast_kernels.hip
 #endif
 
+// Host side of the prologue: the FastHeader / FastWave records of a launch.
+static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k, int bpp, int sx, int sy, bool conv) {
+    if (q.order != 0 && !q.planar_round) return false;            // component-major planar tasks: generic kernel
+    if (q.per_group < 1 || q.per_group > 10) return false;
+    FastHeader &h = q.fast_hdr;
+    memset(&h, 0, sizeof h);
+    h.pixels = (uint64_t)(uintptr_t)q.pixels; h.coeffs = (uint64_t)(uintptr_t)q.coeffs;
+    h.pixel_frame_stride = q.pixel_frame_stride; h.coeff_frame_stride = q.coeff_frame_stride;
+    h.width = (uint32_t)q.width; h.height = (uint32_t)q.height; h.pitch = (uint32_t)q.width * (uint32_t)bpp;
+    h.order = (uint32_t)q.order; h.bpm = q.bpm; h.mcu_w = 8u * (uint32_t)q.hmax; h.mcu_h = 8u * (uint32_t)q.vmax;
+    memset(q.fast_wave, 0, sizeof q.fast_wave);
+    for (uint32_t w = 0; w < q.per_group; w++) {
+        FastWave &f = q.fast_wave[w];
+        int c = 0;
+        while (c + 1 < q.ncomp && w >= q.wave_start[c + 1]) c++;
+        const uint32_t in_comp = w - q.wave_start[c], hc = (uint32_t)q.h[c];
+        uint32_t lg = 0, vrow = 0;
+        if (q.order == 0) {       // one row of the component's blocks inside the MCU from 64 / h MCUs (wave_tasks.hip.h)
+            while ((1u << lg) < hc) lg++;
+            const uint32_t range = in_comp % hc;
+            vrow = in_comp / hc;
+            f.first_off = range * (64u / hc);
+            f.units_x = q.mcus_x; f.limit = q.total_mcus;
+            const uint64_t ob = (uint64_t)q.comp_first[c] + (uint64_t)vrow * hc;
+            f.out_base_lo = (uint32_t)ob; f.out_base_hi = (uint32_t)(ob >> 32);
+        } else {
+            f.first_off = in_comp; f.hv = (uint32_t)(q.h[c] * q.v[c]);
+            f.units_x = q.cols[c]; f.limit = q.nblocks[c];
+            f.out_base_lo = (uint32_t)q.comp_off[c]; f.out_base_hi = (uint32_t)(q.comp_off[c] >> 32);
+        }
+        if (f.units_x == 0 || f.limit > (1u << 26)) return false;
+        // n / d == (n * magic) >> shift for n < 2^26: magic = ceil(2^shift / d), shift = 26 + ceil(log2 d);
+        // the error term n * (magic * d - 2^shift) stays below 2^shift because magic * d - 2^shift < d <= 2^(shift - 26)
+        uint32_t l2 = 0;
+        while ((1u << l2) < f.units_x) l2++;
+        f.shift = 26u + l2;
+        f.magic = (uint32_t)((((uint64_t)1 << f.shift) + f.units_x - 1u) / f.units_x);
+        const bool sub = q.sx[c] > 1 || q.sy[c] > 1;
+        const int role = k.role[c];
+        f.bits = ((uint32_t)c << FW_COMP_SHIFT) | ((uint32_t)role << FW_ROLE_SHIFT) | ((uint32_t)(q.qsel[c] & 1) << FW_QSEL_SHIFT) |
+                 ((uint32_t)sub << FW_SUB_SHIFT) | (lg << FW_LG_SHIFT) | (vrow << FW_VROW_SHIFT) | (1u << FW_VALID_SHIFT);
+        if (conv && role == ROLE_Y) { f.conv[0] = k.y_lo; f.conv[1] = k.y_hi; }
+        else if (conv && role != ROLE_BYTE) {
+            const bool cb = role == ROLE_CB;
+            if (sx * sy == 1) { f.conv[0] = cb ? k.cb_lo : k.cr_lo; f.conv[1] = cb ? k.cb_hi : k.cr_hi; f.conv[2] = cb ? k.cb_xor : k.cr_xor; }
+            else { f.conv[0] = cb ? k.sel_cb : k.sel_cr; f.conv[1] = cb ? k.k_cb : k.k_cr; f.conv[2] = cb ? k.sh_b : k.sh_r; }
+        }
+        const uint32_t b = (uint32_t)k.byte_index[c];
+        f.byte_pack = 0x0C040C00u | b | (b << 16);     // byte b of each pixel word -> zero-extended 16-bit pair
+        f.invert = (uint32_t)k.invert[c];
+        f.plane_lo = (uint32_t)k.plane_offset[c]; f.plane_hi = (uint32_t)(k.plane_offset[c] >> 32);
+    }
+    return true;
+}
+
 template <int BPP, int SX, int SY, bool CONV>
 static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k, int num_frames, int variant,
                               hipStream_t stream) {
-    dim3 grid, block;
-    size_t lds;
     BlockKernelParams q = p;
-    // measured: no gain over one workgroup per group (profiles/README.md), so it stays opt-in
-    static const bool per_wave = getenv("JPEGENC_WAVE_WORKGROUPS") != nullptr;
-    const uint32_t per_group = p.per_group, groups = p.groups;                 // <= 10 waves for sampling factors 1 and 2
-    if (per_wave) {
-        q.wave_groups = groups;
-        grid = dim3(((groups + 7u) / 8u) * 8u * per_group, (unsigned)num_frames);
-        block = dim3(64);
-        lds = kStageBytes;
-    } else {
-        static const bool xcd_contig = getenv("JPEGENC_XCD_CONTIGUOUS") != nullptr;
-        uint32_t gx = groups;
-        if (xcd_contig) { q.xcd_chunk = (groups + 7u) / 8u; gx = q.xcd_chunk * 8u; }
-        grid = dim3(gx, (unsigned)num_frames);
-        block = dim3(per_group * 64u);
-        lds = (size_t)per_group * kStageBytes;
-    }
-    // diagnostic: extra dynamic LDS per workgroup lowers the number of resident workgroups per CU
+    if (!fill_fast_params(q, k, BPP, SX, SY, CONV)) return hipErrorInvalidValue;      // launch_blocks_fast checked the preconditions
+    const dim3 grid(p.groups, (unsigned)num_frames), block(p.per_group * 64u);          // <= 10 waves for sampling factors 1 and 2
+    size_t lds = (size_t)p.per_group * kStageBytes;
 #ifdef JPEGENC_WAVE_TIMING
     q.timing = wave_timing_buffer();
 #endif
+    // diagnostic: extra dynamic LDS per workgroup lowers the number of resident workgroups per CU
     static const char *pad_env = getenv("JPEGENC_LDS_PAD_KB");
     if (pad_env) lds += (size_t)atoi(pad_env) * 1024u;
     if (variant == 1) hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 1, CONV>), grid, block, lds, stream, q, k);

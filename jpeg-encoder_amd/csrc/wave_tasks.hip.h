@@ -80,31 +80,6 @@ __device__ __forceinline__ BlockRef locate(const BlockKernelParams &p, const Wav
     return r;
 }
 
-// Which (group, wave-in-group) a hardware wave works on.  Default: a workgroup holds all waves of one
-// group.  With p.wave_groups != 0 every wave is its own 64-thread workgroup (LDS and wave slots are
-// recycled per wave instead of per 6-wave group, which matters because luma and chroma waves finish
-// at different times) and the id is remapped so that the waves of one group - which read the same
-// pixels - still land on one XCD and share its L2: workgroup ids are dealt round-robin over the 8
-// XCDs (observed, speed only - never correctness), so id = xcd + 8 * (slot) puts slots of equal
-// id % 8 together.
-__device__ __forceinline__ void wave_identity(const BlockKernelParams &p, uint32_t per_group, uint32_t *group,
-                                              uint32_t *wave_in_group) {
-    if (p.wave_groups) {
-        const uint32_t w = blockIdx.x, xcd = w & 7u, j = w >> 3;
-        *group = (j / per_group) * 8u + xcd;          // >= wave_groups for the padding ids: no valid block
-        *wave_in_group = j % per_group;
-    } else {
-        uint32_t bx = blockIdx.x;
-        if (p.xcd_chunk) {
-            bx = (bx & 7u) * p.xcd_chunk + (bx >> 3);
-            if ((blockIdx.x >> 3) >= p.xcd_chunk || bx >= p.groups) bx = 0x00FFFFFFu;     // padding id: no valid block
-        }
-        // the workgroup holds exactly the per_group waves of one group (launchers): no division
-        *group = bx;
-        *wave_in_group = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    }
-}
-
 __device__ __forceinline__ WaveTask decode_task(const BlockKernelParams &p, uint32_t wave_in_group,
                                                 uint32_t group) {
     WaveTask t;
@@ -151,8 +126,30 @@ __device__ __forceinline__ WaveTask decode_task(const BlockKernelParams &p, uint
 // The destination of slot s needs no division: in MCU order slot -> (MCU first + s / hv, k = s % hv)
 // with hv in {1,2,4,8}, and consecutive iterations advance the slot by 8, i.e. the block index by a
 // wave-uniform step; in planar order blocks are simply consecutive.
-__device__ __forceinline__ void stage_and_store(const BlockKernelParams &p, const WaveTask &t, uint8_t *stage,
-                                                uint32_t lane, const uint32_t packed[32], uint4 *frame_out) {
+// Where the 64 staged blocks of a wave go: wave-uniform, built from BlockKernelParams + WaveTask by
+// the generic kernel and from the FastWave record by the tuned kernels.
+struct StoreMap {
+    uint32_t order;      // 0 = MCU order, 1 = planar
+    uint32_t lg;         // MCU order: log2 of the blocks per MCU this wave handles
+    uint32_t first;      // first MCU (MCU order) / first block of the component (planar)
+    uint32_t limit;      // MCUs of the frame / blocks of the component
+    uint32_t bpm;        // blocks per MCU
+    uint64_t out_base;   // MCU order: index of the wave's first block inside an MCU; planar: component offset
+};
+
+__device__ __forceinline__ StoreMap store_map(const BlockKernelParams &p, const WaveTask &t) {
+    StoreMap m;
+    m.order = (uint32_t)p.order;
+    m.lg = 31u - (uint32_t)__builtin_clz(t.per_mcu);
+    m.first = t.first;
+    m.limit = p.order == 0 ? p.total_mcus : p.nblocks[t.comp];
+    m.bpm = p.bpm;
+    m.out_base = p.order == 0 ? (uint64_t)(p.comp_first[t.comp] + t.k_base) : p.comp_off[t.comp];
+    return m;
+}
+
+__device__ __forceinline__ void stage_and_store(const StoreMap &m, uint8_t *stage, uint32_t lane, const uint32_t packed[32],
+                                                uint4 *frame_out) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         uint4 v = make_uint4(packed[4 * j], packed[4 * j + 1], packed[4 * j + 2], packed[4 * j + 3]);
@@ -163,23 +160,21 @@ __device__ __forceinline__ void stage_and_store(const BlockKernelParams &p, cons
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    // (the index arithmetic sits AFTER the deposit on purpose: it overlaps the LDS latency; placed
+    // before it the 4K bench loses 7 %, profiles/README.md)
     const uint32_t slot0 = lane >> 3, j = lane & 7u;
-    uint32_t unit, unit_step, unit_limit;     // "unit" = MCU (MCU order) or block (planar)
+    uint32_t unit, unit_step;                 // "unit" = MCU (MCU order) or block (planar)
     uint64_t index;                           // output block index of slot0
     uint32_t index_step;
-    if (p.order == 0) {
-        const uint32_t lg = 31u - (uint32_t)__builtin_clz(t.per_mcu);          // hv is a power of two
-        unit = t.first + (slot0 >> lg);
-        unit_step = 8u >> lg;
-        unit_limit = p.total_mcus;
-        index = (uint64_t)unit * p.bpm + p.comp_first[t.comp] + t.k_base + (slot0 & (t.per_mcu - 1u));
-        index_step = unit_step * p.bpm;
-        if (t.per_mcu > 8u) { unit_step = 0; index_step = 0; }                 // not reachable (hv <= 8)
+    if (m.order == 0) {
+        unit = m.first + (slot0 >> m.lg);
+        unit_step = 8u >> m.lg;                                                // lg <= 3 (hv <= 8)
+        index = (uint64_t)unit * m.bpm + m.out_base + (slot0 & ((1u << m.lg) - 1u));
+        index_step = unit_step * m.bpm;
     } else {
-        unit = t.first + slot0;
+        unit = m.first + slot0;
         unit_step = 8u;
-        unit_limit = p.nblocks[t.comp];
-        index = p.comp_off[t.comp] + unit;
+        index = m.out_base + unit;
         index_step = 8u;
     }
     const uint8_t *src = stage + slot0 * 128u + ((j ^ (slot0 & 7u)) << 4);     // (slot0 + 8*it) & 7 == slot0 & 7
@@ -187,7 +182,7 @@ __device__ __forceinline__ void stage_and_store(const BlockKernelParams &p, cons
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + it * 1024);
-        if (unit + (uint32_t)it * unit_step < unit_limit) {
+        if (unit + (uint32_t)it * unit_step < m.limit) {
 #ifndef JPEGENC_PLAIN_STORE   // streaming stores: +1.6 % on the 4K bench (nothing re-reads the coefficients)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(&dst[(size_t)it * index_step * 8u]));
