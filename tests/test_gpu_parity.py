@@ -167,6 +167,24 @@ def test_blocks_frame_beyond_2gib(binding, oracle, synth):
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+def test_blocks_random_geometry(binding, oracle):
+    """Random mid-size geometry: every ColorType, every sampling factor the colour type takes, both
+    block orders and FDCT builds (exercises the per-wave records of the tuned kernels' prologue, the
+    one-wrap / general row arithmetic and the generic kernel for sampling factors of 4)."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("JPEGENC_FUZZ_SEED", "5")))
+    for trial in range(int(os.environ.get("JPEGENC_GEOMETRY_TRIALS", "48"))):
+        ct = int(rng.integers(0, 9))
+        w = int(rng.integers(1, 1600)) if trial % 4 else int(rng.integers(1, 90))       # also narrower than one wave's 64 units
+        h = int(rng.integers(1, 700))
+        hs, vs = SAMPLINGS[int(rng.integers(0, len(SAMPLINGS)))]
+        order, variant, q = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(1, 101))
+        px = rng.integers(0, 256, (h, w, binding.BPP[ct]), dtype=np.uint8)
+        got = binding.blocks_host(px, w, h, ct, hs, vs, q, order, variant)
+        want = oracle.encode_blocks(px, w, h, ct, hs, vs, q, order, variant)
+        assert np.array_equal(got, want), (trial, ct, w, h, hs, vs, order, variant, q)
+
+
 def test_config2_4k_420_full_size(binding, oracle, synth):
     """BASELINE config 2: 3840x2160 RGB q=90 4:2:0 — full compare plus size-independent checks."""
     w, h = 3840, 2160
