@@ -176,3 +176,24 @@ def test_sampling_factor_from_factors(binding):
             want = (h << 4) | v if (h, v) in valid else -1
             assert f(h, v) == want
     assert f(2, 2) == binding.F_2_2 and f(4, 1) == binding.F_4_1
+
+
+def _build_example(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "encode_ppm"
+    libdir = os.path.join(root, "jpeg-encoder_amd")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "encode_ppm.c"), "-o", str(exe), "-L" + libdir, "-ljpegenc_mi355x",
+                    "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_c_example_builds_against_the_header(binding, tmp_path):
+    """examples/encode_ppm.c: plain C against include/jpegenc_mi355x.h and the shared library (no torch in
+    the process); without arguments it prints its usage."""
+    import subprocess
+    exe = _build_example(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr

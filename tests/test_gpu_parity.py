@@ -708,3 +708,17 @@ def test_encode_to_file_like_new_file(binding, oracle, synth, tmp_path):
     with pytest.raises(binding.JpegEncError) as e:
         binding.Encoder(85).encode_to_file(str(short), px.reshape(-1)[:-1], 258, 128, binding.RGB)
     assert e.value.status == binding.ERR_BAD_IMAGE_DATA and short.exists() and short.stat().st_size == 0
+
+
+def test_c_example_program(binding, oracle, synth, tmp_path):
+    """The plain-C example (system HIP runtime, no Python in the process): PPM in, JPEG out, same bytes."""
+    import subprocess
+    from test_abi import _build_example
+    exe = _build_example(tmp_path)
+    px = synth.test_img_rgb(322, 200)
+    ppm = tmp_path / "in.ppm"
+    ppm.write_bytes(b"P6\n# gradient\n322 200\n255\n" + px.tobytes())
+    out = tmp_path / "out.jpg"
+    r = subprocess.run([str(exe), str(ppm), str(out), "82", "4:2:0", "progressive", "optimize"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == oracle.encode_jpeg(px, 322, 200, oracle.RGB, 82, sampling=(2, 2), progressive_scans=4, optimize=True)
