@@ -305,6 +305,40 @@ def main():
             del d_out, d_ws
         except Exception as exc:                                   # side figure only
             result["device_resident_full_encode"] = {"error": str(exc)}
+        # side figure (never `value`): frames in HBM -> complete JPEG files in host buffers through the Encoder
+        # (jpegenc_encoder_encode_batch_device_to_buffers: batched launches, only compressed bytes cross PCIe)
+        try:
+            import ctypes as C
+            Fd = min(F, 32)
+            base_px = torch.from_numpy(np.ascontiguousarray(synth.criterion_pattern(W, H)).reshape(-1)).to(dev)
+            d_crit = torch.stack([torch.roll(base_px, 48 * i) for i in range(Fd)])        # the reference's bench image, shifted
+            enc_d = binding.Encoder(QUALITY, device=local_rank)
+            enc_d.set_sampling_factor(binding.F_2_2)
+            cap = 16 << 20
+            outs_d = [np.empty(cap, dtype=np.uint8) for _ in range(Fd)]
+            optrs_d = (C.c_void_p * Fd)(*[o.ctypes.data for o in outs_d])
+            caps_d = (C.c_size_t * Fd)(*([cap] * Fd))
+            lens_d = (C.c_size_t * Fd)()
+            fn = binding.lib().jpegenc_encoder_encode_batch_device_to_buffers
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+            def run_d():
+                binding.check(fn(enc_d._h, d_crit.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, optrs_d, caps_d, lens_d))
+            run_d()
+            times = []
+            for _ in range(5):
+                t1 = time.perf_counter()
+                run_d()
+                times.append(time.perf_counter() - t1)
+            dt = sorted(times)[2]
+            result["device_resident_to_host_jpeg"] = {
+                "value": round(Fd * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
+                "what": f"{Fd} 4K frames (Criterion pattern) in HBM -> JPEG files in host buffers, one Encoder call, batched "
+                        "launches, median of 5", "jpeg_bytes_per_frame": int(sum(lens_d) / Fd)}
+            del d_crit, outs_d
+        except Exception as exc:                                   # side figure only
+            result["device_resident_to_host_jpeg"] = {"error": str(exc)}
         if args.e2e_frames > 0:
             # side figure (never `value`): host frames -> JPEG bytes through the Encoder batch API
             # (H2D + kernel + D2H + host Huffman, one host thread per in-flight frame)

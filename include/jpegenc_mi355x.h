@@ -260,6 +260,14 @@ int  jpegenc_encoder_encode(jpegenc_encoder *e, const uint8_t *data, size_t len,
  * valid and unmodified until the call returns). */
 int  jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int width, int height,
                                    int color_type, jpegenc_write_fn sink, void *user);
+/* A batch of same-geometry images that already live in device memory, `frame_stride` bytes apart:
+ * frame i -> sink(users[i], ...), one complete file each, in order.  The device work of the whole batch
+ * shares its launches (one fused block-encode launch, one launch sequence per scan for all frames);
+ * only the compressed bytes come back.  With optimised Huffman tables (per-frame tables) or the host
+ * entropy coder the frames are encoded one at a time - same bytes either way. */
+int  jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride,
+                                         int num_frames, int width, int height, int color_type,
+                                         jpegenc_write_fn sink, void *const *users);
 /* Same, into a caller buffer; *out_len is always set to the size the file needs. */
 int  jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len,
                                       int width, int height, int color_type, uint8_t *out,
@@ -288,6 +296,11 @@ int  jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *fram
 int  jpegenc_encoder_encode_batch_to_buffers(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len,
                                              int num_frames, int width, int height, int color_type,
                                              uint8_t *const *outs, const size_t *capacities, size_t *lengths);
+
+/* The device-resident batch, each frame into its own caller (host) buffer. */
+int  jpegenc_encoder_encode_batch_device_to_buffers(jpegenc_encoder *e, const void *d_frames, size_t frame_stride,
+                                                    int num_frames, int width, int height, int color_type,
+                                                    uint8_t *const *outs, const size_t *capacities, size_t *lengths);
 
 /* free functions re-exported by the crate (src/lib.rs:45-49) — host arithmetic, for callers that
  * implement their own ImageBuffer. */

@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_restart_interval", "jpegenc_encoder_set_optimized_huffman_tables",
     "jpegenc_encoder_optimized_huffman_tables", "jpegenc_encoder_add_app_segment",
     "jpegenc_encoder_add_icc_profile", "jpegenc_encoder_add_exif_metadata",
-    "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_to_file",
+    "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_batch_device", "jpegenc_encoder_encode_batch_device_to_buffers", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_to_file",
     "jpegenc_encoder_encode_image",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
@@ -376,6 +376,22 @@ class Encoder:
         cb = WRITE_FN(sink)
         check(lib().jpegenc_encoder_encode_device(self._h, d_pixels_ptr, width, height, color_type, cb, None))
         return b"".join(chunks)
+
+    def encode_batch_device(self, d_frames_ptr, frame_stride, num_frames, width, height, color_type):
+        """Device-resident batch (raw pointer, frames `frame_stride` bytes apart) -> list of bytes."""
+        outs = [[] for _ in range(num_frames)]
+
+        def sink(user, ptr, nbytes):
+            outs[(user or 0)].append(C.string_at(ptr, nbytes))
+            return 0
+
+        cb = WRITE_FN(sink)
+        users = (C.c_void_p * max(num_frames, 1))(*[i for i in range(num_frames)])
+        lib().jpegenc_encoder_encode_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                                             C.c_int, WRITE_FN, C.POINTER(C.c_void_p)]
+        check(lib().jpegenc_encoder_encode_batch_device(self._h, d_frames_ptr, frame_stride, num_frames, width, height,
+                                                        color_type, cb, users))
+        return [b"".join(o) for o in outs]
 
     def encode_image(self, jpeg_color_type, width, height, fill_buffers):
         """Encoder::encode_image with a user ImageBuffer: fill_buffers(y) -> list of per-plane rows."""

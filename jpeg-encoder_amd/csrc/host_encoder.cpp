@@ -359,6 +359,55 @@ struct Config {                      // the fields of struct Encoder, encoder.rs
     std::vector<std::pair<uint8_t, std::vector<uint8_t>>> app_segments;
 };
 
+// Buffers of the device-resident batch path (jpegenc_encoder_encode_batch_device), kept in the handle
+// across calls and only ever grown: pinned allocations of a few hundred MB cost tens of milliseconds.
+struct BatchBuffers {
+    void *d_coeffs = nullptr, *d_out = nullptr, *d_ws = nullptr;
+    uint32_t *d_len = nullptr, *h_len = nullptr;
+    uint8_t *h_out = nullptr;
+    size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, h_out_cap = 0;
+    static int grow_device(void **p, size_t *cap, size_t need) {
+        if (need <= *cap) return JPEGENC_OK;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr; *cap = 0;
+        JPEGENC_HIP(hipMalloc(p, need));
+        *cap = need;
+        return JPEGENC_OK;
+    }
+    int reserve(size_t coeffs, size_t out, size_t ws, size_t nlen) {
+        int rc = grow_device(&d_coeffs, &coeffs_cap, coeffs);
+        if (!rc) rc = grow_device(&d_out, &out_cap, out);
+        if (!rc) rc = grow_device(&d_ws, &ws_cap, ws);
+        if (rc) return rc;
+        if (nlen > len_cap) {
+            if (d_len) (void)hipFree(d_len);
+            if (h_len) (void)hipHostFree(h_len);
+            d_len = nullptr; h_len = nullptr; len_cap = 0;
+            JPEGENC_HIP(hipMalloc((void **)&d_len, nlen * sizeof(uint32_t)));
+            JPEGENC_HIP(hipHostMalloc((void **)&h_len, nlen * sizeof(uint32_t), hipHostMallocDefault));
+            len_cap = nlen;
+        }
+        return JPEGENC_OK;
+    }
+    int reserve_host(size_t bytes) {
+        if (bytes <= h_out_cap) return JPEGENC_OK;
+        if (h_out) (void)hipHostFree(h_out);
+        h_out = nullptr; h_out_cap = 0;
+        const size_t cap = bytes + (bytes >> 2) + 4096;
+        JPEGENC_HIP(hipHostMalloc((void **)&h_out, cap, hipHostMallocDefault));
+        h_out_cap = cap;
+        return JPEGENC_OK;
+    }
+    ~BatchBuffers() {
+        if (d_coeffs) (void)hipFree(d_coeffs);
+        if (d_out) (void)hipFree(d_out);
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_len) (void)hipFree(d_len);
+        if (h_len) (void)hipHostFree(h_len);
+        if (h_out) (void)hipHostFree(h_out);
+    }
+};
+
 }  // namespace jpegenc
 
 using namespace jpegenc;
@@ -368,6 +417,7 @@ struct jpegenc_encoder {
     int device = 0;
     DeviceCtx ctx;
     std::vector<std::unique_ptr<DeviceCtx>> workers;   // batch API: one per in-flight frame, kept across calls
+    BatchBuffers batch;                                  // device-resident batch API
 };
 
 namespace jpegenc {
@@ -748,6 +798,181 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     return JPEGENC_OK;
 }
 
+// A batch of device-resident frames (a decoder's or camera pipeline's output) -> complete files, with
+// the device work of the whole batch in one launch per step: one fused block-encode launch, one launch
+// sequence per scan for all frames (jpegenc_scan_device is batched), then the lengths and only the
+// compressed bytes come back.  Per-frame Huffman tables (optimised mode) cannot share the scan
+// launches; the caller falls back to one encode_frame per image for them.
+
+static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b, int device, const void *d_frames,
+                               size_t frame_stride, int num_frames, int width, int height, int color_type,
+                               jpegenc_write_fn sink, void *const *users) {
+    const int bpp = jpegenc_bytes_per_pixel(color_type);
+    const size_t bytes = (size_t)width * (size_t)height * (size_t)bpp;
+    if (frame_stride < bytes) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "frame stride smaller than a frame");
+    int rc = ctx.open(device);
+    if (rc) return rc;
+    Tables t;
+    rc = jpegenc_qtable_init(&t.q[0], c.qtype[0], c.qcustom[0], c.quality, 1);
+    if (rc) return rc;
+    rc = jpegenc_qtable_init(&t.q[1], c.qtype[1], c.qcustom[1], c.quality, 0);
+    if (rc) return rc;
+    default_huffman(t);
+    int hs, vs;
+    sampling_hv(c.sampling, &hs, &vs);
+    const Mode mode = select_mode(c);
+    const int jct = jpeg_color_type_of(color_type);
+    const int order = mode == MODE_INTERLEAVED ? JPEGENC_ORDER_MCU : JPEGENC_ORDER_PLANAR;
+    jpegenc_layout L;
+    rc = jpegenc_layout_init(&L, width, height, color_type, hs, vs, order);
+    if (rc) return rc;
+
+    struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap; };
+    std::vector<Job> jobs;
+    auto add = [&](int comp, int with_dc, int s0, int s1, int first, int n, int ss, int se) {
+        Job j;
+        j.sc = jpegenc_scan{comp, with_dc, s0, s1, c.restart_interval};
+        j.first = first; j.n = n; j.ss = ss; j.se = se; j.off = 0; j.cap = 0;
+        jobs.push_back(j);
+    };
+    if (mode == MODE_INTERLEAVED) {
+        add(-1, 1, 1, 64, 0, L.num_components, 0, 63);
+    } else if (mode == MODE_SEQUENTIAL) {                                   // encoder.rs:823-861
+        for (int i = 0; i < L.num_components; i++) add(i, 1, 1, 64, i, 1, 0, 63);
+    } else {                                                                // encoder.rs:885-972
+        for (int i = 0; i < L.num_components; i++) add(i, 1, 1, 1, i, 1, 0, 0);
+        const int scans = c.progressive_scans - 1, per = 64 / scans;
+        for (int sidx = 0; sidx < scans; sidx++) {
+            const int start = sidx * per < 1 ? 1 : sidx * per;
+            const int end = sidx == scans - 1 ? 64 : (sidx + 1) * per;
+            for (int i = 0; i < L.num_components; i++) add(i, 0, start, end, i, 1, start, end - 1);
+        }
+    }
+    size_t out_total = 0;
+    for (auto &j : jobs) {
+        if (!j.sc.with_dc && j.sc.ac_end == j.sc.ac_start) continue;          // empty band: nothing to code
+        j.cap = scan_max_bytes(L, j.sc);
+        if (!j.cap) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan not supported by the device entropy coder");
+        j.off = out_total;
+        out_total += j.cap;
+    }
+    const size_t coeff_bytes = (size_t)L.total_blocks * 128;
+    // frames per round: bounded device footprint (coefficients + worst-case scan bytes), at most 64
+    int per_round = (int)(((size_t)6 << 30) / (coeff_bytes + out_total + 1));
+    if (per_round < 1) per_round = 1;
+    if (per_round > 64) per_round = 64;
+    if (per_round > num_frames) per_round = num_frames;
+    size_t ws = 0;
+    for (auto &j : jobs) {
+        if (!j.cap) continue;
+        const size_t w = scan_workspace_size(L, j.sc, per_round);
+        if (!w) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan not supported by the device entropy coder");
+        if (w > ws) ws = w;
+    }
+    const size_t nlen = jobs.size() * (size_t)per_round;
+    rc = b.reserve(coeff_bytes * (size_t)per_round, out_total * (size_t)per_round, ws, nlen);
+    if (rc) return rc;
+
+    jpegenc_huffman_spec specs[2][2];
+    for (int d = 0; d < 2; d++)
+        for (int k = 0; k < 2; k++) {
+            memset(&specs[d][k], 0, sizeof specs[d][k]);
+            memcpy(specs[d][k].bits, t.h[d][k].bits, 16);
+            memcpy(specs[d][k].values, t.h[d][k].vals, (size_t)t.h[d][k].nvals);
+            specs[d][k].num_values = t.h[d][k].nvals;
+        }
+    rc = upload_huffman_luts(specs, ctx.d_lut, ctx.stream);
+    if (rc) return rc;
+
+    for (int f0 = 0; f0 < num_frames; f0 += per_round) {
+        const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
+        BlockKernelParams p;
+        rc = build_block_params(&p, L, width, height, color_type, t.q, order);
+        if (rc) return rc;
+        p.pixels = (const uint8_t *)d_frames + (size_t)f0 * frame_stride;
+        p.coeffs = b.d_coeffs;
+        p.pixel_frame_stride = frame_stride;
+        p.coeff_frame_stride = L.total_blocks;
+        hipError_t err = hipSuccess;
+        if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, n, c.fdct_variant, ctx.stream);
+        if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+        JPEGENC_HIP(hipMemsetAsync(b.d_len, 0, nlen * sizeof(uint32_t), ctx.stream));
+        for (size_t k = 0; k < jobs.size(); k++) {
+            const Job &j = jobs[k];
+            if (!j.cap) continue;
+            rc = scan_device(b.d_coeffs, L.total_blocks, n, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)b.d_out + j.off, out_total,
+                             b.d_len + k * (size_t)per_round, b.d_ws, ws, ctx.stream);
+            if (rc) return rc;
+        }
+        JPEGENC_HIP(hipMemcpyAsync(b.h_len, b.d_len, nlen * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
+        JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+        size_t need = 0;
+        for (size_t k = 0; k < jobs.size(); k++)
+            for (int f = 0; f < n; f++) need += b.h_len[k * (size_t)per_round + (size_t)f];
+        rc = b.reserve_host(need);
+        if (rc) return rc;
+        size_t at = 0;
+        for (int f = 0; f < n; f++)                                            // frame-major on the host: one file after the other
+            for (size_t k = 0; k < jobs.size(); k++) {
+                const size_t len = b.h_len[k * (size_t)per_round + (size_t)f];
+                if (len) JPEGENC_HIP(hipMemcpyAsync(b.h_out + at, (const uint8_t *)b.d_out + (size_t)f * out_total + jobs[k].off, len,
+                                                    hipMemcpyDeviceToHost, ctx.stream));
+                at += len;
+            }
+        JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+        // assemble the files: headers from this thread's small writer, the scan bytes straight from the
+        // pinned buffer to the sink; frames are independent, so a few host threads share them (each
+        // frame's sink calls stay in order, different frames' calls may interleave - as in encode_batch)
+        std::vector<size_t> frame_at((size_t)n + 1, 0);
+        for (int f = 0; f < n; f++) {
+            size_t sum = 0;
+            for (size_t k = 0; k < jobs.size(); k++) sum += b.h_len[k * (size_t)per_round + (size_t)f];
+            frame_at[(size_t)f + 1] = frame_at[(size_t)f] + sum;
+        }
+        std::atomic<int> next(0), failed(0);
+        auto assemble = [&]() {
+            for (;;) {
+                const int f = next.fetch_add(1);
+                if (f >= n || failed.load()) break;
+                size_t pos = frame_at[(size_t)f];
+                Out o;
+                o.sink = sink; o.user = users[f0 + f];
+                write_prologue(o, c, jct);
+                write_frame_header(o, c, width, height, L, t);
+                for (size_t k = 0; k < jobs.size(); k++) {
+                    const Job &j = jobs[k];
+                    write_scan_header(o, L, j.first, j.n, j.ss, j.se);
+                    if (j.cap) {
+                        const size_t len = b.h_len[k * (size_t)per_round + (size_t)f];
+                        o.drain(true);
+                        if (len && !o.failed && sink(o.user, b.h_out + pos, len) != 0) o.failed = true;
+                        pos += len;
+                    } else if (c.restart_interval) {   // empty band: only the restart bookkeeping (encoder.rs:947-951)
+                        const uint64_t nb = L.blocks[j.sc.component];
+                        for (uint64_t bi = (uint64_t)c.restart_interval, r = 0; bi < nb; bi += (uint64_t)c.restart_interval, r++) {
+                            o.u8(0xFF); o.u8(0xD0 + (unsigned)(r & 7));
+                        }
+                    }
+                }
+                o.marker(0xD9);
+                o.drain(true);
+                if (o.failed) failed.store(1);
+            }
+        };
+        unsigned hw = std::thread::hardware_concurrency();
+        int nthreads = (int)(hw ? hw : 4);
+        if (nthreads > 8) nthreads = 8;
+        if (nthreads > n) nthreads = n;
+        if ((size_t)frame_at[(size_t)n] < ((size_t)4 << 20)) nthreads = 1;      // little to copy: not worth the threads
+        std::vector<std::thread> pool;
+        for (int w = 1; w < nthreads; w++) pool.emplace_back(assemble);
+        assemble();
+        for (auto &th : pool) th.join();
+        if (failed.load()) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
+    }
+    return JPEGENC_OK;
+}
+
 static int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *data, size_t len, int width,
                          int height, int color_type, jpegenc_write_fn sink, void *user, bool staged = false) {
     int rc = validate_image(len, width, height, color_type);      // before any device work
@@ -962,6 +1187,28 @@ int jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int 
     return rc;
 }
 
+int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride, int num_frames,
+                                        int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
+    REQUIRE(e);
+    if (num_frames < 0 || (num_frames && (!d_frames || !users)) || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
+    const int bpp = jpegenc_bytes_per_pixel(color_type);
+    if (!bpp) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");
+    if (width < 0 || height < 0 || width > 65535 || height > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "width/height must fit u16");
+    if (width == 0 || height == 0) return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "Image dimensions must be non zero");
+    if (num_frames == 0) return JPEGENC_OK;
+    const bool per_frame_tables = e->cfg.optimize && select_mode(e->cfg) != MODE_INTERLEAVED;
+    if (!e->cfg.device_entropy || per_frame_tables) {
+        // host entropy coding was asked for, or every frame gets its own Huffman tables: one image at a time
+        for (int i = 0; i < num_frames; i++) {
+            int rc = jpegenc_encoder_encode_device(e, (const uint8_t *)d_frames + (size_t)i * frame_stride, width, height, color_type,
+                                                   sink, users[i]);
+            if (rc) return rc;
+        }
+        return JPEGENC_OK;
+    }
+    return encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
+}
+
 int jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len, int width, int height,
                                      int color_type, uint8_t *out, size_t cap, size_t *out_len) {
     REQUIRE(e);
@@ -1067,6 +1314,27 @@ int jpegenc_encoder_encode_batch_to_buffers(jpegenc_encoder *e, const uint8_t *c
         users[(size_t)i] = &sinks[(size_t)i];
     }
     int rc = jpegenc_encoder_encode_batch(e, frames, frame_len, num_frames, width, height, color_type, buffer_sink, users.data());
+    bool fits = true;
+    for (int i = 0; i < num_frames; i++) {
+        lengths[i] = sinks[(size_t)i].len;
+        if (sinks[(size_t)i].len > sinks[(size_t)i].cap) fits = false;
+    }
+    if (rc) return rc;
+    return fits ? JPEGENC_OK : fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "at least one output buffer is too small");
+}
+
+int jpegenc_encoder_encode_batch_device_to_buffers(jpegenc_encoder *e, const void *d_frames, size_t frame_stride,
+                                                   int num_frames, int width, int height, int color_type,
+                                                   uint8_t *const *outs, const size_t *capacities, size_t *lengths) {
+    REQUIRE(e);
+    if (num_frames < 0 || (num_frames && (!outs || !capacities || !lengths))) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
+    std::vector<BufferSink> sinks((size_t)num_frames);
+    std::vector<void *> users((size_t)num_frames);
+    for (int i = 0; i < num_frames; i++) {
+        sinks[(size_t)i] = BufferSink{outs[i], outs[i] ? capacities[i] : 0, 0};
+        users[(size_t)i] = &sinks[(size_t)i];
+    }
+    int rc = jpegenc_encoder_encode_batch_device(e, d_frames, frame_stride, num_frames, width, height, color_type, buffer_sink, users.data());
     bool fits = true;
     for (int i = 0; i < num_frames; i++) {
         lengths[i] = sinks[(size_t)i].len;

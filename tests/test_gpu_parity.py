@@ -722,3 +722,26 @@ def test_c_example_program(binding, oracle, synth, tmp_path):
     r = subprocess.run([str(exe), str(ppm), str(out), "82", "4:2:0", "progressive", "optimize"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert out.read_bytes() == oracle.encode_jpeg(px, 322, 200, oracle.RGB, 82, sampling=(2, 2), progressive_scans=4, optimize=True)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(quality=88), dict(quality=75, sampling=(2, 2), restart_interval=5), dict(quality=60, sampling=(4, 1)),
+    dict(quality=92, progressive_scans=5, restart_interval=11), dict(quality=80, optimize=True),
+    dict(quality=70, progressive_scans=64)], ids=["baseline", "420-restart", "sequential-411", "progressive-restart", "optimised", "progressive-64"])
+def test_encode_batch_device_resident(binding, oracle, synth, kw):
+    """jpegenc_encoder_encode_batch_device: frames already in HBM, the whole batch sharing its launches
+    (70 frames = more than one round of 64), every scan mode; optimised tables take the per-frame path."""
+    import torch
+    w, h, n = 150, 97, 70
+    frames = np.stack([synth.lcg_image(w, h, 3, 3000 + i) for i in range(n)])
+    frames[1::3] = (np.add.outer(np.arange(h), np.arange(w))[..., None] // 2 + np.arange(3)).astype(np.uint8)   # smooth ones too
+    stride = w * h * 3 + 64                                     # frames need not be packed
+    buf = torch.zeros(n * stride, dtype=torch.uint8, device="cuda:0")
+    for i in range(n):
+        buf[i * stride:i * stride + w * h * 3] = torch.from_numpy(frames[i].reshape(-1).copy()).to("cuda:0")
+    for on in (True, False):
+        got = _encoder(binding, kw, on).encode_batch_device(buf.data_ptr(), stride, n, w, h, binding.RGB)
+        assert len(got) == n
+        for i in (0, 1, 2, 33, 63, 64, 69):
+            assert got[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, **kw), (i, on)
+        assert len(set(got)) > n // 2
