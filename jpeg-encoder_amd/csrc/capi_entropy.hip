@@ -8,21 +8,32 @@
 namespace jpegenc {
 
 // Canonical code assignment (Figures C.1-C.3, huffman.rs:240-288) done on the device so that no
-// host buffer has to outlive an asynchronous copy: one thread per table.
+// host buffer has to outlive an asynchronous copy: one thread per (table, symbol).  A thread finds
+// its symbol's code length by walking the 16 counts and takes first_code(length) + its rank in it.
+// The specs are read through the kernarg segment pointer (per-lane addresses into a by-value
+// argument otherwise go through scratch: the first, one-thread-per-table version took 36 us).
 struct LutSpecs { jpegenc_huffman_spec t[2][2]; };
 
-__global__ void k_build_lut(const LutSpecs specs, uint32_t *lut) {
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) lut[i] = 0;
+__global__ void __launch_bounds__(1024) k_build_lut(const LutSpecs specs, uint32_t *lut) {
+    (void)specs;                                      // read below through the kernarg segment (first argument, offset 0)
+    const uint32_t id = threadIdx.x >> 8, k = threadIdx.x & 255u;       // [destination][class], symbol rank
+    lut[threadIdx.x] = 0;
     __syncthreads();
-    const int id = threadIdx.x;                       // 0..3 = [destination][class]
-    if (id >= 4) return;
-    const jpegenc_huffman_spec &s = specs.t[id >> 1][id & 1];
-    uint32_t *out = lut + id * 256;
-    uint32_t code = 0;
-    int k = 0;
-    for (int len = 1; len <= 16; len++) {
-        for (int i = 0; i < s.bits[len - 1] && k < s.num_values; i++, k++) out[s.values[k]] = ((uint32_t)len << 16) | code++;
-        code <<= 1;
+    const uint8_t __attribute__((address_space(4))) *s =
+        (const uint8_t __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + id * sizeof(jpegenc_huffman_spec);
+    const uint32_t num_values = *(const uint32_t __attribute__((address_space(4))) *)(s + __builtin_offsetof(jpegenc_huffman_spec, num_values));
+    if (k >= num_values) return;
+    uint32_t code = 0, first = 0;
+#pragma unroll
+    for (uint32_t len = 1; len <= 16; len++) {
+        const uint32_t n = s[__builtin_offsetof(jpegenc_huffman_spec, bits) + len - 1];
+        if (k < first + n) {
+            const uint32_t sym = s[__builtin_offsetof(jpegenc_huffman_spec, values) + k];
+            lut[id * 256u + sym] = (len << 16) | (code + (k - first));
+            return;
+        }
+        code = (code + n) << 1;
+        first += n;
     }
 }
 
@@ -113,7 +124,7 @@ int upload_huffman_luts(const jpegenc_huffman_spec (*tables)[2], void *d_lut, hi
         default_spec(&specs.t[1][0], k_k3_chroma_dc_bits, k_k3_chroma_dc_vals, 12);
         default_spec(&specs.t[1][1], k_k3_chroma_ac_bits, k_k3_chroma_ac_vals, 162);
     }
-    hipLaunchKernelGGL(k_build_lut, dim3(1), dim3(256), 0, st, specs, (uint32_t *)d_lut);
+    hipLaunchKernelGGL(k_build_lut, dim3(1), dim3(1024), 0, st, specs, (uint32_t *)d_lut);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_build_lut");
     return JPEGENC_OK;
