@@ -37,6 +37,12 @@ namespace jpegenc {
 
 enum Role : int32_t { ROLE_Y = 0, ROLE_CB = 1, ROLE_CR = 2, ROLE_BYTE = 3 };
 
+// Pixel and coefficient addresses reach the tuned kernels as integers (FastHeader): typed as global
+// memory they compile to global_load / global_store with a scalar base + 32-bit lane offset; as generic
+// pointers they would be flat_ instructions with 64-bit lane addresses (18 more VGPRs).
+typedef const uint8_t __attribute__((address_space(1))) *gbytes;
+typedef uint4 __attribute__((address_space(1))) *gchunks;
+
 struct ColourConsts {
     uint32_t y_lo, y_hi;        // udot4 byte coefficients of Y, in memory byte order
     uint32_t sel_cb, sel_cr;    // v_perm selectors building the zero-extended (r,g) / (g,b) u16 pair
@@ -58,23 +64,30 @@ struct ColourConsts {
 
 constexpr int kBias = (128 << 16) + 0x7FFF;   // image_buffer.rs:23-28
 
+// One block row of a lane: N dwords from global memory as explicit 16- / 8- / 4-byte vector loads.  (As
+// scalar loads the compiler may merge the decimated and the full-resolution path of the byte kernels
+// into one block of 64 single-dword loads with a selected stride: 4-byte pixels with 2x decimation
+// ran 4x slower that way.)
+#define JPEGENC_LOAD_ROW_BODY(ALIGN)                                                                    \
+    typedef uint32_t v4 __attribute__((ext_vector_type(4), aligned(ALIGN)));                           \
+    typedef uint32_t v2 __attribute__((ext_vector_type(2), aligned(ALIGN)));                           \
+    typedef uint32_t v1 __attribute__((aligned(ALIGN)));                                               \
+    int i = 0;                                                                                         \
+    _Pragma("unroll") for (; i + 4 <= N; i += 4) {                                                     \
+        const v4 v = *(const v4 __attribute__((address_space(1))) *)(p + 4 * i);                       \
+        d[i] = v.x; d[i + 1] = v.y; d[i + 2] = v.z; d[i + 3] = v.w;                                    \
+    }                                                                                                  \
+    if (i + 2 <= N) {                                                                                  \
+        const v2 v = *(const v2 __attribute__((address_space(1))) *)(p + 4 * i);                       \
+        d[i] = v.x; d[i + 1] = v.y;                                                                    \
+        i += 2;                                                                                        \
+    }                                                                                                  \
+    if (i < N) d[i] = *(const v1 __attribute__((address_space(1))) *)(p + 4 * i);
 template <int N>
-struct __attribute__((packed, aligned(4))) Raw4 { uint32_t v[N]; };
-template <int N>
-struct __attribute__((packed, aligned(1))) Raw1 { uint32_t v[N]; };
-
-template <int N>
-__device__ __forceinline__ void load_row(const uint8_t *p, bool aligned4, uint32_t (&d)[N]) {
-    if (aligned4) {
-        const Raw4<N> r = *reinterpret_cast<const Raw4<N> *>(p);
-#pragma unroll
-        for (int i = 0; i < N; i++) d[i] = r.v[i];
-    } else {
-        const Raw1<N> r = *reinterpret_cast<const Raw1<N> *>(p);
-#pragma unroll
-        for (int i = 0; i < N; i++) d[i] = r.v[i];
-    }
+__device__ __forceinline__ void load_row(gbytes p, bool aligned4, uint32_t (&d)[N]) {
+    if (aligned4) { JPEGENC_LOAD_ROW_BODY(4) } else { JPEGENC_LOAD_ROW_BODY(1) }
 }
+#undef JPEGENC_LOAD_ROW_BODY
 
 // dword holding pixel `p` of a row of STRIDE-spaced pixels (bytes [c0 c1 c2 x]).
 template <int BPP, int STEP, int N>
@@ -110,7 +123,7 @@ __device__ __forceinline__ uint32_t chroma16(uint32_t w, uint32_t lo, uint32_t h
 }
 
 // scalar arithmetic for the clamped edge path (identical results by construction)
-__device__ __forceinline__ uint32_t edge_sample(const uint8_t *px, int role, int c, const ColourConsts &k) {
+__device__ __forceinline__ uint32_t edge_sample(gbytes px, int role, int c, const ColourConsts &k) {
     if (role == ROLE_BYTE) {
         const uint32_t v = px[k.byte_index[c]];
         return k.invert[c] ? 255u - v : v;
@@ -157,7 +170,7 @@ struct ChromaConv {        // Cb or Cr = two udot4 of the pixel word with two ch
 
 // rows[y] = {(x0,x1),(x3,x2),(x7,x6),(x4,x5)}; `pack` selects the result byte of each converted word.
 template <int BPP, int STEPX, int STEPY, class Conv>
-__device__ __forceinline__ void fetch_rows(const uint8_t *frame, bool aligned4, uint32_t first, uint32_t last,
+__device__ __forceinline__ void fetch_rows(gbytes frame, bool aligned4, uint32_t first, uint32_t last,
                                            uint32_t pitch, uint32_t pack, const Conv &conv, uint32_t (&rows)[8][4]) {
     constexpr int N = (BPP * 8 * STEPX + 3) / 4;
 #pragma unroll
@@ -177,10 +190,17 @@ struct ByteConv {          // the sample is a byte of the pixel word itself
     __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w; }
 };
 
+// Register budget: at least 5 waves per SIMD (<= 102 VGPRs).  Left to itself the compiler keeps every
+// row load of a decimated chroma block in flight (104 VGPRs, 4 waves per SIMD); the kernel needs its
+// residency more (profiles/README.md).
+#ifndef JPEGENC_MIN_WAVES
+#define JPEGENC_MIN_WAVES 5
+#endif
+#define JPEGENC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(JPEGENC_MIN_WAVES)))
 // CONV = the kernel carries the RGB -> YCbCr roles (RGB family, CmykAsYcck); otherwise byte planes only.
 // 3-byte RGB has at most 6 waves per 64-MCU group; CmykAsYcck / 4-component layouts up to 10.
 template <int BPP, int SX, int SY, int VARIANT, bool CONV>
-__global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
+__global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef JPEGENC_WAVE_TIMING
     const uint64_t tm0 = __builtin_readcyclecounter();
@@ -203,8 +223,8 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
     if (first_unit >= limit) return;                                // padding wave of the last group: nothing to do
     const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0], co_base = ((uint64_t)H[3] << 32) | H[2];
     const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4], co_stride = ((uint64_t)H[7] << 32) | H[6];
-    const uint8_t *frame = reinterpret_cast<const uint8_t *>(px_base) + (size_t)blockIdx.y * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]);
-    uint4 *frame_out = reinterpret_cast<uint4 *>(co_base) + (size_t)blockIdx.y * co_stride * 8u;
+    const gbytes frame = (gbytes)(uintptr_t)(px_base + (size_t)blockIdx.y * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]));
+    const gchunks frame_out = (gchunks)(uintptr_t)(co_base + (size_t)blockIdx.y * co_stride * 128u);
     const int width = (int)H[8], hlim = (int)H[9] - 1;
     const uint32_t pitch = H[10];                                   // frame bytes < 2^31 (checked by the launcher)
     const int sxc = sub ? SX : 1, syc = sub ? SY : 1;
@@ -271,7 +291,7 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
         // (encoder.rs:738-744); one shared copy for all roles, taken by a handful of lanes
 #pragma unroll
         for (int y = 0; y < 8; y++) {
-            const uint8_t *row = frame + (size_t)min(me.y0 + y * syc, hlim) * pitch;
+            const gbytes row = frame + (size_t)min(me.y0 + y * syc, hlim) * pitch;
             uint32_t v[8];
 #pragma unroll
             for (int x = 0; x < 8; x++) v[x] = edge_sample(row + (size_t)min(me.x0 + x * sxc, width - 1) * BPP, role, c, k);
@@ -317,7 +337,7 @@ __global__ void __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(co
         if (id < (1u << 20)) {
             uint32_t *tq = reinterpret_cast<uint32_t *>(p.timing) + id * 8;
             tq[0] = (uint32_t)(tm1 - tm0); tq[1] = (uint32_t)(tm2 - tm1); tq[2] = (uint32_t)(tm3 - tm2); tq[3] = (uint32_t)(tm4 - tm3);
-            tq[4] = 1u + (uint32_t)(role == ROLE_Y || role == ROLE_BYTE ? 0 : 1);
+            tq[4] = 1u + (uint32_t)(sub ? 1 : 0);      // class: full-resolution waves, decimated waves
         }
     }
 #endif

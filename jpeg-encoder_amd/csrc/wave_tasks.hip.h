@@ -148,8 +148,15 @@ __device__ __forceinline__ StoreMap store_map(const BlockKernelParams &p, const 
     return m;
 }
 
+typedef uint32_t u32x4_store __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store16(u32x4_store v, uint4 *p) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_store *>(p)); }
+__device__ __forceinline__ void nt_store16(u32x4_store v, uint4 __attribute__((address_space(1))) *p) {
+    __builtin_nontemporal_store(v, (u32x4_store __attribute__((address_space(1))) *)p);
+}
+
+template <class ChunkPtr>      // uint4 * (generic kernel) or its address_space(1) twin (tuned kernels)
 __device__ __forceinline__ void stage_and_store(const StoreMap &m, uint8_t *stage, uint32_t lane, const uint32_t packed[32],
-                                                uint4 *frame_out) {
+                                                ChunkPtr frame_out) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         uint4 v = make_uint4(packed[4 * j], packed[4 * j + 1], packed[4 * j + 2], packed[4 * j + 3]);
@@ -178,14 +185,14 @@ __device__ __forceinline__ void stage_and_store(const StoreMap &m, uint8_t *stag
         index_step = 8u;
     }
     const uint8_t *src = stage + slot0 * 128u + ((j ^ (slot0 & 7u)) << 4);     // (slot0 + 8*it) & 7 == slot0 & 7
-    uint4 *dst = frame_out + index * 8u + j;
+    const ChunkPtr dst = frame_out + index * 8u + j;
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + it * 1024);
         if (unit + (uint32_t)it * unit_step < m.limit) {
 #ifndef JPEGENC_PLAIN_STORE   // streaming stores: +1.6 % on the 4K bench (nothing re-reads the coefficients)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(&dst[(size_t)it * index_step * 8u]));
+            nt_store16(u32x4{v.x, v.y, v.z, v.w}, &dst[(size_t)it * index_step * 8u]);
 #else
             dst[(size_t)it * index_step * 8u] = v;
 #endif
