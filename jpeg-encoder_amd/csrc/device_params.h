@@ -22,7 +22,7 @@ enum Xform : int32_t {
 // Stored in the order the kernel consumes them — pass 2 finishes one COLUMN x at a time, rows k =
 // 0..7 — so each column's 16 constants are one contiguous scalar load:
 //   qc[(x * 8 + k) * 2 + 0] = kq of natural coefficient k*8+x,  qc[.. + 1] = its aq.
-struct QuantDev {
+struct alignas(64) QuantDev {      // 64-byte aligned: each column's 16 constants are one s_load_dwordx16
     uint32_t qc[128];
 };
 

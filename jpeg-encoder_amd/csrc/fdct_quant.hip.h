@@ -181,11 +181,12 @@ __device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], qcon
         int col[8];
         if (VARIANT == 1 && (x & 1)) islow_pass<2, true>(a, b, c, d, K, col);
         else islow_pass<2, false>(a, b, c, d, K, col);
+        // the column's 8 (kq, aq) pairs as ONE 64-byte scalar load (left as 16 dword loads the compiler
+        // does not always merge them: 128 s_load_dword per block after the table-driven prologue)
+        typedef uint32_t u32x16q __attribute__((ext_vector_type(16)));
+        const u32x16q qv = *reinterpret_cast<const u32x16q __attribute__((address_space(4))) *>(qc + x * 16);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = (x * 8 + k) * 2;
-            prod[k * 8 + x] = dot2((uint32_t)col[k], qc[i], (int)qc[i + 1]);
-        }
+        for (int k = 0; k < 8; k++) prod[k * 8 + x] = dot2((uint32_t)col[k], qv[2 * k], (int)qv[2 * k + 1]);
     }
 #pragma unroll
     for (int j = 0; j < 32; j++) out[j] = pack_hi(prod[kZigzag[2 * j]], prod[kZigzag[2 * j + 1]]);
