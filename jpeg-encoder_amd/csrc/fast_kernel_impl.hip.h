@@ -175,11 +175,24 @@ __device__ __forceinline__ void fetch_rows(gbytes frame, bool aligned4, uint32_t
     constexpr int N = (BPP * 8 * STEPX + 3) / 4;
 #pragma unroll
     for (int y = 0; y < 8; y++) {
-        uint32_t d[N], v[8];
+        uint32_t v[8];
         // byte offset of row y = min(first + y*pitch, last): bottom-edge rows repeat row h-1
-        load_row<N>(frame + min(first + (uint32_t)(y * STEPY) * pitch, last), aligned4, d);
+        const gbytes row = frame + min(first + (uint32_t)(y * STEPY) * pitch, last);
+        if (STEPX == 4) {          // 32 pixels per row and lane: two halves of four samples keep the live registers down
+            constexpr int NH = N / 2;
 #pragma unroll
-        for (int x = 0; x < 8; x++) v[x] = conv(pixel_word<BPP, STEPX, N>(d, x));
+            for (int half = 0; half < 2; half++) {
+                uint32_t d[NH];
+                load_row<NH>(row + half * NH * 4, aligned4, d);
+#pragma unroll
+                for (int x = 0; x < 4; x++) v[half * 4 + x] = conv(pixel_word<BPP, STEPX, NH>(d, x));
+            }
+        } else {
+            uint32_t d[N];
+            load_row<N>(row, aligned4, d);
+#pragma unroll
+            for (int x = 0; x < 8; x++) v[x] = conv(pixel_word<BPP, STEPX, N>(d, x));
+        }
         rows[y][0] = __builtin_amdgcn_perm(v[1], v[0], pack);
         rows[y][1] = __builtin_amdgcn_perm(v[2], v[3], pack);
         rows[y][2] = __builtin_amdgcn_perm(v[6], v[7], pack);
@@ -198,9 +211,10 @@ struct ByteConv {          // the sample is a byte of the pixel word itself
 #endif
 #define JPEGENC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(JPEGENC_MIN_WAVES)))
 // CONV = the kernel carries the RGB -> YCbCr roles (RGB family, CmykAsYcck); otherwise byte planes only.
-// 3-byte RGB has at most 6 waves per 64-MCU group; CmykAsYcck / 4-component layouts up to 10.
+// 3-byte RGB with sampling factors 1 and 2 has at most 6 waves per 64-MCU group; 4:1:0-style factors (4x2), CmykAsYcck
+// and 4-component layouts up to 10.
 template <int BPP, int SX, int SY, int VARIANT, bool CONV>
-__global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
+__global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY <= 4 ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef JPEGENC_WAVE_TIMING
     const uint64_t tm0 = __builtin_readcyclecounter();
@@ -420,6 +434,11 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
     return hipGetLastError();
 }
 
+// fast_kernels_s4.hip / fast_kernels_bytes_s4.hip: the instantiations for a sampling factor of 4
+bool launch_conv_s4(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant,
+                    hipStream_t stream, hipError_t *err);
+bool launch_bytes_s4(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant,
+                     hipStream_t stream, hipError_t *err);
 // fast_kernels_bytes.hip
 bool launch_bytes_family(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant,
                          hipStream_t stream, hipError_t *err);

@@ -46,7 +46,7 @@ static bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx
     // every component is either full resolution or decimated by one common (SX, SY) in {1,2}^2
     int sx = 1, sy = 1;
     for (int c = 0; c < p.ncomp; c++) {
-        if (p.sx[c] > 2 || p.sy[c] > 2) return false;
+        if (p.sx[c] > 4 || p.sy[c] > 4) return false;
         if (p.sx[c] > 1 || p.sy[c] > 1) {
             if ((sx > 1 || sy > 1) && (sx != p.sx[c] || sy != p.sy[c])) return false;
             sx = p.sx[c]; sy = p.sy[c];
@@ -74,6 +74,7 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
     JPEGENC_CASE(3, 1, 1) JPEGENC_CASE(3, 2, 1) JPEGENC_CASE(3, 1, 2) JPEGENC_CASE(3, 2, 2)
     JPEGENC_CASE(4, 1, 1) JPEGENC_CASE(4, 2, 1) JPEGENC_CASE(4, 1, 2) JPEGENC_CASE(4, 2, 2)
 #undef JPEGENC_CASE
+    if (sx == 4 || sy == 4) return launch_conv_s4(p, k, sx, sy, num_frames, variant, stream, err);
     return false;
 }
 

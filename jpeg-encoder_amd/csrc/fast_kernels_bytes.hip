@@ -11,6 +11,7 @@ bool launch_bytes_family(const BlockKernelParams &p, const ColourConsts &k, int 
     JPEGENC_CASE(3, 1, 1) JPEGENC_CASE(3, 2, 1) JPEGENC_CASE(3, 1, 2) JPEGENC_CASE(3, 2, 2)
     JPEGENC_CASE(4, 1, 1) JPEGENC_CASE(4, 2, 1) JPEGENC_CASE(4, 1, 2) JPEGENC_CASE(4, 2, 2)
 #undef JPEGENC_CASE
+    if (sx == 4 || sy == 4) return launch_bytes_s4(p, k, sx, sy, num_frames, variant, stream, err);
     return false;
 }
 
