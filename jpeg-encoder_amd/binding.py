@@ -359,6 +359,15 @@ class Encoder:
         check(lib().jpegenc_encoder_encode(self._h, px.ctypes.data, px.size, width, height, color_type, cb, None))
         return b"".join(chunks)
 
+    def encode_to_buffer(self, pixels, width, height, color_type, out):
+        """jpegenc_encoder_encode_to_buffer into a caller-owned uint8 array; returns the file size."""
+        px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
+        n = C.c_size_t(0)
+        fn = lib().jpegenc_encoder_encode_to_buffer
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        check(fn(self._h, px.ctypes.data, px.size, width, height, color_type, out.ctypes.data, out.size, C.byref(n)))
+        return n.value
+
     def encode_to_file(self, path, pixels, width, height, color_type):
         """Encoder::new_file(path, q) + encode: the file is created first, then written."""
         px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
