@@ -207,8 +207,8 @@ static void islow_1d(const int32_t in[8], int32_t out[8], int second_pass) {
     int n = second_pass ? CONST_BITS + PASS1_BITS : CONST_BITS - PASS1_BITS;
 
     if (!second_pass) {
-        out[0] = (tmp10 + tmp11) << PASS1_BITS;
-        out[4] = (tmp10 - tmp11) << PASS1_BITS;
+        out[0] = (tmp10 + tmp11) * (1 << PASS1_BITS);      /* `<<` of a negative i32: defined in Rust, not in C */
+        out[4] = (tmp10 - tmp11) * (1 << PASS1_BITS);
     } else {
         out[0] = descale(tmp10 + tmp11, PASS1_BITS);
         out[4] = descale(tmp10 - tmp11, PASS1_BITS);
