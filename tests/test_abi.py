@@ -197,3 +197,16 @@ def test_c_example_builds_against_the_header(binding, tmp_path):
     exe = _build_example(tmp_path)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_integration_notes_show_every_entry_point():
+    """INTEGRATION.md's Rust `extern "C"` block binds everything include/jpegenc_mi355x.h declares."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "jpegenc_mi355x.h")).read()
+    notes = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(jpegenc_[a-z0-9_]+)\s*\((?!\*)", header)))
+    assert len(names) > 40
+    missing = [n for n in names if n not in notes]
+    assert not missing, missing
