@@ -35,6 +35,9 @@
 
 namespace jpegenc {
 
+#ifndef JPEGENC_DOT4_MAX_DECIMATION
+#define JPEGENC_DOT4_MAX_DECIMATION 2      // chroma decimated by more than this (4:2:0, 4:1:1 ...) takes the perm + sdot2 form: measured per case
+#endif
 enum Role : int32_t { ROLE_Y = 0, ROLE_CB = 1, ROLE_CR = 2, ROLE_BYTE = 3 };
 
 // Pixel and coefficient addresses reach the tuned kernels as integers (FastHeader): typed as global
@@ -280,7 +283,7 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
         if (CONV && role == ROLE_Y) {
             fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, LumaConv::kPack, LumaConv{Wv[9], Wv[10]}, rows);
         } else if (CONV && role != ROLE_BYTE) {
-            if (SX * SY == 1) {
+            if (SX * SY <= JPEGENC_DOT4_MAX_DECIMATION) {
                 const ChromaConv cc = {Wv[9], Wv[10], Wv[11]};
                 fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, ChromaConv::kPack, cc, rows);
             } else {
@@ -405,7 +408,7 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
         if (conv && role == ROLE_Y) { f.conv[0] = k.y_lo; f.conv[1] = k.y_hi; }
         else if (conv && role != ROLE_BYTE) {
             const bool cb = role == ROLE_CB;
-            if (sx * sy == 1) { f.conv[0] = cb ? k.cb_lo : k.cr_lo; f.conv[1] = cb ? k.cb_hi : k.cr_hi; f.conv[2] = cb ? k.cb_xor : k.cr_xor; }
+            if (sx * sy <= JPEGENC_DOT4_MAX_DECIMATION) { f.conv[0] = cb ? k.cb_lo : k.cr_lo; f.conv[1] = cb ? k.cb_hi : k.cr_hi; f.conv[2] = cb ? k.cb_xor : k.cr_xor; }
             else { f.conv[0] = cb ? k.sel_cb : k.sel_cr; f.conv[1] = cb ? k.k_cb : k.k_cr; f.conv[2] = cb ? k.sh_b : k.sh_r; }
         }
         const uint32_t b = (uint32_t)k.byte_index[c];
