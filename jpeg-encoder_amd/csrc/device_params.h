@@ -40,15 +40,15 @@ struct alignas(64) FastHeader {
 };
 struct alignas(64) FastWave {         // one per wave of a group, indexed by the wave's number in the workgroup
     uint32_t bits;                    // see FW_* below
-    uint32_t first_off;               // MCU order: first MCU = group * 64 + first_off; planar: task = group * hv + first_off
-    uint32_t hv;                      // planar: tasks of this component per round
-    uint32_t units_x;                 // MCUs (MCU order) / blocks of this component (planar) per row
-    uint32_t limit;                   // MCUs of the frame / blocks of this component
+    uint32_t first_off;               // first MCU of the wave = group * 64 + first_off (both block orders walk MCUs)
+    uint32_t cols;                    // planar order: blocks per row of this component's plane (encoder.rs:1012-1025)
+    uint32_t units_x;                 // MCUs per row
+    uint32_t limit;                   // MCUs of the frame
     uint32_t magic, shift;            // n / units_x == (n * magic) >> shift for every n < 2^26
     uint32_t out_base_lo, out_base_hi;   // MCU order: index of the wave's first block inside an MCU; planar: component offset
     uint32_t conv[3];                 // the role's conversion constants (luma / chroma udot4: lo, hi, xor; chroma sdot2: sel, k, shift)
     uint32_t byte_pack;               // ROLE_BYTE: v_perm selector of the sample byte
-    uint32_t invert;                  // ROLE_BYTE: sample = 255 - byte
+    uint32_t rows;                    // planar order: block rows of this component's plane
     uint32_t plane_lo, plane_hi;      // XF_PLANES: byte offset of the component's plane
 };
 enum : uint32_t {                     // FastWave::bits
@@ -58,7 +58,8 @@ enum : uint32_t {                     // FastWave::bits
     FW_SUB_SHIFT = 5,                 // 1 bit: decimated by the kernel's (SX, SY)
     FW_LG_SHIFT = 6,                  // 2 bits: log2 of the component's blocks per MCU row that this wave handles (= log2 h)
     FW_VROW_SHIFT = 8,                // 3 bits: which block row inside the MCU
-    FW_VALID_SHIFT = 11,              // 1 bit: wave has work (padding waves of short groups exit)
+    FW_INVERT_SHIFT = 11,             // 1 bit: ROLE_BYTE sample = 255 - byte
+    FW_LGV_SHIFT = 12,                // 2 bits: log2 of the component's block rows per MCU (= log2 v)
 };
 
 struct BlockKernelParams {

@@ -234,9 +234,11 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
     const int role = (int)((bits >> FW_ROLE_SHIFT) & 3u);
     const int qsel = (int)((bits >> FW_QSEL_SHIFT) & 1u);
     const bool sub = (bits >> FW_SUB_SHIFT) & 1u;                   // this component is decimated by (SX, SY)
-    const uint32_t lg = (bits >> FW_LG_SHIFT) & 3u, vrow = (bits >> FW_VROW_SHIFT) & 7u;
+    const uint32_t lg = (bits >> FW_LG_SHIFT) & 3u, vrow = (bits >> FW_VROW_SHIFT) & 7u, lgv = (bits >> FW_LGV_SHIFT) & 3u;
     const uint32_t order = H[11], units_x = Wv[3], limit = Wv[4], magic = Wv[5], shift = Wv[6];
-    const uint32_t first_unit = order == 0 ? blockIdx.x * 64u + Wv[1] : (blockIdx.x * Wv[2] + Wv[1]) * 64u;
+    // Both block orders walk the image MCU by MCU - that is what makes the waves of a workgroup read the
+    // same pixels; the order only decides where a block is stored (stage_and_store).
+    const uint32_t first_unit = blockIdx.x * 64u + Wv[1];
     if (first_unit >= limit) return;                                // padding wave of the last group: nothing to do
     const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0], co_base = ((uint64_t)H[3] << 32) | H[2];
     const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4], co_stride = ((uint64_t)H[7] << 32) | H[6];
@@ -246,9 +248,9 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
     const uint32_t pitch = H[10];                                   // frame bytes < 2^31 (checked by the launcher)
     const int sxc = sub ? SX : 1, syc = sub ? SY : 1;
 
-    // this lane's block: (ux, uy) = MCU (MCU order) or block of the component (planar) in the frame
+    // this lane's block: MCU (ux, uy), then block sub_k of the wave's block row inside it
     const uint32_t row0 = (uint32_t)(((uint64_t)first_unit * magic) >> shift), col0 = first_unit - row0 * units_x;   // wave-uniform
-    const uint32_t dm = order == 0 ? lane >> lg : lane, sub_k = order == 0 ? lane & ((1u << lg) - 1u) : 0u;
+    const uint32_t dm = lane >> lg, sub_k = lane & ((1u << lg) - 1u);
     uint32_t ux = col0 + dm, uy = row0;
     if (units_x >= 64u) {                      // at most one wrap: dm < 64 <= units_x
         if (ux >= units_x) { ux -= units_x; uy++; }
@@ -256,10 +258,12 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
         const uint32_t q = (uint32_t)(((uint64_t)ux * magic) >> shift);
         uy += q; ux -= q * units_x;
     }
-    if (first_unit + dm >= limit) { ux = 0; uy = 0; }               // slots past the end read block 0 and store nothing
+    bool inside = first_unit + dm < limit;
+    if (order != 0) inside = inside && (ux << lg) + sub_k < Wv[2] && (uy << lgv) + vrow < Wv[13];   // planar: the plane may end inside the last MCUs
+    if (!inside) { ux = 0; uy = 0; }                                // such slots read block 0 and store nothing
     BlockRef me;
-    me.x0 = order == 0 ? (int)(ux * H[13] + sub_k * 8u) : (int)(ux * 8u * (uint32_t)sxc);
-    me.y0 = order == 0 ? (int)(uy * H[14] + vrow * 8u) : (int)(uy * 8u * (uint32_t)syc);
+    me.x0 = (int)(ux * H[13] + sub_k * 8u * (uint32_t)sxc);
+    me.y0 = (int)(uy * H[14] + vrow * 8u * (uint32_t)syc);
     const bool aligned4 = (((uintptr_t)frame | pitch) & 3u) == 0;   // wave-uniform
     const uint32_t first = (uint32_t)me.y0 * pitch + (uint32_t)me.x0 * BPP;
     const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * BPP;
@@ -296,7 +300,7 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
             const uint32_t pack = Wv[12];
             if (!CONV && sub && (SX > 1 || SY > 1)) fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
             else fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
-            if (Wv[13]) {
+            if ((bits >> FW_INVERT_SHIFT) & 1u) {
 #pragma unroll
                 for (int y = 0; y < 8; y++)
 #pragma unroll
@@ -342,8 +346,13 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
     __builtin_amdgcn_sched_barrier(0);
 #endif
     StoreMap sm;
-    sm.order = order; sm.lg = lg; sm.first = first_unit; sm.limit = limit; sm.bpm = H[12];
+    // planar order: a component with one block per MCU whose plane is as wide as the MCU grid stores 64
+    // consecutive blocks (chroma of 4:2:0, everything in 4:4:4); the others map each slot through its MCU
+    sm.order = order == 0 ? 0u : (lg == 0u && lgv == 0u && Wv[2] == units_x ? 1u : 2u);
+    sm.lg = lg; sm.first = first_unit; sm.limit = limit; sm.bpm = H[12];
     sm.out_base = ((uint64_t)Wv[8] << 32) | Wv[7];
+    sm.units_x = units_x; sm.magic = magic; sm.shift = shift; sm.col0 = col0; sm.row0 = row0;
+    sm.lgv = lgv; sm.vrow = vrow; sm.cols = Wv[2]; sm.rows = Wv[13];
     stage_and_store(sm, smem + wave * kStageBytes, lane, packed, frame_out);
 #endif
 #ifdef JPEGENC_WAVE_TIMING
@@ -366,8 +375,11 @@ unsigned long long *wave_timing_buffer();      // fast_kernels.hip
 
 // Host side of the prologue: the FastHeader / FastWave records of a launch.
 static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k, int bpp, int sx, int sy, bool conv) {
-    if (q.order != 0 && !q.planar_round) return false;            // component-major planar tasks: generic kernel
-    if (q.per_group < 1 || q.per_group > 10) return false;
+    uint32_t waves = 0;
+    for (int c = 0; c < q.ncomp; c++) waves += (uint32_t)(q.h[c] * q.v[c]);
+    if (waves < 1 || waves > 10 || waves != q.wave_start[q.ncomp]) return false;
+    q.per_group = waves;                                          // both orders: the waves of 64 MCUs
+    q.groups = (q.total_mcus + 63u) / 64u;
     FastHeader &h = q.fast_hdr;
     memset(&h, 0, sizeof h);
     h.pixels = (uint64_t)(uintptr_t)q.pixels; h.coeffs = (uint64_t)(uintptr_t)q.coeffs;
@@ -380,19 +392,20 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
         int c = 0;
         while (c + 1 < q.ncomp && w >= q.wave_start[c + 1]) c++;
         const uint32_t in_comp = w - q.wave_start[c], hc = (uint32_t)q.h[c];
-        uint32_t lg = 0, vrow = 0;
-        if (q.order == 0) {       // one row of the component's blocks inside the MCU from 64 / h MCUs (wave_tasks.hip.h)
-            while ((1u << lg) < hc) lg++;
-            const uint32_t range = in_comp % hc;
-            vrow = in_comp / hc;
-            f.first_off = range * (64u / hc);
-            f.units_x = q.mcus_x; f.limit = q.total_mcus;
+        // one row of the component's blocks inside the MCU from 64 / h MCUs (wave_tasks.hip.h), in both orders
+        uint32_t lg = 0, lgv = 0;
+        while ((1u << lg) < hc) lg++;
+        while ((1u << lgv) < (uint32_t)q.v[c]) lgv++;
+        const uint32_t range = in_comp % hc, vrow = in_comp / hc;
+        f.first_off = range * (64u / hc);
+        f.units_x = q.mcus_x; f.limit = q.total_mcus;
+        if (q.order == 0) {
             const uint64_t ob = (uint64_t)q.comp_first[c] + (uint64_t)vrow * hc;
             f.out_base_lo = (uint32_t)ob; f.out_base_hi = (uint32_t)(ob >> 32);
         } else {
-            f.first_off = in_comp; f.hv = (uint32_t)(q.h[c] * q.v[c]);
-            f.units_x = q.cols[c]; f.limit = q.nblocks[c];
             f.out_base_lo = (uint32_t)q.comp_off[c]; f.out_base_hi = (uint32_t)(q.comp_off[c] >> 32);
+            f.cols = q.cols[c];
+            f.rows = q.cols[c] ? q.nblocks[c] / q.cols[c] : 0;
         }
         if (f.units_x == 0 || f.limit > (1u << 26)) return false;
         // n / d == (n * magic) >> shift for n < 2^26: magic = ceil(2^shift / d), shift = 26 + ceil(log2 d);
@@ -404,7 +417,8 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
         const bool sub = q.sx[c] > 1 || q.sy[c] > 1;
         const int role = k.role[c];
         f.bits = ((uint32_t)c << FW_COMP_SHIFT) | ((uint32_t)role << FW_ROLE_SHIFT) | ((uint32_t)(q.qsel[c] & 1) << FW_QSEL_SHIFT) |
-                 ((uint32_t)sub << FW_SUB_SHIFT) | (lg << FW_LG_SHIFT) | (vrow << FW_VROW_SHIFT) | (1u << FW_VALID_SHIFT);
+                 ((uint32_t)sub << FW_SUB_SHIFT) | (lg << FW_LG_SHIFT) | (vrow << FW_VROW_SHIFT) |
+                 ((uint32_t)(k.invert[c] != 0) << FW_INVERT_SHIFT) | (lgv << FW_LGV_SHIFT);
         if (conv && role == ROLE_Y) { f.conv[0] = k.y_lo; f.conv[1] = k.y_hi; }
         else if (conv && role != ROLE_BYTE) {
             const bool cb = role == ROLE_CB;
@@ -413,7 +427,6 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
         }
         const uint32_t b = (uint32_t)k.byte_index[c];
         f.byte_pack = 0x0C040C00u | b | (b << 16);     // byte b of each pixel word -> zero-extended 16-bit pair
-        f.invert = (uint32_t)k.invert[c];
         f.plane_lo = (uint32_t)k.plane_offset[c]; f.plane_hi = (uint32_t)(k.plane_offset[c] >> 32);
     }
     return true;
@@ -424,8 +437,8 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
                               hipStream_t stream) {
     BlockKernelParams q = p;
     if (!fill_fast_params(q, k, BPP, SX, SY, CONV)) return hipErrorInvalidValue;      // launch_blocks_fast checked the preconditions
-    const dim3 grid(p.groups, (unsigned)num_frames), block(p.per_group * 64u);          // <= 10 waves for sampling factors 1 and 2
-    size_t lds = (size_t)p.per_group * kStageBytes;
+    const dim3 grid(q.groups, (unsigned)num_frames), block(q.per_group * 64u);          // <= 10 waves
+    size_t lds = (size_t)q.per_group * kStageBytes;
 #ifdef JPEGENC_WAVE_TIMING
     q.timing = wave_timing_buffer();
 #endif

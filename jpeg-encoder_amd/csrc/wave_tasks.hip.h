@@ -129,12 +129,15 @@ __device__ __forceinline__ WaveTask decode_task(const BlockKernelParams &p, uint
 // Where the 64 staged blocks of a wave go: wave-uniform, built from BlockKernelParams + WaveTask by
 // the generic kernel and from the FastWave record by the tuned kernels.
 struct StoreMap {
-    uint32_t order;      // 0 = MCU order, 1 = planar
+    uint32_t order;      // 0 = MCU order, 1 = planar (64 consecutive blocks), 2 = planar output of an MCU-shaped walk
     uint32_t lg;         // MCU order: log2 of the blocks per MCU this wave handles
     uint32_t first;      // first MCU (MCU order) / first block of the component (planar)
     uint32_t limit;      // MCUs of the frame / blocks of the component
     uint32_t bpm;        // blocks per MCU
     uint64_t out_base;   // MCU order: index of the wave's first block inside an MCU; planar: component offset
+    // order 2 only: the wave walks MCUs like order 0 but its blocks land at their place in the component's
+    // plane (row-major cols x rows blocks); blocks of padding MCUs outside the plane are dropped
+    uint32_t units_x, magic, shift, col0, row0, lgv, vrow, cols, rows;
 };
 
 __device__ __forceinline__ StoreMap store_map(const BlockKernelParams &p, const WaveTask &t) {
@@ -145,6 +148,7 @@ __device__ __forceinline__ StoreMap store_map(const BlockKernelParams &p, const 
     m.limit = p.order == 0 ? p.total_mcus : p.nblocks[t.comp];
     m.bpm = p.bpm;
     m.out_base = p.order == 0 ? (uint64_t)(p.comp_first[t.comp] + t.k_base) : p.comp_off[t.comp];
+    m.units_x = m.magic = m.shift = m.col0 = m.row0 = m.lgv = m.vrow = m.cols = m.rows = 0;      // order 2 only
     return m;
 }
 
@@ -173,7 +177,7 @@ __device__ __forceinline__ void stage_and_store(const StoreMap &m, uint8_t *stag
     uint32_t unit, unit_step;                 // "unit" = MCU (MCU order) or block (planar)
     uint64_t index;                           // output block index of slot0
     uint32_t index_step;
-    if (m.order == 0) {
+    if (m.order != 1) {
         unit = m.first + (slot0 >> m.lg);
         unit_step = 8u >> m.lg;                                                // lg <= 3 (hv <= 8)
         index = (uint64_t)unit * m.bpm + m.out_base + (slot0 & ((1u << m.lg) - 1u));
@@ -185,13 +189,32 @@ __device__ __forceinline__ void stage_and_store(const StoreMap &m, uint8_t *stag
         index_step = 8u;
     }
     const uint8_t *src = stage + slot0 * 128u + ((j ^ (slot0 & 7u)) << 4);     // (slot0 + 8*it) & 7 == slot0 & 7
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (m.order == 2) {           // wave-uniform; kept out of the other orders' loop (its body is the hot path)
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src + it * 1024);
+            // slot -> MCU -> block (bx, by) of the component's plane
+            const uint32_t slot = slot0 + 8u * (uint32_t)it, dm = slot >> m.lg, sk = slot & ((1u << m.lg) - 1u);
+            uint32_t ux = m.col0 + dm, uy = m.row0;
+            if (m.units_x >= 64u) {                  // at most one wrap (dm < 64)
+                if (ux >= m.units_x) { ux -= m.units_x; uy++; }
+            } else {
+                const uint32_t q = (uint32_t)(((uint64_t)ux * m.magic) >> m.shift);
+                uy += q; ux -= q * m.units_x;
+            }
+            const uint32_t bx = (ux << m.lg) + sk, by = (uy << m.lgv) + m.vrow;
+            if (m.first + dm < m.limit && bx < m.cols && by < m.rows)
+                nt_store16(u32x4{v.x, v.y, v.z, v.w}, &frame_out[(m.out_base + (uint64_t)by * m.cols + bx) * 8u + j]);
+        }
+        return;
+    }
     const ChunkPtr dst = frame_out + index * 8u + j;
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + it * 1024);
         if (unit + (uint32_t)it * unit_step < m.limit) {
 #ifndef JPEGENC_PLAIN_STORE   // streaming stores: +1.6 % on the 4K bench (nothing re-reads the coefficients)
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             nt_store16(u32x4{v.x, v.y, v.z, v.w}, &dst[(size_t)it * index_step * 8u]);
 #else
             dst[(size_t)it * index_step * 8u] = v;
