@@ -73,6 +73,25 @@ def cpu_baseline(seconds_budget, synth, gpu_frame=None, gpu_coeffs=None):
         "sample": f"{n} frames of 3840x2160 RGB q=90 4:2:0 in {dt:.1f} s, pixels->coefficients only "
                   f"(oracle/jpegenc_oracle.c, gcc -O3 -march=native, {os.cpu_count()} host cores present)",
     }
+    # the same port through to the file (block path + Huffman coding + markers), one core: the CPU figure
+    # comparable with `end_to_end`
+    try:
+        if seconds_budget < 2.0:
+            raise RuntimeError("skipped (short --cpu-seconds)")
+        pattern = synth.criterion_pattern(W, H)
+        pyoracle.encode_jpeg(pattern, W, H, pyoracle.RGB, QUALITY, sampling=(HS, VS))
+        m, t1 = 0, time.perf_counter()
+        while True:
+            jpg = pyoracle.encode_jpeg(pattern, W, H, pyoracle.RGB, QUALITY, sampling=(HS, VS))
+            m += 1
+            dt1 = time.perf_counter() - t1
+            if dt1 >= min(3.0, seconds_budget / 4) or m >= 50:
+                break
+        base["full_encode"] = {"value": round(m * W * H / dt1 / 1e6, 2), "unit": "Mpixels/s", "cores": 1,
+                               "sample": f"{m} complete JPEG files of the 3840x2160 Criterion pattern in {dt1:.1f} s "
+                                         f"({len(jpg)} bytes each), block path + Huffman coding + markers"}
+    except Exception as exc:                                    # side figure only
+        base["full_encode"] = {"error": str(exc)}
     # the same port, frame-parallel over every core of this host on the C3 frame
     # shape (the reference itself is single-threaded; a caller would run one encoder per thread)
     try:
