@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed run-in before the warm-up steps: the first ~50 launches (~15 ms) after an idle "
                          "period run up to 35 %% slower while the power management settles "
-                         "(profiles/r01_j_step_series.txt); sustained encoding is what the metric describes")
+                         "(profiles/r01_k_step_series.txt); sustained encoding is what the metric describes")
     ap.add_argument("--frames", type=int, default=32, help="4K frames per launch and per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-frames", type=int, default=32, help="frames for the end-to-end (JPEG bytes) side figure; 0 disables")

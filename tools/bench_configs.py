@@ -31,7 +31,7 @@ def time_blocks(name, w, h, ct, hs, vs, q, order, frames, reps=100):
     def run():
         b.blocks_device(d_px.data_ptr(), fb, frames, w, h, ct, hs, vs, qt, order, 0, d_co.data_ptr(), nblk, st.cuda_stream)
     import time
-    t0 = time.perf_counter()                      # run-in: see profiles/r01_j_step_series.txt
+    t0 = time.perf_counter()                      # run-in: see profiles/r01_k_step_series.txt
     while time.perf_counter() - t0 < 0.15:
         for _ in range(8):
             run()
