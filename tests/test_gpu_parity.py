@@ -745,3 +745,17 @@ def test_encode_batch_device_resident(binding, oracle, synth, kw):
         for i in (0, 1, 2, 33, 63, 64, 69):
             assert got[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, **kw), (i, on)
         assert len(set(got)) > n // 2
+
+
+def test_blocks_stream_planar_cmyk(binding, oracle, synth):
+    """The tile stream with a 4-component layout, vertical decimation and planar order (the order the
+    sequential / progressive writers consume)."""
+    w, h, n = 203, 157, 6
+    frames = [np.ascontiguousarray(synth.lcg_image(w, h, 4, 40 + i)) for i in range(n)]
+    q = binding.qtables(64)
+    seen = {}
+    binding.blocks_stream([f.ctypes.data for f in frames], frames[0].size, w, h, binding.CMYK, 1, 2, q,
+                          lambda i, t: seen.__setitem__(i, t.copy()), order=binding.ORDER_PLANAR)
+    assert sorted(seen) == list(range(n))
+    for i in range(n):
+        _same(seen[i], oracle.encode_blocks(frames[i], w, h, oracle.CMYK, 1, 2, 64, 1))
