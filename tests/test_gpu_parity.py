@@ -759,3 +759,31 @@ def test_blocks_stream_planar_cmyk(binding, oracle, synth):
     assert sorted(seen) == list(range(n))
     for i in range(n):
         _same(seen[i], oracle.encode_blocks(frames[i], w, h, oracle.CMYK, 1, 2, 64, 1))
+
+
+def test_handles_release_their_device_memory(binding, synth):
+    """300 encoder handles created, used (every API family) and freed: device memory returns to where it was."""
+    import gc
+    import torch
+    px = synth.lcg_image(320, 200, 3, 9)
+    d = torch.from_numpy(px.copy()).to("cuda:0")
+    frames = [px] * 3
+
+    def cycle():
+        e = binding.Encoder(80)
+        e.encode(px, 320, 200, binding.RGB)
+        e.encode_device(d.data_ptr(), 320, 200, binding.RGB)
+        e.encode_batch(frames, 320, 200, binding.RGB)
+        e.encode_batch_device(d.data_ptr(), px.size, 1, 320, 200, binding.RGB)
+        del e
+    for _ in range(5):
+        cycle()
+    gc.collect()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(300):
+        cycle()
+    gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), f"{(free0 - free1) >> 20} MiB of device memory not returned"
