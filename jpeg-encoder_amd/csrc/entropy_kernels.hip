@@ -114,6 +114,52 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *in, uint64_t
     }
 }
 
+// reduce + this kernel = the whole scan when there are few tiles: every workgroup sums the raw tile sums
+// before its own (instead of a third, single-workgroup kernel turning them into prefixes first), and
+// the workgroup of the last tile also writes the total.  Two launches per scan instead of three - the
+// scans are launch-bound (a 4K frame has 48 tiles of block lengths).
+__global__ void __launch_bounds__(256) k_scan_apply_fused(const uint32_t *in, uint64_t in_stride, uint32_t *out,
+                                                          uint64_t out_stride, const uint32_t *tile_sums, uint32_t max_tiles,
+                                                          uint32_t *totals, const uint32_t *n_dev, uint32_t n_const) {
+    const uint32_t f = blockIdx.y, n = frame_n(n_dev, n_const, f);
+    const uint32_t tile = blockIdx.x;
+    if (n == 0) { if (tile == 0 && threadIdx.x == 0) totals[f] = 0; return; }
+    if ((uint64_t)tile * kScanTile >= n) return;
+    const uint32_t *src = in + (size_t)f * in_stride;
+    uint32_t *dst = out + (size_t)f * out_stride;
+    const uint32_t *ts = tile_sums + (size_t)f * max_tiles;
+    __shared__ uint32_t buf[256];
+    uint32_t before = 0;
+    for (uint32_t i = threadIdx.x; i < tile; i += 256u) before += ts[i];
+    buf[threadIdx.x] = before;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) buf[threadIdx.x] += buf[threadIdx.x + s];
+        __syncthreads();
+    }
+    const uint32_t base = buf[0];
+    __syncthreads();
+    const uint32_t first = tile * kScanTile + threadIdx.x * 16;      // each thread owns 16 consecutive elements
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { v[i] = first + i < n ? src[first + i] : 0; sum += v[i]; }
+    buf[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {
+        const uint32_t t = (int)threadIdx.x >= s ? buf[threadIdx.x - s] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = base + buf[threadIdx.x] - sum;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (first + i < n) dst[first + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 255 && (uint64_t)(tile + 1) * kScanTile >= n) totals[f] = base + buf[255];
+}
+
 // ---- walking one block's symbols ----------------------------------------------------------------
 __device__ __forceinline__ uint32_t bit_size(int v) {          // get_code().0 / get_num_bits (writer.rs:455-470)
     const uint32_t a = (uint32_t)(v < 0 ? -v : v);
@@ -407,6 +453,11 @@ static hipError_t scan(const uint32_t *in, uint64_t in_stride, uint32_t *out, ui
                        hipStream_t st) {
     const uint32_t tiles = (n_max + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(k_scan_reduce, dim3(tiles, frames), dim3(256), 0, st, in, in_stride, partials, max_tiles, n_dev, n_max);
+    if (tiles <= 2048) {       // every workgroup can afford to add up the tile sums before its own
+        hipLaunchKernelGGL(k_scan_apply_fused, dim3(tiles ? tiles : 1, frames), dim3(256), 0, st, in, in_stride, out, out_stride,
+                           partials, max_tiles, totals, n_dev, n_max);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_scan_partials, dim3(frames), dim3(256), 0, st, partials, max_tiles, totals, n_dev, n_max);
     hipLaunchKernelGGL(k_scan_apply, dim3(tiles, frames), dim3(256), 0, st, in, in_stride, out, out_stride, partials,
                        max_tiles, n_dev, n_max);
