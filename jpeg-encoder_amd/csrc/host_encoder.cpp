@@ -247,6 +247,9 @@ struct DeviceCtx {
     size_t h_scan_out_cap = 0;
     static constexpr int kChunks = 8;
     hipEvent_t chunk_done[kChunks] = {};
+    // captured launch sequence of a frame (encode_frame) and what it was captured for
+    hipGraphExec_t graph_exec = nullptr;
+    std::string graph_key, last_key;
 
     int open(int dev) {
         if (device == dev && stream) return JPEGENC_OK;
@@ -324,6 +327,7 @@ struct DeviceCtx {
         (void)hipSetDevice(device);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
         for (auto &e : chunk_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (d_pixels) (void)hipFree(d_pixels);
         if (d_coeffs) (void)hipFree(d_coeffs);
         if (d_freq) (void)hipFree(d_freq);
@@ -594,24 +598,19 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     p.coeffs = ctx.d_coeffs;
     p.pixel_frame_stride = pixel_bytes;
     p.coeff_frame_stride = L.total_blocks;
-    hipError_t err = hipSuccess;
-    if (!launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, 1, c.fdct_variant, ctx.stream);
-    if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
     const bool optimize = c.optimize && mode != MODE_INTERLEAVED;
-    if (optimize) {
-        rc = jpegenc_histogram_device(ctx.d_coeffs, &L, c.progressive_scans, ctx.d_freq, ctx.stream);
-        if (rc) return rc;
-        JPEGENC_HIP(hipMemcpyAsync(ctx.h_freq, ctx.d_freq, sizeof(uint32_t) * 2 * 2 * 257, hipMemcpyDeviceToHost, ctx.stream));
-    }
-    // ---- entropy-code every scan on the device and fetch only the compressed bytes ----------------
     static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
     const auto t_begin = now();
+
+    // ---- the scans the device entropy coder will produce (planned before anything is launched: their
+    // buffers must exist before a launch sequence can be captured) ------------------------------------
+    struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap; };
+    std::vector<Job> jobs;
+    bool supported = false;
     if (c.device_entropy) {
-        struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap; };
-        std::vector<Job> jobs;
         auto add = [&](int comp, int with_dc, int s0, int s1, int first, int n, int ss, int se) {
             Job j;
             j.sc = jpegenc_scan{comp, with_dc, s0, s1, c.restart_interval};
@@ -631,7 +630,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                 for (int i = 0; i < L.num_components; i++) add(i, 0, start, end, i, 1, start, end - 1);
             }
         }
-        bool supported = (int)jobs.size() <= DeviceCtx::kMaxScans;
+        supported = (int)jobs.size() <= DeviceCtx::kMaxScans;
         size_t ws = 0, out_total = 0;
         for (auto &j : jobs) {
             if (!j.sc.with_dc && j.sc.ac_end == j.sc.ac_start) continue;       // empty band: nothing to code
@@ -645,32 +644,86 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         if (supported) {
             rc = ctx.reserve_scan(ws, out_total);
             if (rc) return rc;
+        }
+    }
+
+    // ---- launch sequence of the frame.  With fixed Huffman tables nothing in it depends on the image
+    // content, so the second consecutive frame with identical parameters and buffers captures it into a
+    // hipGraph and later ones replay it.  Measured (profiles/README.md): 3-10 % off the latency of a
+    // baseline image (about 12 launches); nothing for the ~140 launches of a progressive file, whose
+    // small kernels are bound by their own dependent execution on the GPU, not by enqueueing - so only
+    // single-scan frames use it.  (JPEGENC_NO_GRAPH=1 disables it.)
+    static const bool graphs_off = getenv("JPEGENC_NO_GRAPH") != nullptr;
+    enum { DIRECT, CAPTURE, REPLAY } how = DIRECT;
+    if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1) {
+        std::string key;
+        auto put = [&](const void *v, size_t n) { key.append((const char *)v, n); };
+        const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, ctx.h_scan_len};
+        const int64_t vals[] = {width, height, color_type_or_planes, (int64_t)pixel_bytes, order, c.fdct_variant, c.sampling,
+                                c.progressive_scans, c.restart_interval, (int64_t)ctx.d_scan_ws_cap, (int64_t)jobs.size()};
+        put(ptrs, sizeof ptrs); put(vals, sizeof vals); put(t.q, sizeof t.q);
+        if (ctx.graph_exec && key == ctx.graph_key) how = REPLAY;
+        else if (key == ctx.last_key) how = CAPTURE;
+        ctx.last_key.swap(key);
+    }
+    if (how == CAPTURE) JPEGENC_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
+    struct CaptureGuard {            // a failure between begin and end must not leave the stream capturing
+        hipStream_t st; bool active;
+        ~CaptureGuard() { if (active) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); } }
+    } capture_guard{ctx.stream, how == CAPTURE};
+    const bool enqueue = how != REPLAY;
+    if (enqueue) {
+        hipError_t err = hipSuccess;
+        if (!launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, 1, c.fdct_variant, ctx.stream);
+        if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+    }
+    if (optimize) {
+        rc = jpegenc_histogram_device(ctx.d_coeffs, &L, c.progressive_scans, ctx.d_freq, ctx.stream);
+        if (rc) return rc;
+        JPEGENC_HIP(hipMemcpyAsync(ctx.h_freq, ctx.d_freq, sizeof(uint32_t) * 2 * 2 * 257, hipMemcpyDeviceToHost, ctx.stream));
+    }
+    // ---- entropy-code every scan on the device and fetch only the compressed bytes ----------------
+    if (c.device_entropy && supported) {
+        {
             if (optimize) {                                  // optimize_huffman_table, encoder.rs:1086-1200
                 JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
                 const int max_tables = L.num_components < 2 ? L.num_components : 2;
                 for (int d = 0; d < max_tables; d++)
                     for (int k = 0; k < 2; k++) t.h[d][k].assign_optimized(ctx.h_freq + (d * 2 + k) * 257);
             }
-            jpegenc_huffman_spec specs[2][2];
-            for (int d = 0; d < 2; d++)
-                for (int k = 0; k < 2; k++) {
-                    memset(&specs[d][k], 0, sizeof specs[d][k]);
-                    memcpy(specs[d][k].bits, t.h[d][k].bits, 16);
-                    memcpy(specs[d][k].values, t.h[d][k].vals, (size_t)t.h[d][k].nvals);
-                    specs[d][k].num_values = t.h[d][k].nvals;
-                }
-            rc = upload_huffman_luts(specs, ctx.d_lut, ctx.stream);
-            if (rc) return rc;
-            JPEGENC_HIP(hipMemsetAsync(ctx.d_scan_len, 0, sizeof(uint32_t) * jobs.size(), ctx.stream));
-            for (size_t k = 0; k < jobs.size(); k++) {
-                Job &j = jobs[k];
-                if (!j.cap) continue;
-                rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)ctx.d_scan_out + j.off,
-                                 j.cap, ctx.d_scan_len + k, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream);
+            if (enqueue) {
+                jpegenc_huffman_spec specs[2][2];
+                for (int d = 0; d < 2; d++)
+                    for (int k = 0; k < 2; k++) {
+                        memset(&specs[d][k], 0, sizeof specs[d][k]);
+                        memcpy(specs[d][k].bits, t.h[d][k].bits, 16);
+                        memcpy(specs[d][k].values, t.h[d][k].vals, (size_t)t.h[d][k].nvals);
+                        specs[d][k].num_values = t.h[d][k].nvals;
+                    }
+                rc = upload_huffman_luts(specs, ctx.d_lut, ctx.stream);
                 if (rc) return rc;
+                JPEGENC_HIP(hipMemsetAsync(ctx.d_scan_len, 0, sizeof(uint32_t) * jobs.size(), ctx.stream));
+                for (size_t k = 0; k < jobs.size(); k++) {
+                    Job &j = jobs[k];
+                    if (!j.cap) continue;
+                    rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)ctx.d_scan_out + j.off,
+                                     j.cap, ctx.d_scan_len + k, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream);
+                    if (rc) return rc;
+                }
+                JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_len, ctx.d_scan_len, sizeof(uint32_t) * jobs.size(), hipMemcpyDeviceToHost, ctx.stream));
             }
+            if (how == CAPTURE) {
+                hipGraph_t g = nullptr;
+                capture_guard.active = false;
+                JPEGENC_HIP(hipStreamEndCapture(ctx.stream, &g));
+                if (ctx.graph_exec) { (void)hipGraphExecDestroy(ctx.graph_exec); ctx.graph_exec = nullptr; }
+                const hipError_t ge = hipGraphInstantiate(&ctx.graph_exec, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (ge != hipSuccess) { ctx.graph_exec = nullptr; return hip_fail(ge, "hipGraphInstantiate"); }
+                ctx.graph_key = ctx.last_key;
+            }
+            if (how != DIRECT) JPEGENC_HIP(hipGraphLaunch(ctx.graph_exec, ctx.stream));
             const auto t_launched = now();
-            JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_len, ctx.d_scan_len, sizeof(uint32_t) * jobs.size(), hipMemcpyDeviceToHost, ctx.stream));
             JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
             const auto t_len = now();
             size_t nbytes = 0;

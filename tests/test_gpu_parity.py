@@ -787,3 +787,31 @@ def test_handles_release_their_device_memory(binding, synth):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (64 << 20), f"{(free0 - free1) >> 20} MiB of device memory not returned"
+
+
+def test_replayed_launch_sequence_follows_content_and_settings(binding, oracle, synth):
+    """A handle that sees the same geometry again replays a captured launch sequence (hipGraph): the
+    output must still follow the pixels, and any setting that changes the device work must re-capture."""
+    w, h = 211, 135
+    imgs = [synth.lcg_image(w, h, 3, 700 + i) for i in range(4)]
+    e = binding.Encoder(83)
+    for rep in range(3):
+        for i, px in enumerate(imgs):                      # same key every call, different content
+            assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, 83), (rep, i)
+    e.set_restart_interval(4)                               # changes the scan: new sequence
+    for px in imgs[:3]:
+        assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, 83, restart_interval=4)
+    e.set_sampling_factor(binding.F_2_1)
+    for px in imgs[:3]:
+        assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, 83, restart_interval=4, sampling=(2, 1))
+    e.set_quantization_tables(binding.Q_FLAT, binding.Q_FLAT, None, None)        # same geometry, other tables
+    for px in imgs[:3]:
+        assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, 83, restart_interval=4, sampling=(2, 1),
+                                                                     qpresets=(oracle.Q_FLAT, oracle.Q_FLAT))
+    for px in imgs[:3]:                                      # another size on the same handle, then back
+        small = np.ascontiguousarray(px[:100, :150])
+        assert e.encode(small, 150, 100, binding.RGB) == oracle.encode_jpeg(small, 150, 100, oracle.RGB, 83, restart_interval=4,
+                                                                            sampling=(2, 1), qpresets=(oracle.Q_FLAT, oracle.Q_FLAT))
+    for px in imgs[:3]:
+        assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, 83, restart_interval=4, sampling=(2, 1),
+                                                                     qpresets=(oracle.Q_FLAT, oracle.Q_FLAT))
