@@ -1,22 +1,27 @@
 // fast_kernel_impl.hip.h — tuned block-encode kernels for every built-in ColorType at sampling factors
-// 1 and 2 (the paths all five BASELINE configs take): the RGB family (Rgb / Rgba / Bgr / Bgra ->
-// YCbCr, and CmykAsYcck's C,M,Y -> YCC) and the "byte-plane" formats whose component is one byte of
-// the pixel, optionally inverted (Luma, Ycbcr, Ycck, Cmyk = 255 - v, the K of CmykAsYcck, and the
-// planar rows of a user ImageBuffer).
+// 1, 2 and 4 (every layout with at most 10 waves per 64 MCUs; the paths all five BASELINE configs
+// take): the RGB family (Rgb / Rgba / Bgr / Bgra -> YCbCr, and CmykAsYcck's C,M,Y -> YCC) and the
+// "byte-plane" formats whose component is one byte of the pixel, optionally inverted (Luma, Ycbcr,
+// Ycck, Cmyk = 255 - v, the K of CmykAsYcck, and the planar rows of a user ImageBuffer).
 //
-// Same decomposition as the generic kernel (wave_tasks.hip.h); what changes is how a lane gets its
-// 64 samples:
-//   * a block row is fetched with ONE or TWO wide vector loads per lane (24 / 32 / 48 / 64 bytes),
-//     straight from HBM into registers — adjacent lanes own adjacent blocks, so a wave's load covers
-//     a dense span of the image row; there is no LDS round trip and no barrier on the input side;
+// Decomposition: one lane = one 8x8 block, one wave = 64 blocks of one component (one block row of the
+// component inside 64 / h consecutive MCUs), one workgroup = all waves of 64 MCUs.  Both block orders
+// walk the image this way; the order only decides where a block is stored (wave_tasks.hip.h).
+//   * prologue: two s_load_dwordx16 (FastHeader + the wave's FastWave record filled by the host);
+//   * a block row is fetched with explicit 16/8/4-byte vector loads from address_space(1) pointers
+//     (24 / 32 / 48 / 64 bytes per lane, 96 / 128 in two halves for 4x decimation), straight from HBM
+//     into registers - adjacent lanes own adjacent blocks, so a wave's load covers a dense span of
+//     the image row; there is no LDS round trip and no barrier on the input side;
 //   * each pixel is isolated as one dword W = [c0 c1 c2 x] with v_alignbyte_b32 (3-byte pixels) or
 //     is already one (4-byte pixels);
 //   * Y  = (19595 r + 38470 g + 7471 b + 0x7FFF) >> 16 (image_buffer.rs:22-26) is evaluated with the
 //     8-bit dot product unit: coefficients split into high and low bytes,
 //         t = udot4(W, LO, 0x7FFF) >> 8;   Y = byte1(udot4(W, HI, t))
 //     which is exact because floor((256*HI + LO') / 65536) = floor((HI + floor(LO'/256)) / 256);
-//   * Cb / Cr (image_buffer.rs:23-28) use one v_dot2_i32_i16 on the zero-extended (r,g) or (g,b)
-//     pair with the 32768*b / 32768*r term and the rounding bias in the accumulator;
+//   * Cb / Cr (image_buffer.rs:23-28) have two exact forms, chosen per instantiation by measurement:
+//     one v_dot2_i32_i16 on the zero-extended (r,g) or (g,b) pair with the 32768*b / 32768*r term and
+//     the rounding bias in the accumulator, or - rewritten with non-negative coefficients on
+//     complemented channels - the same two-udot4 shape as Y;
 //   * only the samples get_block would read (encoder.rs:1232-1237) are ever converted: for 4:2:0 a
 //     chroma lane converts 64 of the 256 pixels it covers;
 //   * results are packed by v_perm_b32 directly into the 16-bit pair order the FDCT consumes.

@@ -3,9 +3,10 @@
 //   * one WAVE owns 64 consecutive blocks of ONE component (all control flow, the quantiser table
 //     and the colour constants are wave-uniform); one LANE owns one block;
 //   * MCU order: a group is 64 MCUs and holds h*v waves per component (slot -> MCU, h_off, v_off as
-//     encode_image_interleaved walks them, encoder.rs:747-769); planar order: a task is 64
-//     consecutive blocks of a component in encode_blocks order (encoder.rs:1020-1054) and a group
-//     holds h*v tasks of every component, i.e. the tasks that read the same pixel rows;
+//     encode_image_interleaved walks them, encoder.rs:747-769).  Planar order (encode_blocks,
+//     encoder.rs:1020-1054): the tuned kernels keep that MCU walk and only store each block at its
+//     place in the component's plane (StoreMap order 2); the generic kernel deals 64-block tasks of a
+//     component, a group holding h*v tasks of every component (decode_task / locate below);
 //   * waves never synchronise with each other.  A wave stages its 64 x 128 B of output in a
 //     private, XOR-swizzled 8 KiB LDS region so that every global store instruction writes whole
 //     128-B lines (16 B per lane, 8 consecutive lanes per block).
