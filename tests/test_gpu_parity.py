@@ -815,3 +815,17 @@ def test_replayed_launch_sequence_follows_content_and_settings(binding, oracle, 
     for px in imgs[:3]:
         assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, 83, restart_interval=4, sampling=(2, 1),
                                                                      qpresets=(oracle.Q_FLAT, oracle.Q_FLAT))
+
+
+@pytest.mark.parametrize("interval", [1, 2, 63, 65535])
+def test_restart_interval_extremes(binding, oracle, synth, interval):
+    """Every MCU its own restart interval (thousands of intervals: the interval prefix sums and the RSTn
+    insertion of the stuffing pass), odd small ones, and one larger than the image."""
+    w, h = 1000, 600
+    px = synth.noise_image(w, h, 3, 77)
+    px[::3] = 255                                            # rows that produce long 0xFF runs next to markers
+    for kw in (dict(quality=91, restart_interval=interval), dict(quality=70, sampling=(2, 2), restart_interval=interval),
+               dict(quality=80, sampling=(2, 1), progressive_scans=3, restart_interval=interval)):
+        for on in (True, False):
+            got = _encoder(binding, kw, on).encode(px, w, h, binding.RGB)
+            assert got == oracle.encode_jpeg(px, w, h, oracle.RGB, **kw), (kw, on)
