@@ -167,6 +167,12 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
     p.coeffs = (const int16_t *)d_coeffs + first_block * 64;
     p.coeff_frame_stride = coeff_frame_stride;
     p.nblocks = (uint32_t)nblocks;
+    static const uint32_t window_words = [] {
+        const char *e = getenv("JPEGENC_PACK_WINDOW_WORDS");
+        const long v = e ? atol(e) : 2048;
+        return (uint32_t)(v < 0 ? 0 : v > 2048 ? 2048 : v);
+    }();
+    p.window_words = window_words;
     p.with_dc = sc.with_dc ? 1u : 0u;
     p.ac_start = (uint32_t)sc.ac_start;
     p.ac_end = (uint32_t)sc.ac_end;

@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
     const uint32_t nvalid = (uint32_t)__popcll(vmask);
     const uint32_t w0 = (uint32_t)__shfl((int)first_word, 0), w1 = (uint32_t)__shfl((int)last_word, (int)nvalid - 1);
     const uint32_t nwords = w1 - w0 + 1u;
-    const bool staged = nwords <= kPackWindowWords;                              // wave-uniform
+    const bool staged = nwords <= p.window_words;                                // wave-uniform
     uint32_t *win = window[wave];
     if (staged) {
         for (uint32_t i = lane; i < nwords; i += 64u) win[i] = 0;

@@ -36,6 +36,8 @@ struct EntropyParams {
     uint8_t *raw;                    // [frames][raw_stride]   unstuffed bits, every interval 16-byte aligned
     uint64_t raw_stride;             // bytes, multiple of 16
     uint32_t max_chunks;             // raw_stride / 16
+    uint32_t window_words;           // bit-packer runs up to this many words go through the LDS window (<= 2048;
+                                     // JPEGENC_PACK_WINDOW_WORDS lowers it so that tests reach the direct path)
     uint32_t *ffcount;               // [frames][max_chunks]
     uint32_t *ffprefix;              // [frames][max_chunks]
     uint32_t *total_ff;              // [frames]

@@ -829,3 +829,32 @@ def test_restart_interval_extremes(binding, oracle, synth, interval):
         for on in (True, False):
             got = _encoder(binding, kw, on).encode(px, w, h, binding.RGB)
             assert got == oracle.encode_jpeg(px, w, h, oracle.RGB, **kw), (kw, on)
+
+
+def test_device_entropy_pack_window_overflow_path(binding, oracle, synth):
+    """The bit packer writes runs that do not fit its LDS window straight to memory.  Real content hardly
+    ever gets there (binary noise with an all-ones table reaches ~800 of the 1 024 bits per block it
+    takes), so a child process lowers the window (JPEGENC_PACK_WINDOW_WORDS) and every wave takes that path."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "ge.load_package()\n"
+        "from jpeg_encoder_amd import binding as b, synth\n"
+        "from oracle import pyoracle as o\n"
+        "for seed, (w, h), kw in ((1, (264, 200), dict(quality=100)), (2, (500, 333), dict(quality=75, sampling=(2, 2), restart_interval=7)),\n"
+        "                         (3, (200, 120), dict(quality=90, progressive_scans=4))):\n"
+        "    px = (synth.noise_image(w, h, 3, seed) >> 7) * np.uint8(255) if seed == 1 else synth.lcg_image(w, h, 3, seed)\n"
+        "    e = b.Encoder(kw['quality'])\n"
+        "    if 'sampling' in kw: e.set_sampling_factor(b.sampling_factor(*kw['sampling']))\n"
+        "    if kw.get('restart_interval'): e.set_restart_interval(kw['restart_interval'])\n"
+        "    if kw.get('progressive_scans'): e.set_progressive_scans(kw['progressive_scans'])\n"
+        "    assert e.encode(px, w, h, b.RGB) == o.encode_jpeg(px, w, h, o.RGB, **kw), kw\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for words in ("0", "16"):
+        env = dict(os.environ, JPEGENC_PACK_WINDOW_WORDS=words)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
