@@ -910,10 +910,14 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         out_total += j.cap;
     }
     const size_t coeff_bytes = (size_t)L.total_blocks * 128;
-    // frames per round: bounded device footprint (coefficients + worst-case scan bytes), at most 64
+    // frames per round: bounded device footprint (coefficients + worst-case scan bytes), at most 1024
     int per_round = (int)(((size_t)6 << 30) / (coeff_bytes + out_total + 1));
     if (per_round < 1) per_round = 1;
-    if (per_round > 64) per_round = 64;
+    if (per_round > 1024) per_round = 1024;
+    if (const char *cap = getenv("JPEGENC_BATCH_ROUND_FRAMES")) {        // tests: force several rounds on small batches
+        const int v = atoi(cap);
+        if (v >= 1 && v < per_round) per_round = v;
+    }
     if (per_round > num_frames) per_round = num_frames;
     size_t ws = 0;
     for (auto &j : jobs) {

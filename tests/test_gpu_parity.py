@@ -730,7 +730,7 @@ def test_c_example_program(binding, oracle, synth, tmp_path):
     dict(quality=70, progressive_scans=64)], ids=["baseline", "420-restart", "sequential-411", "progressive-restart", "optimised", "progressive-64"])
 def test_encode_batch_device_resident(binding, oracle, synth, kw):
     """jpegenc_encoder_encode_batch_device: frames already in HBM, the whole batch sharing its launches
-    (70 frames = more than one round of 64), every scan mode; optimised tables take the per-frame path."""
+    (in one round and split into two), every scan mode; optimised tables take the per-frame path."""
     import torch
     w, h, n = 150, 97, 70
     frames = np.stack([synth.lcg_image(w, h, 3, 3000 + i) for i in range(n)])
@@ -739,8 +739,14 @@ def test_encode_batch_device_resident(binding, oracle, synth, kw):
     buf = torch.zeros(n * stride, dtype=torch.uint8, device="cuda:0")
     for i in range(n):
         buf[i * stride:i * stride + w * h * 3] = torch.from_numpy(frames[i].reshape(-1).copy()).to("cuda:0")
-    for on in (True, False):
-        got = _encoder(binding, kw, on).encode_batch_device(buf.data_ptr(), stride, n, w, h, binding.RGB)
+    import os
+    for on, round_frames in ((True, "64"), (True, None), (False, None)):     # 64: the batch takes two rounds
+        if round_frames:
+            os.environ["JPEGENC_BATCH_ROUND_FRAMES"] = round_frames
+        try:
+            got = _encoder(binding, kw, on).encode_batch_device(buf.data_ptr(), stride, n, w, h, binding.RGB)
+        finally:
+            os.environ.pop("JPEGENC_BATCH_ROUND_FRAMES", None)
         assert len(got) == n
         for i in (0, 1, 2, 33, 63, 64, 69):
             assert got[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, **kw), (i, on)
