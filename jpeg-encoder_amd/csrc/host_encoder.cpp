@@ -363,6 +363,44 @@ struct Config {                      // the fields of struct Encoder, encoder.rs
     std::vector<std::pair<uint8_t, std::vector<uint8_t>>> app_segments;
 };
 
+// Staging of the small-frame batch path (jpegenc_encoder_encode_batch): two rounds of frames in pinned
+// host memory and on the device, so that copying / uploading one round overlaps encoding the other.
+struct SmallBatchBuffers {
+    uint8_t *h[2] = {nullptr, nullptr};
+    void *d[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    hipStream_t up = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int reserve(size_t bytes) {
+        if (!up) {
+            JPEGENC_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+            for (auto &ev : done) JPEGENC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        if (bytes <= cap) return JPEGENC_OK;
+        release_buffers();
+        for (int i = 0; i < 2; i++) {
+            JPEGENC_HIP(hipHostMalloc((void **)&h[i], bytes, hipHostMallocDefault));
+            JPEGENC_HIP(hipMalloc(&d[i], bytes));
+        }
+        cap = bytes;
+        return JPEGENC_OK;
+    }
+    void release_buffers() {
+        for (int i = 0; i < 2; i++) {
+            if (h[i]) (void)hipHostFree(h[i]);
+            if (d[i]) (void)hipFree(d[i]);
+            h[i] = nullptr; d[i] = nullptr;
+        }
+        cap = 0;
+    }
+    ~SmallBatchBuffers() {
+        if (up) (void)hipStreamSynchronize(up);
+        release_buffers();
+        for (auto &ev : done) if (ev) (void)hipEventDestroy(ev);
+        if (up) (void)hipStreamDestroy(up);
+    }
+};
+
 // Buffers of the device-resident batch path (jpegenc_encoder_encode_batch_device), kept in the handle
 // across calls and only ever grown: pinned allocations of a few hundred MB cost tens of milliseconds.
 struct BatchBuffers {
@@ -422,6 +460,7 @@ struct jpegenc_encoder {
     DeviceCtx ctx;
     std::vector<std::unique_ptr<DeviceCtx>> workers;   // batch API: one per in-flight frame, kept across calls
     BatchBuffers batch;                                  // device-resident batch API
+    SmallBatchBuffers small;                             // batches of small frames
 };
 
 namespace jpegenc {
@@ -1324,6 +1363,60 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     if (rc) return rc;
     rc = ensure_device_ready(e->device);
     if (rc) return rc;
+    // Many small frames (thumbnails): per-frame launch sequences would dominate, so rounds of frames are
+    // copied into pinned memory by a few threads, uploaded in one transfer and encoded by the
+    // device-resident batch path (one launch sequence per round); the staging + upload of the next
+    // round overlaps the encoding of the current one.
+    const size_t frame_bytes = (size_t)width * (size_t)height * (size_t)jpegenc_bytes_per_pixel(color_type);
+    static const bool small_off = getenv("JPEGENC_NO_SMALL_BATCH") != nullptr;
+    const bool per_frame_tables = e->cfg.optimize && select_mode(e->cfg) != MODE_INTERLEAVED;
+    if (!small_off && frame_bytes <= ((size_t)2 << 20) && num_frames >= 16 && e->cfg.device_entropy && !per_frame_tables) {
+        for (int i = 0; i < num_frames; i++)
+            if (!frames[i]) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
+        int per_round = (int)(((size_t)64 << 20) / frame_bytes);
+        if (per_round > 1024) per_round = 1024;
+        if (per_round > num_frames) per_round = num_frames;
+        JPEGENC_HIP(hipSetDevice(e->device));
+        rc = e->small.reserve((size_t)per_round * frame_bytes);
+        if (rc) return rc;
+        SmallBatchBuffers &sb = e->small;
+        std::atomic<int> up_status(JPEGENC_OK);
+        auto stage_and_upload = [&](int first, int slot) {
+            const int n = num_frames - first < per_round ? num_frames - first : per_round;
+            unsigned hwt = std::thread::hardware_concurrency();
+            int nt = (int)(hwt ? hwt : 4);
+            if (nt > 8) nt = 8;
+            if (nt > n) nt = n;
+            std::atomic<int> nextf(0);
+            auto copy = [&]() {
+                for (;;) {
+                    const int i = nextf.fetch_add(1);
+                    if (i >= n) break;
+                    memcpy(sb.h[slot] + (size_t)i * frame_bytes, frames[first + i], frame_bytes);
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; t++) th.emplace_back(copy);
+            copy();
+            for (auto &x : th) x.join();
+            if (hipSetDevice(e->device) != hipSuccess ||
+                hipMemcpyAsync(sb.d[slot], sb.h[slot], (size_t)n * frame_bytes, hipMemcpyHostToDevice, sb.up) != hipSuccess ||
+                hipEventRecord(sb.done[slot], sb.up) != hipSuccess)
+                up_status.store(JPEGENC_ERR_HIP);
+        };
+        stage_and_upload(0, 0);
+        for (int first = 0, r = 0; first < num_frames; first += per_round, r++) {
+            const int slot = r & 1, n = num_frames - first < per_round ? num_frames - first : per_round;
+            if (up_status.load() != JPEGENC_OK) return fail(JPEGENC_ERR_HIP, "upload of a batch round failed");
+            JPEGENC_HIP(hipEventSynchronize(sb.done[slot]));
+            std::thread next_round;
+            if (first + per_round < num_frames) next_round = std::thread(stage_and_upload, first + per_round, slot ^ 1);
+            rc = jpegenc_encoder_encode_batch_device(e, sb.d[slot], frame_bytes, n, width, height, color_type, sink, users + first);
+            if (next_round.joinable()) next_round.join();
+            if (rc) return rc;
+        }
+        return JPEGENC_OK;
+    }
     // one host worker per in-flight frame; each owns a stream + buffers, so H2D / kernel / D2H of
     // one frame overlap the entropy coding of the others
     unsigned hw = std::thread::hardware_concurrency();

@@ -864,3 +864,19 @@ def test_device_entropy_pack_window_overflow_path(binding, oracle, synth):
         env = dict(os.environ, JPEGENC_PACK_WINDOW_WORDS=words)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("kw", [dict(quality=90), dict(quality=77, sampling=(2, 2), restart_interval=9),
+                                dict(quality=85, progressive_scans=4), dict(quality=80, optimize=True)],
+                         ids=["baseline", "420-restart", "progressive", "optimised-per-frame"])
+def test_encode_batch_of_small_frames(binding, oracle, synth, kw):
+    """encode_batch with many small frames takes the staged, round-based path (copy to pinned memory,
+    one upload and one launch sequence per round, next round overlapped); 1100 frames = two rounds.
+    (JPEGENC_NO_SMALL_BATCH=1 switches the path off.)"""
+    w, h, n = 96, 80, 1100
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) if i % 3 else synth.test_img_rgb(w, h) + np.uint8(i % 7) for i in range(n)]
+    got = _encoder(binding, kw).encode_batch(frames, w, h, binding.RGB)
+    assert len(got) == n
+    for i in (0, 1, 2, 511, 1023, 1024, 1025, 1099):
+        assert got[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, **kw), i
