@@ -9,8 +9,9 @@ roofline the fused kernel reaches.
   value     = pixels of all ranks' frames / wall time of the K timed steps (max over ranks).
   roofline  = algorithmic bytes per launch (6 B/px: 3 read + 3 written) / mean
               kernel duration measured with HIP events on the launch stream, against 8 TB/s.
-  cpu_baseline = the CPU oracle (a C port of the reference's scalar path; the Rust crate cannot be
-              built in this image) timed on one host core over a bounded sample, rank 0, N=1 only.
+  cpu_baseline = the CPU oracle (C ports of the reference: an AVX2 stand-in for its `simd` feature and the
+              scalar path; the Rust crate cannot be built in this image) timed on one host core over a
+              bounded sample, rank 0, N=1 only.
 
 Multi-GPU: frames are independent, so ranks shard the batch (one process per GPU, no data-path
 collective); scaling is weak (per-GPU work fixed).  Launch: python -m torch.distributed.run
@@ -56,23 +57,46 @@ def cpu_baseline(seconds_budget, synth, gpu_frame=None, gpu_coeffs=None):
         rc = lib.orc_encode_blocks(flat.ctypes.data, flat.size, W, H, pyoracle.RGB, HS, VS, q,
                                    pyoracle.ORDER_MCU, pyoracle.FDCT_SCALAR, out.ctypes.data)
         assert rc == 0
-    one()                                   # warm-up (page faults, caches)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds_budget or n >= 200:
-            break
+    # the AVX2 stand-in for the crate's `simd` feature (oracle/jpegenc_oracle_avx2.c, same coefficients as the
+    # scalar port by test) is the headline CPU figure where the host has AVX2; the scalar port is kept beside it
+    avx2 = getattr(lib, "orc_encode_blocks_avx2", None)
+    if avx2 is not None:
+        avx2.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(pyoracle.QTable), C.c_int, C.c_void_p]
+        if avx2(flat.ctypes.data, flat.size, W, H, pyoracle.RGB, HS, VS, q, pyoracle.ORDER_MCU, out.ctypes.data) != 0:
+            avx2 = None
+
+    def one_avx2():
+        rc = avx2(flat.ctypes.data, flat.size, W, H, pyoracle.RGB, HS, VS, q, pyoracle.ORDER_MCU, out.ctypes.data)
+        assert rc == 0
+
+    def timed(fn, budget):
+        fn()                                # warm-up (page faults, caches)
+        k, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            k += 1
+            d = time.perf_counter() - t0
+            if d >= budget or k >= 200:
+                return k, d
+    if avx2 is not None:
+        ns, dts = timed(one, seconds_budget / 3)
+        n, dt = timed(one_avx2, seconds_budget * 2 / 3)
+    else:
+        n, dt = timed(one, seconds_budget)
     parity = None
     if gpu_frame is not None:
         want = pyoracle.encode_blocks(gpu_frame, W, H, pyoracle.RGB, HS, VS, QUALITY, pyoracle.ORDER_MCU)
         parity = bool(np.array_equal(gpu_coeffs.reshape(want.shape), want))
+    which = "oracle/jpegenc_oracle_avx2.c: AVX2 stand-in for the crate's `simd` feature" if avx2 is not None else \
+            "oracle/jpegenc_oracle.c: scalar port"
     base = {
         "value": round(n * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
         "sample": f"{n} frames of 3840x2160 RGB q=90 4:2:0 in {dt:.1f} s, pixels->coefficients only "
-                  f"(oracle/jpegenc_oracle.c, gcc -O3 -march=native, {os.cpu_count()} host cores present)",
+                  f"({which}, gcc -O3 -march=native, {os.cpu_count()} host cores present)",
     }
+    if avx2 is not None:
+        base["scalar"] = {"value": round(ns * W * H / dts / 1e6, 2), "unit": "Mpixels/s", "cores": 1,
+                          "sample": f"{ns} frames in {dts:.1f} s with the scalar port (oracle/jpegenc_oracle.c)"}
     # the same port through to the file (block path + Huffman coding + markers), one core: the CPU figure
     # comparable with `end_to_end`
     try:
@@ -109,13 +133,18 @@ def cpu_baseline(seconds_budget, synth, gpu_frame=None, gpu_coeffs=None):
 
         def worker(i):
             out3 = np.empty((total3, 64), dtype=np.int16)
-            lib.orc_encode_blocks(px3.ctypes.data, px3.size, w3, h3, pyoracle.RGB, HS, VS, qt3,
-                                  pyoracle.ORDER_MCU, pyoracle.FDCT_SCALAR, out3.ctypes.data)
+
+            def frame():
+                if avx2 is not None:
+                    avx2(px3.ctypes.data, px3.size, w3, h3, pyoracle.RGB, HS, VS, qt3, pyoracle.ORDER_MCU, out3.ctypes.data)
+                else:
+                    lib.orc_encode_blocks(px3.ctypes.data, px3.size, w3, h3, pyoracle.RGB, HS, VS, qt3,
+                                          pyoracle.ORDER_MCU, pyoracle.FDCT_SCALAR, out3.ctypes.data)
+            frame()
             start.wait()
             t = time.perf_counter()
             while time.perf_counter() - t < budget:
-                lib.orc_encode_blocks(px3.ctypes.data, px3.size, w3, h3, pyoracle.RGB, HS, VS, qt3,
-                                      pyoracle.ORDER_MCU, pyoracle.FDCT_SCALAR, out3.ctypes.data)
+                frame()
                 counts[i] += 1
         threads = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
         for t in threads:
@@ -135,7 +164,7 @@ def cpu_baseline(seconds_budget, synth, gpu_frame=None, gpu_coeffs=None):
             pass
         base["all_cores"] = {"value": round(sum(counts) * w3 * h3 / dt3 / 1e6, 1), "unit": "Mpixels/s", "cores": cores,
                              "sample": f"{sum(counts)} frames of 1920x1080 RGB q=80 4:2:0 in {dt3:.1f} s, one frame per thread "
-                                       f"at a time, {cores} threads, {model}"}
+                                       f"at a time, {cores} threads, {'AVX2' if avx2 is not None else 'scalar'} port, {model}"}
     except Exception as exc:                                    # side figure only
         base["all_cores"] = {"error": str(exc)}
     return base, parity

@@ -95,6 +95,12 @@ int orc_encode_blocks(const uint8_t *pixels, size_t pixels_len, int width, int h
                       int color_type, int hs, int vs, const orc_qtable q[2],
                       int order, int fdct_variant, int16_t *out);
 
+/* The same coefficients as orc_encode_blocks(..., ORC_FDCT_SCALAR), computed with AVX2 intrinsics
+ * (jpegenc_oracle_avx2.c: the CPU baseline's stand-in for the reference's `simd` feature).  RGB family,
+ * sampling factors 1 and 2; returns 100 (unsupported) otherwise or when the CPU lacks AVX2. */
+int orc_encode_blocks_avx2(const uint8_t *pixels, size_t pixels_len, int width, int height,
+                           int color_type, int hs, int vs, const orc_qtable q[2], int order, int16_t *out);
+
 /* Symbol statistics gathered by optimize_huffman_table (encoder.rs:1086-1200) on PLANAR-order
  * blocks.  freq[t][0] = DC, freq[t][1] = AC, 257 entries each (entry 256 planted with 1).
  * progressive_scans = 0 for sequential. */

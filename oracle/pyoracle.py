@@ -44,11 +44,12 @@ def build(force=False, extra_cflags=None, out_path=None):
     """Compile the oracle with gcc (no GPU, no reference tree needed)."""
     out = out_path or _LIB_PATH
     src = os.path.join(_HERE, "jpegenc_oracle.c")
-    deps = [src, os.path.join(_HERE, "jpegenc_oracle.h"), os.path.join(_HERE, "orc_tables.h")]
+    src_avx2 = os.path.join(_HERE, "jpegenc_oracle_avx2.c")
+    deps = [src, src_avx2, os.path.join(_HERE, "jpegenc_oracle.h"), os.path.join(_HERE, "orc_tables.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     flags = extra_cflags or ["-mavx2"]
-    subprocess.check_call(["gcc", "-O3", "-fPIC", "-std=c11", *flags, "-shared", "-o", out, src])
+    subprocess.check_call(["gcc", "-O3", "-fPIC", "-std=gnu11", *flags, "-shared", "-o", out, src, src_avx2])
     return out
 
 
@@ -177,6 +178,24 @@ def encode_blocks(pixels, width, height, color_type, hs, vs, quality=None, order
     out = np.empty((max(total, 1), 64), dtype=np.int16)
     rc = lib().orc_encode_blocks(px.ctypes.data, px.size, width, height, color_type, hs, vs, q, order,
                                  variant, out.ctypes.data)
+    if rc:
+        raise OracleError(rc)
+    return out[:total]
+
+
+def encode_blocks_avx2(pixels, width, height, color_type, hs, vs, quality=None, order=ORDER_MCU, q=None):
+    """The AVX2 stand-in for the reference's `simd` feature (jpegenc_oracle_avx2.c): must equal
+    encode_blocks(..., FDCT_SCALAR).  Returns None where it does not apply (layout or CPU)."""
+    px = np.ascontiguousarray(pixels, dtype=np.uint8).reshape(-1)
+    if q is None:
+        q = qtables(quality)
+    total, _ = block_counts(width, height, color_type, hs, vs, order)
+    out = np.empty((max(total, 1), 64), dtype=np.int16)
+    fn = lib().orc_encode_blocks_avx2
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(QTable), C.c_int, C.c_void_p]
+    rc = fn(px.ctypes.data, px.size, width, height, color_type, hs, vs, q, order, out.ctypes.data)
+    if rc == 100:
+        return None
     if rc:
         raise OracleError(rc)
     return out[:total]

@@ -228,3 +228,33 @@ def test_numpy_restatement_reproduces_survey_anchors(oracle):
     assert sha(100, 1, 1, 0) == (1584, "6ff6a9e6cfd396d7")
     assert sha(100, 2, 1, 1) == (1072, "31286d6f3953e72a")
     assert sha(90, 4, 1, 1) == (816, "ac2aba65585604c7")
+
+
+def test_avx2_baseline_port_equals_scalar_port(oracle):
+    """oracle/jpegenc_oracle_avx2.c — bench.py's CPU baseline, the stand-in for the crate's `simd` feature
+    (src/avx2/ycbcr.rs + src/avx2/fdct.rs structure: 8-pixel colour rows, 16-bit-lane pmaddwd transform) —
+    must produce the scalar port's coefficients: a baseline that computed something else would be timing
+    different work.  Returns None (not applicable) on a host without AVX2 and for layouts it does not cover."""
+    import numpy as np
+    rng = np.random.default_rng(21)
+    covered = 0
+    for trial in range(160):
+        ct = [oracle.RGB, oracle.RGBA, oracle.BGR, oracle.BGRA][trial % 4]
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        hs, vs = [(1, 1), (2, 1), (1, 2), (2, 2)][int(rng.integers(0, 4))]
+        order = int(rng.integers(0, 2))
+        quality = int(rng.integers(1, 101))
+        px = rng.integers(0, 256, (h, w, oracle.BPP[ct]), dtype=np.uint8)
+        if trial % 5 == 0:
+            px[...] = [0, 255][trial % 2]                                  # the transform's extremes
+        got = oracle.encode_blocks_avx2(px, w, h, ct, hs, vs, quality, order)
+        if got is None:
+            continue
+        covered += 1
+        want = oracle.encode_blocks(px, w, h, ct, hs, vs, quality, order, oracle.FDCT_SCALAR)
+        assert np.array_equal(got, want), (trial, ct, w, h, hs, vs, order, quality)
+    # what it declines, it declines by returning None — never by a wrong answer
+    assert oracle.encode_blocks_avx2(np.zeros((8, 8, 1), np.uint8), 8, 8, oracle.LUMA, 1, 1, 80) is None
+    assert oracle.encode_blocks_avx2(np.zeros((8, 8, 3), np.uint8), 8, 8, oracle.RGB, 4, 1, 80) is None
+    if covered == 0:
+        pytest.skip("host CPU has no AVX2")
