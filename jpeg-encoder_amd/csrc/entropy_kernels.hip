@@ -166,45 +166,71 @@ __device__ __forceinline__ uint32_t bit_size(int v) {          // get_code().0 /
     return a ? 32u - (uint32_t)__builtin_clz(a) : 0u;
 }
 
-struct BitSink {          // k_block_pack: bits go to memory; k_block_bits: only counted
-    uint32_t *words;      // word pointer of the next flush
-    uint64_t acc;
-    uint32_t nacc;
-    bool first;
-};
+// Where a block's bits go.  k_block_bits only adds up lengths; k_block_pack shifts codes into a 64-bit
+// accumulator and ORs every completed 32-bit word (MSB-first byte order) into zeroed memory - the wave's
+// LDS window (ds_or_b32, no address-space guessing: the pointer type says LDS) or, for runs longer than
+// the window, the raw stream in HBM.  OR-ing every word (not only the ones shared with a neighbouring
+// block) keeps a per-lane "is this my first word" flag and its branches out of the 63-symbol walk.
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+typedef __attribute__((address_space(1))) uint32_t hbm_word;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const u32x4 hbm_chunk;
 
-template <bool EMIT>
-__device__ __forceinline__ void put_bits(BitSink &s, uint32_t &total, uint32_t code, uint32_t len) {
-    total += len;
-    if (EMIT) {
-        s.acc = (s.acc << len) | code;
-        s.nacc += len;
-        if (s.nacc >= 32) {
-            const uint32_t w = __builtin_bswap32((uint32_t)(s.acc >> (s.nacc - 32)));   // MSB-first byte stream
-            if (s.first) atomicOr(s.words, w); else *s.words = w;
-            s.first = false;
-            s.words++;
-            s.nacc -= 32;
+struct CountSink {
+    uint32_t total;
+    __device__ __forceinline__ void put(uint32_t, uint32_t len) { total += len; }
+};
+struct LdsWords {
+    lds_word *w;
+    __device__ __forceinline__ void or_next(uint32_t v) {
+        __hip_atomic_fetch_or(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        w++;
+    }
+};
+struct HbmWords {
+    hbm_word *w;
+    __device__ __forceinline__ void or_next(uint32_t v) {
+        __hip_atomic_fetch_or(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w++;
+    }
+};
+template <class Words>
+struct PackSink {
+    Words words;          // next word to complete
+    uint64_t acc;
+    uint32_t nacc;        // valid low bits of acc; < 32 between puts
+    __device__ __forceinline__ void put(uint32_t code, uint32_t len) {          // len <= 27
+        acc = (acc << len) | code;
+        nacc += len;
+        if (nacc >= 32) {
+            nacc -= 32;
+            words.or_next(__builtin_bswap32((uint32_t)(acc >> nacc)));
         }
     }
-}
+    __device__ __forceinline__ void finish() {                                   // the partial last word
+        if (nacc) words.or_next(__builtin_bswap32((uint32_t)(acc << (32 - nacc))));
+    }
+};
 
-// lut: [table][0 = DC, 1 = AC][256] of (size << 16 | code), in LDS
-template <bool EMIT>
-__device__ __forceinline__ uint32_t walk_block(const EntropyParams &p, const uint32_t *lut, const int16_t *frame_coeffs,
-                                               uint32_t b, BitSink &s) {
+// lut: [table][0 = DC, 1 = AC][256] of (size << 16 | code), in LDS.
+// BASELINE = the scan codes DC and the whole band 1..63 (every non-progressive scan): no band tests in the walk.
+// All eight 16-byte pieces of the block are requested up front (the lane's 128-byte line is fetched once and
+// the other seven loads hit L1 while it is hot; walking piece by piece with the next one in flight re-missed
+// the line for every piece: 52 vs 39 us per 4K frame), so the walk is fully unrolled over registers.
+template <bool BASELINE, class Sink>
+__device__ __forceinline__ void walk_block(const EntropyParams &p, const uint32_t *lut, const int16_t *frame_coeffs,
+                                           uint32_t b, Sink &s) {
     const uint32_t mcu = b / p.bpm, pos = b - mcu * p.bpm;
     const uint32_t table = p.pos_table[pos];
     const uint32_t *dc_lut = lut + table * 512, *ac_lut = dc_lut + 256;
-    const uint4 *src = reinterpret_cast<const uint4 *>(frame_coeffs + (size_t)b * 64);
+    hbm_chunk *src = (hbm_chunk *)(frame_coeffs + (size_t)b * 64);
     uint32_t c[32];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const uint4 u = src[i];
+        const u32x4 u = src[i];
         c[4 * i] = u.x; c[4 * i + 1] = u.y; c[4 * i + 2] = u.z; c[4 * i + 3] = u.w;
     }
-    uint32_t total = 0;
-    if (p.with_dc) {
+    if (BASELINE || p.with_dc) {
         // DC: predecessor = previous block of the same component (write_dc, writer.rs:342-354;
         // predictors reset at the start of the scan and at restart boundaries, encoder.rs:748-757)
         int prev = 0;
@@ -219,29 +245,31 @@ __device__ __forceinline__ uint32_t walk_block(const EntropyParams &p, const uin
         const uint32_t n = bit_size(diff);
         const uint32_t e = dc_lut[n];
         const uint32_t mag = (uint32_t)(diff - (diff < 0)) & ((1u << n) - 1u);
-        put_bits<EMIT>(s, total, ((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
+        s.put(((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
     }
     // AC: write_ac_block(block, start, end) (writer.rs:356-388)
-    if (p.ac_end <= p.ac_start) return total;
+    if (!BASELINE && p.ac_end <= p.ac_start) return;
     uint32_t run = 0;
     const uint32_t zrl = ac_lut[0xF0];
 #pragma unroll
-    for (int k = 1; k < 64; k++) {
-        const int v = (k & 1) ? (int)c[k >> 1] >> 16 : (int)(int16_t)(c[k >> 1] & 0xFFFFu);
-        if ((uint32_t)k < p.ac_start || (uint32_t)k >= p.ac_end) continue;
+    for (uint32_t k = 1; k < 64; k++) {
+        if (!BASELINE && (k < p.ac_start || k >= p.ac_end)) continue;
+        const int v = (k & 1u) ? (int)c[k >> 1] >> 16 : (int)(int16_t)(c[k >> 1] & 0xFFFFu);
         if (v != 0) {
-            while (run > 15) { put_bits<EMIT>(s, total, zrl & 0xFFFFu, zrl >> 16); run -= 16; }
+            if (run > 15) {
+#pragma nounroll
+                do { s.put(zrl & 0xFFFFu, zrl >> 16); run -= 16; } while (run > 15);
+            }
             const uint32_t n = bit_size(v);
             const uint32_t e = ac_lut[(run << 4) | n];
             const uint32_t mag = (uint32_t)(v - (v < 0)) & ((1u << n) - 1u);
-            put_bits<EMIT>(s, total, ((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
+            s.put(((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
             run = 0;
         } else {
             run++;
         }
     }
-    if (run > 0) { const uint32_t e = ac_lut[0]; put_bits<EMIT>(s, total, e & 0xFFFFu, e >> 16); }
-    return total;
+    if (run > 0) { const uint32_t e = ac_lut[0]; s.put(e & 0xFFFFu, e >> 16); }
 }
 
 __device__ __forceinline__ void load_lut(const EntropyParams &p, uint32_t *lut) {
@@ -249,23 +277,35 @@ __device__ __forceinline__ void load_lut(const EntropyParams &p, uint32_t *lut) 
     __syncthreads();
 }
 
+__device__ __forceinline__ bool baseline_band(const EntropyParams &p) { return p.with_dc && p.ac_start == 1 && p.ac_end == 64; }
+
+template <bool BASELINE>
 __global__ void __launch_bounds__(256) k_block_bits(const EntropyParams p) {
     __shared__ uint32_t lut[4 * 256];
     load_lut(p, lut);
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     if (b >= p.nblocks) return;
-    BitSink s = {nullptr, 0, 0, false};
+    CountSink s = {0};
     const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
-    p.bits[(size_t)f * p.nblocks + b] = walk_block<false>(p, lut, frame, b, s);
+    walk_block<BASELINE>(p, lut, frame, b, s);
+    p.bits[(size_t)f * p.nblocks + b] = s.total;
 }
 
 // Bit packing.  A wave's 64 blocks occupy one contiguous run of the raw stream (plus the alignment
-// gaps between restart intervals), so the wave assembles that run in a private LDS window - lanes OR
-// their first/last partial words in, store whole words plainly - and then writes the window to HBM
-// with coalesced stores; only the two words it may share with neighbouring waves go out as atomic
-// ORs into the zeroed buffer.  Runs longer than the window (pathological content) are written
-// straight to HBM with the same code.
+// gaps between restart intervals), so the wave assembles that run in a private, zeroed LDS window -
+// every lane ORs its words in - and then writes the window to HBM with coalesced stores; only the two
+// words it may share with neighbouring waves go out as atomic ORs into the zeroed buffer.  Runs longer
+// than the window (pathological content) are OR-ed straight into HBM by the same walk.
 constexpr uint32_t kPackWindowWords = 2048;      // 8 KiB per wave
+
+template <class Words>
+__device__ __forceinline__ void pack_one(const EntropyParams &p, const uint32_t *lut, const int16_t *frame, uint32_t b,
+                                         Words first, uint32_t in_iv, uint32_t pad, bool baseline) {
+    PackSink<Words> s = {first, 0, in_iv & 31u};
+    if (baseline) walk_block<true>(p, lut, frame, b, s); else walk_block<false>(p, lut, frame, b, s);
+    if (pad) s.put((1u << pad) - 1u, pad);
+    s.finish();
+}
 
 __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
     __shared__ uint32_t lut[4 * 256];
@@ -297,28 +337,14 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
     const uint32_t w0 = (uint32_t)__shfl((int)first_word, 0), w1 = (uint32_t)__shfl((int)last_word, (int)nvalid - 1);
     const uint32_t nwords = w1 - w0 + 1u;
     const bool staged = nwords <= p.window_words;                                // wave-uniform
+    const bool baseline = baseline_band(p);
     uint32_t *win = window[wave];
     if (staged) {
         for (uint32_t i = lane; i < nwords; i += 64u) win[i] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    if (valid) {
-        BitSink s = {staged ? win + (first_word - w0) : stream + first_word, 0, in_iv & 31u, true};
-        walk_block<true>(p, lut, frame, b, s);
-        if (pad) {
-            s.acc = (s.acc << pad) | ((1u << pad) - 1u);
-            s.nacc += pad;
-            if (s.nacc >= 32) {
-                const uint32_t w = __builtin_bswap32((uint32_t)(s.acc >> (s.nacc - 32)));
-                if (s.first) atomicOr(s.words, w); else *s.words = w;
-                s.first = false; s.words++; s.nacc -= 32;
-            }
-        }
-        if (s.nacc) atomicOr(s.words, __builtin_bswap32((uint32_t)(s.acc << (32 - s.nacc))));
-    }
-    if (staged) {
+        if (valid) pack_one(p, lut, frame, b, LdsWords{(lds_word *)win + (first_word - w0)}, in_iv, pad, baseline);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -327,6 +353,8 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
             if (i == 0 || i + 1 == nwords) { if (v) atomicOr(stream + w0 + i, v); }
             else stream[w0 + i] = v;
         }
+    } else if (valid) {
+        pack_one(p, lut, frame, b, HbmWords{(hbm_word *)stream + first_word}, in_iv, pad, baseline);
     }
 }
 
@@ -467,7 +495,8 @@ static hipError_t scan(const uint32_t *in, uint64_t in_stride, uint32_t *out, ui
 hipError_t launch_entropy_scan(const EntropyParams &p, int frames, hipStream_t st) {
     hipError_t e = hipSuccess;
     const uint32_t bgrid = (p.nblocks + 255u) / 256u;
-    hipLaunchKernelGGL(k_block_bits, dim3(bgrid, frames), dim3(256), 0, st, p);
+    if (p.with_dc && p.ac_start == 1 && p.ac_end == 64) hipLaunchKernelGGL(k_block_bits<true>, dim3(bgrid, frames), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_block_bits<false>, dim3(bgrid, frames), dim3(256), 0, st, p);
     e = scan(p.bits, p.nblocks, p.bitoff, p.nblocks, p.partials, p.max_tiles, p.total_bits, nullptr, p.nblocks, frames, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_interval_len, dim3((p.nintervals + 255u) / 256u, frames), dim3(256), 0, st, p);

@@ -42,5 +42,5 @@ def main(kind="noise", frames=16, reps=10):
                       "Mpixels_per_s": round(frames * W * H / ms / 1e3, 1), "scan_bytes_per_frame": int(d_len.float().mean().item())}))
 
 if __name__ == "__main__":
-    for k in ("noise", "pattern", "smooth"):
+    for k in (sys.argv[1:] or ("noise", "pattern", "smooth")):
         main(k)
