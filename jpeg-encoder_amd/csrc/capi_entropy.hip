@@ -38,9 +38,9 @@ __global__ void __launch_bounds__(1024) k_build_lut(const LutSpecs specs, uint32
 }
 
 struct ScanPlan {
-    uint32_t max_blocks, max_chunks, max_tiles;
+    uint32_t max_blocks, max_chunks, max_tiles, max_waves, max_fftiles;
     uint64_t raw_stride;
-    size_t off_lut, off_bits, off_bitoff, off_partials, off_scalars, off_intervals, off_raw, off_ffcount, off_ffprefix, total;
+    size_t off_lut, off_bits, off_wsum, off_woff, off_partials, off_scalars, off_intervals, off_raw, off_fftile, off_fftile_off, total;
 };
 
 // Worst-case code bytes of one block of a scan: DC <= 16 + 11 bits, each AC coefficient <= 16 + 11,
@@ -73,20 +73,22 @@ static void plan_scan(uint64_t max_blocks, uint64_t bound, int frames, ScanPlan 
     pl->max_blocks = (uint32_t)max_blocks;
     pl->raw_stride = (max_blocks * (bound + 16) + 64 + 15) & ~15ull;
     pl->max_chunks = (uint32_t)(pl->raw_stride / 16);
-    const uint32_t big = pl->max_chunks > pl->max_blocks ? pl->max_chunks : pl->max_blocks;
-    pl->max_tiles = (big + 4095) / 4096 + 1;
+    pl->max_waves = (pl->max_blocks + 63u) / 64u;
+    pl->max_fftiles = (pl->max_chunks + 255u) / 256u;
+    pl->max_tiles = (pl->max_blocks + 4095) / 4096 + 1;       // the largest scan is over restart intervals (<= blocks)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     const size_t F = (size_t)frames;
     pl->off_lut = take(4 * 256 * 4);
     pl->off_bits = take(F * pl->max_blocks * 4);
-    pl->off_bitoff = take(F * pl->max_blocks * 4);
+    pl->off_wsum = take(F * pl->max_waves * 4);
+    pl->off_woff = take(F * pl->max_waves * 4);
     pl->off_partials = take(F * pl->max_tiles * 4);
-    pl->off_scalars = take(F * 4 * 4);
-    pl->off_intervals = take(F * (size_t)pl->max_blocks * 4 * 4);
+    pl->off_scalars = take(F * 5 * 4);
+    pl->off_intervals = take(F * (size_t)pl->max_blocks * 5 * 4);
     pl->off_raw = take(F * pl->raw_stride);
-    pl->off_ffcount = take(F * (size_t)pl->max_chunks * 4);
-    pl->off_ffprefix = take(F * (size_t)pl->max_chunks * 4);
+    pl->off_fftile = take(F * (size_t)pl->max_fftiles * 4);
+    pl->off_fftile_off = take(F * (size_t)pl->max_fftiles * 4);
     pl->total = o;
 }
 
@@ -169,8 +171,8 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
     p.nblocks = (uint32_t)nblocks;
     static const uint32_t window_words = [] {
         const char *e = getenv("JPEGENC_PACK_WINDOW_WORDS");
-        const long v = e ? atol(e) : 2048;
-        return (uint32_t)(v < 0 ? 0 : v > 2048 ? 2048 : v);
+        const long v = e ? atol(e) : (long)kPackWindowWords;
+        return (uint32_t)(v < 0 ? 0 : v > (long)kPackWindowWords ? kPackWindowWords : v);
     }();
     p.window_words = window_words;
     p.with_dc = sc.with_dc ? 1u : 0u;
@@ -180,7 +182,9 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
     if (p.interval_blocks > p.nblocks) p.interval_blocks = p.nblocks;
     p.nintervals = (p.nblocks + p.interval_blocks - 1) / p.interval_blocks;
     p.bits = (uint32_t *)(ws + pl.off_bits);
-    p.bitoff = (uint32_t *)(ws + pl.off_bitoff);
+    p.nwaves = (p.nblocks + 63u) / 64u;
+    p.wsum = (uint32_t *)(ws + pl.off_wsum);
+    p.woff = (uint32_t *)(ws + pl.off_woff);
     p.partials = (uint32_t *)(ws + pl.off_partials);
     p.max_tiles = pl.max_tiles;
     uint32_t *scalars = (uint32_t *)(ws + pl.off_scalars);
@@ -188,14 +192,16 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
     p.raw_bytes = scalars + frames;
     p.raw_chunks = scalars + 2 * frames;
     p.total_ff = scalars + 3 * frames;
+    p.nfftiles = scalars + 4 * frames;
     uint32_t *iv = (uint32_t *)(ws + pl.off_intervals);
     const size_t ivn = (size_t)frames * p.nintervals;
-    p.ilen = iv; p.ichunks = iv + ivn; p.iexact = iv + 2 * ivn; p.ichunk = iv + 3 * ivn;
+    p.ilen = iv; p.ichunks = iv + ivn; p.iexact = iv + 2 * ivn; p.ichunk = iv + 3 * ivn; p.ivbit = iv + 4 * ivn;
     p.raw = ws + pl.off_raw;
     p.raw_stride = pl.raw_stride;
     p.max_chunks = pl.max_chunks;
-    p.ffcount = (uint32_t *)(ws + pl.off_ffcount);
-    p.ffprefix = (uint32_t *)(ws + pl.off_ffprefix);
+    p.max_fftiles = pl.max_fftiles;
+    p.fftile = (uint32_t *)(ws + pl.off_fftile);
+    p.fftile_off = (uint32_t *)(ws + pl.off_fftile_off);
     p.out = (uint8_t *)d_out;
     p.out_stride = out_frame_stride;
     p.out_bytes = d_out_lengths;

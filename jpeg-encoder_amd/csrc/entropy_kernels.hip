@@ -6,17 +6,20 @@
 // progressive (spectral selection) mode, with or without restart intervals, any Huffman tables.
 //
 // Variable-length coding is serial in the reference; here it is data-parallel steps:
-//   1. k_block_bits     one lane per block: exact bit length of the block's code
-//                       (DC category + Huffman codes of every (run,size) symbol, ZRLs, EOB)
-//   2. scan             exclusive prefix sum -> bit offset of every block (3 small kernels)
-//   3. k_interval_len   bytes of every restart interval (1-padded to a byte); two more scans give
-//                       each interval a 16-byte aligned place in the raw buffer and its exact offset
-//   4. k_block_pack     one lane per block re-walks its coefficients and writes its bits at its
-//                       offset (64-bit accumulator, whole 32-bit words stored plainly, the boundary
-//                       words OR-ed atomically into the zeroed buffer); the last block of an interval
-//                       adds the 1-padding of finalize_bit_buffer
-//   5. k_count_ff+scan  0xFF bytes per 16-byte chunk and their prefix sum
-//   6. k_stuff          scatter with 0xFF -> 0xFF 0x00 stuffing, RSTn markers between intervals
+//   1. k_block_bits     one lane per block: exact bit length of the block's code (DC category + Huffman
+//                       codes of every (run,size) symbol, ZRLs, EOB) + the sum over the wave's 64 blocks
+//   2. scan             exclusive prefix sum of the WAVE sums (1/64th of the blocks) -> bit offset of every
+//                       wave's run; a block's own offset is that + a 64-lane prefix inside k_block_pack
+//   3. k_interval_len   bit offset and byte length (1-padded to a byte) of every restart interval; two
+//                       more scans give each interval a 16-byte aligned place in the raw buffer
+//   4. k_wave_edges     zeroes the first and last word of every wave's run (the only words two waves share)
+//   5. k_block_pack     one lane per block re-walks its coefficients into a zeroed LDS window of the
+//                       wave's run (64-bit accumulator, words OR-ed in), window copied out coalesced,
+//                       the two shared words as atomic ORs; the last block of an interval adds the
+//                       1-padding of finalize_bit_buffer and zero-fills the interval's last 16-byte chunk
+//   6. k_ff_tiles+scan  0xFF bytes per tile of 256 16-byte chunks and their prefix sum (per-chunk counts
+//                       are recomputed inside k_stuff from the data it loads anyway)
+//   7. k_stuff          scatter with 0xFF -> 0xFF 0x00 stuffing, RSTn markers between intervals
 // DC prediction needs no scan: the predecessor of a block is a fixed earlier block of the same
 // component in MCU order, read straight from the coefficient array.
 #include <hip/hip_runtime.h>
@@ -166,6 +169,42 @@ __device__ __forceinline__ uint32_t bit_size(int v) {          // get_code().0 /
     return a ? 32u - (uint32_t)__builtin_clz(a) : 0u;
 }
 
+// ---- wave / workgroup prefix sums ------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += (uint32_t)__shfl_xor((int)x, d);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_inclusive(uint32_t x) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+// 256 threads; part[4] in LDS; the caller separates consecutive uses with __syncthreads()
+__device__ __forceinline__ uint32_t wg_exclusive(uint32_t x, uint32_t *part, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive(x);
+    if (lane == 63) part[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) { const uint32_t v = part[w]; if (w < wave) base += v; sum += v; }
+    *total = sum;
+    return base + inc - x;
+}
+
+// bit offset of block b in the scan: its wave's offset + the lengths of the wave's earlier blocks
+__device__ __forceinline__ uint32_t block_bit_offset(const EntropyParams &p, uint32_t f, uint32_t b) {
+    uint32_t s = p.woff[(size_t)f * p.nwaves + (b >> 6)];
+    const uint32_t *bits = p.bits + (size_t)f * p.nblocks;
+    for (uint32_t t = b & ~63u; t < b; t++) s += bits[t];
+    return s;
+}
+
 // Where a block's bits go.  k_block_bits only adds up lengths; k_block_pack shifts codes into a 64-bit
 // accumulator and ORs every completed 32-bit word (MSB-first byte order) into zeroed memory - the wave's
 // LDS window (ds_or_b32, no address-space guessing: the pointer type says LDS) or, for runs longer than
@@ -284,11 +323,14 @@ __global__ void __launch_bounds__(256) k_block_bits(const EntropyParams p) {
     __shared__ uint32_t lut[4 * 256];
     load_lut(p, lut);
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    if (b >= p.nblocks) return;
     CountSink s = {0};
-    const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
-    walk_block<BASELINE>(p, lut, frame, b, s);
-    p.bits[(size_t)f * p.nblocks + b] = s.total;
+    if (b < p.nblocks) {
+        const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
+        walk_block<BASELINE>(p, lut, frame, b, s);
+        p.bits[(size_t)f * p.nblocks + b] = s.total;
+    }
+    const uint32_t sum = wave_sum(s.total);
+    if ((threadIdx.x & 63u) == 0 && (b >> 6) < p.nwaves) p.wsum[(size_t)f * p.nwaves + (b >> 6)] = sum;
 }
 
 // Bit packing.  A wave's 64 blocks occupy one contiguous run of the raw stream (plus the alignment
@@ -296,7 +338,6 @@ __global__ void __launch_bounds__(256) k_block_bits(const EntropyParams p) {
 // every lane ORs its words in - and then writes the window to HBM with coalesced stores; only the two
 // words it may share with neighbouring waves go out as atomic ORs into the zeroed buffer.  Runs longer
 // than the window (pathological content) are OR-ed straight into HBM by the same walk.
-constexpr uint32_t kPackWindowWords = 2048;      // 8 KiB per wave
 
 template <class Words>
 __device__ __forceinline__ void pack_one(const EntropyParams &p, const uint32_t *lut, const int16_t *frame, uint32_t b,
@@ -317,21 +358,22 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
     const uint64_t vmask = __ballot(valid);
     if (vmask == 0) return;                                                      // whole wave past the end
     const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
-    const uint32_t *G = p.bitoff + (size_t)f * p.nblocks;
     uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
 
-    uint32_t in_iv = 0, first_word = 0, last_word = 0, pad = 0, iv_last = 0;
+    const uint32_t mine = valid ? p.bits[(size_t)f * p.nblocks + b] : 0u;
+    const uint32_t before = p.woff[(size_t)f * p.nwaves + (b >> 6)] + wave_inclusive(mine) - mine;   // bits of the scan before b
+    uint32_t in_iv = 0, first_word = 0, last_word = 0, pad = 0;
     if (valid) {
-        const uint32_t iv = b / p.interval_blocks, iv_first = iv * p.interval_blocks;
-        iv_last = min(iv_first + p.interval_blocks, p.nblocks) - 1;
-        in_iv = G[b] - G[iv_first];                                              // bits before b in its interval
+        const uint32_t iv = b / p.interval_blocks;
+        const uint32_t iv_last = min((iv + 1u) * p.interval_blocks, p.nblocks) - 1u;
+        in_iv = before - p.ivbit[(size_t)f * p.nintervals + iv];                 // bits before b in its interval
         const uint32_t base = p.ichunk[(size_t)f * p.nintervals + iv] * 4u;      // interval base (words), 16-B aligned
-        const uint32_t mine = p.bits[(size_t)f * p.nblocks + b];
         // finalize_bit_buffer (writer.rs:138-154): seven 1-bits, then only whole bytes are kept
         if (b == iv_last) pad = (8u - ((in_iv + mine) & 7u)) & 7u;
         const uint32_t end = in_iv + mine + pad;
         first_word = base + (in_iv >> 5);
         last_word = base + ((end ? end - 1u : 0u) >> 5);
+        if (b == iv_last) last_word |= 3u;       // the rest of the interval's last 16-byte chunk is written too (as zeros)
     }
     const uint32_t nvalid = (uint32_t)__popcll(vmask);
     const uint32_t w0 = (uint32_t)__shfl((int)first_word, 0), w1 = (uint32_t)__shfl((int)last_word, (int)nvalid - 1);
@@ -353,32 +395,53 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
             if (i == 0 || i + 1 == nwords) { if (v) atomicOr(stream + w0 + i, v); }
             else stream[w0 + i] = v;
         }
-    } else if (valid) {
-        pack_one(p, lut, frame, b, HbmWords{(hbm_word *)stream + first_word}, in_iv, pad, baseline);
+    } else {
+        // no window: zero the words only this wave writes (its two end words were cleared by k_wave_edges), then OR
+        for (uint32_t i = 1u + lane; i + 1u < nwords; i += 64u) stream[w0 + i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (valid) pack_one(p, lut, frame, b, HbmWords{(hbm_word *)stream + first_word}, in_iv, pad, baseline);
     }
 }
 
-// Clear the part of the raw buffer this frame's scan will use (its size is only known on the device).
-__global__ void __launch_bounds__(256) k_zero_raw(const EntropyParams p) {
-    const uint32_t f = blockIdx.y, n = min(p.raw_chunks[f] + 1u, p.max_chunks);
-    uint4 *raw = reinterpret_cast<uint4 *>(p.raw + (size_t)f * p.raw_stride);
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) raw[q] = make_uint4(0, 0, 0, 0);
-}
-
-// bytes of every restart interval after 1-padding (finalize_bit_buffer keeps whole bytes only)
+// bit offset and bytes of every restart interval after 1-padding (finalize_bit_buffer keeps whole bytes only)
 __global__ void __launch_bounds__(256) k_interval_len(const EntropyParams p) {
     const uint32_t f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.nintervals) return;
-    const uint32_t *G = p.bitoff + (size_t)f * p.nblocks;
     const uint32_t first = i * p.interval_blocks, end = min(first + p.interval_blocks, p.nblocks);
-    const uint32_t bits = (end == p.nblocks ? p.total_bits[f] : G[end]) - G[first];
+    const uint32_t at = block_bit_offset(p, f, first);
+    const uint32_t bits = (end == p.nblocks ? p.total_bits[f] : block_bit_offset(p, f, end)) - at;
     const uint32_t bytes = (bits + 7u) >> 3;
+    p.ivbit[(size_t)f * p.nintervals + i] = at;
     p.ilen[(size_t)f * p.nintervals + i] = bytes;
     p.ichunks[(size_t)f * p.nintervals + i] = (bytes + 15u) >> 4;
     if (p.nintervals == 1) {                       // no restart markers: the two interval scans are trivial
         p.iexact[f] = 0; p.ichunk[f] = 0;
         p.raw_bytes[f] = bytes; p.raw_chunks[f] = (bytes + 15u) >> 4;
     }
+}
+
+// The raw buffer is not cleared as a whole (its used size is data dependent and the clear cost as much as
+// a fifth of the bit packing): every word of a wave's run is written by that wave alone, except the first
+// and the last, which a neighbouring wave may share.  Those two are zeroed here, one thread per wave,
+// with the same arithmetic k_block_pack uses for its lanes 0 and nvalid-1.
+__global__ void __launch_bounds__(256) k_wave_edges(const EntropyParams p) {
+    const uint32_t f = blockIdx.y, w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= p.nwaves) return;
+    if (w == 0) p.nfftiles[f] = (p.raw_chunks[f] + 255u) >> 8;
+    uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
+    const uint32_t *woff = p.woff + (size_t)f * p.nwaves;
+    const uint32_t *ivbit = p.ivbit + (size_t)f * p.nintervals, *ichunk = p.ichunk + (size_t)f * p.nintervals;
+    const uint32_t b0 = w * 64u, b1 = min(b0 + 63u, p.nblocks - 1u);
+    const uint32_t iv0 = b0 / p.interval_blocks, iv1 = b1 / p.interval_blocks;
+    stream[ichunk[iv0] * 4u + ((woff[w] - ivbit[iv0]) >> 5)] = 0;
+    uint32_t end = (w + 1u < p.nwaves ? woff[w + 1u] : p.total_bits[f]) - ivbit[iv1];      // bits of interval iv1 up to and including b1
+    const bool closes = b1 == min((iv1 + 1u) * p.interval_blocks, p.nblocks) - 1u;
+    if (closes) end += (8u - (end & 7u)) & 7u;
+    uint32_t last = ichunk[iv1] * 4u + ((end ? end - 1u : 0u) >> 5);
+    if (closes) last |= 3u;
+    stream[last] = 0;
 }
 
 // ---- byte stuffing --------------------------------------------------------------------------------
@@ -393,13 +456,21 @@ __device__ __forceinline__ uint32_t ff_count4(uint32_t w) {           // number 
 // the device): a bounded grid walks them with a stride instead of launching the worst case.
 constexpr uint32_t kChunkGrid = 1024;
 
-__global__ void __launch_bounds__(256) k_count_ff(const EntropyParams p) {
+__device__ __forceinline__ uint32_t ff_count16(const uint4 v) { return ff_count4(v.x) + ff_count4(v.y) + ff_count4(v.z) + ff_count4(v.w); }
+
+// 0xFF bytes per tile of 256 chunks (bytes beyond an interval's length are zero - k_block_pack fills the
+// interval's last chunk - so they never count).
+__global__ void __launch_bounds__(256) k_ff_tiles(const EntropyParams p) {
+    __shared__ uint32_t part[4];
     const uint32_t f = blockIdx.y, n = p.raw_chunks[f];
     const uint4 *raw = reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride);
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
-        const uint4 v = raw[q];
-        // bytes beyond an interval's length are zero (k_zero_raw), so they never count
-        p.ffcount[(size_t)f * p.max_chunks + q] = ff_count4(v.x) + ff_count4(v.y) + ff_count4(v.z) + ff_count4(v.w);
+    for (uint32_t tile = blockIdx.x; tile * 256u < n; tile += gridDim.x) {
+        const uint32_t q = tile * 256u + threadIdx.x;
+        const uint32_t sum = wave_sum(q < n ? ff_count16(raw[q]) : 0u);
+        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) p.fftile[(size_t)f * p.max_fftiles + tile] = part[0] + part[1] + part[2] + part[3];
+        __syncthreads();
     }
 }
 
@@ -409,7 +480,7 @@ __global__ void __launch_bounds__(256) k_count_ff(const EntropyParams p) {
 // at the two ends, which neighbouring workgroups also touch, are written byte by byte.
 __global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[256 * 34 + 32];
-    __shared__ uint32_t tile_begin, tile_end;
+    __shared__ uint32_t tile_begin, tile_end, part[4];
     const uint32_t f = blockIdx.y, n = p.raw_chunks[f];
     const uint32_t *ichunk = p.ichunk + (size_t)f * p.nintervals;
     uint8_t *out = p.out + (size_t)f * p.out_stride;
@@ -417,6 +488,9 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
         const uint32_t q = tile * 256u + threadIdx.x;
         const bool active = q < n;
         uint32_t pos = 0, o = 0, iv = 0, j = 0, ilen = 0, nchunks = 0;
+        const uint4 v = active ? reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride)[q] : make_uint4(0, 0, 0, 0);
+        uint32_t tile_ff;
+        const uint32_t ffprefix = p.fftile_off[(size_t)f * p.max_fftiles + tile] + wg_exclusive(ff_count16(v), part, &tile_ff);
         if (active) {
             // interval of this chunk: the last i with ichunk[i] <= q
             uint32_t lo = 0, hi = p.nintervals;
@@ -427,7 +501,7 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
             iv = lo; j = q - ichunk[iv];
             ilen = p.ilen[(size_t)f * p.nintervals + iv]; nchunks = p.ichunks[(size_t)f * p.nintervals + iv];
             // raw bytes of earlier intervals + this interval's earlier bytes + stuffed zeros + 2-byte markers so far
-            pos = p.iexact[(size_t)f * p.nintervals + iv] + j * 16u + p.ffprefix[(size_t)f * p.max_chunks + q] + 2u * iv;
+            pos = p.iexact[(size_t)f * p.nintervals + iv] + j * 16u + ffprefix + 2u * iv;
         }
         if (threadIdx.x == 0) tile_begin = pos;
         __syncthreads();
@@ -435,7 +509,6 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
         const uint32_t phase = (uint32_t)((uintptr_t)(out + begin) & 3u);          // LDS image shares the destination's alignment
         if (active) {
             uint8_t *dst = stage + phase + (pos - begin);
-            const uint4 v = reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride)[q];
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             const uint32_t valid = ilen - j * 16u < 16u ? ilen - j * 16u : 16u;
 #pragma unroll
@@ -497,7 +570,7 @@ hipError_t launch_entropy_scan(const EntropyParams &p, int frames, hipStream_t s
     const uint32_t bgrid = (p.nblocks + 255u) / 256u;
     if (p.with_dc && p.ac_start == 1 && p.ac_end == 64) hipLaunchKernelGGL(k_block_bits<true>, dim3(bgrid, frames), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(k_block_bits<false>, dim3(bgrid, frames), dim3(256), 0, st, p);
-    e = scan(p.bits, p.nblocks, p.bitoff, p.nblocks, p.partials, p.max_tiles, p.total_bits, nullptr, p.nblocks, frames, st);
+    e = scan(p.wsum, p.nwaves, p.woff, p.nwaves, p.partials, p.max_tiles, p.total_bits, nullptr, p.nwaves, frames, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_interval_len, dim3((p.nintervals + 255u) / 256u, frames), dim3(256), 0, st, p);
     if (p.nintervals > 1) {
@@ -506,12 +579,11 @@ hipError_t launch_entropy_scan(const EntropyParams &p, int frames, hipStream_t s
         e = scan(p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, p.nintervals, frames, st);
         if (e != hipSuccess) return e;
     }
-    const uint32_t cgrid = min((p.max_chunks + 255u) / 256u, kChunkGrid);
-    hipLaunchKernelGGL(k_zero_raw, dim3(cgrid, frames), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_wave_edges, dim3((p.nwaves + 255u) / 256u, frames), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_block_pack, dim3(bgrid, frames), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(k_count_ff, dim3(cgrid, frames), dim3(256), 0, st, p);
-    e = scan(p.ffcount, p.max_chunks, p.ffprefix, p.max_chunks, p.partials, p.max_tiles, p.total_ff, p.raw_chunks,
-             p.max_chunks, frames, st);
+    const uint32_t cgrid = min(p.max_fftiles, kChunkGrid);
+    hipLaunchKernelGGL(k_ff_tiles, dim3(cgrid, frames), dim3(256), 0, st, p);
+    e = scan(p.fftile, p.max_fftiles, p.fftile_off, p.max_fftiles, p.partials, p.max_tiles, p.total_ff, p.nfftiles, p.max_fftiles, frames, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_stuff, dim3(cgrid, frames), dim3(256), 0, st, p);
     return hipGetLastError();

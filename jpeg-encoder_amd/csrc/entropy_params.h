@@ -4,6 +4,11 @@
 
 namespace jpegenc {
 
+#ifndef JPEGENC_PACK_WINDOW
+#define JPEGENC_PACK_WINDOW 2048
+#endif
+constexpr uint32_t kPackWindowWords = JPEGENC_PACK_WINDOW;      // words of LDS per wave of the bit packer
+
 // One scan = one entropy-coded segment: either all components interleaved (blocks in MCU order,
 // encode_image_interleaved, encoder.rs:747-790) or one component's blocks in planar order
 // (sequential / progressive scans, encoder.rs:823-861, 885-972).
@@ -23,10 +28,13 @@ struct EntropyParams {
     const uint32_t *lut;
     // workspace (device), per frame
     uint32_t *bits;                  // [frames][nblocks]      code length of each block
-    uint32_t *bitoff;                // [frames][nblocks]      exclusive prefix sum over the scan
+    uint32_t nwaves;                 // ceil(nblocks / 64): a wave of the block kernels = 64 consecutive blocks
+    uint32_t *wsum;                  // [frames][nwaves]       code length of each wave's 64 blocks
+    uint32_t *woff;                  // [frames][nwaves]       exclusive prefix sum of wsum = bit offset of the wave's run
     uint32_t *partials;              // [frames][max_tiles]    scan scratch
     uint32_t max_tiles;
     uint32_t *total_bits;            // [frames]
+    uint32_t *ivbit;                 // [frames][nintervals]   bit offset of the interval's first block in the scan
     uint32_t *ilen;                  // [frames][nintervals]   bytes of each interval (1-padded, unstuffed)
     uint32_t *ichunks;               // [frames][nintervals]   ceil(ilen / 16)
     uint32_t *iexact;                // [frames][nintervals]   exclusive prefix of ilen
@@ -36,11 +44,13 @@ struct EntropyParams {
     uint8_t *raw;                    // [frames][raw_stride]   unstuffed bits, every interval 16-byte aligned
     uint64_t raw_stride;             // bytes, multiple of 16
     uint32_t max_chunks;             // raw_stride / 16
-    uint32_t window_words;           // bit-packer runs up to this many words go through the LDS window (<= 2048;
+    uint32_t window_words;           // bit-packer runs up to this many words go through the LDS window (<= kPackWindowWords;
                                      // JPEGENC_PACK_WINDOW_WORDS lowers it so that tests reach the direct path)
-    uint32_t *ffcount;               // [frames][max_chunks]
-    uint32_t *ffprefix;              // [frames][max_chunks]
+    uint32_t max_fftiles;            // ceil(max_chunks / 256)
+    uint32_t *fftile;                // [frames][max_fftiles]  0xFF bytes per tile of 256 chunks
+    uint32_t *fftile_off;            // [frames][max_fftiles]  its exclusive prefix sum
     uint32_t *total_ff;              // [frames]
+    uint32_t *nfftiles;              // [frames] ceil(raw_chunks / 256)
     uint8_t *out;                    // [frames][out_stride]   stuffed segment incl. RSTn markers
     uint64_t out_stride;
     uint32_t *out_bytes;             // [frames] its length
