@@ -553,7 +553,8 @@ static hipError_t scan(const uint32_t *in, uint64_t in_stride, uint32_t *out, ui
                        uint32_t max_tiles, uint32_t *totals, const uint32_t *n_dev, uint32_t n_max, int frames,
                        hipStream_t st) {
     const uint32_t tiles = (n_max + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(tiles, frames), dim3(256), 0, st, in, in_stride, partials, max_tiles, n_dev, n_max);
+    if (tiles > 1)         // a single tile has no tiles before it: the fused kernel alone is the scan
+        hipLaunchKernelGGL(k_scan_reduce, dim3(tiles, frames), dim3(256), 0, st, in, in_stride, partials, max_tiles, n_dev, n_max);
     if (tiles <= 2048) {       // every workgroup can afford to add up the tile sums before its own
         hipLaunchKernelGGL(k_scan_apply_fused, dim3(tiles ? tiles : 1, frames), dim3(256), 0, st, in, in_stride, out, out_stride,
                            partials, max_tiles, totals, n_dev, n_max);
