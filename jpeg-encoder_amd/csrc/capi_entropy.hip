@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(1024) k_build_lut(const LutSpecs specs, uint32
 struct ScanPlan {
     uint32_t max_blocks, max_chunks, max_tiles, max_waves, max_fftiles;
     uint64_t raw_stride;
-    size_t off_lut, off_bits, off_wsum, off_woff, off_partials, off_scalars, off_intervals, off_raw, off_fftile, off_fftile_off, total;
+    size_t off_params, off_lut, off_bits, off_wsum, off_woff, off_partials, off_scalars, off_intervals, off_raw, off_fftile, off_fftile_off, total;
 };
 
 // Worst-case code bytes of one block of a scan: DC <= 16 + 11 bits, each AC coefficient <= 16 + 11,
@@ -79,6 +79,7 @@ static void plan_scan(uint64_t max_blocks, uint64_t bound, int frames, ScanPlan 
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     const size_t F = (size_t)frames;
+    pl->off_params = take(kMaxScansPerLaunch * sizeof(EntropyParams));      // the parameter blocks of a launch live in the first scan's workspace
     pl->off_lut = take(4 * 256 * 4);
     pl->off_bits = take(F * pl->max_blocks * 4);
     pl->off_wsum = take(F * pl->max_waves * 4);
@@ -132,10 +133,13 @@ int upload_huffman_luts(const jpegenc_huffman_spec (*tables)[2], void *d_lut, hi
     return JPEGENC_OK;
 }
 
-// d_lut == nullptr: build the tables into the workspace first.
-int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
-                const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
-                size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st) {
+// Fills the parameter block of one scan (no launch).  d_lut == nullptr: the tables are built into the
+// workspace first (that one does launch).  *d_params_out = where this workspace keeps parameter blocks.
+static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
+                     const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
+                     size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st,
+                     EntropyParams *out, EntropyParams **d_params_out) {
+    EntropyParams &p = *out;
     if (!valid_scan(L, sc)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan not supported on the device");
     if (frames <= 0) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "num_frames must be positive");
     const uint64_t nblocks = scan_blocks(L, sc);
@@ -147,7 +151,6 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
     if (coeff_frame_stride < L.total_blocks) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "coeff_frame_stride < total_blocks");
     const ScanPlan &pl = need;
     uint8_t *ws = (uint8_t *)d_ws;
-    EntropyParams p;
     memset(&p, 0, sizeof p);
     uint64_t first_block = 0;
     if (sc.component < 0) {
@@ -212,9 +215,40 @@ int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, con
         if (rc) return rc;
         p.lut = (const uint32_t *)(ws + pl.off_lut);
     }
-    hipError_t e = hipMemsetAsync(d_out_lengths, 0, sizeof(uint32_t) * (size_t)frames, st);   // empty scans stay 0
-    if (e == hipSuccess) e = launch_entropy_scan(p, frames, st);
+    *d_params_out = (EntropyParams *)(ws + pl.off_params);
+    return JPEGENC_OK;
+}
+
+int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
+                const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
+                size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st) {
+    EntropyParams p, *d_params = nullptr;
+    const int rc = fill_scan(d_coeffs, coeff_frame_stride, frames, L, sc, tables, d_lut, d_out, out_frame_stride, d_out_lengths,
+                             d_ws, ws_bytes, st, &p, &d_params);
+    if (rc) return rc;
+    const hipError_t e = launch_entropy_scans(&p, 1, d_params, frames, st);
     if (e != hipSuccess) return hip_fail(e, "entropy kernels");
+    return JPEGENC_OK;
+}
+
+// Several scans of the same frames (the per-component / per-band scans of a sequential or progressive file)
+// in shared launches, kMaxScansPerLaunch at a time.  Every scan brings its own workspace and output.
+int scan_device_multi(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L, const ScanJob *jobs,
+                      int njobs, const void *d_lut, hipStream_t st) {
+    if (!d_lut) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan_device_multi needs prepared tables");
+    for (int first = 0; first < njobs; first += (int)kMaxScansPerLaunch) {
+        const int n = njobs - first < (int)kMaxScansPerLaunch ? njobs - first : (int)kMaxScansPerLaunch;
+        EntropyParams p[kMaxScansPerLaunch], *d_params = nullptr, *d_first = nullptr;
+        for (int j = 0; j < n; j++) {
+            const ScanJob &job = jobs[first + j];
+            const int rc = fill_scan(d_coeffs, coeff_frame_stride, frames, L, job.sc, nullptr, d_lut, job.d_out, job.out_frame_stride,
+                                     job.d_out_lengths, job.d_ws, job.ws_bytes, st, &p[j], &d_params);
+            if (rc) return rc;
+            if (j == 0) d_first = d_params;
+        }
+        const hipError_t e = launch_entropy_scans(p, n, d_first, frames, st);
+        if (e != hipSuccess) return hip_fail(e, "entropy kernels");
+    }
     return JPEGENC_OK;
 }
 

@@ -32,14 +32,55 @@ namespace jpegenc {
 
 constexpr int kScanTile = 4096;      // elements per workgroup in the scans (256 threads x 16)
 
+// ---- parameters ------------------------------------------------------------------------------------
+// Every kernel runs over (x: work of one frame of one scan, y: frame, z: scan).  The scans of a frame are
+// independent of one another (a progressive 4K frame has 12, each ~9 small launches): coding them in the
+// same launches is what keeps such frames from being launch-bound.  The parameter blocks of the scans of
+// a launch live in device memory (written by k_store_params from its kernel arguments, so the sequence
+// stays capturable); they are read through the constant address space: invariant scalar loads, exactly
+// what by-value kernel arguments were.
+typedef const __attribute__((address_space(4))) EntropyParams &Params;
+#define JPEGENC_JOB(params) (*(const __attribute__((address_space(4))) EntropyParams *)((params) + blockIdx.z))
+
+struct ParamPack {
+    uint32_t n;
+    EntropyParams p[kMaxScansPerLaunch];
+};
+static_assert(sizeof(ParamPack) <= 4096, "kernel arguments are limited to 4 KiB");
+
+__global__ void __launch_bounds__(256) k_store_params(const ParamPack pack, EntropyParams *dst) {
+    const uint32_t words = pack.n * (uint32_t)(sizeof(EntropyParams) / 4);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(pack.p);
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) reinterpret_cast<uint32_t *>(dst)[i] = src[i];
+}
+
 // ---- generic exclusive scan of uint32 (per frame: blockIdx.y) ---------------------------------
 // n is read from device memory when n_dev != nullptr (data-dependent sizes never visit the host).
 __device__ __forceinline__ uint32_t frame_n(const uint32_t *n_dev, uint32_t n_const, uint32_t frame) {
     return n_dev ? n_dev[frame] : n_const;
 }
 
-__global__ void __launch_bounds__(256) k_scan_reduce(const uint32_t *in, uint64_t in_stride, uint32_t *partials,
-                                                     uint32_t max_tiles, const uint32_t *n_dev, uint32_t n_const) {
+// the four prefix sums of a scan's pipeline, by number
+enum { SCAN_WAVES = 0, SCAN_ILEN = 1, SCAN_ICHUNKS = 2, SCAN_FFTILES = 3 };
+struct ScanArgs {
+    const uint32_t *in; uint64_t in_stride; uint32_t *out; uint64_t out_stride;
+    uint32_t *partials; uint32_t max_tiles; uint32_t *totals; const uint32_t *n_dev; uint32_t n_const;
+};
+__device__ __forceinline__ ScanArgs scan_args(Params p, int which) {
+    if (which == SCAN_WAVES) return {p.wsum, p.nwaves, p.woff, p.nwaves, p.partials, p.max_tiles, p.total_bits, nullptr, p.nwaves};
+    if (which == SCAN_ILEN) return {p.ilen, p.nintervals, p.iexact, p.nintervals, p.partials, p.max_tiles, p.raw_bytes, nullptr, p.nintervals};
+    if (which == SCAN_ICHUNKS) return {p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, p.nintervals};
+    return {p.fftile, p.max_fftiles, p.fftile_off, p.max_fftiles, p.partials, p.max_tiles, p.total_ff, p.nfftiles, p.max_fftiles};
+}
+#define JPEGENC_SCAN_ARGS                                                                                     \
+    const ScanArgs a = scan_args(JPEGENC_JOB(params), which);                                                 \
+    const uint32_t *in = a.in; const uint64_t in_stride = a.in_stride; uint32_t *out = a.out;                 \
+    const uint64_t out_stride = a.out_stride; uint32_t *partials = a.partials; const uint32_t max_tiles = a.max_tiles; \
+    uint32_t *totals = a.totals; const uint32_t *n_dev = a.n_dev; const uint32_t n_const = a.n_const;         \
+    (void)in; (void)in_stride; (void)out; (void)out_stride; (void)partials; (void)max_tiles; (void)totals
+
+__global__ void __launch_bounds__(256) k_scan_reduce(const EntropyParams *params, int which) {
+    JPEGENC_SCAN_ARGS;
     const uint32_t f = blockIdx.y, n = frame_n(n_dev, n_const, f);
     const uint32_t tile = blockIdx.x;
     if ((uint64_t)tile * kScanTile >= n) return;
@@ -59,18 +100,18 @@ __global__ void __launch_bounds__(256) k_scan_reduce(const uint32_t *in, uint64_
     if (threadIdx.x == 0) partials[(size_t)f * max_tiles + tile] = red[0];
 }
 
-__global__ void __launch_bounds__(256) k_scan_partials(uint32_t *partials, uint32_t max_tiles, uint32_t *totals,
-                                                       const uint32_t *n_dev, uint32_t n_const) {
+__global__ void __launch_bounds__(256) k_scan_partials(const EntropyParams *params, int which) {
+    JPEGENC_SCAN_ARGS;
     const uint32_t f = blockIdx.x, n = frame_n(n_dev, n_const, f);
     const uint32_t tiles = (uint32_t)(((uint64_t)n + kScanTile - 1) / kScanTile);
-    uint32_t *p = partials + (size_t)f * max_tiles;
+    uint32_t *pp = partials + (size_t)f * max_tiles;
     __shared__ uint32_t buf[256];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < tiles; base += 256) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < tiles ? p[i] : 0;
+        const uint32_t v = i < tiles ? pp[i] : 0;
         buf[threadIdx.x] = v;
         __syncthreads();
         for (int s = 1; s < 256; s <<= 1) {          // Hillis-Steele inclusive scan
@@ -79,7 +120,7 @@ __global__ void __launch_bounds__(256) k_scan_partials(uint32_t *partials, uint3
             buf[threadIdx.x] += t;
             __syncthreads();
         }
-        if (i < tiles) p[i] = carry + buf[threadIdx.x] - v;      // exclusive
+        if (i < tiles) pp[i] = carry + buf[threadIdx.x] - v;      // exclusive
         __syncthreads();
         if (threadIdx.x == 255) carry += buf[255];
         __syncthreads();
@@ -87,9 +128,8 @@ __global__ void __launch_bounds__(256) k_scan_partials(uint32_t *partials, uint3
     if (threadIdx.x == 0) totals[f] = carry;
 }
 
-__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *in, uint64_t in_stride, uint32_t *out,
-                                                    uint64_t out_stride, const uint32_t *partials, uint32_t max_tiles,
-                                                    const uint32_t *n_dev, uint32_t n_const) {
+__global__ void __launch_bounds__(256) k_scan_apply(const EntropyParams *params, int which) {
+    JPEGENC_SCAN_ARGS;
     const uint32_t f = blockIdx.y, n = frame_n(n_dev, n_const, f);
     const uint32_t tile = blockIdx.x;
     if ((uint64_t)tile * kScanTile >= n) return;
@@ -121,9 +161,9 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *in, uint64_t
 // before its own (instead of a third, single-workgroup kernel turning them into prefixes first), and
 // the workgroup of the last tile also writes the total.  Two launches per scan instead of three - the
 // scans are launch-bound (a 4K frame has 48 tiles of block lengths).
-__global__ void __launch_bounds__(256) k_scan_apply_fused(const uint32_t *in, uint64_t in_stride, uint32_t *out,
-                                                          uint64_t out_stride, const uint32_t *tile_sums, uint32_t max_tiles,
-                                                          uint32_t *totals, const uint32_t *n_dev, uint32_t n_const) {
+__global__ void __launch_bounds__(256) k_scan_apply_fused(const EntropyParams *params, int which) {
+    JPEGENC_SCAN_ARGS;
+    const uint32_t *tile_sums = partials;
     const uint32_t f = blockIdx.y, n = frame_n(n_dev, n_const, f);
     const uint32_t tile = blockIdx.x;
     if (n == 0) { if (tile == 0 && threadIdx.x == 0) totals[f] = 0; return; }
@@ -198,7 +238,7 @@ __device__ __forceinline__ uint32_t wg_exclusive(uint32_t x, uint32_t *part, uin
 }
 
 // bit offset of block b in the scan: its wave's offset + the lengths of the wave's earlier blocks
-__device__ __forceinline__ uint32_t block_bit_offset(const EntropyParams &p, uint32_t f, uint32_t b) {
+__device__ __forceinline__ uint32_t block_bit_offset(Params p, uint32_t f, uint32_t b) {
     uint32_t s = p.woff[(size_t)f * p.nwaves + (b >> 6)];
     const uint32_t *bits = p.bits + (size_t)f * p.nblocks;
     for (uint32_t t = b & ~63u; t < b; t++) s += bits[t];
@@ -257,7 +297,7 @@ struct PackSink {
 // the other seven loads hit L1 while it is hot; walking piece by piece with the next one in flight re-missed
 // the line for every piece: 52 vs 39 us per 4K frame), so the walk is fully unrolled over registers.
 template <bool BASELINE, class Sink>
-__device__ __forceinline__ void walk_block(const EntropyParams &p, const uint32_t *lut, const int16_t *frame_coeffs,
+__device__ __forceinline__ void walk_block(Params p, const uint32_t *lut, const int16_t *frame_coeffs,
                                            uint32_t b, Sink &s) {
     const uint32_t mcu = b / p.bpm, pos = b - mcu * p.bpm;
     const uint32_t table = p.pos_table[pos];
@@ -311,22 +351,22 @@ __device__ __forceinline__ void walk_block(const EntropyParams &p, const uint32_
     if (run > 0) { const uint32_t e = ac_lut[0]; s.put(e & 0xFFFFu, e >> 16); }
 }
 
-__device__ __forceinline__ void load_lut(const EntropyParams &p, uint32_t *lut) {
+__device__ __forceinline__ void load_lut(Params p, uint32_t *lut) {
     for (uint32_t i = threadIdx.x; i < 4 * 256; i += blockDim.x) lut[i] = p.lut[i];
     __syncthreads();
 }
 
-__device__ __forceinline__ bool baseline_band(const EntropyParams &p) { return p.with_dc && p.ac_start == 1 && p.ac_end == 64; }
+__device__ __forceinline__ bool baseline_band(Params p) { return p.with_dc && p.ac_start == 1 && p.ac_end == 64; }
 
-template <bool BASELINE>
-__global__ void __launch_bounds__(256) k_block_bits(const EntropyParams p) {
+__global__ void __launch_bounds__(256) k_block_bits(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
     __shared__ uint32_t lut[4 * 256];
     load_lut(p, lut);
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     CountSink s = {0};
     if (b < p.nblocks) {
         const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
-        walk_block<BASELINE>(p, lut, frame, b, s);
+        if (baseline_band(p)) walk_block<true>(p, lut, frame, b, s); else walk_block<false>(p, lut, frame, b, s);
         p.bits[(size_t)f * p.nblocks + b] = s.total;
     }
     const uint32_t sum = wave_sum(s.total);
@@ -340,7 +380,7 @@ __global__ void __launch_bounds__(256) k_block_bits(const EntropyParams p) {
 // than the window (pathological content) are OR-ed straight into HBM by the same walk.
 
 template <class Words>
-__device__ __forceinline__ void pack_one(const EntropyParams &p, const uint32_t *lut, const int16_t *frame, uint32_t b,
+__device__ __forceinline__ void pack_one(Params p, const uint32_t *lut, const int16_t *frame, uint32_t b,
                                          Words first, uint32_t in_iv, uint32_t pad, bool baseline) {
     PackSink<Words> s = {first, 0, in_iv & 31u};
     if (baseline) walk_block<true>(p, lut, frame, b, s); else walk_block<false>(p, lut, frame, b, s);
@@ -348,7 +388,8 @@ __device__ __forceinline__ void pack_one(const EntropyParams &p, const uint32_t 
     s.finish();
 }
 
-__global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
+__global__ void __launch_bounds__(256) k_block_pack(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
     __shared__ uint32_t lut[4 * 256];
     __shared__ uint32_t window[4][kPackWindowWords];
     load_lut(p, lut);
@@ -406,7 +447,8 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams p) {
 }
 
 // bit offset and bytes of every restart interval after 1-padding (finalize_bit_buffer keeps whole bytes only)
-__global__ void __launch_bounds__(256) k_interval_len(const EntropyParams p) {
+__global__ void __launch_bounds__(256) k_interval_len(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
     const uint32_t f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.nintervals) return;
     const uint32_t first = i * p.interval_blocks, end = min(first + p.interval_blocks, p.nblocks);
@@ -426,10 +468,11 @@ __global__ void __launch_bounds__(256) k_interval_len(const EntropyParams p) {
 // a fifth of the bit packing): every word of a wave's run is written by that wave alone, except the first
 // and the last, which a neighbouring wave may share.  Those two are zeroed here, one thread per wave,
 // with the same arithmetic k_block_pack uses for its lanes 0 and nvalid-1.
-__global__ void __launch_bounds__(256) k_wave_edges(const EntropyParams p) {
+__global__ void __launch_bounds__(256) k_wave_edges(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
     const uint32_t f = blockIdx.y, w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= p.nwaves) return;
-    if (w == 0) p.nfftiles[f] = (p.raw_chunks[f] + 255u) >> 8;
+    if (w == 0) { p.nfftiles[f] = (p.raw_chunks[f] + 255u) >> 8; p.out_bytes[f] = 0; }      // k_stuff sets the length
     uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
     const uint32_t *woff = p.woff + (size_t)f * p.nwaves;
     const uint32_t *ivbit = p.ivbit + (size_t)f * p.nintervals, *ichunk = p.ichunk + (size_t)f * p.nintervals;
@@ -460,7 +503,8 @@ __device__ __forceinline__ uint32_t ff_count16(const uint4 v) { return ff_count4
 
 // 0xFF bytes per tile of 256 chunks (bytes beyond an interval's length are zero - k_block_pack fills the
 // interval's last chunk - so they never count).
-__global__ void __launch_bounds__(256) k_ff_tiles(const EntropyParams p) {
+__global__ void __launch_bounds__(256) k_ff_tiles(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
     __shared__ uint32_t part[4];
     const uint32_t f = blockIdx.y, n = p.raw_chunks[f];
     const uint4 *raw = reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride);
@@ -478,7 +522,8 @@ __global__ void __launch_bounds__(256) k_ff_tiles(const EntropyParams p) {
 // range, so the bytes (with the inserted 0x00 and the RSTn markers) are laid out in LDS first -
 // phase-aligned with the destination - and then copied out as whole dwords; only the partial words
 // at the two ends, which neighbouring workgroups also touch, are written byte by byte.
-__global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
+__global__ void __launch_bounds__(256) k_stuff(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
     __shared__ __attribute__((aligned(16))) uint8_t stage[256 * 34 + 32];
     __shared__ uint32_t tile_begin, tile_end, part[4];
     const uint32_t f = blockIdx.y, n = p.raw_chunks[f];
@@ -549,44 +594,51 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams p) {
 }
 
 // ---- launcher ----------------------------------------------------------------------------------------
-static hipError_t scan(const uint32_t *in, uint64_t in_stride, uint32_t *out, uint64_t out_stride, uint32_t *partials,
-                       uint32_t max_tiles, uint32_t *totals, const uint32_t *n_dev, uint32_t n_max, int frames,
-                       hipStream_t st) {
+static hipError_t scan(const EntropyParams *d_params, int which, uint32_t n_max, int njobs, int frames, hipStream_t st) {
     const uint32_t tiles = (n_max + kScanTile - 1) / kScanTile;
     if (tiles > 1)         // a single tile has no tiles before it: the fused kernel alone is the scan
-        hipLaunchKernelGGL(k_scan_reduce, dim3(tiles, frames), dim3(256), 0, st, in, in_stride, partials, max_tiles, n_dev, n_max);
+        hipLaunchKernelGGL(k_scan_reduce, dim3(tiles, frames, njobs), dim3(256), 0, st, d_params, which);
     if (tiles <= 2048) {       // every workgroup can afford to add up the tile sums before its own
-        hipLaunchKernelGGL(k_scan_apply_fused, dim3(tiles ? tiles : 1, frames), dim3(256), 0, st, in, in_stride, out, out_stride,
-                           partials, max_tiles, totals, n_dev, n_max);
+        hipLaunchKernelGGL(k_scan_apply_fused, dim3(tiles ? tiles : 1, frames, njobs), dim3(256), 0, st, d_params, which);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_scan_partials, dim3(frames), dim3(256), 0, st, partials, max_tiles, totals, n_dev, n_max);
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles, frames), dim3(256), 0, st, in, in_stride, out, out_stride, partials,
-                       max_tiles, n_dev, n_max);
+    hipLaunchKernelGGL(k_scan_partials, dim3(frames, 1, njobs), dim3(256), 0, st, d_params, which);
+    hipLaunchKernelGGL(k_scan_apply, dim3(tiles, frames, njobs), dim3(256), 0, st, d_params, which);
     return hipGetLastError();
 }
 
-hipError_t launch_entropy_scan(const EntropyParams &p, int frames, hipStream_t st) {
+// njobs <= kMaxScansPerLaunch scans (same number of frames each) in one launch sequence; d_params: room
+// for njobs parameter blocks in device memory
+hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t st) {
+    if (njobs < 1 || njobs > (int)kMaxScansPerLaunch) return hipErrorInvalidValue;
+    ParamPack pack;
+    pack.n = (uint32_t)njobs;
+    uint32_t nblocks = 0, nwaves = 0, nintervals = 0, fftiles = 0;
+    for (int j = 0; j < njobs; j++) {
+        pack.p[j] = jobs[j];
+        nblocks = max(nblocks, jobs[j].nblocks); nwaves = max(nwaves, jobs[j].nwaves);
+        nintervals = max(nintervals, jobs[j].nintervals); fftiles = max(fftiles, jobs[j].max_fftiles);
+    }
+    hipLaunchKernelGGL(k_store_params, dim3(1), dim3(256), 0, st, pack, d_params);
     hipError_t e = hipSuccess;
-    const uint32_t bgrid = (p.nblocks + 255u) / 256u;
-    if (p.with_dc && p.ac_start == 1 && p.ac_end == 64) hipLaunchKernelGGL(k_block_bits<true>, dim3(bgrid, frames), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(k_block_bits<false>, dim3(bgrid, frames), dim3(256), 0, st, p);
-    e = scan(p.wsum, p.nwaves, p.woff, p.nwaves, p.partials, p.max_tiles, p.total_bits, nullptr, p.nwaves, frames, st);
+    const uint32_t bgrid = (nblocks + 255u) / 256u;
+    hipLaunchKernelGGL(k_block_bits, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
+    e = scan(d_params, SCAN_WAVES, nwaves, njobs, frames, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_interval_len, dim3((p.nintervals + 255u) / 256u, frames), dim3(256), 0, st, p);
-    if (p.nintervals > 1) {
-        e = scan(p.ilen, p.nintervals, p.iexact, p.nintervals, p.partials, p.max_tiles, p.raw_bytes, nullptr, p.nintervals, frames, st);
+    hipLaunchKernelGGL(k_interval_len, dim3((nintervals + 255u) / 256u, frames, njobs), dim3(256), 0, st, d_params);
+    if (nintervals > 1) {      // (a scan with a single interval already has its trivial results; scanning them again is harmless)
+        e = scan(d_params, SCAN_ILEN, nintervals, njobs, frames, st);
         if (e != hipSuccess) return e;
-        e = scan(p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, p.nintervals, frames, st);
+        e = scan(d_params, SCAN_ICHUNKS, nintervals, njobs, frames, st);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_wave_edges, dim3((p.nwaves + 255u) / 256u, frames), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(k_block_pack, dim3(bgrid, frames), dim3(256), 0, st, p);
-    const uint32_t cgrid = min(p.max_fftiles, kChunkGrid);
-    hipLaunchKernelGGL(k_ff_tiles, dim3(cgrid, frames), dim3(256), 0, st, p);
-    e = scan(p.fftile, p.max_fftiles, p.fftile_off, p.max_fftiles, p.partials, p.max_tiles, p.total_ff, p.nfftiles, p.max_fftiles, frames, st);
+    hipLaunchKernelGGL(k_wave_edges, dim3((nwaves + 255u) / 256u, frames, njobs), dim3(256), 0, st, d_params);
+    hipLaunchKernelGGL(k_block_pack, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
+    const uint32_t cgrid = min(fftiles, kChunkGrid);
+    hipLaunchKernelGGL(k_ff_tiles, dim3(cgrid, frames, njobs), dim3(256), 0, st, d_params);
+    e = scan(d_params, SCAN_FFTILES, fftiles, njobs, frames, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stuff, dim3(cgrid, frames), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_stuff, dim3(cgrid, frames, njobs), dim3(256), 0, st, d_params);
     return hipGetLastError();
 }
 

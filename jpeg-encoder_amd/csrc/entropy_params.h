@@ -8,6 +8,7 @@ namespace jpegenc {
 #define JPEGENC_PACK_WINDOW 2048
 #endif
 constexpr uint32_t kPackWindowWords = JPEGENC_PACK_WINDOW;      // words of LDS per wave of the bit packer
+constexpr uint32_t kMaxScansPerLaunch = 8;                       // scans coded by one launch sequence (blockIdx.z)
 
 // One scan = one entropy-coded segment: either all components interleaved (blocks in MCU order,
 // encode_image_interleaved, encoder.rs:747-790) or one component's blocks in planar order

@@ -40,12 +40,19 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
                         hipError_t *err);
 
 // entropy_kernels.hip
-hipError_t launch_entropy_scan(const EntropyParams &p, int frames, hipStream_t stream);
+hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t stream);
 
 // capi_entropy.hip
 int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                 const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
                 size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st);
+struct ScanJob {                 // one scan of scan_device_multi
+    jpegenc_scan sc;
+    void *d_out; size_t out_frame_stride; uint32_t *d_out_lengths;
+    void *d_ws; size_t ws_bytes;
+};
+int scan_device_multi(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L, const ScanJob *jobs,
+                      int njobs, const void *d_lut, hipStream_t st);
 int upload_huffman_luts(const jpegenc_huffman_spec (*tables)[2], void *d_lut, hipStream_t st);
 size_t scan_workspace_size(const jpegenc_layout &L, const jpegenc_scan &sc, int frames);
 size_t scan_max_bytes(const jpegenc_layout &L, const jpegenc_scan &sc);
