@@ -593,6 +593,32 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams *params) {
     }
 }
 
+// ---- gathering the scans of a frame ----------------------------------------------------------------
+// dst: [kGatherHeader bytes: the length of every scan, u32][the scans' bytes back to back].  The host then
+// fetches header + a fixed first piece in ONE copy - for small files that is everything, no second round trip.
+__global__ void __launch_bounds__(256) k_gather_scans(const GatherArgs a, const uint8_t *src, const uint32_t *len, uint8_t *dst) {
+    const uint32_t job = blockIdx.x;
+    __shared__ uint32_t part[4];
+    uint32_t before = 0;
+    for (uint32_t i = threadIdx.x; i < job; i += 256u) before += len[i];
+    before = wave_sum(before);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = before;
+    __syncthreads();
+    const uint32_t start = part[0] + part[1] + part[2] + part[3];
+    const uint32_t n = len[job];
+    if (blockIdx.y == 0 && threadIdx.x == 0) reinterpret_cast<uint32_t *>(dst)[job] = n;
+    const uint32_t per = ((n + gridDim.y - 1) / gridDim.y + 15u) & ~15u;
+    const uint32_t lo = min(n, blockIdx.y * per), hi = min(n, lo + per);
+    const uint8_t *s = src + a.off[job];
+    uint8_t *d = dst + kGatherHeader + start;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u) d[i] = s[i];
+}
+
+hipError_t launch_gather_scans(const GatherArgs &a, const void *d_src, const uint32_t *d_len, void *d_dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_scans, dim3(a.n, 64), dim3(256), 0, st, a, (const uint8_t *)d_src, d_len, (uint8_t *)d_dst);
+    return hipGetLastError();
+}
+
 // ---- launcher ----------------------------------------------------------------------------------------
 static hipError_t scan(const EntropyParams *d_params, int which, uint32_t n_max, int njobs, int frames, hipStream_t st) {
     const uint32_t tiles = (n_max + kScanTile - 1) / kScanTile;

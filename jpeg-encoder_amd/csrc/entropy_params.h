@@ -10,6 +10,14 @@ namespace jpegenc {
 constexpr uint32_t kPackWindowWords = JPEGENC_PACK_WINDOW;      // words of LDS per wave of the bit packer
 constexpr uint32_t kMaxScansPerLaunch = 8;                       // scans coded by one launch sequence (blockIdx.z)
 
+// k_gather_scans: the coded scans of one frame, collected behind a header of their lengths
+constexpr uint32_t kGatherMaxScans = 256;
+constexpr uint32_t kGatherHeader = kGatherMaxScans * 4;
+struct GatherArgs {
+    uint32_t n, reserved;
+    uint64_t off[kGatherMaxScans];      // byte offset of each scan's output inside the source buffer
+};
+
 // One scan = one entropy-coded segment: either all components interleaved (blocks in MCU order,
 // encode_image_interleaved, encoder.rs:747-790) or one component's blocks in planar order
 // (sequential / progressive scans, encoder.rs:823-861, 885-972).

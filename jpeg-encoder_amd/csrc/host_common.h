@@ -42,6 +42,8 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
 // entropy_kernels.hip
 hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t stream);
 
+hipError_t launch_gather_scans(const GatherArgs &a, const void *d_src, const uint32_t *d_len, void *d_dst, hipStream_t stream);
+
 // capi_entropy.hip
 int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                 const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,

@@ -238,8 +238,9 @@ struct DeviceCtx {
     size_t h_pixels_cap = 0;
     uint32_t *h_freq = nullptr;
     // device entropy coding (interleaved scans): scratch, coded segment, its length
-    void *d_scan_ws = nullptr, *d_scan_out = nullptr;
-    size_t d_scan_ws_cap = 0, d_scan_out_cap = 0;
+    void *d_scan_ws = nullptr, *d_scan_out = nullptr, *d_gather = nullptr;       // d_gather: [lengths][all scans back to back]
+    size_t d_scan_ws_cap = 0, d_scan_out_cap = 0, d_gather_cap = 0;
+    static constexpr size_t kFirstPiece = 256 << 10;      // bytes of coded data fetched together with the lengths
     uint32_t *d_scan_len = nullptr, *h_scan_len = nullptr;     // kMaxScans entries
     void *d_lut = nullptr;
     static constexpr int kMaxScans = 4 * 64;
@@ -288,14 +289,24 @@ struct DeviceCtx {
             JPEGENC_HIP(hipMalloc(&d_scan_out, out_bytes));
             d_scan_out_cap = out_bytes;
         }
-        return JPEGENC_OK;
+        if (kGatherHeader + out_bytes > d_gather_cap) {
+            if (d_gather) (void)hipFree(d_gather);
+            d_gather = nullptr; d_gather_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_gather, kGatherHeader + out_bytes));
+            d_gather_cap = kGatherHeader + out_bytes;
+        }
+        return reserve_scan_host(kGatherHeader + kFirstPiece);
     }
-    int reserve_scan_host(size_t bytes) {
+    int reserve_scan_host(size_t bytes, size_t keep = 0) {     // keep: leading bytes that must survive a growth
         if (bytes > h_scan_out_cap) {
-            if (h_scan_out) (void)hipHostFree(h_scan_out);
-            h_scan_out = nullptr; h_scan_out_cap = 0;
             const size_t cap = bytes + bytes / 2 + (1u << 20);
-            JPEGENC_HIP(hipHostMalloc((void **)&h_scan_out, cap, hipHostMallocDefault));
+            uint8_t *bigger = nullptr;
+            JPEGENC_HIP(hipHostMalloc((void **)&bigger, cap, hipHostMallocDefault));
+            if (h_scan_out) {
+                if (keep) memcpy(bigger, h_scan_out, keep < h_scan_out_cap ? keep : h_scan_out_cap);
+                (void)hipHostFree(h_scan_out);
+            }
+            h_scan_out = bigger;
             h_scan_out_cap = cap;
         }
         return JPEGENC_OK;
@@ -336,6 +347,7 @@ struct DeviceCtx {
         if (h_freq) (void)hipHostFree(h_freq);
         if (d_scan_ws) (void)hipFree(d_scan_ws);
         if (d_scan_out) (void)hipFree(d_scan_out);
+        if (d_gather) (void)hipFree(d_gather);
         if (d_scan_len) (void)hipFree(d_scan_len);
         if (d_lut) (void)hipFree(d_lut);
         if (h_scan_len) (void)hipHostFree(h_scan_len);
@@ -649,6 +661,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap, ws_off, ws; };
     std::vector<Job> jobs;
     bool supported = false;
+    size_t first_piece = 0;             // coded bytes fetched in the same copy as the scan lengths
     bool together = false;              // the frame's scans share launches (scan_device_multi), each with its own workspace
     if (c.device_entropy) {
         auto add = [&](int comp, int with_dc, int s0, int s1, int first, int n, int ss, int se) {
@@ -684,6 +697,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             ws_sum += (w + 255) & ~(size_t)255;
             if (w > ws) ws = w;
         }
+        first_piece = out_total < DeviceCtx::kFirstPiece ? out_total : DeviceCtx::kFirstPiece;
         if (supported) {
             // The scans of a sequential / progressive frame are independent: coded in shared launches they cost
             // ~10 launches per 8 scans instead of ~10 per scan (a 4K progressive frame: 12 scans; such frames were
@@ -706,7 +720,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1) {
         std::string key;
         auto put = [&](const void *v, size_t n) { key.append((const char *)v, n); };
-        const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, ctx.h_scan_len};
+        const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, ctx.d_gather, ctx.h_scan_out};
         const int64_t vals[] = {width, height, color_type_or_planes, (int64_t)pixel_bytes, order, c.fdct_variant, c.sampling,
                                 c.progressive_scans, c.restart_interval, (int64_t)ctx.d_scan_ws_cap, (int64_t)jobs.size()};
         put(ptrs, sizeof ptrs); put(vals, sizeof vals); put(t.q, sizeof t.q);
@@ -770,7 +784,12 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                         if (rc) return rc;
                     }
                 }
-                JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_len, ctx.d_scan_len, sizeof(uint32_t) * jobs.size(), hipMemcpyDeviceToHost, ctx.stream));
+                GatherArgs ga;
+                ga.n = (uint32_t)jobs.size(); ga.reserved = 0;
+                for (size_t k = 0; k < jobs.size(); k++) ga.off[k] = jobs[k].off;
+                const hipError_t ge = launch_gather_scans(ga, ctx.d_scan_out, ctx.d_scan_len, ctx.d_gather, ctx.stream);
+                if (ge != hipSuccess) return hip_fail(ge, "gather kernel launch");
+                JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out, ctx.d_gather, kGatherHeader + first_piece, hipMemcpyDeviceToHost, ctx.stream));
             }
             if (how == CAPTURE) {
                 hipGraph_t g = nullptr;
@@ -787,28 +806,27 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
             const auto t_len = now();
             size_t nbytes = 0;
-            for (size_t k = 0; k < jobs.size(); k++) nbytes += ctx.h_scan_len[k];
-            rc = ctx.reserve_scan_host(nbytes);
-            if (rc) return rc;
-            size_t at = 0;
-            for (size_t k = 0; k < jobs.size(); k++) {
-                const size_t n = ctx.h_scan_len[k];
-                if (n) JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out + at, (const uint8_t *)ctx.d_scan_out + jobs[k].off, n, hipMemcpyDeviceToHost, ctx.stream));
-                at += n;
+            uint32_t scan_len[DeviceCtx::kMaxScans];                            // (the header may move if the buffer grows)
+            for (size_t k = 0; k < jobs.size(); k++) { scan_len[k] = reinterpret_cast<const uint32_t *>(ctx.h_scan_out)[k]; nbytes += scan_len[k]; }
+            if (nbytes > first_piece) {                                         // the rest of a large file
+                rc = ctx.reserve_scan_host(kGatherHeader + nbytes, kGatherHeader + first_piece);
+                if (rc) return rc;
+                JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out + kGatherHeader + first_piece, (const uint8_t *)ctx.d_gather + kGatherHeader + first_piece,
+                                           nbytes - first_piece, hipMemcpyDeviceToHost, ctx.stream));
             }
+            size_t at = kGatherHeader;
             Out o;
             o.sink = sink; o.user = user;
             write_prologue(o, c, jct);
             write_frame_header(o, c, width, height, L, t);          // after the tables are final (:821, :881)
             JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
             const auto t_copied = now();
-            at = 0;
             for (size_t k = 0; k < jobs.size(); k++) {
                 const Job &j = jobs[k];
                 write_scan_header(o, L, j.first, j.n, j.ss, j.se);
                 if (j.cap) {
-                    o.bytes(ctx.h_scan_out + at, ctx.h_scan_len[k]);
-                    at += ctx.h_scan_len[k];
+                    o.bytes(ctx.h_scan_out + at, scan_len[k]);
+                    at += scan_len[k];
                 } else if (c.restart_interval) {
                     // empty band (progressive with > 33 scans, encoder.rs:927-944): no bits at all, but the
                     // restart bookkeeping still emits its markers (encoder.rs:947-951)
