@@ -159,14 +159,14 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
         for (int c = 0; c < L.num_components; c++) {
             const uint32_t hv = (uint32_t)(L.h[c] * L.v[c]);
             for (uint32_t k = 0; k < hv; k++, pos++) {
-                p.pos_table[pos] = (uint32_t)L.table[c];
-                p.pos_prev_delta[pos] = k > 0 ? 1u : 0u;
-                p.pos_last_of_comp[pos] = pos - k + hv - 1;
+                p.pos_table[pos] = (uint8_t)L.table[c];
+                p.pos_prev_delta[pos] = k > 0 ? 1 : 0;
+                p.pos_last_of_comp[pos] = (uint8_t)(pos - k + hv - 1);
             }
         }
     } else {
         p.bpm = 1;
-        p.pos_table[0] = (uint32_t)L.table[sc.component];
+        p.pos_table[0] = (uint8_t)L.table[sc.component];
         for (int c = 0; c < sc.component; c++) first_block += L.blocks[c];
     }
     p.coeffs = (const int16_t *)d_coeffs + first_block * 64;

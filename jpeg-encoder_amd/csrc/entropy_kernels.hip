@@ -42,11 +42,12 @@ constexpr int kScanTile = 4096;      // elements per workgroup in the scans (256
 typedef const __attribute__((address_space(4))) EntropyParams &Params;
 #define JPEGENC_JOB(params) (*(const __attribute__((address_space(4))) EntropyParams *)((params) + blockIdx.z))
 
+constexpr uint32_t kScansPerStore = (4096 - 16) / sizeof(EntropyParams);     // kernel arguments are limited to 4 KiB
 struct ParamPack {
     uint32_t n;
-    EntropyParams p[kMaxScansPerLaunch];
+    EntropyParams p[kScansPerStore];
 };
-static_assert(sizeof(ParamPack) <= 4096, "kernel arguments are limited to 4 KiB");
+static_assert(sizeof(ParamPack) <= 4096 && kScansPerStore >= 8, "parameter blocks per store launch");
 
 __global__ void __launch_bounds__(256) k_store_params(const ParamPack pack, EntropyParams *dst) {
     const uint32_t words = pack.n * (uint32_t)(sizeof(EntropyParams) / 4);
@@ -637,15 +638,17 @@ static hipError_t scan(const EntropyParams *d_params, int which, uint32_t n_max,
 // for njobs parameter blocks in device memory
 hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t st) {
     if (njobs < 1 || njobs > (int)kMaxScansPerLaunch) return hipErrorInvalidValue;
-    ParamPack pack;
-    pack.n = (uint32_t)njobs;
     uint32_t nblocks = 0, nwaves = 0, nintervals = 0, fftiles = 0;
     for (int j = 0; j < njobs; j++) {
-        pack.p[j] = jobs[j];
         nblocks = max(nblocks, jobs[j].nblocks); nwaves = max(nwaves, jobs[j].nwaves);
         nintervals = max(nintervals, jobs[j].nintervals); fftiles = max(fftiles, jobs[j].max_fftiles);
     }
-    hipLaunchKernelGGL(k_store_params, dim3(1), dim3(256), 0, st, pack, d_params);
+    for (int first = 0; first < njobs; first += (int)kScansPerStore) {
+        ParamPack pack;
+        pack.n = (uint32_t)min(njobs - first, (int)kScansPerStore);
+        for (uint32_t j = 0; j < pack.n; j++) pack.p[j] = jobs[first + j];
+        hipLaunchKernelGGL(k_store_params, dim3(1), dim3(256), 0, st, pack, d_params + first);
+    }
     hipError_t e = hipSuccess;
     const uint32_t bgrid = (nblocks + 255u) / 256u;
     hipLaunchKernelGGL(k_block_bits, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);

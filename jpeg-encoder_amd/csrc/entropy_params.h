@@ -8,7 +8,7 @@ namespace jpegenc {
 #define JPEGENC_PACK_WINDOW 2048
 #endif
 constexpr uint32_t kPackWindowWords = JPEGENC_PACK_WINDOW;      // words of LDS per wave of the bit packer
-constexpr uint32_t kMaxScansPerLaunch = 8;                       // scans coded by one launch sequence (blockIdx.z)
+constexpr uint32_t kMaxScansPerLaunch = 16;                      // scans coded by one launch sequence (blockIdx.z)
 
 // k_gather_scans: the coded scans of one frame, collected behind a header of their lengths
 constexpr uint32_t kGatherMaxScans = 256;
@@ -30,9 +30,9 @@ struct EntropyParams {
     uint32_t ac_start, ac_end;       // zig-zag band [ac_start, ac_end), ac_start >= 1; empty = no AC
     uint32_t interval_blocks;        // restart interval in blocks (R * bpm), = nblocks when there is none
     uint32_t nintervals;
-    uint32_t pos_table[10];          // Huffman table destination of each block position in the MCU
-    uint32_t pos_prev_delta[10];     // 1 when the previous block of the MCU has the same component
-    uint32_t pos_last_of_comp[10];   // position of the component's last block inside an MCU
+    uint8_t pos_table[12];           // Huffman table destination of each block position in the MCU (<= 10 positions)
+    uint8_t pos_prev_delta[12];      // 1 when the previous block of the MCU has the same component
+    uint8_t pos_last_of_comp[12];    // position of the component's last block inside an MCU
     // Huffman code tables: [destination][0 = DC, 1 = AC][symbol] = size << 16 | code
     const uint32_t *lut;
     // workspace (device), per frame
