@@ -69,8 +69,9 @@ struct ScanArgs {
 };
 __device__ __forceinline__ ScanArgs scan_args(Params p, int which) {
     if (which == SCAN_WAVES) return {p.wsum, p.nwaves, p.woff, p.nwaves, p.partials, p.max_tiles, p.total_bits, nullptr, p.nwaves};
-    if (which == SCAN_ILEN) return {p.ilen, p.nintervals, p.iexact, p.nintervals, p.partials, p.max_tiles, p.raw_bytes, nullptr, p.nintervals};
-    if (which == SCAN_ICHUNKS) return {p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, p.nintervals};
+    const uint32_t ni = p.nintervals == 1 ? 0u : p.nintervals;      // a single interval needs no scan (k_wave_edges fills it in)
+    if (which == SCAN_ILEN) return {p.ilen, p.nintervals, p.iexact, p.nintervals, p.partials, p.max_tiles, p.raw_bytes, nullptr, ni};
+    if (which == SCAN_ICHUNKS) return {p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, ni};
     return {p.fftile, p.max_fftiles, p.fftile_off, p.max_fftiles, p.partials, p.max_tiles, p.total_ff, p.nfftiles, p.max_fftiles};
 }
 #define JPEGENC_SCAN_ARGS                                                                                     \
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams *params)
 __global__ void __launch_bounds__(256) k_interval_len(const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
     const uint32_t f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.nintervals) return;
+    if (i >= p.nintervals || p.nintervals == 1) return;         // a single interval is k_wave_edges' business
     const uint32_t first = i * p.interval_blocks, end = min(first + p.interval_blocks, p.nblocks);
     const uint32_t at = block_bit_offset(p, f, first);
     const uint32_t bits = (end == p.nblocks ? p.total_bits[f] : block_bit_offset(p, f, end)) - at;
@@ -459,10 +460,6 @@ __global__ void __launch_bounds__(256) k_interval_len(const EntropyParams *param
     p.ivbit[(size_t)f * p.nintervals + i] = at;
     p.ilen[(size_t)f * p.nintervals + i] = bytes;
     p.ichunks[(size_t)f * p.nintervals + i] = (bytes + 15u) >> 4;
-    if (p.nintervals == 1) {                       // no restart markers: the two interval scans are trivial
-        p.iexact[f] = 0; p.ichunk[f] = 0;
-        p.raw_bytes[f] = bytes; p.raw_chunks[f] = (bytes + 15u) >> 4;
-    }
 }
 
 // The raw buffer is not cleared as a whole (its used size is data dependent and the clear cost as much as
@@ -473,17 +470,32 @@ __global__ void __launch_bounds__(256) k_wave_edges(const EntropyParams *params)
     Params p = JPEGENC_JOB(params);
     const uint32_t f = blockIdx.y, w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= p.nwaves) return;
-    if (w == 0) { p.nfftiles[f] = (p.raw_chunks[f] + 255u) >> 8; p.out_bytes[f] = 0; }      // k_stuff sets the length
+    const bool single = p.nintervals == 1;       // no restart markers: the interval bookkeeping is trivial and done here
+    if (w == 0) {
+        uint32_t chunks;
+        if (single) {
+            const uint32_t bytes = (p.total_bits[f] + 7u) >> 3;
+            chunks = (bytes + 15u) >> 4;
+            p.ivbit[f] = 0; p.ilen[f] = bytes; p.ichunks[f] = chunks; p.iexact[f] = 0; p.ichunk[f] = 0;
+            p.raw_bytes[f] = bytes; p.raw_chunks[f] = chunks;
+        } else {
+            chunks = p.raw_chunks[f];
+        }
+        p.nfftiles[f] = (chunks + 255u) >> 8;
+        p.out_bytes[f] = 0;                      // k_stuff sets the length
+    }
     uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
     const uint32_t *woff = p.woff + (size_t)f * p.nwaves;
     const uint32_t *ivbit = p.ivbit + (size_t)f * p.nintervals, *ichunk = p.ichunk + (size_t)f * p.nintervals;
     const uint32_t b0 = w * 64u, b1 = min(b0 + 63u, p.nblocks - 1u);
     const uint32_t iv0 = b0 / p.interval_blocks, iv1 = b1 / p.interval_blocks;
-    stream[ichunk[iv0] * 4u + ((woff[w] - ivbit[iv0]) >> 5)] = 0;
-    uint32_t end = (w + 1u < p.nwaves ? woff[w + 1u] : p.total_bits[f]) - ivbit[iv1];      // bits of interval iv1 up to and including b1
+    const uint32_t bit0 = single ? 0u : ivbit[iv0], chunk0 = single ? 0u : ichunk[iv0];
+    const uint32_t bit1 = single ? 0u : ivbit[iv1], chunk1 = single ? 0u : ichunk[iv1];
+    stream[chunk0 * 4u + ((woff[w] - bit0) >> 5)] = 0;
+    uint32_t end = (w + 1u < p.nwaves ? woff[w + 1u] : p.total_bits[f]) - bit1;            // bits of interval iv1 up to and including b1
     const bool closes = b1 == min((iv1 + 1u) * p.interval_blocks, p.nblocks) - 1u;
     if (closes) end += (8u - (end & 7u)) & 7u;
-    uint32_t last = ichunk[iv1] * 4u + ((end ? end - 1u : 0u) >> 5);
+    uint32_t last = chunk1 * 4u + ((end ? end - 1u : 0u) >> 5);
     if (closes) last |= 3u;
     stream[last] = 0;
 }
@@ -654,8 +666,8 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
     hipLaunchKernelGGL(k_block_bits, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
     e = scan(d_params, SCAN_WAVES, nwaves, njobs, frames, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_interval_len, dim3((nintervals + 255u) / 256u, frames, njobs), dim3(256), 0, st, d_params);
-    if (nintervals > 1) {      // (a scan with a single interval already has its trivial results; scanning them again is harmless)
+    if (nintervals > 1) {      // (scans with a single interval: k_wave_edges writes their trivial results after these)
+        hipLaunchKernelGGL(k_interval_len, dim3((nintervals + 255u) / 256u, frames, njobs), dim3(256), 0, st, d_params);
         e = scan(d_params, SCAN_ILEN, nintervals, njobs, frames, st);
         if (e != hipSuccess) return e;
         e = scan(d_params, SCAN_ICHUNKS, nintervals, njobs, frames, st);

@@ -243,6 +243,7 @@ struct DeviceCtx {
     static constexpr size_t kFirstPiece = 256 << 10;      // bytes of coded data fetched together with the lengths
     uint32_t *d_scan_len = nullptr, *h_scan_len = nullptr;     // kMaxScans entries
     void *d_lut = nullptr;
+    std::string lut_key;               // the Huffman tables d_lut was built from (uploads of unchanged tables are skipped)
     static constexpr int kMaxScans = 4 * 64;
     uint8_t *h_scan_out = nullptr;
     size_t h_scan_out_cap = 0;
@@ -728,6 +729,27 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         else if (key == ctx.last_key) how = CAPTURE;
         ctx.last_key.swap(key);
     }
+    // The device code tables are rebuilt only when the Huffman tables differ from the ones they were built from
+    // (never, for a caller that keeps encoding with the default tables).  Fixed tables: before any capture, so
+    // that a replayed sequence can rely on them; optimised tables: after the histogram, below.
+    auto ensure_lut = [&]() -> int {
+        jpegenc_huffman_spec specs[2][2];
+        for (int d = 0; d < 2; d++)
+            for (int k = 0; k < 2; k++) {
+                memset(&specs[d][k], 0, sizeof specs[d][k]);
+                memcpy(specs[d][k].bits, t.h[d][k].bits, 16);
+                memcpy(specs[d][k].values, t.h[d][k].vals, (size_t)t.h[d][k].nvals);
+                specs[d][k].num_values = t.h[d][k].nvals;
+            }
+        std::string key((const char *)specs, sizeof specs);
+        if (key == ctx.lut_key) return JPEGENC_OK;
+        ctx.lut_key.clear();
+        const int r = upload_huffman_luts(specs, ctx.d_lut, ctx.stream);
+        if (r) return r;
+        ctx.lut_key.swap(key);
+        return JPEGENC_OK;
+    };
+    if (c.device_entropy && supported && !optimize) { rc = ensure_lut(); if (rc) return rc; }
     if (how == CAPTURE) JPEGENC_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
     struct CaptureGuard {            // a failure between begin and end must not leave the stream capturing
         hipStream_t st; bool active;
@@ -753,18 +775,11 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                 for (int d = 0; d < max_tables; d++)
                     for (int k = 0; k < 2; k++) t.h[d][k].assign_optimized(ctx.h_freq + (d * 2 + k) * 257);
             }
+            if (optimize) { rc = ensure_lut(); if (rc) return rc; }
             if (enqueue) {
-                jpegenc_huffman_spec specs[2][2];
-                for (int d = 0; d < 2; d++)
-                    for (int k = 0; k < 2; k++) {
-                        memset(&specs[d][k], 0, sizeof specs[d][k]);
-                        memcpy(specs[d][k].bits, t.h[d][k].bits, 16);
-                        memcpy(specs[d][k].values, t.h[d][k].vals, (size_t)t.h[d][k].nvals);
-                        specs[d][k].num_values = t.h[d][k].nvals;
-                    }
-                rc = upload_huffman_luts(specs, ctx.d_lut, ctx.stream);
-                if (rc) return rc;
-                JPEGENC_HIP(hipMemsetAsync(ctx.d_scan_len, 0, sizeof(uint32_t) * jobs.size(), ctx.stream));
+                bool empty_scans = false;                    // (the coder zeroes the length of every scan it codes)
+                for (const Job &j : jobs) empty_scans = empty_scans || !j.cap;
+                if (empty_scans) JPEGENC_HIP(hipMemsetAsync(ctx.d_scan_len, 0, sizeof(uint32_t) * jobs.size(), ctx.stream));
                 if (together) {
                     std::vector<ScanJob> batch;
                     for (size_t k = 0; k < jobs.size(); k++) {
@@ -775,6 +790,11 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                     }
                     rc = scan_device_multi(ctx.d_coeffs, L.total_blocks, 1, L, batch.data(), (int)batch.size(), ctx.d_lut, ctx.stream);
                     if (rc) return rc;
+                } else if (jobs.size() == 1 && jobs[0].cap) {
+                    // a single scan (every baseline frame) is coded straight into the gathered layout: [length][bytes]
+                    rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, nullptr, ctx.d_lut, (uint8_t *)ctx.d_gather + kGatherHeader,
+                                     jobs[0].cap, (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream);
+                    if (rc) return rc;
                 } else {
                     for (size_t k = 0; k < jobs.size(); k++) {
                         Job &j = jobs[k];
@@ -784,11 +804,13 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                         if (rc) return rc;
                     }
                 }
-                GatherArgs ga;
-                ga.n = (uint32_t)jobs.size(); ga.reserved = 0;
-                for (size_t k = 0; k < jobs.size(); k++) ga.off[k] = jobs[k].off;
-                const hipError_t ge = launch_gather_scans(ga, ctx.d_scan_out, ctx.d_scan_len, ctx.d_gather, ctx.stream);
-                if (ge != hipSuccess) return hip_fail(ge, "gather kernel launch");
+                if (!(jobs.size() == 1 && jobs[0].cap)) {
+                    GatherArgs ga;
+                    ga.n = (uint32_t)jobs.size(); ga.reserved = 0;
+                    for (size_t k = 0; k < jobs.size(); k++) ga.off[k] = jobs[k].off;
+                    const hipError_t ge = launch_gather_scans(ga, ctx.d_scan_out, ctx.d_scan_len, ctx.d_gather, ctx.stream);
+                    if (ge != hipSuccess) return hip_fail(ge, "gather kernel launch");
+                }
                 JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out, ctx.d_gather, kGatherHeader + first_piece, hipMemcpyDeviceToHost, ctx.stream));
             }
             if (how == CAPTURE) {
@@ -1016,6 +1038,7 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
             memcpy(specs[d][k].values, t.h[d][k].vals, (size_t)t.h[d][k].nvals);
             specs[d][k].num_values = t.h[d][k].nvals;
         }
+    ctx.lut_key.clear();                 // (encode_frame's record of what d_lut holds)
     rc = upload_huffman_luts(specs, ctx.d_lut, ctx.stream);
     if (rc) return rc;
 
