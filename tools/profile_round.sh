@@ -16,14 +16,14 @@ PMC_BENCH="bench.py --steps 20 --warmup 5 --settle-ms 0 --cpu-seconds 0.2 --head
 python3 tools/step_series.py 400 > "$out/${tag}_step_series.txt" 2>/dev/null
 python3 bench.py > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- python3 $BENCH \
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -- python3 $BENCH \
     > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err"
 
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_fetch" -- python3 $PMC_BENCH > /dev/null 2> "$out/${tag}_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_write" -- python3 $PMC_BENCH > /dev/null 2> "$out/${tag}_write.err"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_fetch" -- python3 $PMC_BENCH > /dev/null 2> "$out/${tag}_fetch.err"
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_write" -- python3 $PMC_BENCH > /dev/null 2> "$out/${tag}_write.err"
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY \
     --output-format csv -d "$out/${tag}_sq" -- python3 $PMC_BENCH > /dev/null 2> "$out/${tag}_sq.err"
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA \
+timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA \
     --output-format csv -d "$out/${tag}_sq2" -- python3 $PMC_BENCH > /dev/null 2> "$out/${tag}_sq2.err"
 
 # keep only the small summaries (the per-dispatch traces are large)
