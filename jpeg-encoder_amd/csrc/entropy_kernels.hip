@@ -24,6 +24,7 @@
 // component in MCU order, read straight from the coefficient array.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "entropy_params.h"
 #include "host_common.h"
@@ -635,9 +636,13 @@ hipError_t launch_gather_scans(const GatherArgs &a, const void *d_src, const uin
 // ---- launcher ----------------------------------------------------------------------------------------
 static hipError_t scan(const EntropyParams *d_params, int which, uint32_t n_max, int njobs, int frames, hipStream_t st) {
     const uint32_t tiles = (n_max + kScanTile - 1) / kScanTile;
-    if (tiles > 1)         // a single tile has no tiles before it: the fused kernel alone is the scan
-        hipLaunchKernelGGL(k_scan_reduce, dim3(tiles, frames, njobs), dim3(256), 0, st, d_params, which);
-    if (tiles <= 2048) {       // every workgroup can afford to add up the tile sums before its own
+    // up to this many tiles every workgroup can afford to add up the tile sums before its own (tests lower it
+    // to reach the three-kernel form, which real scans need only beyond 8.4 M elements)
+    static const uint32_t fused_max = [] { const char *e = getenv("JPEGENC_SCAN_FUSED_MAX_TILES"); return e ? (uint32_t)atol(e) : 2048u; }();
+    const bool fused = tiles <= fused_max;
+    if (tiles > 1 || !fused)   // a single tile has no tiles before it: the fused kernel alone is the scan
+        hipLaunchKernelGGL(k_scan_reduce, dim3(tiles ? tiles : 1, frames, njobs), dim3(256), 0, st, d_params, which);
+    if (fused) {
         hipLaunchKernelGGL(k_scan_apply_fused, dim3(tiles ? tiles : 1, frames, njobs), dim3(256), 0, st, d_params, which);
         return hipGetLastError();
     }

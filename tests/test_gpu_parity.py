@@ -901,6 +901,9 @@ def test_scans_coded_together_and_one_by_one_agree(binding, oracle, synth):
         "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cases)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JPEGENC_SCANS_ONE_BY_ONE="1"), capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    # the three-kernel form of the prefix sums (real scans need it only beyond 8.4 M elements)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JPEGENC_SCAN_FUSED_MAX_TILES="0"), capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("kw", [dict(quality=90), dict(quality=77, sampling=(2, 2), restart_interval=9),
