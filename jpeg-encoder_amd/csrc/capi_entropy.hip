@@ -38,9 +38,9 @@ __global__ void __launch_bounds__(1024) k_build_lut(const LutSpecs specs, uint32
 }
 
 struct ScanPlan {
-    uint32_t max_blocks, max_chunks, max_tiles, max_waves, max_fftiles;
+    uint32_t max_blocks, max_chunks, max_tiles, max_waves, max_fftiles, slot_words;
     uint64_t raw_stride;
-    size_t off_params, off_lut, off_bits, off_wsum, off_woff, off_partials, off_scalars, off_intervals, off_raw, off_fftile, off_fftile_off, total;
+    size_t off_params, off_lut, off_bits, off_wsum, off_woff, off_partials, off_scalars, off_intervals, off_slots, off_raw, off_fftile, off_fftile_off, total;
 };
 
 // Worst-case code bytes of one block of a scan: DC <= 16 + 11 bits, each AC coefficient <= 16 + 11,
@@ -87,6 +87,9 @@ static void plan_scan(uint64_t max_blocks, uint64_t bound, int frames, ScanPlan 
     pl->off_partials = take(F * pl->max_tiles * 4);
     pl->off_scalars = take(F * 5 * 4);
     pl->off_intervals = take(F * (size_t)pl->max_blocks * 5 * 4);
+    pl->slot_words = (uint32_t)((64 * bound + 3) / 4 + 4);                  // 64 worst-case blocks + the zero word, 16-byte multiple
+    pl->slot_words = (pl->slot_words + 3u) & ~3u;
+    pl->off_slots = take(F * (size_t)pl->max_waves * pl->slot_words * 4);
     pl->off_raw = take(F * pl->raw_stride);
     pl->off_fftile = take(F * (size_t)pl->max_fftiles * 4);
     pl->off_fftile_off = take(F * (size_t)pl->max_fftiles * 4);
@@ -199,6 +202,9 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
     uint32_t *iv = (uint32_t *)(ws + pl.off_intervals);
     const size_t ivn = (size_t)frames * p.nintervals;
     p.ilen = iv; p.ichunks = iv + ivn; p.iexact = iv + 2 * ivn; p.ichunk = iv + 3 * ivn; p.ivbit = iv + 4 * ivn;
+    p.slots = ws + pl.off_slots;
+    p.slot_words = pl.slot_words;
+    p.slot_frame_stride = (uint64_t)pl.max_waves * pl.slot_words * 4;
     p.raw = ws + pl.off_raw;
     p.raw_stride = pl.raw_stride;
     p.max_chunks = pl.max_chunks;

@@ -6,22 +6,27 @@
 // progressive (spectral selection) mode, with or without restart intervals, any Huffman tables.
 //
 // Variable-length coding is serial in the reference; here it is data-parallel steps:
-//   1. k_block_bits     one lane per block: exact bit length of the block's code (DC category + Huffman
-//                       codes of every (run,size) symbol, ZRLs, EOB) + the sum over the wave's 64 blocks
-//   2. scan             exclusive prefix sum of the WAVE sums (1/64th of the blocks) -> bit offset of every
-//                       wave's run; a block's own offset is that + a 64-lane prefix inside k_block_pack
+//   1. k_block_code     one lane per block, the coefficients read ONCE: the lane walks its symbols twice over
+//                       registers - first for the exact bit length of its block (DC category + Huffman codes
+//                       of every (run,size) symbol, ZRLs, EOB), then, after a 64-lane prefix sum, to pack the
+//                       bits at the block's offset inside the wave's run (64-bit accumulator, words OR-ed
+//                       into a zeroed LDS window).  The run goes to the wave's own slot of a scratch buffer,
+//                       its length to wsum: nothing here depends on any other wave.
+//   2. scan             exclusive prefix sum of the wave lengths -> bit offset of every wave's run
 //   3. k_interval_len   bit offset and byte length (1-padded to a byte) of every restart interval; two
 //                       more scans give each interval a 16-byte aligned place in the raw buffer
-//   4. k_wave_edges     zeroes the first and last word of every wave's run (the only words two waves share)
-//   5. k_block_pack     one lane per block re-walks its coefficients into a zeroed LDS window of the
-//                       wave's run (64-bit accumulator, words OR-ed in), window copied out coalesced,
-//                       the two shared words as atomic ORs; the last block of an interval adds the
-//                       1-padding of finalize_bit_buffer and zero-fills the interval's last 16-byte chunk
-//   6. k_ff_tiles+scan  0xFF bytes per tile of 256 16-byte chunks and their prefix sum (per-chunk counts
-//                       are recomputed inside k_stuff from the data it loads anyway)
-//   7. k_stuff          scatter with 0xFF -> 0xFF 0x00 stuffing, RSTn markers between intervals
-// DC prediction needs no scan: the predecessor of a block is a fixed earlier block of the same
-// component in MCU order, read straight from the coefficient array.
+//                       (scans without restart markers skip this: their one interval is trivial)
+//   4. k_push           (scans without restart markers) every run shifts itself into place in the raw stream:
+//                       linear reads, linear writes, the last word completed from the following run
+//      + k_ff_tiles     0xFF bytes per tile of 256 16-byte chunks
+//      k_place          (scans with restart markers) one thread per 16-byte chunk of the raw stream: finds the
+//                       run(s) its bits come from, funnel-shifts them into place, adds the 1-padding of
+//                       finalize_bit_buffer at the end of each interval; counts the 0xFF bytes per tile itself
+//   5. scan             prefix sum of the tile counts
+//   6. k_stuff          scatter with 0xFF -> 0xFF 0x00 stuffing (per-chunk counts recomputed from the data
+//                       it loads anyway), RSTn markers between intervals
+// No atomics on HBM, no buffer clears, every byte written once.  DC prediction needs no scan: the predecessor
+// of a block is a fixed earlier block of the same component in MCU order, read from the coefficient array.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -70,7 +75,7 @@ struct ScanArgs {
 };
 __device__ __forceinline__ ScanArgs scan_args(Params p, int which) {
     if (which == SCAN_WAVES) return {p.wsum, p.nwaves, p.woff, p.nwaves, p.partials, p.max_tiles, p.total_bits, nullptr, p.nwaves};
-    const uint32_t ni = p.nintervals == 1 ? 0u : p.nintervals;      // a single interval needs no scan (k_wave_edges fills it in)
+    const uint32_t ni = p.nintervals == 1 ? 0u : p.nintervals;      // a single interval needs no scan (k_place fills it in)
     if (which == SCAN_ILEN) return {p.ilen, p.nintervals, p.iexact, p.nintervals, p.partials, p.max_tiles, p.raw_bytes, nullptr, ni};
     if (which == SCAN_ICHUNKS) return {p.ichunks, p.nintervals, p.ichunk, p.nintervals, p.partials, p.max_tiles, p.raw_chunks, nullptr, ni};
     return {p.fftile, p.max_fftiles, p.fftile_off, p.max_fftiles, p.partials, p.max_tiles, p.total_ff, p.nfftiles, p.max_fftiles};
@@ -256,6 +261,7 @@ __device__ __forceinline__ uint32_t block_bit_offset(Params p, uint32_t f, uint3
 typedef __attribute__((address_space(3))) uint32_t lds_word;
 typedef __attribute__((address_space(1))) uint32_t hbm_word;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte load from a 4-byte aligned address
 typedef __attribute__((address_space(1))) const u32x4 hbm_chunk;
 
 struct CountSink {
@@ -299,19 +305,24 @@ struct PackSink {
 // All eight 16-byte pieces of the block are requested up front (the lane's 128-byte line is fetched once and
 // the other seven loads hit L1 while it is hot; walking piece by piece with the next one in flight re-missed
 // the line for every piece: 52 vs 39 us per 4K frame), so the walk is fully unrolled over registers.
-template <bool BASELINE, class Sink>
-__device__ __forceinline__ void walk_block(Params p, const uint32_t *lut, const int16_t *frame_coeffs,
-                                           uint32_t b, Sink &s) {
-    const uint32_t mcu = b / p.bpm, pos = b - mcu * p.bpm;
-    const uint32_t table = p.pos_table[pos];
-    const uint32_t *dc_lut = lut + table * 512, *ac_lut = dc_lut + 256;
+struct BlockRegs { uint32_t c[32]; };      // the 64 coefficients of a lane's block
+
+__device__ __forceinline__ void load_block(const int16_t *frame_coeffs, uint32_t b, BlockRegs &r) {
     hbm_chunk *src = (hbm_chunk *)(frame_coeffs + (size_t)b * 64);
-    uint32_t c[32];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const u32x4 u = src[i];
-        c[4 * i] = u.x; c[4 * i + 1] = u.y; c[4 * i + 2] = u.z; c[4 * i + 3] = u.w;
+        r.c[4 * i] = u.x; r.c[4 * i + 1] = u.y; r.c[4 * i + 2] = u.z; r.c[4 * i + 3] = u.w;
     }
+}
+
+template <bool BASELINE, class Sink>
+__device__ __forceinline__ void walk_block(Params p, const uint32_t *lut, const int16_t *frame_coeffs,
+                                           uint32_t b, const BlockRegs &r, Sink &s) {
+    const uint32_t mcu = b / p.bpm, pos = b - mcu * p.bpm;
+    const uint32_t table = p.pos_table[pos];
+    const uint32_t *dc_lut = lut + table * 512, *ac_lut = dc_lut + 256;
+    const uint32_t *c = r.c;
     if (BASELINE || p.with_dc) {
         // DC: predecessor = previous block of the same component (write_dc, writer.rs:342-354;
         // predictors reset at the start of the scan and at restart boundaries, encoder.rs:748-757)
@@ -361,91 +372,64 @@ __device__ __forceinline__ void load_lut(Params p, uint32_t *lut) {
 
 __device__ __forceinline__ bool baseline_band(Params p) { return p.with_dc && p.ac_start == 1 && p.ac_end == 64; }
 
-__global__ void __launch_bounds__(256) k_block_bits(const EntropyParams *params) {
+// One pass over the coefficients.  A wave's 64 blocks form one run of bits; the wave builds it in a private,
+// zeroed LDS window (every lane ORs its words in) and copies it to the wave's slot of the scratch buffer with
+// coalesced stores, followed by one zero word (k_place reads a word past the end of a run when it shifts).
+// Runs longer than the window (pathological content; JPEGENC_PACK_WINDOW_WORDS forces it in tests) are
+// OR-ed straight into the zeroed slot by the same walk.
+__global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
     __shared__ uint32_t lut[4 * 256];
-    load_lut(p, lut);
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    CountSink s = {0};
-    if (b < p.nblocks) {
-        const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
-        if (baseline_band(p)) walk_block<true>(p, lut, frame, b, s); else walk_block<false>(p, lut, frame, b, s);
-        p.bits[(size_t)f * p.nblocks + b] = s.total;
-    }
-    const uint32_t sum = wave_sum(s.total);
-    if ((threadIdx.x & 63u) == 0 && (b >> 6) < p.nwaves) p.wsum[(size_t)f * p.nwaves + (b >> 6)] = sum;
-}
-
-// Bit packing.  A wave's 64 blocks occupy one contiguous run of the raw stream (plus the alignment
-// gaps between restart intervals), so the wave assembles that run in a private, zeroed LDS window -
-// every lane ORs its words in - and then writes the window to HBM with coalesced stores; only the two
-// words it may share with neighbouring waves go out as atomic ORs into the zeroed buffer.  Runs longer
-// than the window (pathological content) are OR-ed straight into HBM by the same walk.
-
-template <class Words>
-__device__ __forceinline__ void pack_one(Params p, const uint32_t *lut, const int16_t *frame, uint32_t b,
-                                         Words first, uint32_t in_iv, uint32_t pad, bool baseline) {
-    PackSink<Words> s = {first, 0, in_iv & 31u};
-    if (baseline) walk_block<true>(p, lut, frame, b, s); else walk_block<false>(p, lut, frame, b, s);
-    if (pad) s.put((1u << pad) - 1u, pad);
-    s.finish();
-}
-
-__global__ void __launch_bounds__(256) k_block_pack(const EntropyParams *params) {
-    Params p = JPEGENC_JOB(params);
-    __shared__ uint32_t lut[4 * 256];
-    __shared__ uint32_t window[4][kPackWindowWords];
+    __shared__ __attribute__((aligned(16))) uint32_t window[4][kPackWindowWords];
     load_lut(p, lut);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     const bool valid = b < p.nblocks;
-    const uint64_t vmask = __ballot(valid);
-    if (vmask == 0) return;                                                      // whole wave past the end
+    if (__ballot(valid) == 0) return;                                            // whole wave past the end
     const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
-    uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
-
-    const uint32_t mine = valid ? p.bits[(size_t)f * p.nblocks + b] : 0u;
-    const uint32_t before = p.woff[(size_t)f * p.nwaves + (b >> 6)] + wave_inclusive(mine) - mine;   // bits of the scan before b
-    uint32_t in_iv = 0, first_word = 0, last_word = 0, pad = 0;
-    if (valid) {
-        const uint32_t iv = b / p.interval_blocks;
-        const uint32_t iv_last = min((iv + 1u) * p.interval_blocks, p.nblocks) - 1u;
-        in_iv = before - p.ivbit[(size_t)f * p.nintervals + iv];                 // bits before b in its interval
-        const uint32_t base = p.ichunk[(size_t)f * p.nintervals + iv] * 4u;      // interval base (words), 16-B aligned
-        // finalize_bit_buffer (writer.rs:138-154): seven 1-bits, then only whole bytes are kept
-        if (b == iv_last) pad = (8u - ((in_iv + mine) & 7u)) & 7u;
-        const uint32_t end = in_iv + mine + pad;
-        first_word = base + (in_iv >> 5);
-        last_word = base + ((end ? end - 1u : 0u) >> 5);
-        if (b == iv_last) last_word |= 3u;       // the rest of the interval's last 16-byte chunk is written too (as zeros)
-    }
-    const uint32_t nvalid = (uint32_t)__popcll(vmask);
-    const uint32_t w0 = (uint32_t)__shfl((int)first_word, 0), w1 = (uint32_t)__shfl((int)last_word, (int)nvalid - 1);
-    const uint32_t nwords = w1 - w0 + 1u;
-    const bool staged = nwords <= p.window_words;                                // wave-uniform
     const bool baseline = baseline_band(p);
+    BlockRegs r;
+    uint32_t mine = 0;
+    if (valid) {
+        load_block(frame, b, r);
+        CountSink cs = {0};
+        if (baseline) walk_block<true>(p, lut, frame, b, r, cs); else walk_block<false>(p, lut, frame, b, r, cs);
+        mine = cs.total;
+        p.bits[(size_t)f * p.nblocks + b] = mine;                               // (interval offsets need them, k_interval_len)
+    }
+    const uint32_t upto = wave_inclusive(mine), at = upto - mine;               // bits of the run before this block
+    const uint32_t total = (uint32_t)__shfl((int)upto, 63);
+    const uint32_t w = b >> 6;
+    if (lane == 0) p.wsum[(size_t)f * p.nwaves + w] = total;
+    const uint32_t nwords = (total + 31u) >> 5;
+    uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)w * p.slot_words;
     uint32_t *win = window[wave];
-    if (staged) {
-        for (uint32_t i = lane; i < nwords; i += 64u) win[i] = 0;
+    if (nwords + 4u <= p.window_words) {                                         // wave-uniform (+4: the zero word, 16-byte copies)
+        for (uint32_t i = lane; i <= nwords; i += 64u) win[i] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (valid) pack_one(p, lut, frame, b, LdsWords{(lds_word *)win + (first_word - w0)}, in_iv, pad, baseline);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t i = lane; i < nwords; i += 64u) {
-            const uint32_t v = win[i];
-            if (i == 0 || i + 1 == nwords) { if (v) atomicOr(stream + w0 + i, v); }
-            else stream[w0 + i] = v;
+        if (valid) {
+            PackSink<LdsWords> ps = {LdsWords{(lds_word *)win + (at >> 5)}, 0, at & 31u};
+            if (baseline) walk_block<true>(p, lut, frame, b, r, ps); else walk_block<false>(p, lut, frame, b, r, ps);
+            ps.finish();
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // (the window was cleared one word past the run; up to three more stale words ride along - never read)
+        for (uint32_t i = lane * 4u; i <= nwords; i += 256u)
+            *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(win + i);
     } else {
-        // no window: zero the words only this wave writes (its two end words were cleared by k_wave_edges), then OR
-        for (uint32_t i = 1u + lane; i + 1u < nwords; i += 64u) stream[w0 + i] = 0;
+        for (uint32_t i = lane; i <= nwords; i += 64u) slot[i] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (valid) pack_one(p, lut, frame, b, HbmWords{(hbm_word *)stream + first_word}, in_iv, pad, baseline);
+        if (valid) {
+            PackSink<HbmWords> ps = {HbmWords{(hbm_word *)slot + (at >> 5)}, 0, at & 31u};
+            if (baseline) walk_block<true>(p, lut, frame, b, r, ps); else walk_block<false>(p, lut, frame, b, r, ps);
+            ps.finish();
+        }
     }
 }
 
@@ -453,7 +437,7 @@ __global__ void __launch_bounds__(256) k_block_pack(const EntropyParams *params)
 __global__ void __launch_bounds__(256) k_interval_len(const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
     const uint32_t f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.nintervals || p.nintervals == 1) return;         // a single interval is k_wave_edges' business
+    if (i >= p.nintervals || p.nintervals == 1) return;         // a single interval is k_place's business
     const uint32_t first = i * p.interval_blocks, end = min(first + p.interval_blocks, p.nblocks);
     const uint32_t at = block_bit_offset(p, f, first);
     const uint32_t bits = (end == p.nblocks ? p.total_bits[f] : block_bit_offset(p, f, end)) - at;
@@ -461,44 +445,6 @@ __global__ void __launch_bounds__(256) k_interval_len(const EntropyParams *param
     p.ivbit[(size_t)f * p.nintervals + i] = at;
     p.ilen[(size_t)f * p.nintervals + i] = bytes;
     p.ichunks[(size_t)f * p.nintervals + i] = (bytes + 15u) >> 4;
-}
-
-// The raw buffer is not cleared as a whole (its used size is data dependent and the clear cost as much as
-// a fifth of the bit packing): every word of a wave's run is written by that wave alone, except the first
-// and the last, which a neighbouring wave may share.  Those two are zeroed here, one thread per wave,
-// with the same arithmetic k_block_pack uses for its lanes 0 and nvalid-1.
-__global__ void __launch_bounds__(256) k_wave_edges(const EntropyParams *params) {
-    Params p = JPEGENC_JOB(params);
-    const uint32_t f = blockIdx.y, w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= p.nwaves) return;
-    const bool single = p.nintervals == 1;       // no restart markers: the interval bookkeeping is trivial and done here
-    if (w == 0) {
-        uint32_t chunks;
-        if (single) {
-            const uint32_t bytes = (p.total_bits[f] + 7u) >> 3;
-            chunks = (bytes + 15u) >> 4;
-            p.ivbit[f] = 0; p.ilen[f] = bytes; p.ichunks[f] = chunks; p.iexact[f] = 0; p.ichunk[f] = 0;
-            p.raw_bytes[f] = bytes; p.raw_chunks[f] = chunks;
-        } else {
-            chunks = p.raw_chunks[f];
-        }
-        p.nfftiles[f] = (chunks + 255u) >> 8;
-        p.out_bytes[f] = 0;                      // k_stuff sets the length
-    }
-    uint32_t *stream = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
-    const uint32_t *woff = p.woff + (size_t)f * p.nwaves;
-    const uint32_t *ivbit = p.ivbit + (size_t)f * p.nintervals, *ichunk = p.ichunk + (size_t)f * p.nintervals;
-    const uint32_t b0 = w * 64u, b1 = min(b0 + 63u, p.nblocks - 1u);
-    const uint32_t iv0 = b0 / p.interval_blocks, iv1 = b1 / p.interval_blocks;
-    const uint32_t bit0 = single ? 0u : ivbit[iv0], chunk0 = single ? 0u : ichunk[iv0];
-    const uint32_t bit1 = single ? 0u : ivbit[iv1], chunk1 = single ? 0u : ichunk[iv1];
-    stream[chunk0 * 4u + ((woff[w] - bit0) >> 5)] = 0;
-    uint32_t end = (w + 1u < p.nwaves ? woff[w + 1u] : p.total_bits[f]) - bit1;            // bits of interval iv1 up to and including b1
-    const bool closes = b1 == min((iv1 + 1u) * p.interval_blocks, p.nblocks) - 1u;
-    if (closes) end += (8u - (end & 7u)) & 7u;
-    uint32_t last = chunk1 * 4u + ((end ? end - 1u : 0u) >> 5);
-    if (closes) last |= 3u;
-    stream[last] = 0;
 }
 
 // ---- byte stuffing --------------------------------------------------------------------------------
@@ -515,12 +461,257 @@ constexpr uint32_t kChunkGrid = 1024;
 
 __device__ __forceinline__ uint32_t ff_count16(const uint4 v) { return ff_count4(v.x) + ff_count4(v.y) + ff_count4(v.z) + ff_count4(v.w); }
 
-// 0xFF bytes per tile of 256 chunks (bytes beyond an interval's length are zero - k_block_pack fills the
-// interval's last chunk - so they never count).
+// ---- placing the wave runs in the raw stream ----------------------------------------------------------
+// The raw stream = for every restart interval, at a 16-byte aligned place: its bits, 1-padded to a whole byte
+// (finalize_bit_buffer, writer.rs:138-154), zero-filled to the end of the 16-byte chunk.  One thread builds
+// one chunk: it finds the wave whose run holds the chunk's first bit (binary search over the wave offsets) and
+// takes 32 bits at a time, moving on to the next run where one ends.  Bit order: a word of the byte stream,
+// byte-swapped, holds its bits MSB first.
+// k_place serves the scans WITH restart markers (k_push below is the fast path for the others).  A workgroup
+// places kPlaceSub tiles of 256 chunks per trip = 32 768 consecutive bits of one or more intervals, so the runs it
+// draws on are a contiguous range of at most 512 + 1 waves (a run has at least 64 bits): their offsets are staged
+// in LDS once per trip and every thread searches there.  The kernel is a chain of dependent loads (search,
+// offsets, source words) and latency-bound: 137 us for 130 MB of output with one tile per trip, 111 us with four
+// (which in turn starves small outputs of parallelism) - the reason the common case does not go through it.
+constexpr uint32_t kPlaceSub = 1;
+constexpr uint32_t kTileRuns = 640;
+struct RunCursor {                // a position in the concatenation of the wave runs of one frame
+    const uint32_t *woff;         // bit offset of every run
+    const uint32_t *slots;        // run w starts at slots + w * slot_words
+    const uint32_t *near;         // LDS copy of woff[near_first .. near_first + near_n)
+    uint32_t near_first, near_n;
+    uint32_t slot_words, nwaves, total_bits;
+    uint32_t w, lo, hi;           // current run and its bit range [lo, hi)
+    __device__ __forceinline__ uint32_t offset_of(uint32_t run) const {
+        return run - near_first < near_n ? near[run - near_first] : woff[run];
+    }
+    __device__ __forceinline__ void seek(uint32_t g) {           // g < total_bits
+        uint32_t a, b;
+        if (near_n && near[0] <= g && (near_first + near_n == nwaves || g < near[near_n - 1])) {
+            a = 0; b = near_n;
+            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (near[m] <= g) a = m; else b = m; }
+            a += near_first;
+        } else {
+            a = 0; b = nwaves;
+            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (woff[m] <= g) a = m; else b = m; }
+        }
+        enter(a);
+    }
+    __device__ __forceinline__ void enter(uint32_t run) {
+        w = run; lo = offset_of(run); hi = run + 1 < nwaves ? offset_of(run + 1) : total_bits;
+    }
+    // the n <= 32 bits at g.. (g + n <= total_bits, g >= lo), MSB-aligned
+    __device__ __forceinline__ uint32_t take(uint32_t g, uint32_t n) {
+        uint32_t out = 0, got = 0;
+        while (got < n) {
+            if (g >= hi) { enter(w + 1); continue; }             // (runs of zero length are skipped the same way)
+            const uint32_t rel = g - lo, k = min(n - got, hi - g);
+            const uint32_t *src = slots + (size_t)w * slot_words + (rel >> 5);
+            const uint32_t sh = rel & 31u;
+            const uint32_t w0 = __builtin_bswap32(src[0]), w1 = __builtin_bswap32(src[1]);   // (a zero word follows every run)
+            uint32_t v = sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
+            if (k < 32u) v &= ~(0xFFFFFFFFu >> k);
+            out |= v >> got;
+            got += k; g += k;
+        }
+        return out;
+    }
+};
+
+__global__ void __launch_bounds__(256) k_place(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
+    __shared__ uint32_t part[kPlaceSub][4];
+    __shared__ uint32_t near[kTileRuns];
+    __shared__ uint32_t trip_first_bit;
+    const uint32_t f = blockIdx.y;
+    const bool single = p.nintervals == 1;
+    if (single) return;                          // k_push + k_ff_tiles
+    const uint32_t total_bits = p.total_bits[f];
+    const uint32_t n = p.raw_chunks[f];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        p.nfftiles[f] = (n + 255u) >> 8;
+        p.out_bytes[f] = 0;                      // k_stuff sets the length
+    }
+    const uint32_t *ivbit = p.ivbit + (size_t)f * p.nintervals, *ichunk = p.ichunk + (size_t)f * p.nintervals;
+    RunCursor cur;
+    cur.woff = p.woff + (size_t)f * p.nwaves;
+    cur.slots = reinterpret_cast<const uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride);
+    cur.slot_words = p.slot_words; cur.nwaves = p.nwaves; cur.total_bits = total_bits;
+    cur.near = near;
+    uint4 *raw = reinterpret_cast<uint4 *>(p.raw + (size_t)f * p.raw_stride);
+    for (uint32_t trip = blockIdx.x; trip * (256u * kPlaceSub) < n; trip += gridDim.x) {
+        // where every chunk of the trip lies: interval, chunk inside it, the interval's bits
+        uint32_t j[kPlaceSub], first_bit[kPlaceSub], ibits[kPlaceSub];
+#pragma unroll
+        for (uint32_t i = 0; i < kPlaceSub; i++) {
+            const uint32_t q = (trip * kPlaceSub + i) * 256u + threadIdx.x;
+            j[i] = q; first_bit[i] = 0; ibits[i] = total_bits;
+            if (q < n && !single) {              // interval of this chunk: the last k with ichunk[k] <= q
+                uint32_t lo = 0, hi = p.nintervals;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ichunk[mid] <= q) lo = mid; else hi = mid;
+                }
+                j[i] = q - ichunk[lo];
+                first_bit[i] = ivbit[lo];
+                ibits[i] = (lo + 1 < p.nintervals ? ivbit[lo + 1] : total_bits) - first_bit[i];
+            }
+        }
+        // the run of the trip's first bit, by a 256-ary search of the whole workgroup (two rounds of one load
+        // each for a 4K frame), then the offsets of the runs from there on into LDS
+        if (threadIdx.x == 0) trip_first_bit = min(first_bit[0] + min(j[0] * 128u, ibits[0]), total_bits ? total_bits - 1u : 0u);
+        __syncthreads();
+        const uint32_t g0 = trip_first_bit;
+        uint32_t lo_run = 0, span = cur.nwaves;          // the answer is in [lo_run, lo_run + span)
+        while (span > 1) {
+            const uint32_t stride = (span + 255u) / 256u;
+            const uint32_t idx = lo_run + threadIdx.x * stride;
+            const int below = __syncthreads_count(threadIdx.x * stride < span && cur.woff[idx] <= g0);   // monotone: the first `below` threads
+            lo_run += (uint32_t)(below - 1) * stride;                                                     // (thread 0 always counts)
+            span = min(stride, cur.nwaves - lo_run);
+        }
+        cur.near_first = lo_run;
+        cur.near_n = min(kTileRuns, cur.nwaves - lo_run);
+        for (uint32_t i = threadIdx.x; i < cur.near_n; i += 256u) near[i] = cur.woff[lo_run + i];
+        __syncthreads();
+        uint32_t ff[kPlaceSub];
+#pragma unroll
+        for (uint32_t i = 0; i < kPlaceSub; i++) {
+            const uint32_t q = (trip * kPlaceSub + i) * 256u + threadIdx.x;
+            uint32_t word[4] = {0, 0, 0, 0};
+            if (q < n) {
+                const uint32_t padded = (ibits[i] + 7u) & ~7u;
+                uint32_t s0 = j[i] * 128u;
+                bool done = false;
+                if (s0 < ibits[i]) cur.seek(first_bit[i] + s0);
+                if (s0 + 128u <= ibits[i] && first_bit[i] + s0 + 128u <= cur.hi) {
+                    // the whole chunk inside one run: five words, four funnel shifts
+                    const uint32_t rel = first_bit[i] + s0 - cur.lo, sh = rel & 31u;
+                    const uint32_t *src = cur.slots + (size_t)cur.w * cur.slot_words + (rel >> 5);
+                    uint32_t m[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) m[k] = __builtin_bswap32(src[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) word[k] = __builtin_bswap32(sh ? (m[k] << sh) | (m[k + 1] >> (32u - sh)) : m[k]);
+                    done = true;
+                }
+                if (!done) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++, s0 += 32u) {
+                        if (s0 >= ibits[i]) break;
+                        const uint32_t have = min(32u, ibits[i] - s0);
+                        uint32_t v = cur.take(first_bit[i] + s0, have);
+                        if (have < 32u) {        // the interval ends in this word: 1-bits up to the byte boundary
+                            const uint32_t ones = min(32u, padded - s0) - have;
+                            v |= ((1u << ones) - 1u) << (32u - have - ones);
+                        }
+                        word[k] = __builtin_bswap32(v);
+                    }
+                }
+                raw[q] = make_uint4(word[0], word[1], word[2], word[3]);
+            }
+            ff[i] = wave_sum(ff_count4(word[0]) + ff_count4(word[1]) + ff_count4(word[2]) + ff_count4(word[3]));   // (the zero fill never counts)
+        }
+        // 0xFF bytes per tile of 256 chunks
+        if ((threadIdx.x & 63u) == 0)
+#pragma unroll
+            for (uint32_t i = 0; i < kPlaceSub; i++) part[i][threadIdx.x >> 6] = ff[i];
+        __syncthreads();
+        if (threadIdx.x < kPlaceSub && (trip * kPlaceSub + threadIdx.x) * 256u < n)
+            p.fftile[(size_t)f * p.max_fftiles + trip * kPlaceSub + threadIdx.x] =
+                part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        __syncthreads();
+    }
+}
+
+// ---- scans without restart markers: every run pushes itself into place ---------------------------------
+// The raw stream is then simply the runs back to back.  Word j of it is written by the run that holds the
+// word's first bit: the run reads its own slot linearly (coalesced), shifts by its offset and writes linearly;
+// only its last word may need the first bits of the following run(s).  No search, no atomics, and each wave's
+// chain is offsets -> slot words -> store.  The last run adds the 1-padding (finalize_bit_buffer,
+// writer.rs:138-154) and zero-fills the final 16-byte chunk.
+__global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
+    if (p.nintervals != 1) return;               // k_place
+    const uint32_t f = blockIdx.y, lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (w >= p.nwaves) return;
+    const uint32_t total_bits = p.total_bits[f];
+    const uint32_t bytes = (total_bits + 7u) >> 3, chunks = (bytes + 15u) >> 4;
+    if (w == 0 && lane == 0) {                   // the trivial interval bookkeeping of the scan
+        p.ivbit[f] = 0; p.ilen[f] = bytes; p.ichunks[f] = chunks; p.iexact[f] = 0; p.ichunk[f] = 0;
+        p.raw_bytes[f] = bytes; p.raw_chunks[f] = chunks;
+        p.nfftiles[f] = (chunks + 255u) >> 8;
+        p.out_bytes[f] = 0;                      // k_stuff sets the length
+    }
+    const uint32_t *woff = p.woff + (size_t)f * p.nwaves;
+    const uint32_t *slots = reinterpret_cast<const uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride);
+    uint32_t *raw = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
+    const bool last = w + 1 == p.nwaves;
+    const uint32_t lo = woff[w], hi = last ? total_bits : woff[w + 1];
+    const uint32_t *slot = slots + (size_t)w * p.slot_words;
+    const uint32_t j0 = (lo + 31u) >> 5;                              // first word whose first bit is ours
+    const uint32_t j1 = last ? chunks * 4u : (hi + 31u) >> 5;         // the last run also owns the padding and the zero fill
+    // groups of four words that lie entirely inside the run: five source words, four funnel shifts, one
+    // 16-byte store per lane (word by word the kernel was bound by its instruction count, not by its bytes)
+    const uint32_t ga = (j0 + 3u) >> 2, gb = hi >> 7;               // groups [ga, gb): 128 * gb <= hi
+    for (uint32_t g4 = ga + lane; g4 < gb; g4 += 64u) {
+        const uint32_t rel = g4 * 128u - lo, sh = rel & 31u;
+        const uint32_t *src = slot + (rel >> 5);
+        const u32x4a4 q = *reinterpret_cast<const u32x4a4 *>(src);
+        const uint32_t m[5] = {__builtin_bswap32(q.x), __builtin_bswap32(q.y), __builtin_bswap32(q.z), __builtin_bswap32(q.w),
+                               __builtin_bswap32(src[4])};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = __builtin_bswap32(sh ? (m[k] << sh) | (m[k + 1] >> (32u - sh)) : m[k]);
+        reinterpret_cast<uint4 *>(raw)[g4] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    // the words before the first and after the last such group (at most three + four, seven more for the last run)
+    const uint32_t head_end = min(j1, max(j0, ga * 4u)), tail_begin = max(head_end, min(j1, max(gb, ga) * 4u));
+    const uint32_t nloose = (head_end - j0) + (j1 - tail_begin);
+    for (uint32_t t = lane; t < nloose; t += 64u) {
+        const uint32_t j = t < head_end - j0 ? j0 + t : tail_begin + (t - (head_end - j0));
+        const uint32_t g = j * 32u;
+        uint32_t v = 0;
+        if (g < hi) {
+            const uint32_t rel = g - lo, sh = rel & 31u;
+            const uint32_t *src = slot + (rel >> 5);
+            const uint32_t w0 = __builtin_bswap32(src[0]), w1 = __builtin_bswap32(src[1]);   // (a zero word follows every run)
+            v = sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
+            uint32_t have = min(32u, hi - g);
+            if (have < 32u) {
+                v &= ~(0xFFFFFFFFu >> have);
+                // the word runs past our end: bits of the following run(s), then, at the end of the stream, the padding
+                uint32_t next = w + 1;
+                while (have < 32u && next < p.nwaves) {
+                    const uint32_t nlo = woff[next], nhi = next + 1 < p.nwaves ? woff[next + 1] : total_bits;
+                    const uint32_t k = min(32u - have, nhi - nlo);
+                    if (k) {
+                        uint32_t t = __builtin_bswap32(slots[(size_t)next * p.slot_words]);
+                        if (k < 32u) t &= ~(0xFFFFFFFFu >> k);
+                        v |= t >> have;
+                        have += k;
+                    }
+                    if (k < nhi - nlo) break;                        // that run goes on: the word is full
+                    next++;
+                }
+                if (have < 32u) {                                    // end of the stream inside this word
+                    const uint32_t ones = (8u - (total_bits & 7u)) & 7u;
+                    v |= ((1u << ones) - 1u) << (32u - have - ones);
+                }
+            }
+        }
+        raw[j] = __builtin_bswap32(v);
+    }
+}
+
+// 0xFF bytes per tile of 256 chunks for the scans k_push placed (k_place counts its own); bytes beyond the
+// stream's length are zero, so they never count.
 __global__ void __launch_bounds__(256) k_ff_tiles(const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
+    if (p.nintervals != 1) return;
     __shared__ uint32_t part[4];
-    const uint32_t f = blockIdx.y, n = p.raw_chunks[f];
+    const uint32_t f = blockIdx.y, n = (((p.total_bits[f] + 7u) >> 3) + 15u) >> 4;
     const uint4 *raw = reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride);
     for (uint32_t tile = blockIdx.x; tile * 256u < n; tile += gridDim.x) {
         const uint32_t q = tile * 256u + threadIdx.x;
@@ -668,20 +859,25 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
     }
     hipError_t e = hipSuccess;
     const uint32_t bgrid = (nblocks + 255u) / 256u;
-    hipLaunchKernelGGL(k_block_bits, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
+    hipLaunchKernelGGL(k_block_code, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
     e = scan(d_params, SCAN_WAVES, nwaves, njobs, frames, st);
     if (e != hipSuccess) return e;
-    if (nintervals > 1) {      // (scans with a single interval: k_wave_edges writes their trivial results after these)
+    if (nintervals > 1) {      // (scans with a single interval: k_place writes their trivial results)
         hipLaunchKernelGGL(k_interval_len, dim3((nintervals + 255u) / 256u, frames, njobs), dim3(256), 0, st, d_params);
         e = scan(d_params, SCAN_ILEN, nintervals, njobs, frames, st);
         if (e != hipSuccess) return e;
         e = scan(d_params, SCAN_ICHUNKS, nintervals, njobs, frames, st);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_wave_edges, dim3((nwaves + 255u) / 256u, frames, njobs), dim3(256), 0, st, d_params);
-    hipLaunchKernelGGL(k_block_pack, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
     const uint32_t cgrid = min(fftiles, kChunkGrid);
-    hipLaunchKernelGGL(k_ff_tiles, dim3(cgrid, frames, njobs), dim3(256), 0, st, d_params);
+    bool any_single = false, any_multi = false;
+    for (int j = 0; j < njobs; j++) { any_single = any_single || jobs[j].nintervals == 1; any_multi = any_multi || jobs[j].nintervals > 1; }
+    if (any_single) {
+        hipLaunchKernelGGL(k_push, dim3((nwaves + 3u) / 4u, frames, njobs), dim3(256), 0, st, d_params);
+        hipLaunchKernelGGL(k_ff_tiles, dim3(cgrid, frames, njobs), dim3(256), 0, st, d_params);
+    }
+    if (any_multi)
+        hipLaunchKernelGGL(k_place, dim3(min((fftiles + kPlaceSub - 1u) / kPlaceSub, kChunkGrid), frames, njobs), dim3(256), 0, st, d_params);
     e = scan(d_params, SCAN_FFTILES, fftiles, njobs, frames, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_stuff, dim3(cgrid, frames, njobs), dim3(256), 0, st, d_params);

@@ -50,6 +50,9 @@ struct EntropyParams {
     uint32_t *ichunk;                // [frames][nintervals]   exclusive prefix of ichunks
     uint32_t *raw_bytes;             // [frames] sum of ilen
     uint32_t *raw_chunks;            // [frames] sum of ichunks
+    uint8_t *slots;                  // [frames][nwaves][slot_words] the bits of each wave's 64 blocks, from bit 0 of the slot
+    uint64_t slot_frame_stride;      // bytes
+    uint32_t slot_words;             // words per slot: worst-case run + the zero word after it
     uint8_t *raw;                    // [frames][raw_stride]   unstuffed bits, every interval 16-byte aligned
     uint64_t raw_stride;             // bytes, multiple of 16
     uint32_t max_chunks;             // raw_stride / 16
