@@ -172,6 +172,11 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
         p.pos_table[0] = (uint8_t)L.table[sc.component];
         for (int c = 0; c < sc.component; c++) first_block += L.blocks[c];
     }
+    for (uint32_t pos = 0; pos < 12; pos++) {
+        p.pos_table_bits |= (uint32_t)(p.pos_table[pos] & 1u) << pos;
+        p.pos_delta_bits |= (uint32_t)(p.pos_prev_delta[pos] & 1u) << pos;
+        p.pos_last_nibbles |= (uint64_t)(p.pos_last_of_comp[pos] & 15u) << (4 * pos);
+    }
     p.coeffs = (const int16_t *)d_coeffs + first_block * 64;
     p.coeff_frame_stride = coeff_frame_stride;
     p.nblocks = (uint32_t)nblocks;

@@ -316,23 +316,31 @@ __device__ __forceinline__ void load_block(const int16_t *frame_coeffs, uint32_t
     }
 }
 
-template <bool BASELINE, class Sink>
-__device__ __forceinline__ void walk_block(Params p, const uint32_t *lut, const int16_t *frame_coeffs,
-                                           uint32_t b, const BlockRegs &r, Sink &s) {
+// DC predecessor of block b = the previous block of the same component (write_dc, writer.rs:342-354; predictors
+// reset at the start of the scan and at restart boundaries, encoder.rs:748-757).  Requested together with the
+// block itself: inside the walk it was one more dependent round trip to HBM per walk, and a wave's life on
+// sparse content is little else than such round trips.  The load is unconditional (index clamped, value selected
+// afterwards) so that it sits in the same load queue as the block's.
+struct BlockPlace { uint32_t table; bool has_prev; uint64_t prev_block; };
+__device__ __forceinline__ BlockPlace place_of(Params p, uint32_t b) {
     const uint32_t mcu = b / p.bpm, pos = b - mcu * p.bpm;
-    const uint32_t table = p.pos_table[pos];
+    BlockPlace q;
+    q.table = (p.pos_table_bits >> pos) & 1u;
+    if ((p.pos_delta_bits >> pos) & 1u) {
+        q.has_prev = true; q.prev_block = (uint64_t)b - 1u;
+    } else {
+        q.has_prev = (b - pos) % p.interval_blocks != 0;
+        q.prev_block = q.has_prev ? (uint64_t)(mcu - 1u) * p.bpm + (uint32_t)((p.pos_last_nibbles >> (4u * pos)) & 15u) : (uint64_t)b;
+    }
+    return q;
+}
+
+template <bool BASELINE, class Sink>
+__device__ __forceinline__ void walk_block(Params p, const uint32_t *lut, uint32_t table, int prev_dc, const BlockRegs &r, Sink &s) {
     const uint32_t *dc_lut = lut + table * 512, *ac_lut = dc_lut + 256;
     const uint32_t *c = r.c;
     if (BASELINE || p.with_dc) {
-        // DC: predecessor = previous block of the same component (write_dc, writer.rs:342-354;
-        // predictors reset at the start of the scan and at restart boundaries, encoder.rs:748-757)
-        int prev = 0;
-        if (p.pos_prev_delta[pos]) {
-            prev = frame_coeffs[(size_t)(b - 1) * 64];
-        } else {
-            const bool interval_start = (b - pos) % p.interval_blocks == 0;
-            if (!interval_start) prev = frame_coeffs[((size_t)(mcu - 1) * p.bpm + p.pos_last_of_comp[pos]) * 64];
-        }
+        const int prev = prev_dc;
         const int dc = (int16_t)(c[0] & 0xFFFFu);
         const int diff = (int16_t)(dc - prev);
         const uint32_t n = bit_size(diff);
@@ -365,8 +373,17 @@ __device__ __forceinline__ void walk_block(Params p, const uint32_t *lut, const 
     if (run > 0) { const uint32_t e = ac_lut[0]; s.put(e & 0xFFFFu, e >> 16); }
 }
 
-__device__ __forceinline__ void load_lut(Params p, uint32_t *lut) {
-    for (uint32_t i = threadIdx.x; i < 4 * 256; i += blockDim.x) lut[i] = p.lut[i];
+// The code tables go to LDS in two steps: fetch (first in the load queue, so waiting for it waits for nothing
+// else), then the kernel requests its own data, then commit.  256 threads, 4 entries each.
+struct LutRegs { uint32_t v[4]; };
+__device__ __forceinline__ void lut_fetch(Params p, LutRegs &l) {
+    const hbm_word *src = (const hbm_word *)p.lut;
+#pragma unroll
+    for (int i = 0; i < 4; i++) l.v[i] = src[i * 256 + threadIdx.x];
+}
+__device__ __forceinline__ void lut_commit(const LutRegs &l, uint32_t *lut) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) lut[i * 256 + threadIdx.x] = l.v[i];
     __syncthreads();
 }
 
@@ -381,19 +398,26 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
     Params p = JPEGENC_JOB(params);
     __shared__ uint32_t lut[4 * 256];
     __shared__ __attribute__((aligned(16))) uint32_t window[4][kPackWindowWords];
-    load_lut(p, lut);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     const bool valid = b < p.nblocks;
-    if (__ballot(valid) == 0) return;                                            // whole wave past the end
     const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
-    const bool baseline = baseline_band(p);
+    // every load of the wave's life in one queue: tables, DC predecessor, the block (clamped for lanes past the end)
+    LutRegs l;
+    lut_fetch(p, l);
+    const uint32_t bc = min(b, p.nblocks - 1u);
+    const BlockPlace where = place_of(p, bc);
+    const int prev_raw = ((const __attribute__((address_space(1))) int16_t *)frame)[where.prev_block * 64u];
     BlockRegs r;
+    load_block(frame, bc, r);
+    lut_commit(l, lut);
+    if (__ballot(valid) == 0) return;                                            // whole wave past the end
+    const int prev_dc = where.has_prev ? prev_raw : 0;
+    const bool baseline = baseline_band(p);
     uint32_t mine = 0;
     if (valid) {
-        load_block(frame, b, r);
         CountSink cs = {0};
-        if (baseline) walk_block<true>(p, lut, frame, b, r, cs); else walk_block<false>(p, lut, frame, b, r, cs);
+        if (baseline) walk_block<true>(p, lut, where.table, prev_dc, r, cs); else walk_block<false>(p, lut, where.table, prev_dc, r, cs);
         mine = cs.total;
         p.bits[(size_t)f * p.nblocks + b] = mine;                               // (interval offsets need them, k_interval_len)
     }
@@ -411,7 +435,7 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (valid) {
             PackSink<LdsWords> ps = {LdsWords{(lds_word *)win + (at >> 5)}, 0, at & 31u};
-            if (baseline) walk_block<true>(p, lut, frame, b, r, ps); else walk_block<false>(p, lut, frame, b, r, ps);
+            if (baseline) walk_block<true>(p, lut, where.table, prev_dc, r, ps); else walk_block<false>(p, lut, where.table, prev_dc, r, ps);
             ps.finish();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -427,7 +451,7 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (valid) {
             PackSink<HbmWords> ps = {HbmWords{(hbm_word *)slot + (at >> 5)}, 0, at & 31u};
-            if (baseline) walk_block<true>(p, lut, frame, b, r, ps); else walk_block<false>(p, lut, frame, b, r, ps);
+            if (baseline) walk_block<true>(p, lut, where.table, prev_dc, r, ps); else walk_block<false>(p, lut, where.table, prev_dc, r, ps);
             ps.finish();
         }
     }

@@ -33,6 +33,9 @@ struct EntropyParams {
     uint8_t pos_table[12];           // Huffman table destination of each block position in the MCU (<= 10 positions)
     uint8_t pos_prev_delta[12];      // 1 when the previous block of the MCU has the same component
     uint8_t pos_last_of_comp[12];    // position of the component's last block inside an MCU
+    // the same three, packed for register arithmetic (bit / nibble `pos`): no memory access on the way to the first load
+    uint32_t pos_table_bits, pos_delta_bits;
+    uint64_t pos_last_nibbles;
     // Huffman code tables: [destination][0 = DC, 1 = AC][symbol] = size << 16 | code
     const uint32_t *lut;
     // workspace (device), per frame
