@@ -866,6 +866,21 @@ def test_device_entropy_pack_window_overflow_path(binding, oracle, synth):
         assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_shortest_possible_runs(binding, oracle):
+    """Flat images: every AC band of a progressive scan is one EOB per block and, with optimised tables, one BIT
+    per block - a wave's run is then 64 bits, the last wave's a handful, several runs meet inside one 32-bit word
+    of the raw stream (k_push completes a word from the following runs, the last run pads).  Sizes chosen so
+    that the last wave holds 1, 2, 3, 63 and 64 blocks."""
+    for w, h in ((8, 8), (16, 8), (24, 8), (8 * 65, 8), (8 * 63, 16), (8 * 64, 8), (8 * 128, 24), (8 * 67, 8 * 3)):
+        for value in (0, 128, 255):
+            px = np.full((h, w, 3), value, dtype=np.uint8)
+            px[..., 1] = (value * 7 + 3) % 256
+            for kw in (dict(quality=90), dict(quality=50, progressive_scans=4, optimize=True), dict(quality=75, optimize=True),
+                       dict(quality=85, progressive_scans=9), dict(quality=60, sampling=(2, 2), restart_interval=3)):
+                got = _encoder(binding, kw).encode(px, w, h, binding.RGB)
+                assert got == oracle.encode_jpeg(px, w, h, oracle.RGB, **kw), (w, h, value, kw)
+
+
 def test_scans_coded_together_and_one_by_one_agree(binding, oracle, synth):
     """A sequential / progressive frame's scans share their launches (up to 8 per launch sequence, so the 12
     scans of progressive(4) and the 33 x 3 of progressive(34) cross group boundaries); JPEGENC_SCANS_ONE_BY_ONE=1
