@@ -253,10 +253,10 @@ __device__ __forceinline__ uint32_t block_bit_offset(Params p, uint32_t f, uint3
     return s;
 }
 
-// Where a block's bits go.  k_block_bits only adds up lengths; k_block_pack shifts codes into a 64-bit
-// accumulator and ORs every completed 32-bit word (MSB-first byte order) into zeroed memory - the wave's
-// LDS window (ds_or_b32, no address-space guessing: the pointer type says LDS) or, for runs longer than
-// the window, the raw stream in HBM.  OR-ing every word (not only the ones shared with a neighbouring
+// Where a block's bits go.  The first walk of k_block_code only adds up lengths; the second shifts codes into
+// a 64-bit accumulator and ORs every completed 32-bit word (MSB-first byte order) into zeroed memory - the
+// wave's LDS window (ds_or_b32, no address-space guessing: the pointer type says LDS) or, for runs longer than
+// the window, the wave's slot in HBM.  OR-ing every word (not only the ones shared with a neighbouring
 // block) keeps a per-lane "is this my first word" flag and its branches out of the 63-symbol walk.
 typedef __attribute__((address_space(3))) uint32_t lds_word;
 typedef __attribute__((address_space(1))) uint32_t hbm_word;
