@@ -419,8 +419,8 @@ struct SmallBatchBuffers {
 struct BatchBuffers {
     void *d_coeffs = nullptr, *d_out = nullptr, *d_ws = nullptr;
     uint32_t *d_len = nullptr, *h_len = nullptr;
-    uint8_t *h_out = nullptr;
-    size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, h_out_cap = 0;
+    uint8_t *h_out[2] = {nullptr, nullptr};      // two: the files of one round are assembled while the next round is coded and fetched
+    size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, h_out_cap[2] = {0, 0};
     static int grow_device(void **p, size_t *cap, size_t need) {
         if (need <= *cap) return JPEGENC_OK;
         if (*p) (void)hipFree(*p);
@@ -429,8 +429,19 @@ struct BatchBuffers {
         *cap = need;
         return JPEGENC_OK;
     }
+    // d_out, d_len and h_len hold TWO rounds (halves): one is downloaded while the next is coded
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t coded[2] = {nullptr, nullptr};
+    int open_streams() {
+        if (copy_stream) return JPEGENC_OK;
+        JPEGENC_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        for (auto &e : coded) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return JPEGENC_OK;
+    }
     int reserve(size_t coeffs, size_t out, size_t ws, size_t nlen) {
-        int rc = grow_device(&d_coeffs, &coeffs_cap, coeffs);
+        int rc = open_streams();
+        out *= 2; nlen *= 2;
+        if (!rc) rc = grow_device(&d_coeffs, &coeffs_cap, coeffs);
         if (!rc) rc = grow_device(&d_out, &out_cap, out);
         if (!rc) rc = grow_device(&d_ws, &ws_cap, ws);
         if (rc) return rc;
@@ -444,13 +455,13 @@ struct BatchBuffers {
         }
         return JPEGENC_OK;
     }
-    int reserve_host(size_t bytes) {
-        if (bytes <= h_out_cap) return JPEGENC_OK;
-        if (h_out) (void)hipHostFree(h_out);
-        h_out = nullptr; h_out_cap = 0;
+    int reserve_host(size_t bytes, int which) {
+        if (bytes <= h_out_cap[which]) return JPEGENC_OK;
+        if (h_out[which]) (void)hipHostFree(h_out[which]);
+        h_out[which] = nullptr; h_out_cap[which] = 0;
         const size_t cap = bytes + (bytes >> 2) + 4096;
-        JPEGENC_HIP(hipHostMalloc((void **)&h_out, cap, hipHostMallocDefault));
-        h_out_cap = cap;
+        JPEGENC_HIP(hipHostMalloc((void **)&h_out[which], cap, hipHostMallocDefault));
+        h_out_cap[which] = cap;
         return JPEGENC_OK;
     }
     ~BatchBuffers() {
@@ -459,7 +470,9 @@ struct BatchBuffers {
         if (d_ws) (void)hipFree(d_ws);
         if (d_len) (void)hipFree(d_len);
         if (h_len) (void)hipHostFree(h_len);
-        if (h_out) (void)hipHostFree(h_out);
+        for (auto *h : h_out) if (h) (void)hipHostFree(h);
+        for (auto &e : coded) if (e) (void)hipEventDestroy(e);
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     }
 };
 
@@ -1018,6 +1031,12 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         const int v = atoi(cap);
         if (v >= 1 && v < per_round) per_round = v;
     }
+    // large frames: at least four rounds, so that the host assembles the files of one round (a copy out of pinned
+    // memory, ~as long as the round's download) while the GPU codes and delivers the next
+    if (coeff_bytes >= ((size_t)4 << 20) && num_frames >= 8) {
+        const int quarter = (num_frames + 3) / 4;
+        if (quarter < per_round) per_round = quarter < 4 ? 4 : quarter;
+    }
     if (per_round > num_frames) per_round = num_frames;
     size_t ws = 0;
     for (auto &j : jobs) {
@@ -1042,11 +1061,19 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
     rc = upload_huffman_luts(specs, ctx.d_lut, ctx.stream);
     if (rc) return rc;
 
-    for (int f0 = 0; f0 < num_frames; f0 += per_round) {
+    std::vector<std::thread> pools[2];                  // the threads assembling the files of the round staged in h_out[slot]
+    std::atomic<int> failed(0);
+    auto join = [&](int slot) { for (auto &th : pools[slot]) th.join(); pools[slot].clear(); };
+    struct JoinAll { decltype(join) &j; ~JoinAll() { j(0); j(1); } } join_all{join};      // also on an early return
+    // Software pipeline over rounds: code(r+1) on the encoder's stream overlaps the download of round r on the
+    // copy stream, which overlaps the assembly of the files of round r-1 on host threads.
+    const size_t round_out = out_total * (size_t)per_round;
+    auto code_round = [&](int r) -> int {                     // enqueue only
+        const int f0 = r * per_round, half = r & 1;
         const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
         BlockKernelParams p;
-        rc = build_block_params(&p, L, width, height, color_type, t.q, order);
-        if (rc) return rc;
+        int e = build_block_params(&p, L, width, height, color_type, t.q, order);
+        if (e) return e;
         p.pixels = (const uint8_t *)d_frames + (size_t)f0 * frame_stride;
         p.coeffs = b.d_coeffs;
         p.pixel_frame_stride = frame_stride;
@@ -1054,45 +1081,66 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         hipError_t err = hipSuccess;
         if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, n, c.fdct_variant, ctx.stream);
         if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
-        JPEGENC_HIP(hipMemsetAsync(b.d_len, 0, nlen * sizeof(uint32_t), ctx.stream));
+        uint32_t *d_len = b.d_len + (size_t)half * nlen;
+        JPEGENC_HIP(hipMemsetAsync(d_len, 0, nlen * sizeof(uint32_t), ctx.stream));
         for (size_t k = 0; k < jobs.size(); k++) {
             const Job &j = jobs[k];
             if (!j.cap) continue;
-            rc = scan_device(b.d_coeffs, L.total_blocks, n, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)b.d_out + j.off, out_total,
-                             b.d_len + k * (size_t)per_round, b.d_ws, ws, ctx.stream);
-            if (rc) return rc;
+            e = scan_device(b.d_coeffs, L.total_blocks, n, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)b.d_out + (size_t)half * round_out + j.off,
+                            out_total, d_len + k * (size_t)per_round, b.d_ws, ws, ctx.stream);
+            if (e) return e;
         }
-        JPEGENC_HIP(hipMemcpyAsync(b.h_len, b.d_len, nlen * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
-        JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+        JPEGENC_HIP(hipMemcpyAsync(b.h_len + (size_t)half * nlen, d_len, nlen * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
+        JPEGENC_HIP(hipEventRecord(b.coded[half], ctx.stream));
+        return JPEGENC_OK;
+    };
+    rc = code_round(0);
+    if (rc) return rc;
+    int round = 0;
+    for (int f0 = 0; f0 < num_frames; f0 += per_round, round++) {
+        const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
+        const bool more = f0 + per_round < num_frames;
+        const uint32_t *h_len = b.h_len + (size_t)(round & 1) * nlen;
+        const uint8_t *d_out = (const uint8_t *)b.d_out + (size_t)(round & 1) * round_out;
+        JPEGENC_HIP(hipEventSynchronize(b.coded[round & 1]));                  // this round is coded, its lengths are on the host
+        const int slot = round & 1;
+        join(slot);                                                            // the files last assembled out of this staging buffer
+        if (failed.load()) break;
+        // this round's lengths, frame-major (b.h_len is overwritten by the next round while the files are assembled)
+        auto lens = std::make_shared<std::vector<uint32_t>>((size_t)n * jobs.size());
         size_t need = 0;
-        for (size_t k = 0; k < jobs.size(); k++)
-            for (int f = 0; f < n; f++) need += b.h_len[k * (size_t)per_round + (size_t)f];
-        rc = b.reserve_host(need);
-        if (rc) return rc;
-        size_t at = 0;
-        for (int f = 0; f < n; f++)                                            // frame-major on the host: one file after the other
+        for (int f = 0; f < n; f++)
             for (size_t k = 0; k < jobs.size(); k++) {
-                const size_t len = b.h_len[k * (size_t)per_round + (size_t)f];
-                if (len) JPEGENC_HIP(hipMemcpyAsync(b.h_out + at, (const uint8_t *)b.d_out + (size_t)f * out_total + jobs[k].off, len,
-                                                    hipMemcpyDeviceToHost, ctx.stream));
+                const uint32_t len = h_len[k * (size_t)per_round + (size_t)f];
+                (*lens)[(size_t)f * jobs.size() + k] = len;
+                need += len;
+            }
+        rc = b.reserve_host(need, slot);
+        if (rc) break;
+        uint8_t *h_out = b.h_out[slot];
+        auto frame_at = std::make_shared<std::vector<size_t>>((size_t)n + 1, 0);
+        size_t at = 0;
+        for (int f = 0; f < n; f++) {                                          // frame-major on the host: one file after the other
+            (*frame_at)[(size_t)f] = at;
+            for (size_t k = 0; k < jobs.size(); k++) {
+                const size_t len = (*lens)[(size_t)f * jobs.size() + k];
+                if (len) JPEGENC_HIP(hipMemcpyAsync(h_out + at, d_out + (size_t)f * out_total + jobs[k].off, len,
+                                                    hipMemcpyDeviceToHost, b.copy_stream));
                 at += len;
             }
-        JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
-        // assemble the files: headers from this thread's small writer, the scan bytes straight from the
-        // pinned buffer to the sink; frames are independent, so a few host threads share them (each
-        // frame's sink calls stay in order, different frames' calls may interleave - as in encode_batch)
-        std::vector<size_t> frame_at((size_t)n + 1, 0);
-        for (int f = 0; f < n; f++) {
-            size_t sum = 0;
-            for (size_t k = 0; k < jobs.size(); k++) sum += b.h_len[k * (size_t)per_round + (size_t)f];
-            frame_at[(size_t)f + 1] = frame_at[(size_t)f] + sum;
         }
-        std::atomic<int> next(0), failed(0);
-        auto assemble = [&]() {
+        (*frame_at)[(size_t)n] = at;
+        if (more) { rc = code_round(round + 1); if (rc) break; }               // (its half of d_out was downloaded a round ago)
+        JPEGENC_HIP(hipStreamSynchronize(b.copy_stream));
+        // assemble the files in the background: headers from each thread's small writer, the scan bytes straight
+        // from the pinned buffer to the sink; frames are independent, so a few host threads share them (each
+        // frame's sink calls stay in order, different frames' calls may interleave - as in encode_batch)
+        auto next = std::make_shared<std::atomic<int>>(0);
+        auto assemble = [&, lens, frame_at, next, h_out, n, f0]() {
             for (;;) {
-                const int f = next.fetch_add(1);
+                const int f = next->fetch_add(1);
                 if (f >= n || failed.load()) break;
-                size_t pos = frame_at[(size_t)f];
+                size_t pos = (*frame_at)[(size_t)f];
                 Out o;
                 o.sink = sink; o.user = users[f0 + f];
                 write_prologue(o, c, jct);
@@ -1101,9 +1149,9 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
                     const Job &j = jobs[k];
                     write_scan_header(o, L, j.first, j.n, j.ss, j.se);
                     if (j.cap) {
-                        const size_t len = b.h_len[k * (size_t)per_round + (size_t)f];
+                        const size_t len = (*lens)[(size_t)f * jobs.size() + k];
                         o.drain(true);
-                        if (len && !o.failed && sink(o.user, b.h_out + pos, len) != 0) o.failed = true;
+                        if (len && !o.failed && sink(o.user, h_out + pos, len) != 0) o.failed = true;
                         pos += len;
                     } else if (c.restart_interval) {   // empty band: only the restart bookkeeping (encoder.rs:947-951)
                         const uint64_t nb = L.blocks[j.sc.component];
@@ -1121,13 +1169,18 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         int nthreads = (int)(hw ? hw : 4);
         if (nthreads > 8) nthreads = 8;
         if (nthreads > n) nthreads = n;
-        if ((size_t)frame_at[(size_t)n] < ((size_t)4 << 20)) nthreads = 1;      // little to copy: not worth the threads
-        std::vector<std::thread> pool;
-        for (int w = 1; w < nthreads; w++) pool.emplace_back(assemble);
-        assemble();
-        for (auto &th : pool) th.join();
-        if (failed.load()) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
+        if (at < ((size_t)4 << 20)) nthreads = 1;                                // little to copy: not worth the threads
+        if (more || nthreads > 1) {
+            for (int w = more ? 0 : 1; w < nthreads; w++) pools[slot].emplace_back(assemble);
+            if (!more) assemble();
+        } else {
+            assemble();
+        }
     }
+    join(0);
+    join(1);
+    if (rc) return rc;
+    if (failed.load()) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
     return JPEGENC_OK;
 }
 
