@@ -199,6 +199,30 @@ def test_c_example_builds_against_the_header(binding, tmp_path):
     assert r.returncode == 2 and "usage" in r.stderr
 
 
+def _build_cpp_example(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "encode_cpp"
+    libdir = os.path.join(root, "jpeg-encoder_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "encode_cpp.cpp"), "-o", str(exe), "-L" + libdir, "-ljpegenc_mi355x",
+                    "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_cpp_face_builds_and_fails_loudly_without_a_gpu(binding, tmp_path):
+    """include/jpegenc_mi355x.hpp (the reference's Encoder API over the C ABI, header-only) compiles warning-free;
+    without a GPU the example ends in EncodingError{NoDevice} - there is no CPU fallback to fall into."""
+    import subprocess
+    import torch
+    exe = _build_cpp_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU suite runs the example for real")
+    r = subprocess.run([str(exe), str(tmp_path / "some.jpeg")], capture_output=True, text=True)
+    assert r.returncode == 2 and "no usable gfx950 device" in r.stderr, (r.returncode, r.stderr)
+
+
 def test_integration_notes_show_every_entry_point():
     """INTEGRATION.md's Rust `extern "C"` block binds everything include/jpegenc_mi355x.h declares."""
     import os

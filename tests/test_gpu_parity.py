@@ -724,6 +724,25 @@ def test_c_example_program(binding, oracle, synth, tmp_path):
     assert out.read_bytes() == oracle.encode_jpeg(px, 322, 200, oracle.RGB, 82, sampling=(2, 2), progressive_scans=4, optimize=True)
 
 
+def test_cpp_example_program(binding, oracle, tmp_path):
+    """examples/encode_cpp.cpp through include/jpegenc_mi355x.hpp: the crate's README example (new_file + encode),
+    an in-memory progressive 4:2:0 encode, an ImageBuffer source and the two error paths; same bytes as the oracle."""
+    import subprocess
+    from test_abi import _build_cpp_example
+    exe = _build_cpp_example(tmp_path)
+    path = tmp_path / "some.jpeg"
+    r = subprocess.run([str(exe), str(path)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout, r.stderr)
+    tiny = np.array([255, 0, 0, 0, 255, 0, 0, 0, 255, 255, 255, 255], dtype=np.uint8)
+    assert path.read_bytes() == oracle.encode_jpeg(tiny, 2, 2, oracle.RGB, 100)
+    idx = np.arange(64 * 48 * 3, dtype=np.uint64)
+    px = ((idx * 7 + idx // 192) & 0xFF).astype(np.uint8)
+    want = oracle.encode_jpeg(px, 64, 48, oracle.RGB, 85, sampling=(2, 2), progressive_scans=4, density=(1, 72, 72))
+    assert (tmp_path / "some.jpeg.progressive").read_bytes() == want
+    ramp = (np.add.outer(np.arange(24), np.arange(40) * 6) & 0xFF).astype(np.uint8)
+    assert (tmp_path / "some.jpeg.gray").read_bytes() == oracle.encode_jpeg(ramp, 40, 24, oracle.LUMA, 90)
+
+
 @pytest.mark.parametrize("kw", [
     dict(quality=88), dict(quality=75, sampling=(2, 2), restart_interval=5), dict(quality=60, sampling=(4, 1)),
     dict(quality=92, progressive_scans=5, restart_interval=11), dict(quality=80, optimize=True),
