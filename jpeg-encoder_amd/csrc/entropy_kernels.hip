@@ -17,8 +17,8 @@
 //                       more scans give each interval a 16-byte aligned place in the raw buffer
 //                       (scans without restart markers skip this: their one interval is trivial)
 //   4. k_push           (scans without restart markers) every run shifts itself into place in the raw stream:
-//                       linear reads, linear writes, the last word completed from the following run
-//      + k_ff_tiles     0xFF bytes per tile of 256 16-byte chunks
+//                       linear reads, linear writes, the last word completed from the following run; adds its
+//                       0xFF bytes to the counts per tile of 256 16-byte chunks
 //      k_place          (scans with restart markers) one thread per 16-byte chunk of the raw stream: finds the
 //                       run(s) its bits come from, funnel-shifts them into place, adds the 1-padding of
 //                       finalize_bit_buffer at the end of each interval; counts the 0xFF bytes per tile itself
@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
         mine = cs.total;
         p.bits[(size_t)f * p.nblocks + b] = mine;                               // (interval offsets need them, k_interval_len)
     }
+    if (b < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + b] = 0;        // k_push adds its 0xFF counts to these
     const uint32_t upto = wave_inclusive(mine), at = upto - mine;               // bits of the run before this block
     const uint32_t total = (uint32_t)__shfl((int)upto, 63);
     const uint32_t w = b >> 6;
@@ -549,7 +550,7 @@ __global__ void __launch_bounds__(256) k_place(const EntropyParams *params) {
     __shared__ uint32_t trip_first_bit;
     const uint32_t f = blockIdx.y;
     const bool single = p.nintervals == 1;
-    if (single) return;                          // k_push + k_ff_tiles
+    if (single) return;                          // k_push
     const uint32_t total_bits = p.total_bits[f];
     const uint32_t n = p.raw_chunks[f];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -679,6 +680,16 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
     // groups of four words that lie entirely inside the run: five source words, four funnel shifts, one
     // 16-byte store per lane (word by word the kernel was bound by its instruction count, not by its bytes)
     const uint32_t ga = (j0 + 3u) >> 2, gb = hi >> 7;               // groups [ga, gb): 128 * gb <= hi
+    // 0xFF bytes of the words this run writes, per tile of 256 chunks (1 024 words): a run spans one or two
+    // tiles as a rule; those two counts are summed over the wave, anything further goes out lane by lane
+    uint32_t *fftile = p.fftile + (size_t)f * p.max_fftiles;
+    const uint32_t tile0 = j0 >> 10;
+    uint32_t ff0 = 0, ff1 = 0;
+    auto count = [&](uint32_t word_index, uint32_t n) {
+        if (!n) return;
+        const uint32_t tile = word_index >> 10;
+        if (tile == tile0) ff0 += n; else if (tile == tile0 + 1u) ff1 += n; else atomicAdd(&fftile[tile], n);
+    };
     for (uint32_t g4 = ga + lane; g4 < gb; g4 += 64u) {
         const uint32_t rel = g4 * 128u - lo, sh = rel & 31u;
         const uint32_t *src = slot + (rel >> 5);
@@ -689,6 +700,7 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
 #pragma unroll
         for (int k = 0; k < 4; k++) o[k] = __builtin_bswap32(sh ? (m[k] << sh) | (m[k + 1] >> (32u - sh)) : m[k]);
         reinterpret_cast<uint4 *>(raw)[g4] = make_uint4(o[0], o[1], o[2], o[3]);
+        count(g4 * 4u, ff_count4(o[0]) + ff_count4(o[1]) + ff_count4(o[2]) + ff_count4(o[3]));
     }
     // the words before the first and after the last such group (at most three + four, seven more for the last run)
     const uint32_t head_end = min(j1, max(j0, ga * 4u)), tail_begin = max(head_end, min(j1, max(gb, ga) * 4u));
@@ -726,24 +738,12 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
             }
         }
         raw[j] = __builtin_bswap32(v);
+        count(j, ff_count4(v));                  // (byte order does not matter to a count)
     }
-}
-
-// 0xFF bytes per tile of 256 chunks for the scans k_push placed (k_place counts its own); bytes beyond the
-// stream's length are zero, so they never count.
-__global__ void __launch_bounds__(256) k_ff_tiles(const EntropyParams *params) {
-    Params p = JPEGENC_JOB(params);
-    if (p.nintervals != 1) return;
-    __shared__ uint32_t part[4];
-    const uint32_t f = blockIdx.y, n = (((p.total_bits[f] + 7u) >> 3) + 15u) >> 4;
-    const uint4 *raw = reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride);
-    for (uint32_t tile = blockIdx.x; tile * 256u < n; tile += gridDim.x) {
-        const uint32_t q = tile * 256u + threadIdx.x;
-        const uint32_t sum = wave_sum(q < n ? ff_count16(raw[q]) : 0u);
-        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = sum;
-        __syncthreads();
-        if (threadIdx.x == 0) p.fftile[(size_t)f * p.max_fftiles + tile] = part[0] + part[1] + part[2] + part[3];
-        __syncthreads();
+    ff0 = wave_sum(ff0); ff1 = wave_sum(ff1);
+    if (lane == 0) {
+        if (ff0) atomicAdd(&fftile[tile0], ff0);
+        if (ff1) atomicAdd(&fftile[tile0 + 1u], ff1);
     }
 }
 
@@ -896,10 +896,7 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
     const uint32_t cgrid = min(fftiles, kChunkGrid);
     bool any_single = false, any_multi = false;
     for (int j = 0; j < njobs; j++) { any_single = any_single || jobs[j].nintervals == 1; any_multi = any_multi || jobs[j].nintervals > 1; }
-    if (any_single) {
-        hipLaunchKernelGGL(k_push, dim3((nwaves + 3u) / 4u, frames, njobs), dim3(256), 0, st, d_params);
-        hipLaunchKernelGGL(k_ff_tiles, dim3(cgrid, frames, njobs), dim3(256), 0, st, d_params);
-    }
+    if (any_single) hipLaunchKernelGGL(k_push, dim3((nwaves + 3u) / 4u, frames, njobs), dim3(256), 0, st, d_params);
     if (any_multi)
         hipLaunchKernelGGL(k_place, dim3(min((fftiles + kPlaceSub - 1u) / kPlaceSub, kChunkGrid), frames, njobs), dim3(256), 0, st, d_params);
     e = scan(d_params, SCAN_FFTILES, fftiles, njobs, frames, st);
