@@ -843,6 +843,41 @@ __global__ void __launch_bounds__(256) k_gather_scans(const GatherArgs a, const 
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u) d[i] = s[i];
 }
 
+// lengths len[k * per_round + f] -> positions pos[f * njobs + k] (multiples of 16), pos[frames * njobs] = total
+__global__ void __launch_bounds__(256) k_batch_prefix(const BatchGatherArgs a, const uint32_t *len, uint64_t *pos) {
+    __shared__ uint64_t sums[256];
+    const uint32_t n = a.frames * a.njobs, per = (n + 255u) / 256u;
+    const uint32_t first = threadIdx.x * per, end = min(n, first + per);
+    uint64_t sum = 0;
+    for (uint32_t i = first; i < end; i++) sum += (len[(size_t)(i % a.njobs) * a.per_round + i / a.njobs] + 15u) & ~15u;
+    sums[threadIdx.x] = sum;
+    __syncthreads();
+    uint64_t at = 0;
+    for (uint32_t t = 0; t < threadIdx.x; t++) at += sums[t];      // 256 values: not worth a tree
+    for (uint32_t i = first; i < end; i++) {
+        pos[i] = at;
+        at += (len[(size_t)(i % a.njobs) * a.per_round + i / a.njobs] + 15u) & ~15u;
+    }
+    if (n == 0 ? threadIdx.x == 0 : (first < n && end == n)) pos[n] = at;            // the thread that placed the last segment
+}
+
+__global__ void __launch_bounds__(256) k_batch_gather(const BatchGatherArgs a, const uint8_t *src, const uint32_t *len,
+                                                      const uint64_t *pos, uint8_t *dst) {
+    const uint32_t i = blockIdx.x, f = i / a.njobs, k = i - f * a.njobs;
+    const uint32_t n16 = (len[(size_t)k * a.per_round + f] + 15u) >> 4;            // (the bytes after a segment's end ride along)
+    const uint4 *s = reinterpret_cast<const uint4 *>(src + (size_t)f * a.frame_stride + a.off[k]);
+    uint4 *d = reinterpret_cast<uint4 *>(dst + pos[i]);
+    for (uint32_t c = blockIdx.y * 256u + threadIdx.x; c < n16; c += gridDim.y * 256u) d[c] = s[c];
+}
+
+hipError_t launch_batch_gather(const BatchGatherArgs &a, const void *d_src, const uint32_t *d_len, uint64_t *d_pos, void *d_dst,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(k_batch_prefix, dim3(1), dim3(256), 0, st, a, d_len, d_pos);
+    hipLaunchKernelGGL(k_batch_gather, dim3(a.frames * a.njobs, a.frame_stride >= ((uint64_t)4 << 20) ? 64 : 4), dim3(256), 0, st, a,
+                       (const uint8_t *)d_src, d_len, d_pos, (uint8_t *)d_dst);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_scans(const GatherArgs &a, const void *d_src, const uint32_t *d_len, void *d_dst, hipStream_t st) {
     hipLaunchKernelGGL(k_gather_scans, dim3(a.n, 64), dim3(256), 0, st, a, (const uint8_t *)d_src, d_len, (uint8_t *)d_dst);
     return hipGetLastError();

@@ -18,6 +18,14 @@ struct GatherArgs {
     uint64_t off[kGatherMaxScans];      // byte offset of each scan's output inside the source buffer
 };
 
+// k_batch_prefix / k_batch_gather: the coded scans of a ROUND of frames packed back to back (frame-major, scans in
+// order, every segment at a 16-byte aligned position) so that one copy brings a round to the host
+struct BatchGatherArgs {
+    uint32_t frames, njobs, per_round, reserved;
+    uint64_t frame_stride;              // bytes between the frames' outputs
+    uint64_t off[kGatherMaxScans];      // byte offset of each scan's output inside a frame's output
+};
+
 // One scan = one entropy-coded segment: either all components interleaved (blocks in MCU order,
 // encode_image_interleaved, encoder.rs:747-790) or one component's blocks in planar order
 // (sequential / progressive scans, encoder.rs:823-861, 885-972).

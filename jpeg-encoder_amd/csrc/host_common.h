@@ -42,6 +42,8 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
 // entropy_kernels.hip
 hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t stream);
 
+hipError_t launch_batch_gather(const BatchGatherArgs &a, const void *d_src, const uint32_t *d_len, uint64_t *d_pos, void *d_dst,
+                               hipStream_t stream);
 hipError_t launch_gather_scans(const GatherArgs &a, const void *d_src, const uint32_t *d_len, void *d_dst, hipStream_t stream);
 
 // capi_entropy.hip

@@ -417,10 +417,11 @@ struct SmallBatchBuffers {
 // Buffers of the device-resident batch path (jpegenc_encoder_encode_batch_device), kept in the handle
 // across calls and only ever grown: pinned allocations of a few hundred MB cost tens of milliseconds.
 struct BatchBuffers {
-    void *d_coeffs = nullptr, *d_out = nullptr, *d_ws = nullptr;
+    void *d_coeffs = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_packed = nullptr;      // d_packed: a round's scans back to back
+    uint64_t *d_pos = nullptr;
     uint32_t *d_len = nullptr, *h_len = nullptr;
     uint8_t *h_out[2] = {nullptr, nullptr};      // two: the files of one round are assembled while the next round is coded and fetched
-    size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, h_out_cap[2] = {0, 0};
+    size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, packed_cap = 0, pos_cap = 0, h_out_cap[2] = {0, 0};
     static int grow_device(void **p, size_t *cap, size_t need) {
         if (need <= *cap) return JPEGENC_OK;
         if (*p) (void)hipFree(*p);
@@ -444,6 +445,8 @@ struct BatchBuffers {
         if (!rc) rc = grow_device(&d_coeffs, &coeffs_cap, coeffs);
         if (!rc) rc = grow_device(&d_out, &out_cap, out);
         if (!rc) rc = grow_device(&d_ws, &ws_cap, ws);
+        if (!rc) rc = grow_device(&d_packed, &packed_cap, out + 32 * nlen);             // (+16 per segment: aligned positions)
+        if (!rc) rc = grow_device((void **)&d_pos, &pos_cap, (nlen + 2) * sizeof(uint64_t));
         if (rc) return rc;
         if (nlen > len_cap) {
             if (d_len) (void)hipFree(d_len);
@@ -468,6 +471,8 @@ struct BatchBuffers {
         if (d_coeffs) (void)hipFree(d_coeffs);
         if (d_out) (void)hipFree(d_out);
         if (d_ws) (void)hipFree(d_ws);
+        if (d_packed) (void)hipFree(d_packed);
+        if (d_pos) (void)hipFree(d_pos);
         if (d_len) (void)hipFree(d_len);
         if (h_len) (void)hipHostFree(h_len);
         for (auto *h : h_out) if (h) (void)hipHostFree(h);
@@ -1068,6 +1073,7 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
     // Software pipeline over rounds: code(r+1) on the encoder's stream overlaps the download of round r on the
     // copy stream, which overlaps the assembly of the files of round r-1 on host threads.
     const size_t round_out = out_total * (size_t)per_round;
+    const size_t packed_half = round_out + 16 * nlen;
     auto code_round = [&](int r) -> int {                     // enqueue only
         const int f0 = r * per_round, half = r & 1;
         const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
@@ -1091,6 +1097,15 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
             if (e) return e;
         }
         JPEGENC_HIP(hipMemcpyAsync(b.h_len + (size_t)half * nlen, d_len, nlen * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
+        // pack the round's scans back to back (frame-major, 16-byte aligned): ONE download per round instead of one
+        // per frame and scan (1 024 small frames were 1 024 copies, most of the round's time)
+        BatchGatherArgs ga;
+        ga.frames = (uint32_t)n; ga.njobs = (uint32_t)jobs.size(); ga.per_round = (uint32_t)per_round; ga.reserved = 0;
+        ga.frame_stride = out_total;
+        for (size_t k = 0; k < jobs.size(); k++) ga.off[k] = jobs[k].off;
+        const hipError_t ge = launch_batch_gather(ga, (const uint8_t *)b.d_out + (size_t)half * round_out, d_len,
+                                                  b.d_pos + (size_t)half * (nlen + 1), (uint8_t *)b.d_packed + (size_t)half * packed_half, ctx.stream);
+        if (ge != hipSuccess) return hip_fail(ge, "gather kernel launch");
         JPEGENC_HIP(hipEventRecord(b.coded[half], ctx.stream));
         return JPEGENC_OK;
     };
@@ -1101,7 +1116,7 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
         const bool more = f0 + per_round < num_frames;
         const uint32_t *h_len = b.h_len + (size_t)(round & 1) * nlen;
-        const uint8_t *d_out = (const uint8_t *)b.d_out + (size_t)(round & 1) * round_out;
+        const uint8_t *d_packed = (const uint8_t *)b.d_packed + (size_t)(round & 1) * packed_half;
         JPEGENC_HIP(hipEventSynchronize(b.coded[round & 1]));                  // this round is coded, its lengths are on the host
         const int slot = round & 1;
         join(slot);                                                            // the files last assembled out of this staging buffer
@@ -1113,23 +1128,19 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
             for (size_t k = 0; k < jobs.size(); k++) {
                 const uint32_t len = h_len[k * (size_t)per_round + (size_t)f];
                 (*lens)[(size_t)f * jobs.size() + k] = len;
-                need += len;
+                need += ((size_t)len + 15) & ~(size_t)15;
             }
         rc = b.reserve_host(need, slot);
         if (rc) break;
         uint8_t *h_out = b.h_out[slot];
         auto frame_at = std::make_shared<std::vector<size_t>>((size_t)n + 1, 0);
         size_t at = 0;
-        for (int f = 0; f < n; f++) {                                          // frame-major on the host: one file after the other
+        for (int f = 0; f < n; f++) {                                          // the order and alignment k_batch_prefix used
             (*frame_at)[(size_t)f] = at;
-            for (size_t k = 0; k < jobs.size(); k++) {
-                const size_t len = (*lens)[(size_t)f * jobs.size() + k];
-                if (len) JPEGENC_HIP(hipMemcpyAsync(h_out + at, d_out + (size_t)f * out_total + jobs[k].off, len,
-                                                    hipMemcpyDeviceToHost, b.copy_stream));
-                at += len;
-            }
+            for (size_t k = 0; k < jobs.size(); k++) at += ((size_t)(*lens)[(size_t)f * jobs.size() + k] + 15) & ~(size_t)15;
         }
         (*frame_at)[(size_t)n] = at;
+        if (at) JPEGENC_HIP(hipMemcpyAsync(h_out, d_packed, at, hipMemcpyDeviceToHost, b.copy_stream));
         if (more) { rc = code_round(round + 1); if (rc) break; }               // (its half of d_out was downloaded a round ago)
         JPEGENC_HIP(hipStreamSynchronize(b.copy_stream));
         // assemble the files in the background: headers from each thread's small writer, the scan bytes straight
@@ -1152,7 +1163,7 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
                         const size_t len = (*lens)[(size_t)f * jobs.size() + k];
                         o.drain(true);
                         if (len && !o.failed && sink(o.user, h_out + pos, len) != 0) o.failed = true;
-                        pos += len;
+                        pos += (len + 15) & ~(size_t)15;
                     } else if (c.restart_interval) {   // empty band: only the restart bookkeeping (encoder.rs:947-951)
                         const uint64_t nb = L.blocks[j.sc.component];
                         for (uint64_t bi = (uint64_t)c.restart_interval, r = 0; bi < nb; bi += (uint64_t)c.restart_interval, r++) {
