@@ -661,7 +661,19 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
     const uint32_t f = blockIdx.y, lane = threadIdx.x & 63u;
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (w >= p.nwaves) return;
-    const uint32_t total_bits = p.total_bits[f];
+    const uint32_t *wsum = p.wsum + (size_t)f * p.nwaves;
+    uint32_t lo, hi, total_bits;
+    if (p.fused_prefix) {                        // few runs: every wave adds up the lengths itself, no scan launch before this kernel
+        uint32_t before = 0, all = 0;
+        for (uint32_t i = lane; i < p.nwaves; i += 64u) { const uint32_t v = wsum[i]; all += v; if (i < w) before += v; }
+        lo = wave_sum(before); total_bits = wave_sum(all);
+        hi = lo + wsum[w];
+        if (w == 0 && lane == 0) p.total_bits[f] = total_bits;
+    } else {
+        const uint32_t *woff = p.woff + (size_t)f * p.nwaves;
+        total_bits = p.total_bits[f];
+        lo = woff[w]; hi = w + 1 == p.nwaves ? total_bits : woff[w + 1];
+    }
     const uint32_t bytes = (total_bits + 7u) >> 3, chunks = (bytes + 15u) >> 4;
     if (w == 0 && lane == 0) {                   // the trivial interval bookkeeping of the scan
         p.ivbit[f] = 0; p.ilen[f] = bytes; p.ichunks[f] = chunks; p.iexact[f] = 0; p.ichunk[f] = 0;
@@ -669,11 +681,9 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
         p.nfftiles[f] = (chunks + 255u) >> 8;
         p.out_bytes[f] = 0;                      // k_stuff sets the length
     }
-    const uint32_t *woff = p.woff + (size_t)f * p.nwaves;
     const uint32_t *slots = reinterpret_cast<const uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride);
     uint32_t *raw = reinterpret_cast<uint32_t *>(p.raw + (size_t)f * p.raw_stride);
     const bool last = w + 1 == p.nwaves;
-    const uint32_t lo = woff[w], hi = last ? total_bits : woff[w + 1];
     const uint32_t *slot = slots + (size_t)w * p.slot_words;
     const uint32_t j0 = (lo + 31u) >> 5;                              // first word whose first bit is ours
     const uint32_t j1 = last ? chunks * 4u : (hi + 31u) >> 5;         // the last run also owns the padding and the zero fill
@@ -720,15 +730,15 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
                 // the word runs past our end: bits of the following run(s), then, at the end of the stream, the padding
                 uint32_t next = w + 1;
                 while (have < 32u && next < p.nwaves) {
-                    const uint32_t nlo = woff[next], nhi = next + 1 < p.nwaves ? woff[next + 1] : total_bits;
-                    const uint32_t k = min(32u - have, nhi - nlo);
+                    const uint32_t next_bits = wsum[next];
+                    const uint32_t k = min(32u - have, next_bits);
                     if (k) {
                         uint32_t t = __builtin_bswap32(slots[(size_t)next * p.slot_words]);
                         if (k < 32u) t &= ~(0xFFFFFFFFu >> k);
                         v |= t >> have;
                         have += k;
                     }
-                    if (k < nhi - nlo) break;                        // that run goes on: the word is full
+                    if (k < next_bits) break;                        // that run goes on: the word is full
                     next++;
                 }
                 if (have < 32u) {                                    // end of the stream inside this word
@@ -764,7 +774,20 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams *params) {
         uint32_t pos = 0, o = 0, iv = 0, j = 0, ilen = 0, nchunks = 0;
         const uint4 v = active ? reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride)[q] : make_uint4(0, 0, 0, 0);
         uint32_t tile_ff;
-        const uint32_t ffprefix = p.fftile_off[(size_t)f * p.max_fftiles + tile] + wg_exclusive(ff_count16(v), part, &tile_ff);
+        uint32_t tiles_before;
+        if (p.fused_prefix) {                    // few tiles: add up the counts of the tiles before this one here, no scan launch
+            uint32_t sum = 0;
+            for (uint32_t t = threadIdx.x; t < tile; t += 256u) sum += p.fftile[(size_t)f * p.max_fftiles + t];
+            sum = wave_sum(sum);
+            __syncthreads();                     // (part is reused below)
+            if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            tiles_before = part[0] + part[1] + part[2] + part[3];
+            __syncthreads();
+        } else {
+            tiles_before = p.fftile_off[(size_t)f * p.max_fftiles + tile];
+        }
+        const uint32_t ffprefix = tiles_before + wg_exclusive(ff_count16(v), part, &tile_ff);
         if (active) {
             // interval of this chunk: the last i with ichunk[i] <= q
             uint32_t lo = 0, hi = p.nintervals;
@@ -910,17 +933,24 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
         nblocks = max(nblocks, jobs[j].nblocks); nwaves = max(nwaves, jobs[j].nwaves);
         nintervals = max(nintervals, jobs[j].nintervals); fftiles = max(fftiles, jobs[j].max_fftiles);
     }
+    bool any_single = false, any_multi = false;
+    for (int j = 0; j < njobs; j++) { any_single = any_single || jobs[j].nintervals == 1; any_multi = any_multi || jobs[j].nintervals > 1; }
+    // few runs, few tiles, no restart markers (every frame up to about 1080p): the consumers of the two prefix sums
+    // compute them on the fly and the scan launches - pure launch latency at that size - are skipped
+    const bool fused_prefix = !any_multi && nwaves <= kFusedPrefixMax && fftiles <= 4u * kFusedPrefixMax;   // (fftiles is the worst-case bound)
     for (int first = 0; first < njobs; first += (int)kScansPerStore) {
         ParamPack pack;
         pack.n = (uint32_t)min(njobs - first, (int)kScansPerStore);
-        for (uint32_t j = 0; j < pack.n; j++) pack.p[j] = jobs[first + j];
+        for (uint32_t j = 0; j < pack.n; j++) { pack.p[j] = jobs[first + j]; pack.p[j].fused_prefix = fused_prefix ? 1u : 0u; }
         hipLaunchKernelGGL(k_store_params, dim3(1), dim3(256), 0, st, pack, d_params + first);
     }
     hipError_t e = hipSuccess;
     const uint32_t bgrid = (nblocks + 255u) / 256u;
     hipLaunchKernelGGL(k_block_code, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
-    e = scan(d_params, SCAN_WAVES, nwaves, njobs, frames, st);
-    if (e != hipSuccess) return e;
+    if (!fused_prefix) {
+        e = scan(d_params, SCAN_WAVES, nwaves, njobs, frames, st);
+        if (e != hipSuccess) return e;
+    }
     if (nintervals > 1) {      // (scans with a single interval: k_place writes their trivial results)
         hipLaunchKernelGGL(k_interval_len, dim3((nintervals + 255u) / 256u, frames, njobs), dim3(256), 0, st, d_params);
         e = scan(d_params, SCAN_ILEN, nintervals, njobs, frames, st);
@@ -929,13 +959,13 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
         if (e != hipSuccess) return e;
     }
     const uint32_t cgrid = min(fftiles, kChunkGrid);
-    bool any_single = false, any_multi = false;
-    for (int j = 0; j < njobs; j++) { any_single = any_single || jobs[j].nintervals == 1; any_multi = any_multi || jobs[j].nintervals > 1; }
     if (any_single) hipLaunchKernelGGL(k_push, dim3((nwaves + 3u) / 4u, frames, njobs), dim3(256), 0, st, d_params);
     if (any_multi)
         hipLaunchKernelGGL(k_place, dim3(min((fftiles + kPlaceSub - 1u) / kPlaceSub, kChunkGrid), frames, njobs), dim3(256), 0, st, d_params);
-    e = scan(d_params, SCAN_FFTILES, fftiles, njobs, frames, st);
-    if (e != hipSuccess) return e;
+    if (!fused_prefix) {
+        e = scan(d_params, SCAN_FFTILES, fftiles, njobs, frames, st);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_stuff, dim3(cgrid, frames, njobs), dim3(256), 0, st, d_params);
     return hipGetLastError();
 }
