@@ -232,13 +232,27 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
 
 int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                 const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
-                size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st) {
+                size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st,
+                std::string *stored_params) {
     EntropyParams p, *d_params = nullptr;
     const int rc = fill_scan(d_coeffs, coeff_frame_stride, frames, L, sc, tables, d_lut, d_out, out_frame_stride, d_out_lengths,
                              d_ws, ws_bytes, st, &p, &d_params);
     if (rc) return rc;
-    const hipError_t e = launch_entropy_scans(&p, 1, d_params, frames, st);
+    const hipError_t e = launch_entropy_scans(&p, 1, d_params, frames, st, stored_params);
     if (e != hipSuccess) return hip_fail(e, "entropy kernels");
+    return JPEGENC_OK;
+}
+
+int scan_store_params(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
+                      const jpegenc_scan &sc, const void *d_lut, void *d_out, size_t out_frame_stride, uint32_t *d_out_lengths,
+                      void *d_ws, size_t ws_bytes, hipStream_t st, std::string *stored_params) {
+    if (!d_lut) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan_store_params needs prepared tables");
+    EntropyParams p, *d_params = nullptr;
+    const int rc = fill_scan(d_coeffs, coeff_frame_stride, frames, L, sc, nullptr, d_lut, d_out, out_frame_stride, d_out_lengths,
+                             d_ws, ws_bytes, st, &p, &d_params);
+    if (rc) return rc;
+    const hipError_t e = store_entropy_params(&p, 1, d_params, st, stored_params);
+    if (e != hipSuccess) return hip_fail(e, "entropy parameter store");
     return JPEGENC_OK;
 }
 

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string>
 
 #include "entropy_params.h"
 #include "host_common.h"
@@ -926,25 +927,49 @@ static hipError_t scan(const EntropyParams *d_params, int which, uint32_t n_max,
 
 // njobs <= kMaxScansPerLaunch scans (same number of frames each) in one launch sequence; d_params: room
 // for njobs parameter blocks in device memory
-hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t st) {
-    if (njobs < 1 || njobs > (int)kMaxScansPerLaunch) return hipErrorInvalidValue;
-    uint32_t nblocks = 0, nwaves = 0, nintervals = 0, fftiles = 0;
+struct LaunchShape { uint32_t nblocks, nwaves, nintervals, fftiles; bool any_single, any_multi, fused_prefix; };
+static LaunchShape shape_of(const EntropyParams *jobs, int njobs) {
+    LaunchShape s = {0, 0, 0, 0, false, false, false};
     for (int j = 0; j < njobs; j++) {
-        nblocks = max(nblocks, jobs[j].nblocks); nwaves = max(nwaves, jobs[j].nwaves);
-        nintervals = max(nintervals, jobs[j].nintervals); fftiles = max(fftiles, jobs[j].max_fftiles);
+        s.nblocks = max(s.nblocks, jobs[j].nblocks); s.nwaves = max(s.nwaves, jobs[j].nwaves);
+        s.nintervals = max(s.nintervals, jobs[j].nintervals); s.fftiles = max(s.fftiles, jobs[j].max_fftiles);
+        s.any_single = s.any_single || jobs[j].nintervals == 1; s.any_multi = s.any_multi || jobs[j].nintervals > 1;
     }
-    bool any_single = false, any_multi = false;
-    for (int j = 0; j < njobs; j++) { any_single = any_single || jobs[j].nintervals == 1; any_multi = any_multi || jobs[j].nintervals > 1; }
     // few runs, few tiles, no restart markers (every frame up to about 1080p): the consumers of the two prefix sums
     // compute them on the fly and the scan launches - pure launch latency at that size - are skipped
-    const bool fused_prefix = !any_multi && nwaves <= kFusedPrefixMax && fftiles <= 4u * kFusedPrefixMax;   // (fftiles is the worst-case bound)
+    s.fused_prefix = !s.any_multi && s.nwaves <= kFusedPrefixMax && s.fftiles <= 4u * kFusedPrefixMax;   // (fftiles is the worst-case bound)
+    return s;
+}
+
+// Puts the parameter blocks of njobs scans at d_params unless `stored` says they are there already.
+hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, hipStream_t st, std::string *stored) {
+    if (njobs < 1 || njobs > (int)kMaxScansPerLaunch) return hipErrorInvalidValue;
+    const LaunchShape shape = shape_of(jobs, njobs);
+    std::string now;
+    if (stored) {            // (the blocks were zero-filled before their fields were set: comparable byte for byte)
+        now.assign((const char *)&d_params, sizeof d_params);
+        now.append((const char *)jobs, sizeof(EntropyParams) * (size_t)njobs);
+        now.push_back(shape.fused_prefix ? 1 : 0);
+        if (now == *stored) return hipSuccess;
+        stored->clear();
+    }
     for (int first = 0; first < njobs; first += (int)kScansPerStore) {
         ParamPack pack;
         pack.n = (uint32_t)min(njobs - first, (int)kScansPerStore);
-        for (uint32_t j = 0; j < pack.n; j++) { pack.p[j] = jobs[first + j]; pack.p[j].fused_prefix = fused_prefix ? 1u : 0u; }
+        for (uint32_t j = 0; j < pack.n; j++) { pack.p[j] = jobs[first + j]; pack.p[j].fused_prefix = shape.fused_prefix ? 1u : 0u; }
         hipLaunchKernelGGL(k_store_params, dim3(1), dim3(256), 0, st, pack, d_params + first);
     }
-    hipError_t e = hipSuccess;
+    if (stored) stored->swap(now);
+    return hipGetLastError();
+}
+
+hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t st,
+                                std::string *stored) {
+    hipError_t e = store_entropy_params(jobs, njobs, d_params, st, stored);
+    if (e != hipSuccess) return e;
+    const LaunchShape shape = shape_of(jobs, njobs);
+    const uint32_t nblocks = shape.nblocks, nwaves = shape.nwaves, nintervals = shape.nintervals, fftiles = shape.fftiles;
+    const bool any_single = shape.any_single, any_multi = shape.any_multi, fused_prefix = shape.fused_prefix;
     const uint32_t bgrid = (nblocks + 255u) / 256u;
     hipLaunchKernelGGL(k_block_code, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
     if (!fused_prefix) {

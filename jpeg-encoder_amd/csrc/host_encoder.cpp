@@ -243,6 +243,7 @@ struct DeviceCtx {
     static constexpr size_t kFirstPiece = 256 << 10;      // bytes of coded data fetched together with the lengths
     uint32_t *d_scan_len = nullptr, *h_scan_len = nullptr;     // kMaxScans entries
     void *d_lut = nullptr;
+    std::string stored_scan_params;    // the parameter blocks a single-scan frame left in d_scan_ws (launch_entropy_scans)
     std::string lut_key;               // the Huffman tables d_lut was built from (uploads of unchanged tables are skipped)
     static constexpr int kMaxScans = 4 * 64;
     uint8_t *h_scan_out = nullptr;
@@ -768,6 +769,13 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         return JPEGENC_OK;
     };
     if (c.device_entropy && supported && !optimize) { rc = ensure_lut(); if (rc) return rc; }
+    // likewise the parameter block of a single scan: stored outside any capture (and only when it differs from what
+    // the workspace holds), so that a replayed sequence finds it in place
+    if (c.device_entropy && supported && !optimize && jobs.size() == 1 && jobs[0].cap) {
+        rc = scan_store_params(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, ctx.d_lut, (uint8_t *)ctx.d_gather + kGatherHeader, jobs[0].cap,
+                               (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params);
+        if (rc) return rc;
+    }
     if (how == CAPTURE) JPEGENC_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
     struct CaptureGuard {            // a failure between begin and end must not leave the stream capturing
         hipStream_t st; bool active;
@@ -806,14 +814,16 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                         batch.push_back(ScanJob{j.sc, (uint8_t *)ctx.d_scan_out + j.off, j.cap, ctx.d_scan_len + k,
                                                 (uint8_t *)ctx.d_scan_ws + j.ws_off, j.ws});
                     }
+                    ctx.stored_scan_params.clear();
                     rc = scan_device_multi(ctx.d_coeffs, L.total_blocks, 1, L, batch.data(), (int)batch.size(), ctx.d_lut, ctx.stream);
                     if (rc) return rc;
                 } else if (jobs.size() == 1 && jobs[0].cap) {
                     // a single scan (every baseline frame) is coded straight into the gathered layout: [length][bytes]
                     rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, nullptr, ctx.d_lut, (uint8_t *)ctx.d_gather + kGatherHeader,
-                                     jobs[0].cap, (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream);
+                                     jobs[0].cap, (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params);
                     if (rc) return rc;
                 } else {
+                    ctx.stored_scan_params.clear();
                     for (size_t k = 0; k < jobs.size(); k++) {
                         Job &j = jobs[k];
                         if (!j.cap) continue;

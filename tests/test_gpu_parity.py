@@ -842,6 +842,23 @@ def test_replayed_launch_sequence_follows_content_and_settings(binding, oracle, 
                                                                      qpresets=(oracle.Q_FLAT, oracle.Q_FLAT))
 
 
+def test_replayed_sequence_after_a_single_other_frame(binding, oracle, synth):
+    """A, A, A captures and replays A's launch sequence; ONE frame of another geometry in between is enqueued
+    directly and leaves A's sequence in place - but not A's scan parameters or the workspace contents: the next A
+    replays and must find everything it reads restored (parameter blocks are stored outside the sequence)."""
+    a = [synth.lcg_image(200, 120, 3, 40 + i) for i in range(6)]
+    b = [synth.lcg_image(96, 72, 3, 50 + i) for i in range(3)]
+    e = binding.Encoder(80)
+    for px in a[:3]:
+        assert e.encode(px, 200, 120, binding.RGB) == oracle.encode_jpeg(px, 200, 120, oracle.RGB, 80)
+    for i in range(3):
+        assert e.encode(b[i], 96, 72, binding.RGB) == oracle.encode_jpeg(b[i], 96, 72, oracle.RGB, 80)
+        assert e.encode(a[3 + i], 200, 120, binding.RGB) == oracle.encode_jpeg(a[3 + i], 200, 120, oracle.RGB, 80), i
+    lum = synth.lcg_image(200, 120, 1, 9)
+    assert e.encode(lum, 200, 120, binding.LUMA) == oracle.encode_jpeg(lum, 200, 120, oracle.LUMA, 80)       # other colour type, same size
+    assert e.encode(a[0], 200, 120, binding.RGB) == oracle.encode_jpeg(a[0], 200, 120, oracle.RGB, 80)
+
+
 @pytest.mark.parametrize("interval", [1, 2, 63, 65535])
 def test_restart_interval_extremes(binding, oracle, synth, interval):
     """Every MCU its own restart interval (thousands of intervals: the interval prefix sums and the RSTn
