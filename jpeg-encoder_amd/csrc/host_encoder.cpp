@@ -1523,22 +1523,27 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
             int nt = (int)(hwt ? hwt : 4);
             if (nt > 8) nt = 8;
             if (nt > n) nt = n;
-            std::atomic<int> nextf(0);
-            auto copy = [&]() {
-                for (;;) {
-                    const int i = nextf.fetch_add(1);
-                    if (i >= n) break;
-                    memcpy(sb.h[slot] + (size_t)i * frame_bytes, frames[first + i], frame_bytes);
-                }
-            };
-            std::vector<std::thread> th;
-            for (int t = 1; t < nt; t++) th.emplace_back(copy);
-            copy();
-            for (auto &x : th) x.join();
-            if (hipSetDevice(e->device) != hipSuccess ||
-                hipMemcpyAsync(sb.d[slot], sb.h[slot], (size_t)n * frame_bytes, hipMemcpyHostToDevice, sb.up) != hipSuccess ||
-                hipEventRecord(sb.done[slot], sb.up) != hipSuccess)
-                up_status.store(JPEGENC_ERR_HIP);
+            // in four pieces: the upload of one piece runs while the threads stage the next
+            if (hipSetDevice(e->device) != hipSuccess) { up_status.store(JPEGENC_ERR_HIP); return; }
+            const int pieces = n >= 32 ? 4 : 1;
+            for (int pc = 0; pc < pieces; pc++) {
+                const int lo = (int)((long long)n * pc / pieces), hi = (int)((long long)n * (pc + 1) / pieces);
+                std::atomic<int> nextf(lo);
+                auto copy = [&]() {
+                    for (;;) {
+                        const int i = nextf.fetch_add(1);
+                        if (i >= hi) break;
+                        memcpy(sb.h[slot] + (size_t)i * frame_bytes, frames[first + i], frame_bytes);
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < nt; t++) th.emplace_back(copy);
+                copy();
+                for (auto &x : th) x.join();
+                if (hipMemcpyAsync((uint8_t *)sb.d[slot] + (size_t)lo * frame_bytes, sb.h[slot] + (size_t)lo * frame_bytes, (size_t)(hi - lo) * frame_bytes,
+                                   hipMemcpyHostToDevice, sb.up) != hipSuccess) { up_status.store(JPEGENC_ERR_HIP); return; }
+            }
+            if (hipEventRecord(sb.done[slot], sb.up) != hipSuccess) up_status.store(JPEGENC_ERR_HIP);
         };
         stage_and_upload(0, 0);
         for (int first = 0, r = 0; first < num_frames; first += per_round, r++) {
