@@ -842,6 +842,38 @@ def test_replayed_launch_sequence_follows_content_and_settings(binding, oracle, 
                                                                      qpresets=(oracle.Q_FLAT, oracle.Q_FLAT))
 
 
+def test_device_batch_sink_failure_in_a_later_round(binding, oracle, synth):
+    """The device-resident batch runs in pipelined rounds with the files assembled by background threads: a sink
+    that fails in the middle of the batch must end the call with ERR_WRITE (no hang, no crash), and the handle
+    must be usable afterwards."""
+    import ctypes as C
+    import os
+    import torch
+    w, h, n = 96, 80, 40
+    frames = np.stack([synth.lcg_image(w, h, 3, 900 + i) for i in range(n)])
+    d = torch.from_numpy(frames.reshape(n, -1).copy()).to("cuda:0")
+    e = binding.Encoder(85)
+    seen = []
+
+    def sink(user, ptr, nbytes):
+        seen.append(user or 0)
+        return 3 if (user or 0) == 19 else 0
+
+    cb = binding.WRITE_FN(sink)
+    users = (C.c_void_p * n)(*range(n))
+    fn = binding.lib().jpegenc_encoder_encode_batch_device
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, binding.WRITE_FN, C.POINTER(C.c_void_p)]
+    os.environ["JPEGENC_BATCH_ROUND_FRAMES"] = "8"
+    try:
+        rc = fn(e._h, d.data_ptr(), w * h * 3, n, w, h, binding.RGB, cb, users)
+        assert rc == binding.ERR_WRITE and 19 in seen
+        got = e.encode_batch_device(d.data_ptr(), w * h * 3, n, w, h, binding.RGB)          # five rounds, all fine now
+    finally:
+        del os.environ["JPEGENC_BATCH_ROUND_FRAMES"]
+    for i in (0, 7, 8, 19, 39):
+        assert got[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, 85), i
+
+
 def test_replayed_sequence_after_a_single_other_frame(binding, oracle, synth):
     """A, A, A captures and replays A's launch sequence; ONE frame of another geometry in between is enqueued
     directly and leaves A's sequence in place - but not A's scan parameters or the workspace contents: the next A
