@@ -584,9 +584,11 @@ def test_randomised_configurations(binding, oracle, synth):
     import os
     rng = np.random.default_rng(int(os.environ.get("JPEGENC_FUZZ_SEED", "20261002")))
     samplings = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 2), (1, 4), (2, 4)]
+    # (JPEGENC_FUZZ_MAX_W / _H: larger frames reach the multi-tile prefix sums and thousands of runs per scan)
+    max_w, max_h = int(os.environ.get("JPEGENC_FUZZ_MAX_W", "200")), int(os.environ.get("JPEGENC_FUZZ_MAX_H", "120"))
     for trial in range(int(os.environ.get("JPEGENC_FUZZ_TRIALS", "60"))):     # longer soaks: set the two variables
         ct = int(rng.integers(0, 9))
-        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        w, h = int(rng.integers(1, max_w)), int(rng.integers(1, max_h))
         px = rng.integers(0, 256, (h, w, binding.BPP[ct]), dtype=np.uint8)
         if trial % 3 == 0:                                   # smooth content: long zero runs, EOBs
             px = (np.add.outer(np.arange(h), np.arange(w))[..., None] // 3 + np.arange(binding.BPP[ct])).astype(np.uint8)
