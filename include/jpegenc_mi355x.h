@@ -255,6 +255,16 @@ int  jpegenc_encoder_add_exif_metadata(jpegenc_encoder *e, const uint8_t *data, 
  * the same configuration can encode further images.  Output goes to `sink` in order. */
 int  jpegenc_encoder_encode(jpegenc_encoder *e, const uint8_t *data, size_t len, int width,
                             int height, int color_type, jpegenc_write_fn sink, void *user);
+/* The host half of Encoder::encode on its own (headers, Huffman table construction incl. optimised tables,
+ * entropy coding, markers: writer.rs:108-470, huffman.rs, encoder.rs:517-567, 633-667, 809-975) for a caller that
+ * already holds the image's quantised blocks - from jpegenc_blocks_device / _host / _stream, possibly of another GPU
+ * or an earlier run - in the order this encoder's mode consumes them (jpegenc_encoder_block_order: MCU order for the
+ * interleaved baseline mode, planar order for sequential / progressive / optimised).  Needs no GPU.  The blocks must
+ * have been produced with this encoder's quantisation tables (jpegenc_qtable_init with its quality / table types);
+ * num_blocks must equal the layout's total_blocks (else JPEGENC_ERR_BAD_IMAGE_DATA). */
+int  jpegenc_encoder_block_order(const jpegenc_encoder *e);
+int  jpegenc_encoder_encode_coefficients(jpegenc_encoder *e, const int16_t *coeffs, size_t num_blocks, int width,
+                                         int height, int color_type, jpegenc_write_fn sink, void *user);
 /* Same for an image that already lives in this handle's device memory (a decoder or camera
  * pipeline's output): no host-to-device copy; the kernels read `d_pixels` directly (it must stay
  * valid and unmodified until the call returns). */

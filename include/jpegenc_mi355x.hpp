@@ -123,6 +123,11 @@ public:
     void encode_device(const void *d_pixels, uint16_t width, uint16_t height, ColorType color_type) {
         check(jpegenc_encoder_encode_device(h_, d_pixels, width, height, (int)color_type, &sink, &w_));
     }
+    // the host half on its own (no GPU): quantised zig-zag blocks in block_order() -> the file
+    int block_order() const { return jpegenc_encoder_block_order(h_); }
+    void encode_coefficients(const int16_t *coeffs, size_t num_blocks, uint16_t width, uint16_t height, ColorType color_type) {
+        check(jpegenc_encoder_encode_coefficients(h_, coeffs, num_blocks, width, height, (int)color_type, &sink, &w_));
+    }
     // Encoder::encode_image, :505-515
     void encode_image(ImageBuffer &image) {
         check(jpegenc_encoder_encode_image(h_, (int)image.get_jpeg_color_type(), image.width(), image.height(), &fill_row, &image, &sink, &w_));

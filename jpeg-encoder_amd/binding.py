@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_optimized_huffman_tables", "jpegenc_encoder_add_app_segment",
     "jpegenc_encoder_add_icc_profile", "jpegenc_encoder_add_exif_metadata",
     "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_batch_device", "jpegenc_encoder_encode_batch_device_to_buffers", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_to_file",
-    "jpegenc_encoder_encode_image",
+    "jpegenc_encoder_encode_image", "jpegenc_encoder_block_order", "jpegenc_encoder_encode_coefficients",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
 ]
@@ -357,6 +357,27 @@ class Encoder:
 
         cb = WRITE_FN(sink)
         check(lib().jpegenc_encoder_encode(self._h, px.ctypes.data, px.size, width, height, color_type, cb, None))
+        return b"".join(chunks)
+
+    def block_order(self):
+        """The block order this encoder's mode consumes (ORDER_MCU for interleaved baseline, ORDER_PLANAR otherwise)."""
+        fn = lib().jpegenc_encoder_block_order
+        fn.argtypes = [C.c_void_p]
+        return fn(self._h)
+
+    def encode_coefficients(self, coeffs, width, height, color_type):
+        """The host half only: quantised zig-zag blocks (num_blocks x 64 int16, in block_order()) -> JPEG bytes.  No GPU."""
+        co = np.ascontiguousarray(coeffs, dtype=np.int16).reshape(-1, 64)
+        chunks = []
+
+        def sink(_user, ptr, n):
+            chunks.append(C.string_at(ptr, n))
+            return 0
+
+        cb = WRITE_FN(sink)
+        fn = lib().jpegenc_encoder_encode_coefficients
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, WRITE_FN, C.c_void_p]
+        check(fn(self._h, co.ctypes.data, co.shape[0], width, height, color_type, cb, None))
         return b"".join(chunks)
 
     def encode_to_buffer(self, pixels, width, height, color_type, out):

@@ -621,6 +621,110 @@ static void code_component_scan(Out &o, const Config &c, const HuffTable &dc, co
     o.close_bits();
 }
 
+// ---- host half: headers + entropy coding of coefficients that are (or arrive) in host memory -----------
+// coeffs: MCU order for MODE_INTERLEAVED, planar order otherwise.  In interleaved mode the blocks may still be
+// arriving: wait(k) returns once the MCUs up to chunk_end_mcu[k] are there (coding of piece k overlaps the copy of
+// piece k+1); the other modes wait for piece 0 = everything.  freq: the symbol histogram for optimised tables.
+template <class Wait>
+static int emit_host_coded(const Config &c, int jct, int width, int height, const jpegenc_layout &L, Tables &t, Mode mode, bool optimize,
+                           const int16_t *coeffs, const uint32_t *freq, int nchunks, const uint64_t *chunk_end_mcu, Wait wait,
+                           jpegenc_write_fn sink, void *user) {
+    const uint32_t bpm = (uint32_t)(L.total_blocks / (L.mcus ? L.mcus : 1));
+    int rc;
+    Out o;
+    o.sink = sink; o.user = user;
+    o.buf.reserve((size_t)1 << 20);
+    write_prologue(o, c, jct);
+    if (mode == MODE_INTERLEAVED) {                          // encode_image_interleaved, encoder.rs:699-807
+        write_frame_header(o, c, width, height, L, t);
+        write_scan_header(o, L, 0, L.num_components, 0, 63);
+        InterleavedState st(c.restart_interval);
+        o.open_bits();
+        o.begin_bits();
+        uint64_t m0 = 0;
+        for (int k = 0; k < nchunks; k++) {
+            rc = wait(k);
+            if (rc) return rc;
+            code_mcus(o, L, t, coeffs, m0, chunk_end_mcu[k], bpm, st);
+            m0 = chunk_end_mcu[k];
+        }
+        o.reserve_bits(64);
+        o.finalize_bits();
+        o.close_bits();
+    } else {
+        rc = wait(0);
+        if (rc) return rc;
+        if (optimize) {                                      // optimize_huffman_table, encoder.rs:1086-1200
+            const int max_tables = L.num_components < 2 ? L.num_components : 2;
+            for (int d = 0; d < max_tables; d++)
+                for (int k = 0; k < 2; k++) t.h[d][k].assign_optimized(freq + (d * 2 + k) * 257);
+        }
+        write_frame_header(o, c, width, height, L, t);       // after the tables are final (:821, :881)
+        if (mode == MODE_SEQUENTIAL) {                       // encode_image_sequential, encoder.rs:810-864
+            const int16_t *comp = coeffs;
+            for (int i = 0; i < L.num_components; comp += L.blocks[i] * 64, i++) {
+                write_scan_header(o, L, i, 1, 0, 63);
+                code_component_scan(o, c, t.h[L.table[i]][0], t.h[L.table[i]][1], comp, L.blocks[i], true, 1, 64);
+                o.drain(false);
+            }
+        } else {                                             // encode_image_progressive, encoder.rs:869-975
+            const int16_t *comp = coeffs;
+            for (int i = 0; i < L.num_components; comp += L.blocks[i] * 64, i++) {
+                write_scan_header(o, L, i, 1, 0, 0);
+                code_component_scan(o, c, t.h[L.table[i]][0], t.h[L.table[i]][1], comp, L.blocks[i], true, 0, 0);
+            }
+            const int scans = c.progressive_scans - 1, per = 64 / scans;
+            for (int s = 0; s < scans; s++) {
+                const int start = s * per < 1 ? 1 : s * per;
+                const int end = s == scans - 1 ? 64 : (s + 1) * per;
+                comp = coeffs;
+                for (int i = 0; i < L.num_components; comp += L.blocks[i] * 64, i++) {
+                    write_scan_header(o, L, i, 1, start, end - 1);
+                    code_component_scan(o, c, t.h[L.table[i]][0], t.h[L.table[i]][1], comp, L.blocks[i], false, start, end);
+                    o.drain(false);
+                }
+            }
+        }
+    }
+    o.marker(0xD9);                                          // EOI, encoder.rs:564
+    o.drain(true);
+    if (o.failed) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
+    return JPEGENC_OK;
+}
+
+// The symbol histogram of optimize_huffman_table (encoder.rs:1086-1200) on host coefficients in planar order - what
+// k_histogram computes on the device: [table][0 = DC, 1 = AC][257].
+static void host_histogram(const jpegenc_layout &L, int progressive_scans, const int16_t *coeffs, uint32_t freq[2 * 2 * 257]) {
+    memset(freq, 0, sizeof(uint32_t) * 2 * 2 * 257);
+    auto nbits = [](int v) { unsigned a = (unsigned)(v < 0 ? -v : v), n = 0; while (a) { n++; a >>= 1; } return n; };
+    const int16_t *blk = coeffs;
+    for (int comp = 0; comp < L.num_components; comp++) {
+        uint32_t *dc = freq + (size_t)L.table[comp] * 2 * 257, *ac = dc + 257;
+        int prev = 0;                                        // never reset at restart boundaries (:1104-1116)
+        for (uint64_t b = 0; b < L.blocks[comp]; b++, blk += 64) {
+            dc[nbits((int16_t)(blk[0] - prev))]++;
+            prev = blk[0];
+            int scans = 1, per = 64;
+            if (progressive_scans) { scans = progressive_scans - 1; per = 64 / scans; }
+            for (int band = 0; band < scans; band++) {       // :1123-1134
+                const int start = progressive_scans ? (band * per < 1 ? 1 : band * per) : 1;
+                const int end = progressive_scans ? (band == scans - 1 ? 64 : (band + 1) * per) : 64;
+                int zero_run = 0;
+                for (int k = start; k < end; k++) {          // :1138-1161
+                    const int v = blk[k];
+                    if (v == 0) { zero_run++; continue; }
+                    while (zero_run > 15) { ac[0xF0]++; zero_run -= 16; }
+                    ac[(zero_run << 4) | (int)nbits(v)]++;
+                    zero_run = 0;
+                }
+                if (zero_run > 0) ac[0]++;
+            }
+        }
+    }
+    const int max_tables = L.num_components < 2 ? L.num_components : 2;  // dc_freq[256] = ac_freq[256] = 1 (:1089-1095)
+    for (int d = 0; d < max_tables; d++) { freq[(size_t)d * 2 * 257 + 256]++; freq[(size_t)d * 2 * 257 + 257 + 256]++; }
+}
+
 static int validate_image(size_t len, int width, int height, int color_type) {
     const int bpp = jpegenc_bytes_per_pixel(color_type);
     if (!bpp) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");
@@ -919,64 +1023,8 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         JPEGENC_HIP(hipEventRecord(ctx.chunk_done[0], ctx.stream));
     }
 
-    // ---- host: headers + entropy coding -------------------------------------------------------
-    Out o;
-    o.sink = sink; o.user = user;
-    o.buf.reserve((size_t)1 << 20);
-    write_prologue(o, c, jct);
-    if (mode == MODE_INTERLEAVED) {                          // encode_image_interleaved, encoder.rs:699-807
-        write_frame_header(o, c, width, height, L, t);
-        write_scan_header(o, L, 0, L.num_components, 0, 63);
-        InterleavedState st(c.restart_interval);
-        o.open_bits();
-        o.begin_bits();
-        uint64_t m0 = 0;
-        for (int k = 0; k < nchunks; k++) {
-            JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[k]));
-            code_mcus(o, L, t, ctx.h_coeffs, m0, chunk_end_mcu[k], bpm, st);
-            m0 = chunk_end_mcu[k];
-        }
-        o.reserve_bits(64);
-        o.finalize_bits();
-        o.close_bits();
-    } else {
-        JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[0]));
-        if (optimize) {                                      // optimize_huffman_table, encoder.rs:1086-1200
-            const int max_tables = L.num_components < 2 ? L.num_components : 2;
-            for (int d = 0; d < max_tables; d++)
-                for (int k = 0; k < 2; k++) t.h[d][k].assign_optimized(ctx.h_freq + (d * 2 + k) * 257);
-        }
-        write_frame_header(o, c, width, height, L, t);       // after the tables are final (:821, :881)
-        if (mode == MODE_SEQUENTIAL) {                       // encode_image_sequential, encoder.rs:810-864
-            const int16_t *comp = ctx.h_coeffs;
-            for (int i = 0; i < L.num_components; comp += L.blocks[i] * 64, i++) {
-                write_scan_header(o, L, i, 1, 0, 63);
-                code_component_scan(o, c, t.h[L.table[i]][0], t.h[L.table[i]][1], comp, L.blocks[i], true, 1, 64);
-                o.drain(false);
-            }
-        } else {                                             // encode_image_progressive, encoder.rs:869-975
-            const int16_t *comp = ctx.h_coeffs;
-            for (int i = 0; i < L.num_components; comp += L.blocks[i] * 64, i++) {
-                write_scan_header(o, L, i, 1, 0, 0);
-                code_component_scan(o, c, t.h[L.table[i]][0], t.h[L.table[i]][1], comp, L.blocks[i], true, 0, 0);
-            }
-            const int scans = c.progressive_scans - 1, per = 64 / scans;
-            for (int s = 0; s < scans; s++) {
-                const int start = s * per < 1 ? 1 : s * per;
-                const int end = s == scans - 1 ? 64 : (s + 1) * per;
-                comp = ctx.h_coeffs;
-                for (int i = 0; i < L.num_components; comp += L.blocks[i] * 64, i++) {
-                    write_scan_header(o, L, i, 1, start, end - 1);
-                    code_component_scan(o, c, t.h[L.table[i]][0], t.h[L.table[i]][1], comp, L.blocks[i], false, start, end);
-                    o.drain(false);
-                }
-            }
-        }
-    }
-    o.marker(0xD9);                                          // EOI, encoder.rs:564
-    o.drain(true);
-    if (o.failed) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
-    return JPEGENC_OK;
+    auto wait = [&](int k) -> int { JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[k])); return JPEGENC_OK; };
+    return emit_host_coded(c, jct, width, height, L, t, mode, optimize, ctx.h_coeffs, ctx.h_freq, nchunks, chunk_end_mcu, wait, sink, user);
 }
 
 // A batch of device-resident frames (a decoder's or camera pipeline's output) -> complete files, with
@@ -1399,6 +1447,41 @@ int jpegenc_encoder_encode(jpegenc_encoder *e, const uint8_t *data, size_t len, 
     REQUIRE(e);
     if (len && !data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null data");
     return encode_pixels(e->cfg, e->ctx, e->device, data, len, width, height, color_type, sink, user);
+}
+
+int jpegenc_encoder_block_order(const jpegenc_encoder *e) {
+    if (!e) return -1;
+    return select_mode(e->cfg) == MODE_INTERLEAVED ? JPEGENC_ORDER_MCU : JPEGENC_ORDER_PLANAR;
+}
+
+int jpegenc_encoder_encode_coefficients(jpegenc_encoder *e, const int16_t *coeffs, size_t num_blocks, int width, int height,
+                                        int color_type, jpegenc_write_fn sink, void *user) {
+    REQUIRE(e);
+    if (!coeffs || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535) return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "image dimensions must be 1..=65535");
+    const Config &c = e->cfg;
+    Tables t;
+    int rc = jpegenc_qtable_init(&t.q[0], c.qtype[0], c.qcustom[0], c.quality, 1);
+    if (rc) return rc;
+    rc = jpegenc_qtable_init(&t.q[1], c.qtype[1], c.qcustom[1], c.quality, 0);
+    if (rc) return rc;
+    default_huffman(t);
+    int hs, vs;
+    sampling_hv(c.sampling, &hs, &vs);
+    const Mode mode = select_mode(c);
+    jpegenc_layout L;
+    rc = jpegenc_layout_init(&L, width, height, color_type, hs, vs, mode == MODE_INTERLEAVED ? JPEGENC_ORDER_MCU : JPEGENC_ORDER_PLANAR);
+    if (rc) return rc;
+    if (num_blocks != L.total_blocks) return fail(JPEGENC_ERR_BAD_IMAGE_DATA, "num_blocks is not the layout's total_blocks");
+    const bool optimize = c.optimize && mode != MODE_INTERLEAVED;
+    std::vector<uint32_t> freq;
+    if (optimize) {
+        freq.resize(2 * 2 * 257);
+        host_histogram(L, c.progressive_scans, coeffs, freq.data());
+    }
+    const uint64_t all = L.mcus;
+    auto wait = [](int) -> int { return JPEGENC_OK; };
+    return emit_host_coded(c, jpeg_color_type_of(color_type), width, height, L, t, mode, optimize, coeffs, freq.data(), 1, &all, wait, sink, user);
 }
 
 int jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int width, int height, int color_type,

@@ -178,6 +178,39 @@ def test_sampling_factor_from_factors(binding):
     assert f(2, 2) == binding.F_2_2 and f(4, 1) == binding.F_4_1
 
 
+@pytest.mark.parametrize("kw", [
+    dict(quality=90), dict(quality=75, sampling=(2, 2), restart_interval=5), dict(quality=60, sampling=(4, 1)),
+    dict(quality=85, progressive_scans=4), dict(quality=92, progressive_scans=7, restart_interval=3, sampling=(2, 1)),
+    dict(quality=80, optimize=True), dict(quality=70, progressive_scans=5, optimize=True, sampling=(2, 2)),
+    dict(quality=88, progressive_scans=40)],
+    ids=["baseline", "420-restart", "sequential-411", "progressive", "progressive-restart", "optimised", "progressive-optimised", "progressive-40"])
+def test_host_half_from_coefficients_without_a_gpu(binding, oracle, synth, kw):
+    """jpegenc_encoder_encode_coefficients: the host half of the encoder on its own (markers, Huffman table
+    construction incl. the optimised tables' histogram, the host entropy coder, restart bookkeeping) fed with the
+    oracle's coefficients - the library's host logic, byte for byte against the reference restatement, on CPU."""
+    for ct, bpp in ((oracle.RGB, 3), (oracle.LUMA, 1), (oracle.CMYK, 4), (oracle.YCCK, 4)):
+        w, h = 203, 117
+        px = synth.lcg_image(w, h, bpp, 60 + ct)
+        if ct == oracle.LUMA:
+            px = (np.add.outer(np.arange(h), np.arange(w))[..., None] // 2).astype(np.uint8)       # smooth: long zero runs
+        e = binding.Encoder(kw["quality"])
+        hs, vs = kw.get("sampling", (2, 2) if kw["quality"] < 90 else (1, 1))
+        if "sampling" in kw:
+            e.set_sampling_factor(binding.sampling_factor(*kw["sampling"]))
+        if kw.get("progressive_scans"):
+            e.set_progressive_scans(kw["progressive_scans"])
+        if kw.get("restart_interval"):
+            e.set_restart_interval(kw["restart_interval"])
+        if kw.get("optimize"):
+            e.set_optimized_huffman_tables(True)
+        order = e.block_order()
+        co = oracle.encode_blocks(px, w, h, ct, hs, vs, kw["quality"], order)
+        assert e.encode_coefficients(co, w, h, ct) == oracle.encode_jpeg(px, w, h, ct, **kw), (ct, kw)
+    with pytest.raises(binding.JpegEncError) as err:
+        e.encode_coefficients(co[:-1], w, h, ct)
+    assert err.value.status == binding.ERR_BAD_IMAGE_DATA
+
+
 def _build_example(tmp_path):
     import os
     import subprocess
