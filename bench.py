@@ -350,7 +350,30 @@ def main():
                 "what": f"{Fd} 4K frames in HBM -> entropy-coded scan bytes in HBM (block kernel + device Huffman, "
                         "noise frames = worst case for entropy coding)",
                 "scan_bytes_per_frame": int(d_len.float().mean().item())}
-            del d_out, d_ws
+            # the same on photo-like frames (gradient + a little noise): what entropy coding costs on realistic content
+            base = torch.from_numpy(synth.test_img_rgb(W, H).reshape(-1)).to(dev)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(11)
+            d_photo = torch.clamp(base.to(torch.int16)[None, :] + torch.randint(-6, 7, (Fd, base.numel()), dtype=torch.int16, device=dev, generator=gen),
+                                  0, 255).to(torch.uint8)
+
+            def full_photo():
+                binding.blocks_device(d_photo.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, HS, VS, q, binding.ORDER_MCU,
+                                      binding.FDCT_SCALAR, d_co.data_ptr(), nblk, stream.cuda_stream)
+                binding.scan_device(d_co.data_ptr(), nblk, Fd, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(),
+                                    d_ws.data_ptr(), wsz, stream.cuda_stream)
+            for _ in range(3):
+                full_photo()
+            torch.cuda.synchronize()
+            e0.record(stream)
+            for _ in range(10):
+                full_photo()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            result["device_resident_full_encode"]["photo_like"] = {
+                "value": round(Fd * W * H / ms / 1e3, 1), "unit": "Mpixels/s", "scan_bytes_per_frame": int(d_len.float().mean().item())}
+            del d_out, d_ws, d_photo
         except Exception as exc:                                   # side figure only
             result["device_resident_full_encode"] = {"error": str(exc)}
         # side figure (never `value`): frames in HBM -> complete JPEG files in host buffers through the Encoder
