@@ -211,6 +211,27 @@ def test_host_half_from_coefficients_without_a_gpu(binding, oracle, synth, kw):
     assert err.value.status == binding.ERR_BAD_IMAGE_DATA
 
 
+def test_host_half_metadata_and_custom_tables_without_a_gpu(binding, oracle, synth):
+    """Density, APPn, chunked ICC profile, Exif (encoder.rs:374-435; writer.rs:216-239) and custom / preset
+    quantisation tables in the DQT, through the host half on CPU."""
+    w, h = 130, 70
+    px = synth.lcg_image(w, h, 3, 5)
+    icc = bytes(i % 251 for i in range(150 * 1024))                                   # three ICC chunks
+    e = binding.Encoder(95)
+    e.set_density(1, 300, 150)
+    e.add_app_segment(15, b"HOHOHO\0")
+    e.add_icc_profile(icc)
+    e.add_exif_metadata(b"II*\0")
+    cust = [int(v) for v in (np.arange(64) * 3 + 2)]
+    e.set_quantization_tables(binding.Q_CUSTOM, 4, cust, None)                        # custom luma, preset 4 chroma
+    segs = [(15, b"HOHOHO\0")] + oracle.icc_segments(icc) + [oracle.exif_segment(b"II*\0")]
+    q = oracle.qtables(95, presets=(oracle.Q_CUSTOM, 4), customs=(cust, None))
+    want = oracle.encode_jpeg(px, w, h, oracle.RGB, 95, density=(1, 300, 150), app_segments=segs,
+                              qpresets=(oracle.Q_CUSTOM, 4), qcustoms=(cust, None))
+    co = oracle.encode_blocks(px, w, h, oracle.RGB, 1, 1, None, e.block_order(), q=q)
+    assert e.encode_coefficients(co, w, h, binding.RGB) == want
+
+
 def _build_example(tmp_path):
     import os
     import subprocess
