@@ -211,6 +211,34 @@ def test_host_half_from_coefficients_without_a_gpu(binding, oracle, synth, kw):
     assert err.value.status == binding.ERR_BAD_IMAGE_DATA
 
 
+def _configured(binding, kw):
+    e = binding.Encoder(kw["quality"])
+    if "sampling" in kw:
+        e.set_sampling_factor(binding.sampling_factor(*kw["sampling"]))
+    if kw.get("progressive_scans"):
+        e.set_progressive_scans(kw["progressive_scans"])
+    if kw.get("restart_interval"):
+        e.set_restart_interval(kw["restart_interval"])
+    if kw.get("optimize"):
+        e.set_optimized_huffman_tables(True)
+    return e
+
+
+def test_reference_round_trip_cases_through_the_host_half(binding, oracle, synth):
+    """The reference's own round-trip tests on its 258x128 gradient (src/lib.rs:200-472; the case table is shared
+    with tests/test_oracle_files.py, which decodes the oracle's files with libjpeg): the library's host half must
+    produce those very files, and they must decode within the reference's tolerance (check_result, lib.rs:160-186)."""
+    from test_oracle_files import RGB_CASES, _check
+    px = synth.test_img_rgb()
+    for name, kw in sorted(RGB_CASES.items()):
+        e = _configured(binding, kw)
+        hs, vs = kw.get("sampling", (2, 2) if kw["quality"] < 90 else (1, 1))
+        co = oracle.encode_blocks(px, 258, 128, oracle.RGB, hs, vs, kw["quality"], e.block_order())
+        data = e.encode_coefficients(co, 258, 128, binding.RGB)
+        assert data == oracle.encode_jpeg(px, 258, 128, oracle.RGB, **kw), name
+        _check(data, px, "RGB")
+
+
 def test_host_half_metadata_and_custom_tables_without_a_gpu(binding, oracle, synth):
     """Density, APPn, chunked ICC profile, Exif (encoder.rs:374-435; writer.rs:216-239) and custom / preset
     quantisation tables in the DQT, through the host half on CPU."""
