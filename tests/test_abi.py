@@ -239,6 +239,37 @@ def test_reference_round_trip_cases_through_the_host_half(binding, oracle, synth
         _check(data, px, "RGB")
 
 
+def test_host_half_randomised_without_a_gpu(binding, oracle):
+    """Randomised sweep of the host half on CPU (the GPU suite's sweep covers the whole pipeline): every ColorType,
+    sampling factor, scan mode incl. up to 64 progressive scans, restart intervals, optimised tables."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("JPEGENC_FUZZ_SEED", "77")))
+    samplings = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 2), (1, 4), (2, 4)]
+    for trial in range(int(os.environ.get("JPEGENC_HOST_FUZZ_TRIALS", "150"))):
+        ct = int(rng.integers(0, 9))
+        w, h = int(rng.integers(1, 160)), int(rng.integers(1, 100))
+        px = rng.integers(0, 256, (h, w, binding.BPP[ct]), dtype=np.uint8)
+        if trial % 3 == 0:
+            px = (np.add.outer(np.arange(h), np.arange(w))[..., None] // 3 + np.arange(binding.BPP[ct])).astype(np.uint8)
+        hs, vs = samplings[int(rng.integers(0, 8))]
+        kw = dict(quality=int(rng.integers(1, 101)), sampling=(hs, vs))
+        mode = int(rng.integers(0, 4))
+        if mode == 1:
+            kw["progressive_scans"] = int(rng.integers(2, 65))
+        elif mode == 2:
+            kw["optimize"] = True
+        elif mode == 3:
+            kw["progressive_scans"] = int(rng.integers(2, 8))
+            kw["optimize"] = True
+        if rng.integers(0, 3) == 0:
+            kw["restart_interval"] = int(rng.integers(1, 40))
+        e = _configured(binding, kw)
+        if ct == oracle.LUMA:
+            hs = vs = 1                                     # sampling is ignored for Luma (encoder.rs:574-576)
+        co = oracle.encode_blocks(px, w, h, ct, hs, vs, kw["quality"], e.block_order())
+        assert e.encode_coefficients(co, w, h, ct) == oracle.encode_jpeg(px, w, h, ct, **kw), (trial, ct, w, h, kw)
+
+
 def test_host_half_metadata_and_custom_tables_without_a_gpu(binding, oracle, synth):
     """Density, APPn, chunked ICC profile, Exif (encoder.rs:374-435; writer.rs:216-239) and custom / preset
     quantisation tables in the DQT, through the host half on CPU."""
