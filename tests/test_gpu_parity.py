@@ -936,6 +936,19 @@ def test_device_entropy_pack_window_overflow_path(binding, oracle, synth):
         assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_large_progressive_frame_takes_the_launched_prefix_sums(binding, oracle, synth):
+    """Beyond 2 048 runs per scan the prefix sums are separate launches again (below, k_push / k_stuff fold them in):
+    a 15-Mpixel 4:4:4 frame has 3 663 runs per component scan; progressive + optimised, its 9 scans share their
+    launches.  Also a 4:2:0 baseline frame of that size (5 500 runs in one scan)."""
+    w, h = 5000, 3000
+    px = synth.test_img_rgb(w, h)
+    px = np.clip(px.astype(np.int16) + np.random.default_rng(4).integers(-7, 8, px.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+    for kw in (dict(quality=88, sampling=(1, 1), progressive_scans=3, optimize=True), dict(quality=80, sampling=(2, 2)),
+               dict(quality=85, sampling=(2, 1), progressive_scans=4, restart_interval=700)):
+        got = _encoder(binding, kw).encode(px, w, h, binding.RGB)
+        assert got == oracle.encode_jpeg(px, w, h, oracle.RGB, **kw), kw
+
+
 def test_shortest_possible_runs(binding, oracle):
     """Flat images: every AC band of a progressive scan is one EOB per block and, with optimised tables, one BIT
     per block - a wave's run is then 64 bits, the last wave's a handful, several runs meet inside one 32-bit word
