@@ -949,6 +949,16 @@ def test_large_progressive_frame_takes_the_launched_prefix_sums(binding, oracle,
         assert got == oracle.encode_jpeg(px, w, h, oracle.RGB, **kw), kw
 
 
+def test_golden_coefficient_fixtures(binding):
+    """The HIP path against the committed fixtures (tests/golden/coefficients.npz) - no oracle in the loop."""
+    from test_oracle_kat import GOLDEN_CASES, golden_coefficients
+    g = golden_coefficients()
+    for name, (pk, w, h, ctn, q, (hs, vs)) in GOLDEN_CASES.items():
+        for order, tag in ((binding.ORDER_MCU, "mcu"), (binding.ORDER_PLANAR, "planar")):
+            got = binding.blocks_host(g[pk], w, h, getattr(binding, ctn), hs, vs, q, order)
+            _same(got, g[f"{name}_{tag}"])
+
+
 def test_shortest_possible_runs(binding, oracle):
     """Flat images: every AC band of a progressive scan is one EOB per block and, with optimised tables, one BIT
     per block - a wave's run is then 64 bits, the last wave's a handful, several runs meet inside one 32-bit word

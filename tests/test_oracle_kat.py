@@ -258,3 +258,38 @@ def test_avx2_baseline_port_equals_scalar_port(oracle):
     assert oracle.encode_blocks_avx2(np.zeros((8, 8, 3), np.uint8), 8, 8, oracle.RGB, 4, 1, 80) is None
     if covered == 0:
         pytest.skip("host CPU has no AVX2")
+
+
+GOLDEN_CASES = {
+    # name: (pixels key, w, h, color type name, quality, (hs, vs)) - tests/golden/make_coefficient_fixtures.py
+    "grad_q80_f22": ("pixels_grad_258x128", 258, 128, "RGB", 80, (2, 2)),
+    "grad_q100_f11": ("pixels_grad_258x128", 258, 128, "RGB", 100, (1, 1)),
+    "grad_q100_f21": ("pixels_grad_258x128", 258, 128, "RGB", 100, (2, 1)),
+    "cmyk_q100": ("pixels_cmyk_258x192", 258, 192, "CMYK", 100, (1, 1)),
+    "pixel_fb1515": ("pixels_pixel_1x1", 1, 1, "RGB", 100, (1, 1)),
+    "lcg42_q75_f22": ("pixels_lcg_37x21", 37, 21, "RGB", 75, (2, 2)),
+}
+
+
+def golden_coefficients():
+    import os
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "coefficients.npz"))
+
+
+def test_oracle_reproduces_the_committed_coefficient_fixtures(oracle):
+    """tests/golden/coefficients.npz (gradient at q=80/F_2_2, q=100/F_1_1 and F_2_1, CMYK q=100, the 1x1
+    pixel fb 15 15, LCG noise; MCU and planar order) against today's oracle, and against the survey's SHA-256 anchors
+    where one exists - the fixture cannot drift from the pinned restatement unnoticed."""
+    import hashlib
+    import numpy as np
+    g = golden_coefficients()
+    for name, (pk, w, h, ctn, q, (hs, vs)) in GOLDEN_CASES.items():
+        for order, tag in ((oracle.ORDER_MCU, "mcu"), (oracle.ORDER_PLANAR, "planar")):
+            want = g[f"{name}_{tag}"]
+            got = oracle.encode_blocks(g[pk], w, h, getattr(oracle, ctn), hs, vs, q, order)
+            assert got.shape == want.shape and np.array_equal(got, want), (name, tag)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype="<i2").tobytes()).hexdigest()[:16]
+    assert sha(g["grad_q80_f22_mcu"]) == "904de330bc9ee06c" and sha(g["grad_q80_f22_planar"]) == "2b36c781df2c5567"
+    assert sha(g["grad_q100_f11_mcu"]) == "6ff6a9e6cfd396d7" and sha(g["grad_q100_f21_mcu"]) == "0dd2db06def56cb6"
+    assert sha(g["lcg42_q75_f22_mcu"]) == "1856bafe1ceceec8" and sha(g["lcg42_q75_f22_planar"]) == "b43a71d4ff226cb2"
