@@ -13,9 +13,15 @@ roofline the fused kernel reaches.
               scalar path; the Rust crate cannot be built in this image) timed on one host core over a
               bounded sample, rank 0, N=1 only.
 
+  c3_batch  = BASELINE config 3 on every rank: the 1000-frame 1920x1080 q=80 4:2:0 batch sharded frame-wise
+              (frame k -> rank k % N, jpegenc_shard_frames), each rank encoding ITS frames from pageable host
+              memory to complete JPEG files in host buffers; MAX over ranks of the wall time
+              (jpeg_encoder_amd/batch.py - the function the CPU gloo test drives with an injected encoder).
+
 Multi-GPU: frames are independent, so ranks shard the batch (one process per GPU, no data-path
-collective); scaling is weak (per-GPU work fixed).  Launch: python -m torch.distributed.run
---nproc-per-node N bench.py --gpus N ...
+collective).  `value` (the device-resident hot path) scales weakly (per-GPU work fixed); `c3_batch` is the
+fixed 1000-frame job of the north star (strong: 1000/N frames per rank).  Launch: python -m
+torch.distributed.run --nproc-per-node N bench.py --gpus N ...
 """
 import argparse
 import importlib
@@ -170,6 +176,116 @@ def cpu_baseline(seconds_budget, synth, gpu_frame=None, gpu_coeffs=None):
     return base, parity
 
 
+def link_rates(torch, dev, nbytes=24_883_200, reps=24):
+    """What this box's host link delivers for pinned 25 MB transfers (tools/pcie_rates.py): the `peak` of the
+    PCIe-bound side figures.  One direction at a time and both at once (per direction)."""
+    h_in = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    h_out = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    d = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+    s_up, s_dn = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+    def run(up, dn, n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(n):
+            if up:
+                with torch.cuda.stream(s_up):
+                    d[i & 1].copy_(h_in[i & 1], non_blocking=True)
+            if dn:
+                with torch.cuda.stream(s_dn):
+                    h_out[i & 1].copy_(d[(i + 1) & 1], non_blocking=True)
+        torch.cuda.synchronize()
+        return n * nbytes / (time.perf_counter() - t) / 1e9
+    out = {}
+    for name, up, dn in (("h2d", 1, 0), ("d2h", 0, 1), ("both_each_direction", 1, 1)):
+        run(up, dn, 4)
+        out[name] = round(run(up, dn, reps), 1)
+    out["what"] = f"pinned {nbytes / 1e6:.1f} MB copies measured by this run, GB/s"
+    return out
+
+
+def pcie_roofline(bound, bytes_moved, seconds, link):
+    """Roofline block of a PCIe-bound figure: achieved GB/s of the bounding direction against what this box's
+    link delivered for plain pinned copies in the same run."""
+    peak = link.get("h2d" if bound == "pcie_h2d" else "d2h" if bound == "pcie_d2h" else "both_each_direction")
+    achieved = bytes_moved / seconds / 1e9
+    return {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+            "frac": round(achieved / peak, 4) if peak else None, "peak_source": "link_rates of this run (pinned 25 MB copies)"}
+
+
+CRITERION_VARIANTS = {                                            # criterion/benches/encode.rs:57-86: (Encoder setters, oracle arguments)
+    "encode rgb 100": (dict(quality=100), dict(quality=100)),
+    "encode rgb 4x1": (dict(quality=80, sampling=(4, 1)), dict(quality=80, sampling=(4, 1))),
+    "encode rgb progressive": (dict(quality=80, progressive=True), dict(quality=80, progressive_scans=4)),
+    "encode rgb optimized": (dict(quality=100, optimized=True), dict(quality=100, optimize=True)),
+    "encode rgb optimized progressive": (dict(quality=100, progressive=True, optimized=True),
+                                         dict(quality=100, progressive_scans=4, optimize=True)),
+}
+CRITERION_MIXED = ["encode rgb 100", "encode rgb 4x1", "encode rgb progressive", "encode rgb optimized progressive"]   # encode.rs:150-186
+
+
+def criterion_workloads(binding, synth, device):
+    """The reference's own bench workloads (criterion/benches/encode.rs:57-188): its 2000x1800 pattern through the six
+    Encoder configurations, one call at a time from one host thread (host pixels -> JPEG bytes).  Side figure; the CPU
+    port's times are added beside it by the cpu_baseline leg.  Returns (figures, files)."""
+    import numpy as np
+    w, h = 2000, 1800
+    px = np.ascontiguousarray(synth.criterion_pattern(w, h))
+    out = np.empty(32 << 20, dtype=np.uint8)                      # Vec::with_capacity(32 MiB), encode.rs:89
+
+    def make(quality, sampling=None, progressive=False, optimized=False):
+        e = binding.Encoder(quality, device=device)
+        if sampling is not None:
+            e.set_sampling_factor(binding.sampling_factor(*sampling))
+        if progressive:
+            e.set_progressive(True)
+        if optimized:
+            e.set_optimized_huffman_tables(True)
+        return e
+    res, files = {}, {}
+    encs = {name: make(**g) for name, (g, _) in CRITERION_VARIANTS.items()}
+    for name, enc in encs.items():
+        n = enc.encode_to_buffer(px, w, h, binding.RGB, out)       # warm-up
+        times = []
+        for _ in range(9):
+            t = time.perf_counter()
+            enc.encode_to_buffer(px, w, h, binding.RGB, out)
+            times.append(time.perf_counter() - t)
+        gpu_ms = sorted(times)[len(times) // 2] * 1e3
+        res[name] = {"gpu_ms": round(gpu_ms, 3), "gpu_Mpixels_per_s": round(w * h / gpu_ms / 1e3, 1), "jpeg_bytes": int(n)}
+        files[name] = out[:n].tobytes()
+    t = time.perf_counter()
+    for _ in range(5):
+        for name in CRITERION_MIXED:
+            encs[name].encode_to_buffer(px, w, h, binding.RGB, out)
+    res["encode rgb mixed"] = {"gpu_ms": round((time.perf_counter() - t) / 5 * 1e3, 3)}
+    res["what"] = ("criterion/benches/encode.rs:57-188: 2000x1800 RGB pattern, one Encoder::encode per call from one host thread, pageable "
+                   "host pixels -> JPEG bytes in a host buffer, median of 9; cpu_port_ms = the oracle's C port on one core, one call")
+    return res, files
+
+
+def cpu_baseline_extras(synth, criterion, criterion_files, c3_samples):
+    """Second half of the cpu_baseline leg (the only other place bench.py touches oracle/): the CPU port timed on the
+    reference's Criterion workloads beside the GPU figures, and the oracle as the checker of those files and of a
+    sample of the config-3 batch.  c3_samples: [(pixels, width, height, quality, gpu_file_bytes)]."""
+    from oracle import pyoracle
+    out = {}
+    if criterion and "error" not in criterion:
+        px = synth.criterion_pattern(2000, 1800)
+        for name, (_, c) in CRITERION_VARIANTS.items():
+            c = dict(c)
+            q = c.pop("quality")
+            t = time.perf_counter()
+            ref = pyoracle.encode_jpeg(px, 2000, 1800, pyoracle.RGB, q, **c)
+            criterion[name]["cpu_port_ms"] = round((time.perf_counter() - t) * 1e3, 1)
+            criterion[name]["identical_bytes"] = bool(ref == criterion_files.get(name))
+        criterion["encode rgb mixed"]["cpu_port_ms"] = round(sum(criterion[m]["cpu_port_ms"] for m in CRITERION_MIXED), 1)
+    if c3_samples:
+        out["c3_parity_vs_oracle"] = all(
+            gpu == pyoracle.encode_jpeg(px, w, h, pyoracle.RGB, q) for px, w, h, q, gpu in c3_samples)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +300,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32, help="4K frames per launch and per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-frames", type=int, default=32, help="frames for the end-to-end (JPEG bytes) side figure; 0 disables")
+    ap.add_argument("--c3-frames", type=int, default=1000, help="frames of the config-3 batch (whole job, all ranks); 0 disables")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the side figures, so that every launch of the fused kernel in the process is the "
                          "headline launch (what tools/profile_round.sh runs under rocprofv3)")
@@ -266,11 +383,16 @@ def main():
     value = pixels / elapsed / 1e6
     algo_bytes = F * W * H * ALGO_BYTES_PER_PIXEL
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch come from separate `rocprofv3 --pmc` passes over this same command (tools/profile_round.sh):
+    # counters cannot be read from inside the timed process, so the line says where the number was measured and on
+    # which build - a stale file (kernel sources newer than it) is reported as such, not silently reused
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc))
+            traffic = rec.get("hbm_bytes_per_launch")
+            traffic_source = f"profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of build {rec.get('build', '?')}, not measured by this run)"
         except Exception:
             traffic = None
 
@@ -278,12 +400,15 @@ def main():
         "metric": "Mpixels/s encode (4K RGB q=90 4:2:0)", "value": round(value, 1), "unit": "Mpixels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_ms": args.settle_ms,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u8->i16 (i32 intermediates)", "data": "synthetic",
+        "scope": "block-encode kernel only (colour convert + subsample + FDCT + quantise + zig-zag), pixels and coefficients "
+                 "resident in HBM: no entropy coding, no PCIe; the full-encode figures are device_resident_full_encode, "
+                 "device_resident_to_host_jpeg, end_to_end and c3_batch",
         "config": {"workload": "C2: 3840x2160 RGB q=90 4:2:0 baseline, MCU-order coefficients; "
                                f"pixels and coefficients resident in HBM; {F} frames per launch per GPU",
                    "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "fused colour+subsample+FDCT+quant+zigzag", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": int(algo_bytes),
                      "read_only_frac": round(achieved / 2 / HBM_PEAK_GBPS, 4)},
@@ -292,7 +417,14 @@ def main():
     if rank == 0 and world == 1:
         result["cpu_baseline"], result["parity_vs_oracle"] = cpu_baseline(
             args.cpu_seconds, synth, d_px[0].cpu().numpy(), d_co[0].cpu().numpy())
+    link, criterion_files, c3_samples = None, {}, []
     if rank == 0 and world == 1 and not args.headline_only:
+        try:
+            link = link_rates(torch, dev)
+            result["link_rates"] = link
+        except Exception as exc:                                   # side figure only
+            link = {}
+            result["link_rates"] = {"error": str(exc)}
         # side figure (never `value`): the north-star stream pipeline, jpegenc_blocks_stream — pinned host
         # frames -> H2D -> fused kernel -> D2H of the coefficient tiles into pinned memory -> callback
         # (no entropy coding here), one stream per direction + one for the kernel
@@ -315,7 +447,7 @@ def main():
                                                "coefficient tiles into pinned memory -> callback; one stream per direction + one "
                                                "for the kernel, buffers allocated inside the timed call; 24.9 MB up + 24.9 MB "
                                                "down per frame",
-                                       "GBps_each_direction": round(nfr * frame_bytes / dt / 1e9, 1)}
+                                       "roofline": pcie_roofline("pcie_both", nfr * frame_bytes, dt, link)}
             del pinned
         except Exception as exc:                                   # side figure only
             result["pcie_pipeline"] = {"error": str(exc)}
@@ -406,7 +538,8 @@ def main():
             result["device_resident_to_host_jpeg"] = {
                 "value": round(Fd * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
                 "what": f"{Fd} 4K frames (Criterion pattern) in HBM -> JPEG files in host buffers, one Encoder call, batched "
-                        "launches, median of 5", "jpeg_bytes_per_frame": int(sum(lens_d) / Fd)}
+                        "launches, median of 5", "jpeg_bytes_per_frame": int(sum(lens_d) / Fd),
+                "roofline": pcie_roofline("pcie_d2h", int(sum(lens_d)), dt, link)}
             del d_crit, outs_d
         except Exception as exc:                                   # side figure only
             result["device_resident_to_host_jpeg"] = {"error": str(exc)}
@@ -441,7 +574,57 @@ def main():
                                     "what": "pageable host RGB (Criterion pattern) -> JPEG bytes in host buffers: "
                                             "H2D + fused kernel + device entropy coding + D2H of compressed bytes, "
                                             f"{n} frames per batch (median of 5 batches), one GPU, up to 16 host threads of {os.cpu_count()}",
-                                    "jpeg_bytes_per_frame": int(sum(lens) / n)}
+                                    "jpeg_bytes_per_frame": int(sum(lens) / n),
+                                    "roofline": pcie_roofline("pcie_h2d", n * frame_bytes, dt, link)}
+        try:
+            result["criterion_workloads"], criterion_files = criterion_workloads(binding, synth, local_rank)
+        except Exception as exc:                                   # side figure only
+            result["criterion_workloads"] = {"error": str(exc)}
+    # ---- BASELINE config 3 on every rank: the frame-sharded 1000-frame batch, pageable host pixels -> JPEG files in
+    # host buffers (jpeg_encoder_amd/batch.py; no data-path collective, MAX over ranks of the wall time)
+    if args.c3_frames > 0 and not args.headline_only:
+        try:
+            batch = importlib.import_module("jpeg_encoder_amd.batch")
+            enc3 = binding.Encoder(batch.C3_QUALITY, device=local_rank)         # q=80 -> default F_2_2 (encoder.rs:256-260)
+            cap3 = 4 << 20
+            n_mine = len(binding.shard_frames(args.c3_frames, world, rank))
+            outs3 = [np.empty(cap3, dtype=np.uint8) for _ in range(n_mine)]      # caller-owned output buffers, reused
+
+            def encode_frames(frames):                                          # -> views of the files, no copies
+                lens3 = enc3.encode_batch_into(frames, batch.C3_W, batch.C3_H, binding.RGB, outs3)
+                return [outs3[i][:lens3[i]] for i in range(len(frames))]
+            pool = batch.FramePool(synth)
+            c3, mine = batch.run_sharded_batch(binding, encode_frames, pool, args.c3_frames, batch.C3_W, batch.C3_H, world, rank,
+                                               dist if distributed else None, warmup_frames=32)
+            c3["what"] = (f"C3: {args.c3_frames} frames of 1920x1080 RGB q=80 4:2:0 sharded frame k -> rank k % {world} "
+                          "(jpegenc_shard_frames), each rank: pageable host pixels -> complete JPEG files in host buffers through "
+                          "jpegenc_encoder_encode_batch_to_buffers on its GPU; seconds = MAX over ranks; photo-like frames "
+                          f"({batch.POOL} distinct, frame k = pool[k % {batch.POOL}]); digest = checksum of the per-frame SHA-256s in frame order")
+            c3["scaling"] = "strong"
+            if rank == 0 and world == 1 and link:
+                c3["roofline"] = pcie_roofline("pcie_h2d", args.c3_frames * batch.C3_W * batch.C3_H * 3, c3["seconds"], link)
+            if rank == 0 and world == 1:
+                # the same batch through the library's own multi-device entry point (one process driving the listed GPUs;
+                # here only this rank's GPU, so it measures the API's overhead, not scaling) - same files
+                some = [pool(k) for k in range(min(args.c3_frames, 64))]
+                first = [bytes(mine[k]) for k in range(len(some))]            # (outs3 is reused below)
+                t1 = time.perf_counter()
+                lens_m = enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])
+                dtm = time.perf_counter() - t1
+                c3["multi_api_one_device"] = {"frames": len(some), "frames_per_s": round(len(some) / dtm, 1),
+                                              "identical_files": all(outs3[k][:lens_m[k]].tobytes() == first[k] for k in range(len(some)))}
+                ks = [0, len(some) // 2]                                      # checked against the oracle by the cpu_baseline leg
+                c3_samples = [(pool(k), batch.C3_W, batch.C3_H, batch.C3_QUALITY, first[k]) for k in ks]
+            result["c3_batch"] = c3
+        except Exception as exc:                                   # never lose the headline line to a side leg
+            result["c3_batch"] = {"error": repr(exc)}
+    if rank == 0 and world == 1 and not args.headline_only and args.cpu_seconds >= 2.0:
+        try:
+            extras = cpu_baseline_extras(synth, result.get("criterion_workloads"), criterion_files, c3_samples)
+            if "c3_parity_vs_oracle" in extras and isinstance(result.get("c3_batch"), dict):
+                result["c3_batch"]["parity_vs_oracle"] = extras["c3_parity_vs_oracle"]
+        except Exception as exc:                                   # side figures only
+            result.setdefault("cpu_baseline", {})["extras_error"] = repr(exc)
     if rank == 0:
         print(json.dumps(result))
     if distributed:

@@ -271,10 +271,12 @@ int  jpegenc_encoder_encode_coefficients(jpegenc_encoder *e, const int16_t *coef
 int  jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int width, int height,
                                    int color_type, jpegenc_write_fn sink, void *user);
 /* A batch of same-geometry images that already live in device memory, `frame_stride` bytes apart:
- * frame i -> sink(users[i], ...), one complete file each, in order.  The device work of the whole batch
+ * frame i -> sink(users[i], ...), one complete file each, each file's bytes in order (sink threading: see
+ * jpegenc_encoder_encode_batch).  The device work of the whole batch
  * shares its launches (one fused block-encode launch, one launch sequence per scan for all frames);
- * only the compressed bytes come back.  With optimised Huffman tables (per-frame tables) or the host
- * entropy coder the frames are encoded one at a time - same bytes either way. */
+ * only the compressed bytes come back.  With optimised Huffman tables (per-frame tables), the host
+ * entropy coder, or frames too large for the device entropy coder (jpegenc_scan_max_bytes == 0: about
+ * 2.45 M blocks and more) the frames are encoded one at a time - same bytes either way. */
 int  jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride,
                                          int num_frames, int width, int height, int color_type,
                                          jpegenc_write_fn sink, void *const *users);
@@ -295,7 +297,12 @@ int  jpegenc_encoder_encode_image(jpegenc_encoder *e, int jpeg_color_type, int w
                                   jpegenc_fill_row_fn fill_row, void *image_user,
                                   jpegenc_write_fn sink, void *sink_user);
 /* Batch of same-geometry frames on this handle's device, double-buffered (H2D / kernel / D2H /
- * host entropy coding overlapped).  frames[i] -> sink(users[i], ...). */
+ * host entropy coding overlapped).  frames[i] -> sink(users[i], ...).
+ * THREADING OF BATCH SINKS (every jpegenc_encoder_encode_batch* entry point): the library calls `sink` from its
+ * own worker threads (up to 16 per device).  The calls that carry ONE frame's bytes are made in order, by one
+ * thread at a time; calls for DIFFERENT frames may run concurrently.  A sink that touches state shared between
+ * frames (one output stream, a counter) must synchronise it itself; users[i] that point at per-frame state need
+ * nothing.  The *_to_buffers variants use per-frame buffers and have no such concern. */
 int  jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len,
                                   int num_frames, int width, int height, int color_type,
                                   jpegenc_write_fn sink, void *const *users);
@@ -311,6 +318,29 @@ int  jpegenc_encoder_encode_batch_to_buffers(jpegenc_encoder *e, const uint8_t *
 int  jpegenc_encoder_encode_batch_device_to_buffers(jpegenc_encoder *e, const void *d_frames, size_t frame_stride,
                                                     int num_frames, int width, int height, int color_type,
                                                     uint8_t *const *outs, const size_t *capacities, size_t *lengths);
+
+/* ---- multi-GPU batches (BASELINE config 3) ----------------------------------------------------
+ * Frames are independent, so a batch shards frame-wise with no exchange between GPUs: frame k belongs to shard
+ * k % num_shards (frame k -> GPU k mod 8 for the 1000-frame batch).  jpegenc_shard_frames is that rule as a
+ * function - the library's own multi-device batch, bench.py's one-process-per-GPU ranks and the CPU (gloo) test of
+ * the N>1 path all call it.  Returns the number of frames of `shard` (their ascending indices go to
+ * indices[0..capacity) when indices != NULL), or -JPEGENC_ERR_INVALID_ARGUMENT. */
+int  jpegenc_shard_frames(int num_frames, int num_shards, int shard, int *indices, int capacity);
+
+/* jpegenc_encoder_encode_batch over several GPUs of this node from ONE process: shard d = the frames
+ * jpegenc_shard_frames(num_frames, num_devices, d) names, encoded on HIP device devices[d] by that device's own
+ * worker threads, streams, pinned staging and device buffers (kept in the handle across calls); the threads feeding
+ * a GPU are bound to the NUMA node of its PCIe root complex (best effort; JPEGENC_NO_NUMA_BIND=1 disables it).
+ * A device may be listed more than once (several independent worker sets on it).  The reference has no
+ * counterpart (it is single-threaded, encoder.rs:440-515); same bytes per frame as jpegenc_encoder_encode.
+ * Sink threading: see jpegenc_encoder_encode_batch. */
+int  jpegenc_encoder_encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_devices,
+                                        const uint8_t *const *frames, size_t frame_len, int num_frames, int width,
+                                        int height, int color_type, jpegenc_write_fn sink, void *const *users);
+int  jpegenc_encoder_encode_batch_multi_to_buffers(jpegenc_encoder *e, const int *devices, int num_devices,
+                                                   const uint8_t *const *frames, size_t frame_len, int num_frames,
+                                                   int width, int height, int color_type, uint8_t *const *outs,
+                                                   const size_t *capacities, size_t *lengths);
 
 /* free functions re-exported by the crate (src/lib.rs:45-49) — host arithmetic, for callers that
  * implement their own ImageBuffer. */

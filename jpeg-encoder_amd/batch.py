@@ -1,0 +1,90 @@
+"""BASELINE config 3: a 1000-frame batch of 1920x1080 RGB q=80 4:2:0 frames sharded frame-wise over the
+GPUs of a node, one process (rank) per GPU.
+
+JPEG frames are independent: frame k belongs to shard k % world (`jpegenc_shard_frames`, the same C
+function the library's own multi-device batch uses), every rank encodes its own frames from pageable host
+memory to complete JPEG files in host buffers, and NO pixel or coefficient ever crosses ranks.  The only
+exchange is bookkeeping - frame counts, the slowest rank's wall time, per-frame digests - through
+`torch.distributed` object collectives, which run the same over RCCL (bench.py --gpus N) and gloo (the CPU
+test, tests/test_batch_gloo.py, which injects the per-frame encoder and keeps everything else).
+"""
+import hashlib
+import time
+
+import numpy as np
+
+C3_W, C3_H, C3_QUALITY, C3_FRAMES = 1920, 1080, 80, 1000      # BASELINE.json configs[2]; q=80 -> default F_2_2 (encoder.rs:256-260)
+POOL = 25                                                       # distinct frames; frame k of the batch = pool[k % POOL]
+
+
+def photo_like_frame(synth, k, w=C3_W, h=C3_H):
+    """Frame k of the batch: the reference's test gradient (lib.rs:81-98) scaled to the frame size, shifted by k
+    and carrying +-6 of noise seeded 42 + k (frame k seeded 42+k) - entropy-codes like a photograph."""
+    g = np.roll(synth.test_img_rgb(w, h), 16 * (k % POOL), axis=1).astype(np.int16)
+    rng = np.random.default_rng(42 + (k % POOL))
+    return np.clip(g + rng.integers(-6, 7, g.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+
+
+class FramePool:
+    """make_frame(k) with the POOL distinct frames generated once (a 1000-frame batch is 6.2 GB of pixels)."""
+
+    def __init__(self, synth, w=C3_W, h=C3_H):
+        self.synth, self.w, self.h, self.cache = synth, w, h, {}
+
+    def __call__(self, k):
+        key = k % POOL
+        if key not in self.cache:
+            self.cache[key] = np.ascontiguousarray(photo_like_frame(self.synth, key, self.w, self.h))
+        return self.cache[key]
+
+
+def _dist_ready(dist):
+    return dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def run_sharded_batch(binding, encode_frames, make_frame, num_frames, width, height, world=1, rank=0, dist=None,
+                      warmup_frames=0, digests=True):
+    """One rank's share of a frame-sharded batch + the bookkeeping exchange.
+
+    encode_frames(list of HxWx3 uint8 arrays) -> list of bytes : this rank's encoder (bench.py: the library's
+        batch API on the rank's GPU; the gloo test: anything, e.g. the oracle).
+    make_frame(k) -> pixels of frame k of the batch.
+    Returns a dict every rank agrees on: frames per rank, wall time of the slowest rank, aggregate rates, and -
+    with digests - a checksum of the per-frame checksums in frame order (independent of world size)."""
+    mine = binding.shard_frames(num_frames, world, rank)
+    frames = [make_frame(k) for k in mine]
+    if warmup_frames and frames:
+        encode_frames(frames[:warmup_frames])                      # buffers, page faults, clocks
+    if _dist_ready(dist):
+        dist.barrier()
+    t0 = time.perf_counter()
+    files = encode_frames(frames) if frames else []
+    seconds = time.perf_counter() - t0
+    if len(files) != len(mine):
+        raise RuntimeError(f"rank {rank}: {len(files)} files for {len(mine)} frames")
+    local = {"rank": rank, "frames": len(mine), "seconds": seconds, "bytes": sum(len(f) for f in files),
+             "digests": {k: hashlib.sha256(f).hexdigest()[:16] for k, f in zip(mine, files)} if digests else {}}
+    if _dist_ready(dist):
+        parts = [None] * world
+        dist.all_gather_object(parts, local)
+    else:
+        parts = [local]
+    parts = sorted(parts, key=lambda p: p["rank"])
+    merged = {}
+    for p in parts:
+        for k, d in p["digests"].items():
+            if k in merged:
+                raise RuntimeError(f"frame {k} encoded by two ranks")
+            merged[k] = d
+    total = sum(p["frames"] for p in parts)
+    if total != num_frames or (digests and sorted(merged) != list(range(num_frames))):
+        raise RuntimeError(f"sharding lost frames: {total} of {num_frames}")
+    slowest = max(p["seconds"] for p in parts)
+    out = {"frames": total, "per_rank_frames": [p["frames"] for p in parts], "seconds": round(slowest, 6),
+           "per_rank_seconds": [round(p["seconds"], 6) for p in parts],
+           "frames_per_s": round(total / slowest, 1) if slowest > 0 else None,
+           "Mpixels_per_s": round(total * width * height / slowest / 1e6, 1) if slowest > 0 else None,
+           "jpeg_bytes_per_frame": int(sum(p["bytes"] for p in parts) / max(total, 1))}
+    if digests:
+        out["digest"] = hashlib.sha256("".join(merged[k] for k in range(num_frames)).encode()).hexdigest()[:16]
+    return out, dict(zip(mine, files))

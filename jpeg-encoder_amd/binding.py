@@ -52,6 +52,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_batch_device", "jpegenc_encoder_encode_batch_device_to_buffers", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_to_file",
     "jpegenc_encoder_encode_image", "jpegenc_encoder_block_order", "jpegenc_encoder_encode_coefficients",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
+    "jpegenc_shard_frames", "jpegenc_encoder_encode_batch_multi", "jpegenc_encoder_encode_batch_multi_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
 ]
 
@@ -152,6 +153,13 @@ def lib():
         l.jpegenc_encoder_encode_batch_to_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_int,
                                                               C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                                               C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        l.jpegenc_shard_frames.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+        l.jpegenc_encoder_encode_batch_multi_to_buffers.argtypes = [
+            C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        l.jpegenc_encoder_encode_batch_multi.argtypes = [
+            C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+            WRITE_FN, C.POINTER(C.c_void_p)]
         l.jpegenc_rgb_to_ycbcr.argtypes = [C.c_uint8] * 3 + [C.POINTER(C.c_uint8)]
         l.jpegenc_cmyk_to_ycck.argtypes = [C.c_uint8] * 4 + [C.POINTER(C.c_uint8)]
         _lib = l
@@ -165,6 +173,17 @@ def check(status):
 
 def device_count():
     return lib().jpegenc_device_count()
+
+
+def shard_frames(num_frames, num_shards, shard):
+    """jpegenc_shard_frames: the indices of the frames shard `shard` of `num_shards` encodes (frame k -> shard
+    k % num_shards).  Needs no GPU; the ONE sharding rule of the library, bench.py and the gloo test."""
+    n = lib().jpegenc_shard_frames(num_frames, num_shards, shard, None, 0)
+    if n < 0:
+        raise JpegEncError(-n, lib().jpegenc_last_error().decode(errors="replace"))
+    idx = (C.c_int * max(n, 1))()
+    lib().jpegenc_shard_frames(num_frames, num_shards, shard, idx, n)
+    return [idx[i] for i in range(n)]
 
 
 def qtables(quality, types=(Q_DEFAULT, Q_DEFAULT), customs=(None, None)):
@@ -454,6 +473,40 @@ class Encoder:
         check(lib().jpegenc_encoder_encode_batch_to_buffers(self._h, ptrs, flen, n, width, height, color_type,
                                                            optrs, caps, lens))
         return [outs[i][:lens[i]].tobytes() for i in range(n)], outs, list(lens)
+
+    def encode_batch_into(self, frames, width, height, color_type, outs, devices=None):
+        """Batch encode into caller-owned uint8 arrays `outs` (no copies, no Python per frame inside the call):
+        returns the list of file lengths.  devices=None -> this handle's GPU (jpegenc_encoder_encode_batch_to_buffers),
+        else the multi-device entry point."""
+        n = len(frames)
+        ptrs = (C.c_void_p * max(n, 1))(*[f.ctypes.data for f in frames])
+        optrs = (C.c_void_p * max(n, 1))(*[o.ctypes.data for o in outs[:n]])
+        caps = (C.c_size_t * max(n, 1))(*[o.size for o in outs[:n]])
+        lens = (C.c_size_t * max(n, 1))()
+        flen = frames[0].size if n else 0
+        if devices is None:
+            check(lib().jpegenc_encoder_encode_batch_to_buffers(self._h, ptrs, flen, n, width, height, color_type, optrs, caps, lens))
+        else:
+            devs = (C.c_int * len(devices))(*devices)
+            check(lib().jpegenc_encoder_encode_batch_multi_to_buffers(self._h, devs, len(devices), ptrs, flen, n, width, height,
+                                                                     color_type, optrs, caps, lens))
+        return [lens[i] for i in range(n)]
+
+    def encode_batch_multi_to_buffers(self, devices, frames, width, height, color_type, capacity):
+        """jpegenc_encoder_encode_batch_multi_to_buffers: the batch sharded over `devices` (HIP indices, repeats
+        allowed) from this one process -> list of bytes, in frame order."""
+        arrs = [np.ascontiguousarray(f, dtype=np.uint8).reshape(-1) for f in frames]
+        n = len(arrs)
+        outs = [np.empty(capacity, dtype=np.uint8) for _ in range(n)]
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        optrs = (C.c_void_p * max(n, 1))(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * max(n, 1))(*([capacity] * n))
+        lens = (C.c_size_t * max(n, 1))()
+        devs = (C.c_int * len(devices))(*devices)
+        flen = arrs[0].size if n else 0
+        check(lib().jpegenc_encoder_encode_batch_multi_to_buffers(self._h, devs, len(devices), ptrs, flen, n, width, height,
+                                                                 color_type, optrs, caps, lens))
+        return [outs[i][:lens[i]].tobytes() for i in range(n)]
 
     def encode_batch(self, frames, width, height, color_type):
         """frames: list of equally sized uint8 arrays -> list of bytes (frame-parallel on one GPU)."""

@@ -9,6 +9,7 @@
 // hipMemcpyAsync copies and are coded as they land, with a 64-bit accumulator, word-at-a-time 0xFF
 // stuffing test (like writer.rs:169-184) and zero-run skipping through a non-zero bitmask.  Frames
 // of a batch are driven by one host thread per in-flight frame.
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -61,7 +62,10 @@ struct HuffTable {
     // Annex K.2 as HuffmanTable::new_optimized implements it (huffman.rs:99-221), including its
     // tie rule (`<=`: among equal least frequencies the LARGEST symbol wins) — that rule decides
     // the emitted DHT bytes, so it is part of the drop-in contract.
-    void assign_optimized(const uint32_t freq_in[257]) {
+    // Returns false where the reference panics: Figure K.1 can produce code sizes above 32 (a histogram
+    // that grows like the Fibonacci numbers over more than 33 symbols), which index `bits: [u8; 33]` out of
+    // bounds at huffman.rs:161-165.  Nothing is assigned then.
+    bool assign_optimized(const uint32_t freq_in[257]) {
         uint32_t freq[257];
         int others[257], codesize[257];
         memcpy(freq, freq_in, sizeof freq);
@@ -83,8 +87,10 @@ struct HuffTable {
             for (codesize[v2]++; others[v2] >= 0;) { v2 = others[v2]; codesize[v2]++; }
         }
         int count[33] = {0};
-        for (int i = 0; i < 257; i++)
+        for (int i = 0; i < 257; i++) {
+            if (codesize[i] > 32) return false;
             if (codesize[i]) count[codesize[i]]++;
+        }
         int i = 32;
         for (; i > 16; i--) {                       // Figure K.3: fold lengths > 16 back
             while (count[i] > 0) {
@@ -93,7 +99,8 @@ struct HuffTable {
                 count[i] -= 2; count[i - 1]++; count[j + 1] += 2; count[j]--;
             }
         }
-        while (count[i] == 0) i--;
+        while (i > 0 && count[i] == 0) i--;
+        if (i == 0) return false;                   // (debug_assert upstream, huffman.rs:186: an all-zero histogram)
         count[i]--;                                 // the reserved all-ones code point (symbol 256)
         uint8_t v[256], b[16];
         int n = 0;
@@ -102,6 +109,7 @@ struct HuffTable {
                 if (codesize[sym] == s) v[n++] = (uint8_t)sym;
         for (int s = 0; s < 16; s++) b[s] = (uint8_t)count[s + 1];
         assign(b, v, n);
+        return true;
     }
 };
 
@@ -175,6 +183,11 @@ struct Out {
         acc = 0; nbits = 0;
     }
 };
+
+// where HuffmanTable::new_optimized panics (index out of bounds, huffman.rs:161-165)
+static int fail_code_too_long() {
+    return fail(JPEGENC_ERR_INVALID_ARGUMENT, "optimised Huffman table: a code would be longer than 32 bits (the reference panics here, huffman.rs:161-165)");
+}
 
 static inline int bit_length(unsigned a) { return a ? 32 - __builtin_clz(a) : 0; }
 
@@ -255,11 +268,19 @@ struct DeviceCtx {
     std::string graph_key, last_key;
 
     int open(int dev) {
-        if (device == dev && stream) return JPEGENC_OK;
+        if (device == dev && stream) {        // (the calling thread may have used another device in between)
+            JPEGENC_HIP(hipSetDevice(dev));
+            return JPEGENC_OK;
+        }
         close();
         int rc = ensure_device_ready(dev);
         if (rc) return rc;
         device = dev;
+        rc = allocate_fixed();
+        if (rc) close();                  // never leave a half-open context behind: the next call would find `stream` set
+        return rc;
+    }
+    int allocate_fixed() {
         JPEGENC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (auto &e : chunk_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         JPEGENC_HIP(hipMalloc(&d_freq, sizeof(uint32_t) * 2 * 2 * 257));
@@ -493,6 +514,10 @@ struct jpegenc_encoder {
     std::vector<std::unique_ptr<DeviceCtx>> workers;   // batch API: one per in-flight frame, kept across calls
     BatchBuffers batch;                                  // device-resident batch API
     SmallBatchBuffers small;                             // batches of small frames
+    int max_batch_workers = 16;                          // host threads of jpegenc_encoder_encode_batch
+    // jpegenc_encoder_encode_batch_multi: one child encoder per entry of `devices` (its own workers, streams,
+    // pinned staging and device buffers), kept across calls
+    std::vector<std::unique_ptr<jpegenc_encoder>> shards;
 };
 
 namespace jpegenc {
@@ -657,7 +682,8 @@ static int emit_host_coded(const Config &c, int jct, int width, int height, cons
         if (optimize) {                                      // optimize_huffman_table, encoder.rs:1086-1200
             const int max_tables = L.num_components < 2 ? L.num_components : 2;
             for (int d = 0; d < max_tables; d++)
-                for (int k = 0; k < 2; k++) t.h[d][k].assign_optimized(freq + (d * 2 + k) * 257);
+                for (int k = 0; k < 2; k++)
+                    if (!t.h[d][k].assign_optimized(freq + (d * 2 + k) * 257)) return fail_code_too_long();
         }
         write_frame_header(o, c, width, height, L, t);       // after the tables are final (:821, :881)
         if (mode == MODE_SEQUENTIAL) {                       // encode_image_sequential, encoder.rs:810-864
@@ -903,7 +929,8 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                 JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
                 const int max_tables = L.num_components < 2 ? L.num_components : 2;
                 for (int d = 0; d < max_tables; d++)
-                    for (int k = 0; k < 2; k++) t.h[d][k].assign_optimized(ctx.h_freq + (d * 2 + k) * 257);
+                    for (int k = 0; k < 2; k++)
+                        if (!t.h[d][k].assign_optimized(ctx.h_freq + (d * 2 + k) * 257)) return fail_code_too_long();
             }
             if (optimize) { rc = ensure_lut(); if (rc) return rc; }
             if (enqueue) {
@@ -1033,6 +1060,11 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
 // compressed bytes come back.  Per-frame Huffman tables (optimised mode) cannot share the scan
 // launches; the caller falls back to one encode_frame per image for them.
 
+// encode_device_batch returns this (before any device work) for frames whose scans the device entropy coder declines
+// (32-bit bit offsets: about 2.45 M blocks and more); the caller then encodes frame by frame, where encode_frame
+// hands such scans to the host coder - same bytes.
+constexpr int kBatchNeedsPerFrame = -1000;
+
 static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b, int device, const void *d_frames,
                                size_t frame_stride, int num_frames, int width, int height, int color_type,
                                jpegenc_write_fn sink, void *const *users) {
@@ -1081,7 +1113,7 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
     for (auto &j : jobs) {
         if (!j.sc.with_dc && j.sc.ac_end == j.sc.ac_start) continue;          // empty band: nothing to code
         j.cap = scan_max_bytes(L, j.sc);
-        if (!j.cap) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan not supported by the device entropy coder");
+        if (!j.cap) return kBatchNeedsPerFrame;                               // (before any device work)
         j.off = out_total;
         out_total += j.cap;
     }
@@ -1105,7 +1137,7 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
     for (auto &j : jobs) {
         if (!j.cap) continue;
         const size_t w = scan_workspace_size(L, j.sc, per_round);
-        if (!w) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan not supported by the device entropy coder");
+        if (!w) return kBatchNeedsPerFrame;
         if (w > ws) ws = w;
     }
     const size_t nlen = jobs.size() * (size_t)per_round;
@@ -1521,7 +1553,13 @@ int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames
         }
         return JPEGENC_OK;
     }
-    return encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
+    const int rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
+    if (rc != kBatchNeedsPerFrame) return rc;
+    for (int i = 0; i < num_frames; i++) {
+        const int r = jpegenc_encoder_encode_device(e, (const uint8_t *)d_frames + (size_t)i * frame_stride, width, height, color_type, sink, users[i]);
+        if (r) return r;
+    }
+    return JPEGENC_OK;
 }
 
 int jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len, int width, int height,
@@ -1645,7 +1683,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     // one frame overlap the entropy coding of the others
     unsigned hw = std::thread::hardware_concurrency();
     int workers = (int)(hw ? hw : 4);
-    if (workers > 16) workers = 16;
+    if (workers > e->max_batch_workers) workers = e->max_batch_workers;
     if (workers > num_frames) workers = num_frames;
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
@@ -1709,6 +1747,148 @@ int jpegenc_encoder_encode_batch_device_to_buffers(jpegenc_encoder *e, const voi
         users[(size_t)i] = &sinks[(size_t)i];
     }
     int rc = jpegenc_encoder_encode_batch_device(e, d_frames, frame_stride, num_frames, width, height, color_type, buffer_sink, users.data());
+    bool fits = true;
+    for (int i = 0; i < num_frames; i++) {
+        lengths[i] = sinks[(size_t)i].len;
+        if (sinks[(size_t)i].len > sinks[(size_t)i].cap) fits = false;
+    }
+    if (rc) return rc;
+    return fits ? JPEGENC_OK : fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "at least one output buffer is too small");
+}
+
+
+// ---- multi-GPU batches (frame k -> GPU k mod N, no collective) ---------------------------------
+int jpegenc_shard_frames(int num_frames, int num_shards, int shard, int *indices, int capacity) {
+    if (num_frames < 0 || num_shards < 1 || shard < 0 || shard >= num_shards)
+        return -fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad shard arguments");
+    int n = 0;
+    for (int k = shard; k < num_frames; k += num_shards, n++)
+        if (indices && n < capacity) indices[n] = k;
+    return n;
+}
+
+}  // extern "C"
+
+namespace jpegenc {
+
+// Host threads that feed a GPU should run on the NUMA node its PCIe root complex hangs off (pinned staging memory is
+// then first touched there and the uploads do not cross the socket interconnect).  Best effort: any failure leaves
+// the thread where it was.  JPEGENC_NO_NUMA_BIND=1 disables it.
+static void bind_thread_near_device(int device) {
+    static const bool off = getenv("JPEGENC_NO_NUMA_BIND") != nullptr;
+    if (off) return;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device) != hipSuccess) return;
+    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0) return;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return;
+    char list[4096] = {0};
+    const size_t len = fread(list, 1, sizeof list - 1, f);
+    fclose(f);
+    if (!len) return;
+    cpu_set_t want, have, both;
+    CPU_ZERO(&want);
+    for (const char *c = list; *c;) {                          // "0-31,128-159"
+        char *end = nullptr;
+        const long a = strtol(c, &end, 10);
+        if (end == c) break;
+        long b = a;
+        c = end;
+        if (*c == '-') { b = strtol(c + 1, &end, 10); c = end; }
+        for (long i = a; i <= b && i < CPU_SETSIZE; i++) if (i >= 0) CPU_SET((int)i, &want);
+        if (*c == ',') c++; else break;
+    }
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return;
+    CPU_AND(&both, &want, &have);
+    if (CPU_COUNT(&both) > 0) (void)sched_setaffinity(0, sizeof both, &both);
+}
+
+static int encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_devices, const uint8_t *const *frames, size_t frame_len,
+                              int num_frames, int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
+    if (!devices || num_devices < 1 || num_devices > 64) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad device list");
+    if (num_frames < 0 || (num_frames && (!frames || !users)) || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
+    int rc = validate_image(frame_len, width, height, color_type);         // before any device work
+    if (rc) return rc;
+    for (int d = 0; d < num_devices; d++) {
+        rc = ensure_device_ready(devices[d]);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < num_frames; i++)
+        if (!frames[i]) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
+    if (num_frames == 0) return JPEGENC_OK;
+    if ((int)e->shards.size() > num_devices) e->shards.resize((size_t)num_devices);
+    while ((int)e->shards.size() < num_devices) e->shards.emplace_back(nullptr);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (!hw) hw = 4;
+    int per_shard = (int)(hw / (unsigned)num_devices);
+    if (per_shard < 4) per_shard = 4;
+    if (per_shard > 16) per_shard = 16;
+    for (int d = 0; d < num_devices; d++) {
+        auto &child = e->shards[(size_t)d];
+        if (!child || child->device != devices[d]) {       // its buffers live on the device it was made for
+            child.reset(new (std::nothrow) jpegenc_encoder());
+            if (!child) return fail(JPEGENC_ERR_HIP, "out of memory");
+            child->device = devices[d];
+        }
+        child->cfg = e->cfg;
+        child->max_batch_workers = per_shard;
+    }
+    std::vector<int> status((size_t)num_devices, JPEGENC_OK);
+    std::vector<std::string> messages((size_t)num_devices);
+    auto shard_body = [&](int d) {
+        bind_thread_near_device(devices[d]);                                // the workers this thread spawns inherit the mask
+        const int n = jpegenc_shard_frames(num_frames, num_devices, d, nullptr, 0);
+        if (n <= 0) { status[(size_t)d] = n < 0 ? -n : JPEGENC_OK; return; }
+        std::vector<int> idx((size_t)n);
+        (void)jpegenc_shard_frames(num_frames, num_devices, d, idx.data(), n);
+        std::vector<const uint8_t *> sub_frames((size_t)n);
+        std::vector<void *> sub_users((size_t)n);
+        for (int i = 0; i < n; i++) { sub_frames[(size_t)i] = frames[idx[(size_t)i]]; sub_users[(size_t)i] = users[idx[(size_t)i]]; }
+        const int r = jpegenc_encoder_encode_batch(e->shards[(size_t)d].get(), sub_frames.data(), frame_len, n, width, height, color_type,
+                                                   sink, sub_users.data());
+        status[(size_t)d] = r;
+        if (r) messages[(size_t)d] = jpegenc_last_error();
+    };
+    std::vector<std::thread> pool;
+    for (int d = 0; d < num_devices; d++) pool.emplace_back(shard_body, d);   // (shard threads only drive; the caller's affinity is left alone)
+    for (auto &th : pool) th.join();
+    for (int d = 0; d < num_devices; d++)
+        if (status[(size_t)d] != JPEGENC_OK) { set_last_error("device " + std::to_string(devices[d]) + ": " + messages[(size_t)d]); return status[(size_t)d]; }
+    return JPEGENC_OK;
+}
+
+}  // namespace jpegenc
+
+extern "C" {
+
+int jpegenc_encoder_encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_devices, const uint8_t *const *frames,
+                                       size_t frame_len, int num_frames, int width, int height, int color_type,
+                                       jpegenc_write_fn sink, void *const *users) {
+    REQUIRE(e);
+    return encode_batch_multi(e, devices, num_devices, frames, frame_len, num_frames, width, height, color_type, sink, users);
+}
+
+int jpegenc_encoder_encode_batch_multi_to_buffers(jpegenc_encoder *e, const int *devices, int num_devices, const uint8_t *const *frames,
+                                                  size_t frame_len, int num_frames, int width, int height, int color_type,
+                                                  uint8_t *const *outs, const size_t *capacities, size_t *lengths) {
+    REQUIRE(e);
+    if (num_frames < 0 || (num_frames && (!outs || !capacities || !lengths))) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
+    std::vector<BufferSink> sinks((size_t)num_frames);
+    std::vector<void *> users((size_t)num_frames);
+    for (int i = 0; i < num_frames; i++) {
+        sinks[(size_t)i] = BufferSink{outs[i], outs[i] ? capacities[i] : 0, 0};
+        users[(size_t)i] = &sinks[(size_t)i];
+    }
+    int rc = encode_batch_multi(e, devices, num_devices, frames, frame_len, num_frames, width, height, color_type, buffer_sink, users.data());
     bool fits = true;
     for (int i = 0; i < num_frames; i++) {
         lengths[i] = sinks[(size_t)i].len;

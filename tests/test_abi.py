@@ -347,3 +347,120 @@ def test_integration_notes_show_every_entry_point():
     assert len(names) > 40
     missing = [n for n in names if n not in notes]
     assert not missing, missing
+
+
+def _k1_code_sizes(freq):
+    """Figure K.1 of T.81 as huffman.rs:103-157 runs it (an independent reading: plain Python, no library)."""
+    freq = list(freq)
+    others, size = [-1] * 257, [0] * 257
+    while True:
+        v1 = v2 = None
+        least = 1 << 62
+        for i, f in enumerate(freq):
+            if f and f <= least:
+                least, v1 = f, i
+        if v1 is None:
+            break
+        least = 1 << 62
+        for i, f in enumerate(freq):
+            if f and f <= least and i != v1:
+                least, v2 = f, i
+        if v2 is None:
+            break
+        freq[v1] += freq[v2]
+        freq[v2] = 0
+        size[v1] += 1
+        while others[v1] >= 0:
+            v1 = others[v1]
+            size[v1] += 1
+        others[v1] = v2
+        size[v2] += 1
+        while others[v2] >= 0:
+            v2 = others[v2]
+            size[v2] += 1
+    return size
+
+
+def _fibonacci_ac_blocks(nsym):
+    """Blocks (zig-zag i16, DC 0) whose AC symbol histogram grows like the Fibonacci numbers over `nsym` (run, size)
+    symbols, and that histogram.  Symbols: run 0 for the 15 most frequent, then run 1, then run 2; blocks hold one
+    run class each (a symbol takes run + 1 slots), end in a non-zero coefficient (no EOB) and are topped up with
+    the most frequent symbol (0, 1), whose exact count does not matter to the tree's depth."""
+    fib = [1, 1]
+    while len(fib) < nsym:
+        fib.append(fib[-1] + fib[-2])
+    symbols = [(r, s) for r in range(3) for s in range(1, 16)][:nsym]
+    counts = dict(zip(symbols, reversed(fib)))
+    fillers = placed01 = 0
+    classes = []
+    for r in (2, 1, 0):
+        want = {s: c for (rr, s), c in counts.items() if rr == r}
+        if r == 0:
+            want[1] = placed01 = max(want[1] - fillers, 1)
+        if not want:
+            continue
+        vals = np.concatenate([np.full(c, 1 << (s - 1), dtype=np.int16) for s, c in sorted(want.items())])
+        per = 63 // (r + 1)
+        n = -(-len(vals) // per)
+        blk = np.zeros((n, 64), dtype=np.int16)
+        full = np.zeros(n * per, dtype=np.int16)
+        full[:len(vals)] = vals
+        blk[:, r + 1::r + 1][:, :per] = full.reshape(n, per)
+        last_used = (len(vals) - (n - 1) * per) * (r + 1)                 # zig-zag index of the last real symbol of the last block
+        blk[n - 1, last_used + 1:] = 1                                  # top up: (0, 1) symbols
+        fillers += 63 - last_used
+        if per * (r + 1) < 63:                                          # run 1: slot 63 of every block
+            fillers += int(np.count_nonzero(blk[:n - 1, 63] == 0))
+            blk[:n - 1, 63] = 1
+        classes.append(blk)
+    hist = [0] * 257
+    for (r, s), c in counts.items():
+        hist[(r << 4) | s] = c
+    hist[0x01] = placed01 + fillers
+    hist[256] = 1
+    return np.concatenate(classes[::-1]), hist
+
+
+def test_optimised_table_with_a_code_longer_than_32_bits_is_an_error(binding, oracle):
+    """HuffmanTable::new_optimized indexes `bits: [u8; 33]` with the code size (huffman.rs:161-165) and panics when
+    Figure K.1 produces a size above 32 - an AC histogram that grows like the Fibonacci numbers over 36 symbols does.
+    The drop-in must report an error there (it used to write past a stack array and emit a corrupt DHT)."""
+    # the construction, checked small: its designed histogram is what the oracle counts on its blocks
+    small, hist = _fibonacci_ac_blocks(20)
+    got = oracle.histogram(small, len(small) * 8, 8, oracle.LUMA, 1, 1)[0, 1]
+    assert [int(v) for v in got] == hist
+    assert max(_k1_code_sizes(hist)) <= 32
+    e = binding.Encoder(90)
+    e.set_optimized_huffman_tables(True)
+    jpg = e.encode_coefficients(small, len(small) * 8, 8, binding.LUMA)       # 20 symbols: a valid optimised file ...
+    bits, vals = oracle.huffman_optimized(hist)                         # ... whose AC DHT is the oracle's table for that histogram
+    assert bytes([0xFF, 0xC4]) + (2 + 1 + 16 + len(vals)).to_bytes(2, "big") + bytes([0x10]) + bytes(bits) + bytes(vals) in jpg
+    blocks, hist = _fibonacci_ac_blocks(36)
+    assert max(_k1_code_sizes(hist)) > 32, "the construction must reach a 33-bit code"
+    cols = 8000
+    rows = -(-len(blocks) // cols)
+    blocks = np.concatenate([blocks, np.repeat(blocks[:1], cols * rows - len(blocks), axis=0)])
+    w, h = cols * 8, rows * 8
+    assert w <= 65535
+    with pytest.raises(binding.JpegEncError) as err:
+        e.encode_coefficients(blocks, w, h, binding.LUMA)
+    assert err.value.status == binding.ERR_INVALID_ARGUMENT and "32 bits" in str(err.value)
+    e.set_optimized_huffman_tables(False)                               # the same frame with fixed tables is fine
+    assert e.encode_coefficients(blocks, w, h, binding.LUMA)[:2] == b"\xff\xd8"
+
+
+def test_frames_the_device_entropy_coder_declines(binding):
+    """The decision behind the per-frame fall-back of jpegenc_encoder_encode_batch_device: jpegenc_scan_max_bytes /
+    _workspace_size are 0 from about 2.45 M blocks (32-bit bit offsets), non-zero below."""
+    def cap(w, h, ct, hs, vs):
+        L = binding.layout(w, h, ct, hs, vs, binding.ORDER_MCU)
+        s = binding.baseline_scan()
+        return binding.scan_max_bytes(L, s), binding.scan_workspace_size(L, s, 1)
+    assert cap(10000, 8000, binding.RGB, 1, 1) == (0, 0)
+    assert cap(16384, 16384, binding.RGB, 2, 2) == (0, 0)
+    assert cap(65535, 65535, binding.RGB, 2, 2) == (0, 0)
+    assert cap(16384, 10000, binding.LUMA, 1, 1) == (0, 0)
+    ok = cap(3840, 2160, binding.RGB, 2, 2)
+    assert ok[0] > 0 and ok[1] > 0
+    ok = cap(7680, 4320, binding.CMYK, 1, 1)
+    assert ok[0] > 0 and ok[1] > 0

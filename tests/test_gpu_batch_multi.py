@@ -1,0 +1,125 @@
+"""BASELINE config 3 as a BATCH, and the multi-device batch entry point, through the C ABI against the oracle
+(byte-identical files).  Run with `pytest -m gpu` on an MI355X; the box has one GPU, so the multi-device path is
+exercised with the same device listed twice (two independent worker sets) - the sharding rule, the per-shard
+encoders and the result plumbing are the code under test; the 1 -> 8 scaling itself is the driver's SCALE run."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def binding(pkg):
+    b = importlib.import_module("jpeg_encoder_amd.binding")
+    if b.device_count() < 1:
+        pytest.fail("no MI355X visible: the HIP path has no CPU fallback")
+    return b
+
+
+@pytest.fixture(scope="module")
+def c3(pkg, synth, oracle):
+    """The 125 frames one GPU of eight gets from the 1000-frame batch, and the oracle's files for them."""
+    batch = importlib.import_module("jpeg_encoder_amd.batch")
+    pool = batch.FramePool(synth)
+    want = {k: oracle.encode_jpeg(pool(k), batch.C3_W, batch.C3_H, oracle.RGB, batch.C3_QUALITY) for k in range(batch.POOL)}
+    return batch, pool, want
+
+
+def test_config3_batch_125_frames_byte_identical(binding, c3):
+    """125 frames of 1920x1080 RGB q=80 4:2:0 through jpegenc_encoder_encode_batch_to_buffers (worker pool, one
+    stream per worker, replayed launch sequences), every file compared with the oracle's."""
+    batch, pool, want = c3
+    mine = binding.shard_frames(batch.C3_FRAMES, 8, 3)                 # rank 3 of 8
+    assert len(mine) == 125
+    frames = [pool(k) for k in mine]
+    with binding.Encoder(batch.C3_QUALITY) as enc:
+        outs = [np.empty(2 << 20, dtype=np.uint8) for _ in frames]
+        for _ in range(2):                                             # second pass: captured graphs replayed
+            lens = enc.encode_batch_into(frames, batch.C3_W, batch.C3_H, binding.RGB, outs)
+            for i, k in enumerate(mine):
+                assert outs[i][:lens[i]].tobytes() == want[k % batch.POOL], f"frame {k}"
+
+
+def test_run_sharded_batch_on_the_gpu(binding, c3):
+    """bench.py's c3_batch leg (jpeg_encoder_amd.batch.run_sharded_batch) with the library as the encoder."""
+    batch, pool, want = c3
+    with binding.Encoder(batch.C3_QUALITY) as enc:
+        outs = [np.empty(2 << 20, dtype=np.uint8) for _ in range(64)]
+
+        def encode_frames(frames):
+            lens = enc.encode_batch_into(frames, batch.C3_W, batch.C3_H, binding.RGB, outs)
+            return [outs[i][:lens[i]] for i in range(len(frames))]
+        result, files = batch.run_sharded_batch(binding, encode_frames, pool, 64, batch.C3_W, batch.C3_H, warmup_frames=8)
+    assert result["frames"] == 64 and result["per_rank_frames"] == [64] and result["frames_per_s"] > 0
+    for k, f in files.items():
+        assert bytes(f) == want[k % batch.POOL]
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_encode_batch_multi_shards(binding, c3, devices):
+    """jpegenc_encoder_encode_batch_multi_to_buffers: frame k -> devices[k % n]; same files as the oracle whatever
+    the device list; the handle keeps its shards across calls."""
+    batch, pool, want = c3
+    frames = [pool(k) for k in range(37)]
+    with binding.Encoder(batch.C3_QUALITY) as enc:
+        for _ in range(2):
+            files = enc.encode_batch_multi_to_buffers(devices, frames, batch.C3_W, batch.C3_H, binding.RGB, 2 << 20)
+            assert [f == want[k % batch.POOL] for k, f in enumerate(files)] == [True] * 37
+        # another configuration through the same handle and shards: progressive + optimised (per-frame tables)
+        enc.set_progressive(True)
+        enc.set_optimized_huffman_tables(True)
+        small = [np.ascontiguousarray(f[:120, :200]) for f in frames[:7]]
+        files = enc.encode_batch_multi_to_buffers(devices, small, 200, 120, binding.RGB, 1 << 20)
+    from oracle import pyoracle
+    for f, px in zip(files, small):
+        assert f == pyoracle.encode_jpeg(px, 200, 120, pyoracle.RGB, batch.C3_QUALITY, progressive_scans=4, optimize=True)
+
+
+def test_encode_batch_multi_sink_and_errors(binding, c3, synth):
+    import ctypes as C
+    batch, pool, want = c3
+    frames = [pool(k) for k in range(5)]
+    with binding.Encoder(batch.C3_QUALITY) as enc:
+        # callback form: per-frame users, calls of one frame in order
+        outs = [[] for _ in frames]
+
+        def sink(user, ptr, n):
+            outs[user or 0].append(C.string_at(ptr, n))
+            return 0
+        cb = binding.WRITE_FN(sink)
+        ptrs = (C.c_void_p * 5)(*[f.ctypes.data for f in frames])
+        users = (C.c_void_p * 5)(*range(5))
+        devs = (C.c_int * 2)(0, 0)
+        binding.check(binding.lib().jpegenc_encoder_encode_batch_multi(enc._h, devs, 2, ptrs, frames[0].size, 5, batch.C3_W, batch.C3_H,
+                                                                       binding.RGB, cb, users))
+        assert [b"".join(o) for o in outs] == [want[k] for k in range(5)]
+        # an unknown device is reported before any work, like Encoder::encode's validation
+        with pytest.raises(binding.JpegEncError) as e:
+            enc.encode_batch_multi_to_buffers([0, 99], frames, batch.C3_W, batch.C3_H, binding.RGB, 2 << 20)
+        assert e.value.status == binding.ERR_NO_DEVICE
+        with pytest.raises(binding.JpegEncError) as e:
+            enc.encode_batch_multi_to_buffers([], frames, batch.C3_W, batch.C3_H, binding.RGB, 2 << 20)
+        assert e.value.status == binding.ERR_INVALID_ARGUMENT
+        with pytest.raises(binding.JpegEncError) as e:                 # BadImageData before any device work
+            enc.encode_batch_multi_to_buffers([0, 0], [f[:100] for f in frames], batch.C3_W, batch.C3_H, binding.RGB, 2 << 20)
+        assert e.value.status == binding.ERR_BAD_IMAGE_DATA
+        assert enc.encode_batch_multi_to_buffers([0, 0], [], batch.C3_W, batch.C3_H, binding.RGB, 16) == []
+
+
+def test_batch_device_falls_back_for_frames_the_device_coder_declines(binding, oracle, synth):
+    """A frame of more than ~2.45 M blocks (jpegenc_scan_max_bytes == 0): the device-resident batch entry point must
+    encode it like jpegenc_encoder_encode_device does (host entropy coder) instead of failing - same bytes."""
+    import torch
+    w, h = 16384, 10000                                                 # luma: 2 560 000 blocks
+    L = binding.layout(w, h, binding.LUMA, 1, 1, binding.ORDER_MCU)
+    assert binding.scan_max_bytes(L, binding.baseline_scan()) == 0
+    px = np.ascontiguousarray(np.tile(synth.test_img_gray(256, 250), (40, 64)))     # 10000 x 16384
+    assert px.shape == (h, w)
+    d = torch.from_numpy(np.stack([px, px[::-1].copy()])).cuda()
+    with binding.Encoder(90) as enc:
+        files = enc.encode_batch_device(d.data_ptr(), w * h, 2, w, h, binding.LUMA)
+        one = enc.encode_device(d.data_ptr(), w, h, binding.LUMA)
+    assert files[0] == one == oracle.encode_jpeg(px, w, h, oracle.LUMA, 90)
+    assert files[1] == oracle.encode_jpeg(px[::-1].copy(), w, h, oracle.LUMA, 90)
