@@ -608,6 +608,7 @@ def main():
                 # here only this rank's GPU, so it measures the API's overhead, not scaling) - same files
                 some = [pool(k) for k in range(min(args.c3_frames, 64))]
                 first = [bytes(mine[k]) for k in range(len(some))]            # (outs3 is reused below)
+                enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])     # warm-up: the shard's buffers
                 t1 = time.perf_counter()
                 lens_m = enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])
                 dtm = time.perf_counter() - t1

@@ -93,6 +93,13 @@ extern "C" {
                                out_frame_stride: usize, d_out_lengths: *mut u32, d_workspace: *mut c_void, workspace_bytes: usize,
                                stream: *mut c_void) -> c_int;
 
+    pub fn jpegenc_pixels_scan_fused(width: c_int, height: c_int, color_type: c_int, h: c_int, v: c_int) -> c_int;
+    pub fn jpegenc_pixels_scan_device(d_pixels: *const c_void, pixel_frame_stride: usize, num_frames: c_int, width: c_int, height: c_int,
+                                      color_type: c_int, h: c_int, v: c_int, tables: *const jpegenc_qtable, fdct_variant: c_int,
+                                      restart_interval: c_int, huffman: *const [jpegenc_huffman_spec; 2], d_coeffs: *mut c_void,
+                                      coeff_frame_stride: usize, d_out: *mut c_void, out_frame_stride: usize, d_out_lengths: *mut u32,
+                                      d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
+
     pub fn jpegenc_encoder_new(quality: c_int) -> *mut jpegenc_encoder;
     pub fn jpegenc_encoder_free(e: *mut jpegenc_encoder);
     pub fn jpegenc_encoder_set_device(e: *mut jpegenc_encoder, device: c_int) -> c_int;

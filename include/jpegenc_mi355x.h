@@ -216,6 +216,22 @@ int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num
                         void *d_out, size_t out_frame_stride, uint32_t *d_out_lengths,
                         void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
+/* Pixels in HBM -> the entropy-coded interleaved baseline scan in HBM in one call: what the body of
+ * encode_image_interleaved (encoder.rs:727-804) produces between the SOS header and EOI, for `num_frames` images
+ * laid out as for jpegenc_blocks_device.  For the RGB family (Rgb / Rgba / Bgr / Bgra) ONE fused kernel goes from the
+ * pixels to the coded runs - colour conversion, subsampling, FDCT, quantisation, zig-zag and write_block's bits
+ * (writer.rs:331-388) without the coefficients ever reaching HBM (jpegenc_pixels_scan_fused returns 1; d_coeffs may
+ * be NULL); other layouts run the block kernel into `d_coeffs` (coeff_frame_stride blocks per frame, 0 = total_blocks)
+ * and code from there.  Workspace / output sizing: jpegenc_scan_workspace_size / jpegenc_scan_max_bytes with
+ * jpegenc_scan{-1, 1, 1, 64, restart_interval} on the ORDER_MCU layout.  Same bytes as jpegenc_blocks_device followed
+ * by jpegenc_scan_device; this is the path the Encoder takes.  Asynchronous on hip_stream. */
+int jpegenc_pixels_scan_fused(int width, int height, int color_type, int h_sampling, int v_sampling);
+int jpegenc_pixels_scan_device(const void *d_pixels, size_t pixel_frame_stride, int num_frames, int width, int height,
+                               int color_type, int h_sampling, int v_sampling, const jpegenc_qtable tables[2],
+                               int fdct_variant, int restart_interval, const jpegenc_huffman_spec (*huffman)[2],
+                               void *d_coeffs, size_t coeff_frame_stride, void *d_out, size_t out_frame_stride,
+                               uint32_t *d_out_lengths, void *d_workspace, size_t workspace_bytes, void *hip_stream);
+
 /* ---- Encoder-shaped API (struct Encoder, src/encoder.rs:213-515) ------------------------ */
 typedef struct jpegenc_encoder jpegenc_encoder;
 

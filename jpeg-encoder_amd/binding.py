@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "jpegenc_qtable_init", "jpegenc_bytes_per_pixel", "jpegenc_sampling_factor_from_factors", "jpegenc_layout_init",
     "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_histogram_device",
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
+    "jpegenc_pixels_scan_fused", "jpegenc_pixels_scan_device",
     "jpegenc_encoder_set_device_entropy",
     "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
     "jpegenc_encoder_set_fdct_variant", "jpegenc_encoder_set_density", "jpegenc_encoder_density",
@@ -126,6 +127,10 @@ def lib():
         l.jpegenc_scan_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Layout), C.POINTER(Scan),
                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p]
+        l.jpegenc_pixels_scan_fused.argtypes = [C.c_int] * 5
+        l.jpegenc_pixels_scan_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.POINTER(QTable), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         for name in ("set_device", "set_device_entropy", "set_fdct_variant", "set_sampling_factor", "set_progressive",
                      "set_progressive_scans", "set_optimized_huffman_tables"):
             getattr(l, "jpegenc_encoder_" + name).argtypes = [C.c_void_p, C.c_int]
@@ -262,6 +267,20 @@ def scan_device(d_coeffs_ptr, coeff_frame_stride, num_frames, L, scan, d_out_ptr
     check(lib().jpegenc_scan_device(d_coeffs_ptr, coeff_frame_stride, num_frames, C.byref(L), C.byref(scan), tables,
                                     d_out_ptr, out_frame_stride, d_lengths_ptr, d_workspace_ptr, workspace_bytes,
                                     stream_ptr))
+
+
+def pixels_scan_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, color_type, hs, vs, q, d_out_ptr,
+                       out_frame_stride, d_lengths_ptr, d_workspace_ptr, workspace_bytes, stream_ptr=0, variant=FDCT_SCALAR,
+                       restart_interval=0, d_coeffs_ptr=None, coeff_frame_stride=0, tables=None):
+    """jpegenc_pixels_scan_device: pixels in HBM -> entropy-coded interleaved baseline scan in HBM (fused kernel for
+    the RGB family; d_coeffs_ptr is only needed where pixels_scan_fused() is False)."""
+    check(lib().jpegenc_pixels_scan_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, color_type, hs, vs, q,
+                                           variant, restart_interval, tables, d_coeffs_ptr, coeff_frame_stride, d_out_ptr,
+                                           out_frame_stride, d_lengths_ptr, d_workspace_ptr, workspace_bytes, stream_ptr))
+
+
+def pixels_scan_fused(width, height, color_type, hs, vs):
+    return bool(lib().jpegenc_pixels_scan_fused(width, height, color_type, hs, vs))
 
 
 def scan_workspace_size(L, scan, num_frames):

@@ -73,7 +73,7 @@ static void plan_scan(uint64_t max_blocks, uint64_t bound, int frames, ScanPlan 
     pl->max_blocks = (uint32_t)max_blocks;
     pl->raw_stride = (max_blocks * (bound + 16) + 64 + 15) & ~15ull;
     pl->max_chunks = (uint32_t)(pl->raw_stride / 16);
-    pl->max_waves = (pl->max_blocks + 63u) / 64u;
+    pl->max_waves = pl->max_blocks / 60u + 2u;                 // runs of 64 blocks, or of the 60..64 a wave of the fused kernel holds
     pl->max_fftiles = (pl->max_chunks + 255u) / 256u;
     pl->max_tiles = (pl->max_blocks + 4095) / 4096 + 1;       // the largest scan is over restart intervals (<= blocks)
     size_t o = 0;
@@ -141,7 +141,7 @@ int upload_huffman_luts(const jpegenc_huffman_spec (*tables)[2], void *d_lut, hi
 static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                      const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
                      size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st,
-                     EntropyParams *out, EntropyParams **d_params_out) {
+                     EntropyParams *out, EntropyParams **d_params_out, const FusedSource *fused = nullptr) {
     EntropyParams &p = *out;
     if (!valid_scan(L, sc)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan not supported on the device");
     if (frames <= 0) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "num_frames must be positive");
@@ -193,6 +193,7 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
     if (p.interval_blocks > p.nblocks) p.interval_blocks = p.nblocks;
     p.nintervals = (p.nblocks + p.interval_blocks - 1) / p.interval_blocks;
     p.bits = (uint32_t *)(ws + pl.off_bits);
+    p.run_blocks = 64;
     p.nwaves = (p.nblocks + 63u) / 64u;
     p.wsum = (uint32_t *)(ws + pl.off_wsum);
     p.woff = (uint32_t *)(ws + pl.off_woff);
@@ -226,6 +227,13 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
         if (rc) return rc;
         p.lut = (const uint32_t *)(ws + pl.off_lut);
     }
+    if (fused) {             // runs = what a wave of the fused kernel holds: whole MCUs in scan order
+        if (sc.component >= 0 || !sc.with_dc || sc.ac_start != 1 || sc.ac_end != 64 || !fused_supported(*fused->blocks))
+            return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan cannot be coded by the fused kernel");
+        p.run_blocks = fused_run_blocks(*fused->blocks);
+        p.nwaves = fused_runs(*fused->blocks);
+        if (p.nwaves > pl.max_waves) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "scan workspace too small for the fused kernel's runs");
+    }
     *d_params_out = (EntropyParams *)(ws + pl.off_params);
     return JPEGENC_OK;
 }
@@ -233,23 +241,23 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
 int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                 const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
                 size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st,
-                std::string *stored_params) {
+                std::string *stored_params, const FusedSource *fused) {
     EntropyParams p, *d_params = nullptr;
     const int rc = fill_scan(d_coeffs, coeff_frame_stride, frames, L, sc, tables, d_lut, d_out, out_frame_stride, d_out_lengths,
-                             d_ws, ws_bytes, st, &p, &d_params);
+                             d_ws, ws_bytes, st, &p, &d_params, fused);
     if (rc) return rc;
-    const hipError_t e = launch_entropy_scans(&p, 1, d_params, frames, st, stored_params);
+    const hipError_t e = launch_entropy_scans(&p, 1, d_params, frames, st, stored_params, fused);
     if (e != hipSuccess) return hip_fail(e, "entropy kernels");
     return JPEGENC_OK;
 }
 
 int scan_store_params(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                       const jpegenc_scan &sc, const void *d_lut, void *d_out, size_t out_frame_stride, uint32_t *d_out_lengths,
-                      void *d_ws, size_t ws_bytes, hipStream_t st, std::string *stored_params) {
+                      void *d_ws, size_t ws_bytes, hipStream_t st, std::string *stored_params, const FusedSource *fused) {
     if (!d_lut) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan_store_params needs prepared tables");
     EntropyParams p, *d_params = nullptr;
     const int rc = fill_scan(d_coeffs, coeff_frame_stride, frames, L, sc, nullptr, d_lut, d_out, out_frame_stride, d_out_lengths,
-                             d_ws, ws_bytes, st, &p, &d_params);
+                             d_ws, ws_bytes, st, &p, &d_params, fused);
     if (rc) return rc;
     const hipError_t e = store_entropy_params(&p, 1, d_params, st, stored_params);
     if (e != hipSuccess) return hip_fail(e, "entropy parameter store");
@@ -298,6 +306,53 @@ int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num
     if (!d_coeffs || !layout || !scan || !d_out || !d_out_lengths || !d_workspace) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
     return scan_device(d_coeffs, coeff_frame_stride, num_frames, *layout, *scan, tables, nullptr, d_out, out_frame_stride,
                        d_out_lengths, d_workspace, workspace_bytes, (hipStream_t)hip_stream);
+}
+
+/* pixels in HBM -> the entropy-coded interleaved baseline scan in HBM */
+int jpegenc_pixels_scan_fused(int width, int height, int color_type, int hs, int vs) {
+    jpegenc_layout L;
+    if (jpegenc_layout_init(&L, width, height, color_type, hs, vs, JPEGENC_ORDER_MCU) != JPEGENC_OK) return 0;
+    jpegenc_qtable q[2];
+    if (jpegenc_qtable_init(&q[0], JPEGENC_Q_DEFAULT, nullptr, 90, 1) || jpegenc_qtable_init(&q[1], JPEGENC_Q_DEFAULT, nullptr, 90, 0)) return 0;
+    BlockKernelParams b;
+    if (build_block_params(&b, L, width, height, color_type, q, JPEGENC_ORDER_MCU) != JPEGENC_OK) return 0;
+    const jpegenc_scan sc = {-1, 1, 1, 64, 0};
+    return fused_supported(b) && scan_max_bytes(L, sc) != 0 ? 1 : 0;
+}
+
+int jpegenc_pixels_scan_device(const void *d_pixels, size_t pixel_frame_stride, int num_frames, int width, int height,
+                               int color_type, int hs, int vs, const jpegenc_qtable tables[2], int fdct_variant,
+                               int restart_interval, const jpegenc_huffman_spec (*huffman)[2], void *d_coeffs,
+                               size_t coeff_frame_stride, void *d_out, size_t out_frame_stride, uint32_t *d_out_lengths,
+                               void *d_workspace, size_t workspace_bytes, void *hip_stream) {
+    if (!d_pixels || !tables || !d_out || !d_out_lengths || !d_workspace) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    if (num_frames <= 0 || num_frames > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "num_frames must be 1..65535");
+    if (fdct_variant != JPEGENC_FDCT_SCALAR && fdct_variant != JPEGENC_FDCT_SIMD) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown FDCT variant");
+    jpegenc_layout L;
+    int rc = jpegenc_layout_init(&L, width, height, color_type, hs, vs, JPEGENC_ORDER_MCU);
+    if (rc) return rc;
+    if ((hs != 1 && hs != 2) || (vs != 1 && vs != 2)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "sampling factors of 4 have no interleaved scan (encoder.rs:178-187)");
+    BlockKernelParams b;
+    rc = build_block_params(&b, L, width, height, color_type, tables, JPEGENC_ORDER_MCU);
+    if (rc) return rc;
+    b.pixels = (const uint8_t *)d_pixels;
+    b.pixel_frame_stride = pixel_frame_stride;
+    b.coeffs = d_coeffs;
+    b.coeff_frame_stride = coeff_frame_stride ? coeff_frame_stride : L.total_blocks;
+    const jpegenc_scan sc = {-1, 1, 1, 64, restart_interval};
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (fused_supported(b)) {
+        const FusedSource src = {&b, fdct_variant};
+        return scan_device(d_coeffs, b.coeff_frame_stride, num_frames, L, sc, huffman, nullptr, d_out, out_frame_stride, d_out_lengths,
+                           d_workspace, workspace_bytes, st, nullptr, &src);
+    }
+    if (!d_coeffs) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "this layout needs a coefficient scratch buffer (jpegenc_pixels_scan_fused == 0)");
+    if (b.coeff_frame_stride < L.total_blocks) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "coeff_frame_stride < total_blocks");
+    hipError_t err = hipSuccess;
+    if (!launch_blocks_fast(b, num_frames, fdct_variant, st, &err)) err = launch_blocks_generic(b, num_frames, fdct_variant, st);
+    if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+    return scan_device(d_coeffs, b.coeff_frame_stride, num_frames, L, sc, huffman, nullptr, d_out, out_frame_stride, d_out_lengths,
+                       d_workspace, workspace_bytes, st);
 }
 
 }  // extern "C"

@@ -1,0 +1,198 @@
+// entropy_walk.hip.h — the per-lane symbol walk of the device entropy coder and its sinks, shared by the coefficient-
+// fed coder (entropy_kernels.hip, k_block_code) and the fused pixels -> bits kernel (fused_kernels.hip): both hold the
+// 64 zig-zag coefficients of a lane's block in 32 registers and walk them the same way.
+// Reference bytes: write_block / write_dc / write_ac_block + get_code (writer.rs:331-388, 455-470).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "entropy_params.h"
+
+namespace jpegenc {
+
+// The parameter blocks of the scans of a launch live in device memory (written by k_store_params from its kernel
+// arguments, so the sequence stays capturable); they are read through the constant address space: invariant scalar
+// loads, exactly what by-value kernel arguments were.
+typedef const __attribute__((address_space(4))) EntropyParams &Params;
+#define JPEGENC_JOB(params) (*(const __attribute__((address_space(4))) EntropyParams *)((params) + blockIdx.z))
+
+// ---- walking one block's symbols ----------------------------------------------------------------
+__device__ __forceinline__ uint32_t bit_size(int v) {          // get_code().0 / get_num_bits (writer.rs:455-470)
+    const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    return a ? 32u - (uint32_t)__builtin_clz(a) : 0u;
+}
+
+// ---- wave / workgroup prefix sums ------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += (uint32_t)__shfl_xor((int)x, d);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_inclusive(uint32_t x) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+// 256 threads; part[4] in LDS; the caller separates consecutive uses with __syncthreads()
+__device__ __forceinline__ uint32_t wg_exclusive(uint32_t x, uint32_t *part, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive(x);
+    if (lane == 63) part[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) { const uint32_t v = part[w]; if (w < wave) base += v; sum += v; }
+    *total = sum;
+    return base + inc - x;
+}
+
+// bit offset of block b in the scan: its wave's offset + the lengths of the wave's earlier blocks
+__device__ __forceinline__ uint32_t block_bit_offset(Params p, uint32_t f, uint32_t b) {
+    const uint32_t run = b / p.run_blocks;            // 64 blocks per run, or what the fused kernel's waves hold
+    uint32_t s = p.woff[(size_t)f * p.nwaves + run];
+    const uint32_t *bits = p.bits + (size_t)f * p.nblocks;
+    for (uint32_t t = run * p.run_blocks; t < b; t++) s += bits[t];
+    return s;
+}
+
+// Where a block's bits go.  The first walk of k_block_code only adds up lengths; the second shifts codes into
+// a 64-bit accumulator and ORs every completed 32-bit word (MSB-first byte order) into zeroed memory - the
+// wave's LDS window (ds_or_b32, no address-space guessing: the pointer type says LDS) or, for runs longer than
+// the window, the wave's slot in HBM.  OR-ing every word (not only the ones shared with a neighbouring
+// block) keeps a per-lane "is this my first word" flag and its branches out of the 63-symbol walk.
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+typedef __attribute__((address_space(1))) uint32_t hbm_word;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte load from a 4-byte aligned address
+typedef __attribute__((address_space(1))) const u32x4 hbm_chunk;
+
+struct CountSink {
+    uint32_t total;
+    __device__ __forceinline__ void put(uint32_t, uint32_t len) { total += len; }
+};
+struct LdsWords {
+    lds_word *w;
+    __device__ __forceinline__ void or_next(uint32_t v) {
+        __hip_atomic_fetch_or(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        w++;
+    }
+};
+struct HbmWords {
+    hbm_word *w;
+    __device__ __forceinline__ void or_next(uint32_t v) {
+        __hip_atomic_fetch_or(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w++;
+    }
+};
+template <class Words>
+struct PackSink {
+    Words words;          // next word to complete
+    uint64_t acc;
+    uint32_t nacc;        // valid low bits of acc; < 32 between puts
+    __device__ __forceinline__ void put(uint32_t code, uint32_t len) {          // len <= 27
+        acc = (acc << len) | code;
+        nacc += len;
+        if (nacc >= 32) {
+            nacc -= 32;
+            words.or_next(__builtin_bswap32((uint32_t)(acc >> nacc)));
+        }
+    }
+    __device__ __forceinline__ void finish() {                                   // the partial last word
+        if (nacc) words.or_next(__builtin_bswap32((uint32_t)(acc << (32 - nacc))));
+    }
+};
+
+// lut: [table][0 = DC, 1 = AC][256] of (size << 16 | code), in LDS.
+// BASELINE = the scan codes DC and the whole band 1..63 (every non-progressive scan): no band tests in the walk.
+// All eight 16-byte pieces of the block are requested up front (the lane's 128-byte line is fetched once and
+// the other seven loads hit L1 while it is hot; walking piece by piece with the next one in flight re-missed
+// the line for every piece: 52 vs 39 us per 4K frame), so the walk is fully unrolled over registers.
+struct BlockRegs { uint32_t c[32]; };      // the 64 coefficients of a lane's block
+
+__device__ __forceinline__ void load_block(const int16_t *frame_coeffs, uint32_t b, BlockRegs &r) {
+    hbm_chunk *src = (hbm_chunk *)(frame_coeffs + (size_t)b * 64);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u32x4 u = src[i];
+        r.c[4 * i] = u.x; r.c[4 * i + 1] = u.y; r.c[4 * i + 2] = u.z; r.c[4 * i + 3] = u.w;
+    }
+}
+
+// DC predecessor of block b = the previous block of the same component (write_dc, writer.rs:342-354; predictors
+// reset at the start of the scan and at restart boundaries, encoder.rs:748-757).  Requested together with the
+// block itself: inside the walk it was one more dependent round trip to HBM per walk, and a wave's life on
+// sparse content is little else than such round trips.  The load is unconditional (index clamped, value selected
+// afterwards) so that it sits in the same load queue as the block's.
+struct BlockPlace { uint32_t table; bool has_prev; uint64_t prev_block; };
+__device__ __forceinline__ BlockPlace place_of(Params p, uint32_t b) {
+    const uint32_t mcu = b / p.bpm, pos = b - mcu * p.bpm;
+    BlockPlace q;
+    q.table = (p.pos_table_bits >> pos) & 1u;
+    if ((p.pos_delta_bits >> pos) & 1u) {
+        q.has_prev = true; q.prev_block = (uint64_t)b - 1u;
+    } else {
+        q.has_prev = (b - pos) % p.interval_blocks != 0;
+        q.prev_block = q.has_prev ? (uint64_t)(mcu - 1u) * p.bpm + (uint32_t)((p.pos_last_nibbles >> (4u * pos)) & 15u) : (uint64_t)b;
+    }
+    return q;
+}
+
+template <bool BASELINE, class Sink>
+__device__ __forceinline__ void walk_block(Params p, const uint32_t *lut, uint32_t table, int prev_dc, const BlockRegs &r, Sink &s) {
+    const uint32_t *dc_lut = lut + table * 512, *ac_lut = dc_lut + 256;
+    const uint32_t *c = r.c;
+    if (BASELINE || p.with_dc) {
+        const int prev = prev_dc;
+        const int dc = (int16_t)(c[0] & 0xFFFFu);
+        const int diff = (int16_t)(dc - prev);
+        const uint32_t n = bit_size(diff);
+        const uint32_t e = dc_lut[n];
+        const uint32_t mag = (uint32_t)(diff - (diff < 0)) & ((1u << n) - 1u);
+        s.put(((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
+    }
+    // AC: write_ac_block(block, start, end) (writer.rs:356-388)
+    if (!BASELINE && p.ac_end <= p.ac_start) return;
+    uint32_t run = 0;
+    const uint32_t zrl = ac_lut[0xF0];
+#pragma unroll
+    for (uint32_t k = 1; k < 64; k++) {
+        if (!BASELINE && (k < p.ac_start || k >= p.ac_end)) continue;
+        const int v = (k & 1u) ? (int)c[k >> 1] >> 16 : (int)(int16_t)(c[k >> 1] & 0xFFFFu);
+        if (v != 0) {
+            if (run > 15) {
+#pragma nounroll
+                do { s.put(zrl & 0xFFFFu, zrl >> 16); run -= 16; } while (run > 15);
+            }
+            const uint32_t n = bit_size(v);
+            const uint32_t e = ac_lut[(run << 4) | n];
+            const uint32_t mag = (uint32_t)(v - (v < 0)) & ((1u << n) - 1u);
+            s.put(((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
+            run = 0;
+        } else {
+            run++;
+        }
+    }
+    if (run > 0) { const uint32_t e = ac_lut[0]; s.put(e & 0xFFFFu, e >> 16); }
+}
+
+// The code tables go to LDS in two steps: fetch (first in the load queue, so waiting for it waits for nothing
+// else), then the kernel requests its own data, then commit.  256 threads, 4 entries each.
+struct LutRegs { uint32_t v[4]; };
+__device__ __forceinline__ void lut_fetch(Params p, LutRegs &l) {
+    const hbm_word *src = (const hbm_word *)p.lut;
+#pragma unroll
+    for (int i = 0; i < 4; i++) l.v[i] = src[i * 256 + threadIdx.x];
+}
+__device__ __forceinline__ void lut_commit(const LutRegs &l, uint32_t *lut) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) lut[i * 256 + threadIdx.x] = l.v[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool baseline_band(Params p) { return p.with_dc && p.ac_start == 1 && p.ac_end == 64; }
+
+}  // namespace jpegenc

@@ -43,8 +43,16 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
 // stored: what the parameter blocks at d_params currently hold (nullptr: always store) - a caller that codes the same
 // scan again and again (an Encoder fed frames of one geometry) skips the store launch
 hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, hipStream_t stream, std::string *stored);
+// fused_kernels.hip: the Encoder's interleaved baseline scan coded straight from the pixels (no coefficients in HBM)
+struct FusedSource { const BlockKernelParams *blocks; int variant; };
+bool fused_supported(const BlockKernelParams &b);
+uint32_t fused_run_blocks(const BlockKernelParams &b);
+uint32_t fused_runs(const BlockKernelParams &b);
+hipError_t launch_fused_code(const BlockKernelParams &b, const EntropyParams *d_params, int restart_interval, int frames, int variant,
+                             hipStream_t st);
+// fused != nullptr (one scan): the first kernel of the sequence reads pixels instead of coefficients
 hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t stream,
-                                std::string *stored = nullptr);
+                                std::string *stored = nullptr, const FusedSource *fused = nullptr);
 
 hipError_t launch_batch_gather(const BatchGatherArgs &a, const void *d_src, const uint32_t *d_len, uint64_t *d_pos, void *d_dst,
                                hipStream_t stream);
@@ -54,12 +62,12 @@ hipError_t launch_gather_scans(const GatherArgs &a, const void *d_src, const uin
 int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                 const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
                 size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st,
-                std::string *stored_params = nullptr);
+                std::string *stored_params = nullptr, const FusedSource *fused = nullptr);
 // only fills and (unless `stored_params` says they are there) stores the scan's parameter blocks: what a replayed launch
 // sequence needs done outside of it
 int scan_store_params(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                       const jpegenc_scan &sc, const void *d_lut, void *d_out, size_t out_frame_stride, uint32_t *d_out_lengths,
-                      void *d_ws, size_t ws_bytes, hipStream_t st, std::string *stored_params);
+                      void *d_ws, size_t ws_bytes, hipStream_t st, std::string *stored_params, const FusedSource *fused = nullptr);
 struct ScanJob {                 // one scan of scan_device_multi
     jpegenc_scan sc;
     void *d_out; size_t out_frame_stride; uint32_t *d_out_lengths;

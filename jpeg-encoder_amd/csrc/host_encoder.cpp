@@ -800,6 +800,10 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     p.pixel_frame_stride = pixel_bytes;
     p.coeff_frame_stride = L.total_blocks;
     const bool optimize = c.optimize && mode != MODE_INTERLEAVED;
+    // interleaved baseline scan of an RGB-family image: ONE kernel goes from the pixels to the entropy-coded runs
+    // (fused_kernels.hip); the coefficients never reach HBM
+    const FusedSource fused_src = {&p, c.fdct_variant};
+    bool fused = false;
     static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -848,6 +852,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             if (w > ws) ws = w;
         }
         first_piece = out_total < DeviceCtx::kFirstPiece ? out_total : DeviceCtx::kFirstPiece;
+        fused = supported && mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_supported(p);
         if (supported) {
             // The scans of a sequential / progressive frame are independent: coded in shared launches they cost
             // ~10 launches per 8 scans instead of ~10 per scan (a 4K progressive frame: 12 scans; such frames were
@@ -872,7 +877,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         auto put = [&](const void *v, size_t n) { key.append((const char *)v, n); };
         const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, ctx.d_gather, ctx.h_scan_out};
         const int64_t vals[] = {width, height, color_type_or_planes, (int64_t)pixel_bytes, order, c.fdct_variant, c.sampling,
-                                c.progressive_scans, c.restart_interval, (int64_t)ctx.d_scan_ws_cap, (int64_t)jobs.size()};
+                                c.progressive_scans, c.restart_interval, (int64_t)ctx.d_scan_ws_cap, (int64_t)jobs.size(), (int64_t)fused};
         put(ptrs, sizeof ptrs); put(vals, sizeof vals); put(t.q, sizeof t.q);
         if (ctx.graph_exec && key == ctx.graph_key) how = REPLAY;
         else if (key == ctx.last_key) how = CAPTURE;
@@ -903,7 +908,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     // the workspace holds), so that a replayed sequence finds it in place
     if (c.device_entropy && supported && !optimize && jobs.size() == 1 && jobs[0].cap) {
         rc = scan_store_params(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, ctx.d_lut, (uint8_t *)ctx.d_gather + kGatherHeader, jobs[0].cap,
-                               (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params);
+                               (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params, fused ? &fused_src : nullptr);
         if (rc) return rc;
     }
     if (how == CAPTURE) JPEGENC_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
@@ -912,7 +917,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         ~CaptureGuard() { if (active) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); } }
     } capture_guard{ctx.stream, how == CAPTURE};
     const bool enqueue = how != REPLAY;
-    if (enqueue) {
+    if (enqueue && !fused) {
         hipError_t err = hipSuccess;
         if (!launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, 1, c.fdct_variant, ctx.stream);
         if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
@@ -951,7 +956,8 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                 } else if (jobs.size() == 1 && jobs[0].cap) {
                     // a single scan (every baseline frame) is coded straight into the gathered layout: [length][bytes]
                     rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, nullptr, ctx.d_lut, (uint8_t *)ctx.d_gather + kGatherHeader,
-                                     jobs[0].cap, (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params);
+                                     jobs[0].cap, (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params,
+                                     fused ? &fused_src : nullptr);
                     if (rc) return rc;
                 } else {
                     ctx.stored_scan_params.clear();
@@ -1174,16 +1180,20 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         p.coeffs = b.d_coeffs;
         p.pixel_frame_stride = frame_stride;
         p.coeff_frame_stride = L.total_blocks;
-        hipError_t err = hipSuccess;
-        if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, n, c.fdct_variant, ctx.stream);
-        if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+        const FusedSource fused_src = {&p, c.fdct_variant};
+        const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_supported(p);
+        if (!fused) {
+            hipError_t err = hipSuccess;
+            if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, n, c.fdct_variant, ctx.stream);
+            if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+        }
         uint32_t *d_len = b.d_len + (size_t)half * nlen;
         JPEGENC_HIP(hipMemsetAsync(d_len, 0, nlen * sizeof(uint32_t), ctx.stream));
         for (size_t k = 0; k < jobs.size(); k++) {
             const Job &j = jobs[k];
             if (!j.cap) continue;
             e = scan_device(b.d_coeffs, L.total_blocks, n, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)b.d_out + (size_t)half * round_out + j.off,
-                            out_total, d_len + k * (size_t)per_round, b.d_ws, ws, ctx.stream);
+                            out_total, d_len + k * (size_t)per_round, b.d_ws, ws, ctx.stream, nullptr, fused ? &fused_src : nullptr);
             if (e) return e;
         }
         JPEGENC_HIP(hipMemcpyAsync(b.h_len + (size_t)half * nlen, d_len, nlen * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
@@ -1616,6 +1626,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
                                  int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
     REQUIRE(e);
     if (num_frames < 0 || (num_frames && (!frames || !users)) || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
+    if (num_frames == 0) return JPEGENC_OK;                                // nothing to validate against, nothing to do
     int rc = validate_image(frame_len, width, height, color_type);
     if (rc) return rc;
     rc = ensure_device_ready(e->device);
@@ -1816,6 +1827,7 @@ static int encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_de
                               int num_frames, int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
     if (!devices || num_devices < 1 || num_devices > 64) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad device list");
     if (num_frames < 0 || (num_frames && (!frames || !users)) || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
+    if (num_frames == 0) return JPEGENC_OK;
     int rc = validate_image(frame_len, width, height, color_type);         // before any device work
     if (rc) return rc;
     for (int d = 0; d < num_devices; d++) {
@@ -1824,7 +1836,6 @@ static int encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_de
     }
     for (int i = 0; i < num_frames; i++)
         if (!frames[i]) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
-    if (num_frames == 0) return JPEGENC_OK;
     if ((int)e->shards.size() > num_devices) e->shards.resize((size_t)num_devices);
     while ((int)e->shards.size() < num_devices) e->shards.emplace_back(nullptr);
     unsigned hw = std::thread::hardware_concurrency();

@@ -5,9 +5,10 @@ TEST INFRASTRUCTURE ONLY (like everything under oracle/): it exists so that the 
 that shares no code and no structure with it — SURVEY.md §8(c), "how the build closes the gap", item 2.
 The C oracle walks the image the way the reference does (row buffers, padding, get_block per block);
 this file states WHAT comes out: every sample is `plane[min(Y, h-1)][min(X, w-1)]` of a converted
-plane, gathered with strides, transformed for all blocks at once.  Only the quantisation tables
-(divisor, reciprocal, correction) are taken from the C side; their construction is pinned separately
-by the reference's own KATs (tests/test_oracle_kat.py).
+plane, gathered with strides, transformed for all blocks at once.  The quantisation tables (reciprocal, correction) may be passed in
+(tests that sweep presets take them from the C side, whose construction is pinned by the reference's own KATs) or built
+here for the default Annex-K tables (default_tables: pure Python, nothing shared with the C oracle) - that is how
+tests/golden/coefficients.npz is produced.
 
 Cited lines are of /root/reference/src at the surveyed revision.
 """
@@ -21,6 +22,39 @@ ZIGZAG = np.array([
     0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55,
     62, 63])
+
+
+# T.81 Annex K, Tables K.1 and K.2 (= DEFAULT_LUMA_TABLES[0] / DEFAULT_CHROMA_TABLES[0], quantization.rs:62-183), natural order
+ANNEX_K_LUMA = [16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87,
+                80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92,
+                95, 98, 112, 100, 103, 99]
+ANNEX_K_CHROMA = [17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99,
+                  99, 99] + [99] * 32
+
+
+def default_tables(quality):
+    """[(reciprocals, corrections)] x 2 of Encoder::new(_, quality)'s Annex-K tables, built here without the C oracle:
+    get_with_quality (quantization.rs:261-283) then compute_reciprocal (:187-207).  Pure Python ints."""
+    q = min(max(int(quality), 1), 100)
+    scale = 5000 // q if q < 50 else 200 - 2 * q
+    out = []
+    for base in (ANNEX_K_LUMA, ANNEX_K_CHROMA):
+        recips, corrs = [], []
+        for v in base:
+            d = min(max((v * scale + 50) // 100, 1), 255) << 3          # stored pre-multiplied by 8
+            if d <= 1:
+                r, c = 1, 0
+            else:
+                r, frac, c = (1 << 15) // d, (1 << 15) % d, d // 2
+                if frac != 0:
+                    if frac <= c:
+                        c += 1
+                    else:
+                        r += 1
+            recips.append(r)
+            corrs.append(c)
+        out.append((recips, corrs))
+    return out
 
 
 def ycbcr(r, g, b):

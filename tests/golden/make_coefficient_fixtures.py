@@ -3,10 +3,13 @@
 names (258x128 gradient at q=80 / F_2_2, q=100 / F_1_1 and F_2_1; 258x192 CMYK q=100; the 1x1 pixel fb 15 15 of
 lib.rs:543) plus an LCG-noise image, in MCU and planar order.
 
-Produced by the CPU oracle (oracle/jpegenc_oracle.c) AFTER it passed every reference KAT and reproduced the Appendix-A
-SHA-256 anchors of SURVEY.md (tests/test_oracle_kat.py, tests/test_oracle_files.py) - the reference itself (Rust) cannot
-run in this image.  The file holds numbers only; it travels to the GPU box, where the HIP path is compared against it
-without the oracle in the loop (tests/test_gpu_parity.py::test_golden_coefficient_fixtures).
+Produced by oracle/np_oracle.py - the independent numpy reading of the reference (clamped strided gathers + batched
+transforms, its own Annex-K table construction; no code, structure or table shared with oracle/jpegenc_oracle.c) - and
+NOT by the C oracle that the tests use as their checker: so `test_oracle_reproduces_the_committed_coefficient_fixtures`
+(C oracle vs this file) and `test_golden_coefficient_fixtures` (HIP path vs this file) each compare against a SECOND
+reading of the source, not against the checker's own output.  The arrays that have a SHA-256 anchor in SURVEY.md
+Appendix A (five of the twelve) are re-checked against it by the CPU test.  The reference itself (Rust) cannot run in
+this image.  The file holds numbers only and travels to the GPU box.
 """
 import os
 import sys
@@ -19,7 +22,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 ge.load_package()
 from jpeg_encoder_amd import synth  # noqa: E402
-from oracle import pyoracle as o  # noqa: E402
+from oracle import np_oracle as o  # noqa: E402
 
 CASES = {
     # name: (image, w, h, color type, quality, (hs, vs))
@@ -48,7 +51,7 @@ def main():
         px = image(kind, w, h)
         out[f"pixels_{kind}_{w}x{h}"] = px                  # inputs, once per image
         for order, tag in ((o.ORDER_MCU, "mcu"), (o.ORDER_PLANAR, "planar")):
-            out[f"{name}_{tag}"] = o.encode_blocks(px, w, h, ct, hs, vs, q, order)
+            out[f"{name}_{tag}"] = o.encode_blocks(px, w, h, ct, hs, vs, o.default_tables(q), order)
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "coefficients.npz"), **out)
     print({k: v.shape for k, v in out.items()})
 

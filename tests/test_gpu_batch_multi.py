@@ -123,3 +123,48 @@ def test_batch_device_falls_back_for_frames_the_device_coder_declines(binding, o
         one = enc.encode_device(d.data_ptr(), w, h, binding.LUMA)
     assert files[0] == one == oracle.encode_jpeg(px, w, h, oracle.LUMA, 90)
     assert files[1] == oracle.encode_jpeg(px[::-1].copy(), w, h, oracle.LUMA, 90)
+
+
+@pytest.mark.parametrize("ct,hs,vs,w,h,restart", [
+    (1, 2, 2, 258, 128, 0), (1, 1, 1, 258, 128, 0), (1, 2, 1, 515, 77, 0), (1, 1, 2, 77, 515, 7), (2, 2, 2, 333, 201, 0),
+    (3, 2, 2, 1920, 1080, 0), (4, 1, 1, 640, 360, 40), (1, 2, 2, 37, 21, 1), (1, 2, 2, 8, 8, 0), (1, 2, 2, 3840, 2160, 240),
+    (6, 1, 1, 200, 120, 0), (0, 1, 1, 200, 120, 0), (5, 2, 2, 200, 120, 5)],
+    ids=["rgb420", "rgb444", "rgb422", "rgb440-rst7", "rgba420", "bgr-1080p", "bgra444-rst40", "rgb420-tiny-rst1", "rgb-one-mcu",
+         "rgb-4k-rst240", "cmyk-unfused", "luma-unfused", "ycbcr-unfused-rst5"])
+def test_pixels_scan_device_matches_the_two_kernel_path_and_the_oracle(binding, oracle, synth, ct, hs, vs, w, h, restart):
+    """jpegenc_pixels_scan_device (ONE fused kernel from pixels to coded runs for the RGB family) against
+    jpegenc_blocks_device + jpegenc_scan_device, and against the scan bytes inside the oracle's file."""
+    import torch
+    bpp = binding.BPP[ct]
+    n = 3
+    px = np.stack([synth.lcg_image(w, h, bpp, 5 + i) if i != 1 else
+                   np.ascontiguousarray(np.broadcast_to((np.add.outer(np.arange(h), np.arange(w)) // 3 % 256).astype(np.uint8)[..., None], (h, w, bpp)))
+                   for i in range(n)])
+    d_px = torch.from_numpy(px).cuda()
+    L = binding.layout(w, h, ct, hs, vs, binding.ORDER_MCU)
+    scan = binding.baseline_scan(restart_interval=restart)
+    cap, wsz = binding.scan_max_bytes(L, scan), binding.scan_workspace_size(L, scan, n)
+    q = binding.qtables(85)
+    nblk = int(L.total_blocks)
+    d_co = torch.empty((n, nblk * 64), dtype=torch.int16, device="cuda")
+    d_ws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+    outs = []
+    fused = binding.pixels_scan_fused(w, h, ct, hs, vs)
+    assert fused == (ct in (1, 2, 3, 4))
+    for which in ("pixels", "two"):
+        d_out = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
+        d_len = torch.zeros(n, dtype=torch.int32, device="cuda")
+        if which == "pixels":
+            binding.pixels_scan_device(d_px.data_ptr(), w * h * bpp, n, w, h, ct, hs, vs, q, d_out.data_ptr(), cap, d_len.data_ptr(),
+                                       d_ws.data_ptr(), wsz, restart_interval=restart,
+                                       d_coeffs_ptr=None if fused else d_co.data_ptr())
+        else:
+            binding.blocks_device(d_px.data_ptr(), w * h * bpp, n, w, h, ct, hs, vs, q, binding.ORDER_MCU, binding.FDCT_SCALAR,
+                                  d_co.data_ptr(), nblk)
+            binding.scan_device(d_co.data_ptr(), nblk, n, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(), d_ws.data_ptr(), wsz)
+        torch.cuda.synchronize()
+        outs.append([bytes(d_out[i, :int(d_len[i])].cpu().numpy()) for i in range(n)])
+    assert outs[0] == outs[1]
+    for i in range(n):                                                  # the scan is the tail of the oracle's file: ... SOS header | scan | EOI
+        ref = oracle.encode_jpeg(px[i], w, h, ct, 85, sampling=(hs, vs), restart_interval=restart)
+        assert ref.endswith(outs[0][i] + b"\xff\xd9") and len(outs[0][i]) > 0

@@ -279,8 +279,9 @@ def golden_coefficients():
 
 def test_oracle_reproduces_the_committed_coefficient_fixtures(oracle):
     """tests/golden/coefficients.npz (gradient at q=80/F_2_2, q=100/F_1_1 and F_2_1, CMYK q=100, the 1x1
-    pixel fb 15 15, LCG noise; MCU and planar order) against today's oracle, and against the survey's SHA-256 anchors
-    where one exists - the fixture cannot drift from the pinned restatement unnoticed."""
+    pixel fb 15 15, LCG noise; MCU and planar order) against today's C oracle, and against the survey's SHA-256 anchors
+    where one exists.  The file was produced by oracle/np_oracle.py (tests/golden/make_coefficient_fixtures.py), i.e. by
+    the OTHER reading of the reference: this is a two-readings-agree check, not the oracle against its own output."""
     import hashlib
     import numpy as np
     g = golden_coefficients()
@@ -293,3 +294,4 @@ def test_oracle_reproduces_the_committed_coefficient_fixtures(oracle):
     assert sha(g["grad_q80_f22_mcu"]) == "904de330bc9ee06c" and sha(g["grad_q80_f22_planar"]) == "2b36c781df2c5567"
     assert sha(g["grad_q100_f11_mcu"]) == "6ff6a9e6cfd396d7" and sha(g["grad_q100_f21_mcu"]) == "0dd2db06def56cb6"
     assert sha(g["lcg42_q75_f22_mcu"]) == "1856bafe1ceceec8" and sha(g["lcg42_q75_f22_planar"]) == "b43a71d4ff226cb2"
+    assert sha(g["grad_q100_f21_planar"]) == "31286d6f3953e72a"

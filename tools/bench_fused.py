@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Pixels in HBM -> entropy-coded scan in HBM: the fused kernel (jpegenc_pixels_scan_device) against the two-kernel
+path it replaces (jpegenc_blocks_device + jpegenc_scan_device), 4K RGB q=90 4:2:0, HIP-event timed, output compared
+byte for byte.  Side figure for DESIGN.md / profiles; bench.py carries the same numbers in its JSON line."""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import __graft_entry__ as ge  # noqa: E402
+
+ge.load_package()
+b = importlib.import_module("jpeg_encoder_amd.binding")
+synth = importlib.import_module("jpeg_encoder_amd.synth")
+
+
+def frames_of(kind, n, w, h, dev):
+    if kind == "noise":
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        return torch.randint(0, 256, (n, w * h * 3), dtype=torch.uint8, device=dev, generator=g)
+    base = torch.from_numpy(synth.test_img_rgb(w, h).reshape(-1)).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    if kind == "smooth":
+        return base[None, :].repeat(n, 1).contiguous()
+    return torch.clamp(base.to(torch.int16)[None, :] + torch.randint(-6, 7, (n, base.numel()), dtype=torch.int16, device=dev, generator=g),
+                       0, 255).to(torch.uint8)
+
+
+def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
+    dev = torch.device("cuda", 0)
+    L = b.layout(w, h, b.RGB, hs, vs, b.ORDER_MCU)
+    nblk = int(L.total_blocks)
+    q = b.qtables(quality)
+    scan = b.baseline_scan()
+    cap, wsz = b.scan_max_bytes(L, scan), b.scan_workspace_size(L, scan, n)
+    d_co = torch.empty((n, nblk * 64), dtype=torch.int16, device=dev)
+    d_ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    for kind in ("noise", "photo-like", "smooth"):
+        d_px = frames_of(kind, n, w, h, dev)
+        outs, lens = {}, {}
+        res = {"content": kind, "frames": n, "size": f"{w}x{h}", "sampling": f"{hs}x{vs}", "quality": quality}
+
+        def two_kernel(d_out, d_len):
+            b.blocks_device(d_px.data_ptr(), w * h * 3, n, w, h, b.RGB, hs, vs, q, b.ORDER_MCU, b.FDCT_SCALAR, d_co.data_ptr(), nblk, stream.cuda_stream)
+            b.scan_device(d_co.data_ptr(), nblk, n, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(), d_ws.data_ptr(), wsz, stream.cuda_stream)
+
+        def fused(d_out, d_len):
+            b.pixels_scan_device(d_px.data_ptr(), w * h * 3, n, w, h, b.RGB, hs, vs, q, d_out.data_ptr(), cap, d_len.data_ptr(),
+                                 d_ws.data_ptr(), wsz, stream.cuda_stream)
+        for name, fn in (("two_kernel", two_kernel), ("fused", fused)):
+            d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
+            d_len = torch.zeros(n, dtype=torch.int32, device=dev)
+            for _ in range(3):
+                fn(d_out, d_len)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                fn(d_out, d_len)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            res[name + "_us_per_frame"] = round(ms * 1e3 / n, 2)
+            res[name + "_Mpixels_per_s"] = round(n * w * h / ms / 1e3, 1)
+            lens[name] = d_len.cpu()
+            outs[name] = [d_out[i, :int(lens[name][i])].cpu() for i in range(n)]
+        res["scan_bytes_per_frame"] = int(lens["fused"].float().mean().item())
+        res["identical"] = bool(torch.equal(lens["fused"], lens["two_kernel"]) and
+                                all(torch.equal(x, y) for x, y in zip(outs["fused"], outs["two_kernel"])))
+        res["speedup"] = round(res["two_kernel_us_per_frame"] / res["fused_us_per_frame"], 3)
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "1080p":
+        main(n=32, w=1920, h=1080, quality=80)
+    else:
+        main()
