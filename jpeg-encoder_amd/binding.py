@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjpegenc_mi355x.so")
+# JPEGENC_LIB: a diagnostic variant build (tools/diag/ab_bench.sh) instead of the in-tree library
+LIB_PATH = os.environ.get("JPEGENC_LIB") or os.path.join(_HERE, "libjpegenc_mi355x.so")
 
 # enum jpegenc_color_type == reference `enum ColorType` order (src/encoder.rs:72-99)
 LUMA, RGB, RGBA, BGR, BGRA, YCBCR, CMYK, CMYK_AS_YCCK, YCCK = range(9)

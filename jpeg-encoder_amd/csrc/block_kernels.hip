@@ -169,6 +169,51 @@ __global__ void __launch_bounds__(256) k_histogram(const HistKernelParams p) {
     if (blockIdx.x == 0 && (int)threadIdx.x < 2 * max_tables) atomicAdd(&p.freq[threadIdx.x * 257u + 256u], 1u);
 }
 
+// Second half of the statistics the tuned block kernels gather themselves (fast_kernel_impl.hip.h, ac_histogram): every
+// workgroup sums its share of the kHistCopies partial AC histograms into the final table (one global add per non-zero
+// counter, 256 adders per address at most), and counts the DC categories of its slice of the side array - DC differences chain
+// through the whole component with no restart reset (encoder.rs:1104-1116): block b against block b - 1.
+constexpr uint32_t kHistFinishGroups = 256;          // workgroups of k_hist_finish: kHistCopies / 256 partials each
+__global__ void __launch_bounds__(256) k_hist_finish(const HistFinishParams p) {
+    __shared__ uint32_t dcl[2 * 16];
+    if (threadIdx.x < 32) dcl[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr uint32_t per = kHistCopies / kHistFinishGroups;
+    uint32_t n0 = 0, n1 = 0;                            // bins threadIdx.x and threadIdx.x + 256 of this group's partials: all loads up front
+#pragma unroll
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t *src = p.partials + ((size_t)blockIdx.x * per + k) * 512u;
+        n0 += src[threadIdx.x]; n1 += src[threadIdx.x + 256u];
+    }
+    if (n0) atomicAdd(&p.freq[257u + threadIdx.x], n0);                // table 0, AC
+    if (n1) atomicAdd(&p.freq[514u + 257u + threadIdx.x], n1);         // table 1, AC
+    // DC categories: component c's blocks in plane order, block b against block b - 1 (0 before the first)
+    uint64_t first = 0;
+    for (int c = 0; c < p.ncomp; c++) {
+        const uint32_t nb = p.nblocks[c];
+        const int16_t *dcs = p.dc_side + p.comp_off[c];
+        uint32_t *bins = dcl + (uint32_t)p.table[c] * 16u;
+        for (uint32_t b = blockIdx.x * 256u + threadIdx.x; b < nb; b += kHistFinishGroups * 256u) {
+            const int prev = b == 0 ? 0 : (int)dcs[b - 1];
+            atomicAdd(&bins[nbits((int16_t)(dcs[b] - prev))], 1u);
+        }
+        first += nb;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const uint32_t n = dcl[threadIdx.x];
+        if (n) atomicAdd(&p.freq[(threadIdx.x >> 4) * 514u + (threadIdx.x & 15u)], n);
+    }
+    // dc_freq[256] = ac_freq[256] = 1 for every table that is built (encoder.rs:1089-1095)
+    const int max_tables = p.ncomp < 2 ? p.ncomp : 2;
+    if (blockIdx.x == 0 && (int)threadIdx.x < 2 * max_tables) atomicAdd(&p.freq[threadIdx.x * 257u + 256u], 1u);
+}
+
+hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_hist_finish, dim3(kHistFinishGroups), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 // ---- launchers (called from the C ABI) --------------------------------------------------------
 hipError_t launch_blocks_generic(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream) {
     dim3 grid, block;

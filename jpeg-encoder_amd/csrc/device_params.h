@@ -87,15 +87,37 @@ struct BlockKernelParams {
                                       // component (they cover the same pixels, read from HBM once); 0 -> 4 tasks in
                                       // component-major sequence (more than 10 waves per round)
     uint32_t groups;                  // groups per frame
+    uint32_t persistent_frames;       // -DJPEGENC_PERSISTENT experiment: frames of the launch (the grid is the resident workgroups)
+    // Symbol statistics for optimised Huffman tables folded into the block kernel (planar order, tuned kernels): every wave
+    // counts the AC symbols of its 64 blocks while their coefficients are in registers (encoder.rs:1123-1161) and writes
+    // the DC values to a 2-byte side array; k_hist_finish turns both into the [2][2][257] table of optimize_huffman_table.
+    uint32_t *hist_partials;          // null = off; [frame][kHistCopies][2 tables][256] AC counters, zeroed by the caller
+    int16_t *dc_side;                 // [frame][total planar blocks] DC of every block
+    uint64_t hist_band_mask;          // bit k (2..63): a progressive AC band starts at zig-zag position k (encoder.rs:1123-1134)
+    uint32_t hist_total_blocks;       // planar blocks per frame (stride of dc_side)
+    uint32_t hist_reserved;
     QuantDev q[2];
     FastHeader fast_hdr;
     FastWave fast_wave[10];
 };
 
+constexpr uint32_t kHistCopies = 1024;     // partial AC histograms a frame's waves spread their global adds over
+
 struct HistKernelParams {
     const int16_t *coeffs;            // planar-order blocks of ONE frame
     uint32_t *freq;                   // [2][2][257]
     int32_t ncomp, progressive_scans;
+    uint32_t nblocks[4];
+    uint64_t comp_off[4];
+    int32_t table[4];
+};
+
+// k_hist_finish: the partial AC histograms of the block kernel's waves + the DC side array -> freq[2][2][257]
+struct HistFinishParams {
+    const uint32_t *partials;         // [kHistCopies][2][256]
+    const int16_t *dc_side;           // planar-order DC values of ONE frame
+    uint32_t *freq;                   // [2][2][257], zeroed by the caller
+    int32_t ncomp, reserved;
     uint32_t nblocks[4];
     uint64_t comp_off[4];
     int32_t table[4];

@@ -210,15 +210,18 @@ __global__ void __launch_bounds__(256) k_scan_apply_fused(const EntropyParams *p
     if (threadIdx.x == 255 && (uint64_t)(tile + 1) * kScanTile >= n) totals[f] = base + buf[255];
 }
 
-// One pass over the coefficients.  A wave's 64 blocks form one run of bits; the wave builds it in a private,
-// zeroed LDS window (every lane ORs its words in) and copies it to the wave's slot of the scratch buffer with
-// coalesced stores, followed by one zero word (k_place reads a word past the end of a run when it shifts).
-// Runs longer than the window (pathological content; JPEGENC_PACK_WINDOW_WORDS forces it in tests) are
-// OR-ed straight into the zeroed slot by the same walk.
+// One pass over the coefficients, ONE walk over each block's symbols.  A wave's 64 blocks form one run of bits: every
+// lane packs its block into a lane-private strip of LDS words (walk_once / PrivSink), a 64-lane prefix sum of the strip
+// lengths gives each block its offset in the run, the strips are shifted into the wave's zeroed LDS window
+// (strip_to_window) and the window goes to the wave's slot of the scratch buffer with coalesced stores, followed by one
+// zero word (k_place reads a word past the end of a run when it shifts).  Runs longer than the window or blocks longer
+// than a strip (pathological content; JPEGENC_PACK_WINDOW_WORDS forces it in tests) take a second walk that ORs the
+// bits straight into the zeroed slot.
 __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
-    __shared__ uint32_t lut[4 * 256];
-    __shared__ __attribute__((aligned(16))) uint32_t window[4][kPackWindowWords];
+    __shared__ u32x2 lut64[4 * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t window[4][kOnePassWindowWords];
+    __shared__ uint32_t strips[4][kPrivWords * 64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     const bool valid = b < p.nblocks;
@@ -231,17 +234,18 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
     const int prev_raw = ((const __attribute__((address_space(1))) int16_t *)frame)[where.prev_block * 64u];
     BlockRegs r;
     load_block(frame, bc, r);
-    lut_commit(l, lut);
+    lut64_commit(l, lut64);
     if (__ballot(valid) == 0) return;                                            // whole wave past the end
     const int prev_dc = where.has_prev ? prev_raw : 0;
     const bool baseline = baseline_band(p);
-    uint32_t mine = 0;
+    lds_word *strip = (lds_word *)strips[wave] + lane;
+    PrivSink ps = {strip, strip + (kPrivWords - 1u) * 64u, 0, 0, 0};
     if (valid) {
-        CountSink cs = {0};
-        if (baseline) walk_block<true>(p, lut, where.table, prev_dc, r, cs); else walk_block<false>(p, lut, where.table, prev_dc, r, cs);
-        mine = cs.total;
-        p.bits[(size_t)f * p.nblocks + b] = mine;                               // (interval offsets need them, k_interval_len)
+        if (baseline) walk_once<true>(p, lut64, where.table, prev_dc, r, ps); else walk_once<false>(p, lut64, where.table, prev_dc, r, ps);
+        ps.finish();
     }
+    const uint32_t mine = ps.bits();
+    if (valid) p.bits[(size_t)f * p.nblocks + b] = mine;                         // (interval offsets need them, k_interval_len)
     if (b < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + b] = 0;        // k_push adds its 0xFF counts to these
     const uint32_t upto = wave_inclusive(mine), at = upto - mine;               // bits of the run before this block
     const uint32_t total = (uint32_t)__shfl((int)upto, 63);
@@ -250,16 +254,13 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
     const uint32_t nwords = (total + 31u) >> 5;
     uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)w * p.slot_words;
     uint32_t *win = window[wave];
-    if (nwords + 4u <= p.window_words) {                                         // wave-uniform (+4: the zero word, 16-byte copies)
+    const bool strips_hold = __ballot(mine > kPrivWords * 32u) == 0;            // wave-uniform
+    if (strips_hold && nwords + 4u <= min(p.window_words, kOnePassWindowWords)) {   // wave-uniform (+4: the zero word, 16-byte copies)
         for (uint32_t i = lane; i <= nwords; i += 64u) win[i] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (valid) {
-            PackSink<LdsWords> ps = {LdsWords{(lds_word *)win + (at >> 5)}, 0, at & 31u};
-            if (baseline) walk_block<true>(p, lut, where.table, prev_dc, r, ps); else walk_block<false>(p, lut, where.table, prev_dc, r, ps);
-            ps.finish();
-        }
+        strip_to_window(strip, mine, at, (lds_word *)win);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -272,9 +273,9 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (valid) {
-            PackSink<HbmWords> ps = {HbmWords{(hbm_word *)slot + (at >> 5)}, 0, at & 31u};
-            if (baseline) walk_block<true>(p, lut, where.table, prev_dc, r, ps); else walk_block<false>(p, lut, where.table, prev_dc, r, ps);
-            ps.finish();
+            PackSink<HbmWords> hs = {HbmWords{(hbm_word *)slot + (at >> 5)}, 0, at & 31u};
+            if (baseline) walk_once<true>(p, lut64, where.table, prev_dc, r, hs); else walk_once<false>(p, lut64, where.table, prev_dc, r, hs);
+            hs.finish();
         }
     }
 }

@@ -195,4 +195,122 @@ __device__ __forceinline__ void lut_commit(const LutRegs &l, uint32_t *lut) {
 
 __device__ __forceinline__ bool baseline_band(Params p) { return p.with_dc && p.ac_start == 1 && p.ac_end == 64; }
 
+// ---- the one-walk coder ------------------------------------------------------------------------------------------------
+// k_block_code used to walk a block's symbols twice (bit length, then - after the 64-lane prefix sum gave the block's
+// offset in the wave's run - the bits).  The walk is what the kernel's time goes to (instruction issue, not bytes), so it
+// is done ONCE: the lane packs its block's bits from bit 0 into a lane-private strip of LDS words, and after the prefix
+// sum a short loop shifts those words into place in the wave's window (about bits / 32 + 1 trips instead of a second
+// 63-position walk).  The tables are widened for it: entry (x, y) of symbol s = (code << n, size + n) with n = s & 15,
+// so that a symbol costs one 8-byte LDS read and "bits = x | magnitude, length = y".
+constexpr uint32_t kPrivWords = 16;           // words of a lane's strip: blocks of up to 512 bits; longer ones send the wave down the two-walk path
+constexpr uint32_t kOnePassWindowWords = 1024;   // words of a wave's window in the one-walk kernel (4 KiB)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void lut64_commit(const LutRegs &l, u32x2 *lut64) {
+    const uint32_t n = threadIdx.x & 15u;                                       // size category of symbol threadIdx.x (DC: the symbol itself)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t e = l.v[i];
+        lut64[i * 256 + threadIdx.x] = u32x2{(e & 0xFFFFu) << n, (e >> 16) + n};   // (a symbol without a code still carries its magnitude bits: writer.rs:342-354 with size 0)
+    }
+    __syncthreads();
+}
+
+// size category and magnitude bits of a non-zero coefficient (get_code, writer.rs:455-470): with s = v >> 31 and
+// t = v + s (v - 1 for negative v) the category is 32 - (leading bits of t equal to its sign) and the bits are t's low n.
+// v_ffbh_i32: number of leading bits equal to the sign bit, 0xFFFFFFFF when all 32 are (t = 0 or -1)
+__device__ __forceinline__ uint32_t sign_bits(int t) {
+    uint32_t n;
+    asm("v_ffbh_i32 %0, %1" : "=v"(n) : "v"(t));
+    return n;
+}
+__device__ __forceinline__ uint32_t category_of(int t) { return 32u - min(sign_bits(t), 32u); }
+
+struct PrivSink {                  // bits from bit 0 into words w[0], w[64], w[128] ... (one strip per lane, lane-interleaved)
+    lds_word *w, *last;
+    uint64_t acc;
+    uint32_t nacc, nwords;
+    __device__ __forceinline__ void put(uint32_t bits, uint32_t len) {          // len <= 31
+        acc = (acc << len) | bits;
+        nacc += len;
+        if (nacc >= 32) {
+            nacc -= 32;
+            *w = (uint32_t)(acc >> nacc);
+            w = min(w + 64, last);                                               // (a strip that overflows keeps overwriting its last word: the wave then takes the two-walk path)
+            nwords++;
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        if (nacc) *w = (uint32_t)(acc << (32u - nacc));
+    }
+    __device__ __forceinline__ uint32_t bits() const { return nwords * 32u + nacc; }
+};
+
+// The table read of a symbol is issued where the symbol is found and consumed where the NEXT symbol is found (or at the
+// end of the block): the walk is a chain of predicated regions the compiler cannot schedule across, and with the read
+// and its use in the same region every non-zero position stalled the wave for a full LDS round trip (half a wave's life).
+template <bool BASELINE, class Sink>
+__device__ __forceinline__ void walk_once(Params p, const u32x2 *lut64, uint32_t table, int prev_dc, const BlockRegs &r, Sink &s) {
+    typedef const __attribute__((address_space(3))) u32x2 *lut_ptr;
+    const uint32_t dc_base = (uint32_t)(uintptr_t)(lut_ptr)(lut64 + table * 512u);   // LDS byte addresses
+    const uint32_t ac_base = dc_base + 256u * 8u;
+    const uint32_t *c = r.c;
+    u32x2 pend = {0u, 0u};                         // table entry of the symbol found last, not yet put (put(0, 0) is a no-op)
+    uint32_t pend_mag = 0;
+    if (BASELINE || p.with_dc) {
+        const int dc = (int16_t)(c[0] & 0xFFFFu);
+        const int diff = (int16_t)(dc - prev_dc);
+        const int t = diff + (diff >> 31);
+        const uint32_t n = category_of(t);
+        pend = *(lut_ptr)(uintptr_t)(dc_base + (n << 3));
+        pend_mag = __builtin_amdgcn_ubfe((uint32_t)t, 0u, n);
+    }
+    // AC: write_ac_block(block, start, end) (writer.rs:356-388)
+    if (BASELINE || p.ac_end > p.ac_start) {
+        uint32_t run_at = ac_base;                 // address of the table row of the current zero run: ac_base + run * 128
+        const uint32_t zrl_row = ac_base + 15u * 128u;
+        const u32x2 zrl = *(lut_ptr)(uintptr_t)(ac_base + 0xF0u * 8u), eob = *(lut_ptr)(uintptr_t)ac_base;
+#pragma unroll
+        for (uint32_t k = 1; k < 64; k++) {
+            if (!BASELINE && (k < p.ac_start || k >= p.ac_end)) continue;
+            const int v = (k & 1u) ? (int)c[k >> 1] >> 16 : (int)(int16_t)(c[k >> 1] & 0xFFFFu);
+            if (v != 0) {
+                s.put(pend.x | pend_mag, pend.y);
+                if (run_at > zrl_row) {
+#pragma nounroll
+                    do { s.put(zrl.x, zrl.y); run_at -= 16u * 128u; } while (run_at > zrl_row);
+                }
+                const int t = v + (v >> 31);
+                const uint32_t n = 32u - sign_bits(t);                           // v != 0: t is neither 0 nor -1
+                pend = *(lut_ptr)(uintptr_t)(run_at + (n << 3));
+                pend_mag = __builtin_amdgcn_ubfe((uint32_t)t, 0u, n);
+                run_at = ac_base;
+            } else {
+                run_at += 128u;
+            }
+        }
+        s.put(pend.x | pend_mag, pend.y);
+        if (run_at != ac_base) s.put(eob.x, eob.y);
+    } else {
+        s.put(pend.x | pend_mag, pend.y);
+    }
+}
+
+// After the prefix sum: the lane's strip (bits() bits from bit 0) goes to bit offset `at` of the wave's zeroed window.
+// Word j of the output takes the low bits of strip word j - 1 and the high bits of word j; completed words are OR-ed
+// in (neighbouring lanes share their first / last word).
+__device__ __forceinline__ void strip_to_window(const lds_word *strip, uint32_t nbits, uint32_t at, lds_word *window) {
+    const uint32_t nw = (nbits + 31u) >> 5, sh = at & 31u;
+    lds_word *dst = window + (at >> 5);
+    uint32_t prev = 0;
+    for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j <= nw) != 0; j++) {
+        if (j <= nw) {
+            const uint32_t cur = j < nw ? strip[j * 64u] : 0u;
+            const uint32_t out = sh ? (prev << (32u - sh)) | (cur >> sh) : cur;
+            if (out) __hip_atomic_fetch_or(dst + j, __builtin_bswap32(out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            prev = cur;
+        }
+    }
+}
+
 }  // namespace jpegenc

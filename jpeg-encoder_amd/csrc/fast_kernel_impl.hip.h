@@ -221,9 +221,67 @@ struct ByteConv {          // the sample is a byte of the pixel word itself
 // CONV = the kernel carries the RGB -> YCbCr roles (RGB family, CmykAsYcck); otherwise byte planes only.
 // 3-byte RGB with sampling factors 1 and 2 has at most 6 waves per 64-MCU group; 4:1:0-style factors (4x2), CmykAsYcck
 // and 4-component layouts up to 10.
+// AC symbol statistics of a wave's 64 blocks (the counting half of optimize_huffman_table, encoder.rs:1123-1161) while
+// their coefficients sit in registers: run-length symbols (run << 4 | size) per progressive band, 0xF0 per 16 zeros only
+// when a non-zero follows in the band, 0x00 (EOB) when a band ends in zeros.  Counted with LDS atomics in the wave's own
+// staging area (not yet in use: the output is staged after this) in 4 interleaved copies (lane & 3: the few hot symbols
+// would otherwise serialise a wave's adds on one address), then added to one of kHistCopies partial histograms in
+// global memory - one add per non-zero counter, and no two waves of a frame in flight share a partial for long.
+__device__ __forceinline__ void ac_histogram(const uint32_t (&c)[32], bool counts, uint8_t *stage, uint32_t lane, uint64_t band_mask,
+                                             uint32_t *partial /* [256] of this wave's table */) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32h;
+    uint32_t *h = reinterpret_cast<uint32_t *>(stage);                          // [256 symbols][4 copies]
+#pragma unroll
+    for (int i = 0; i < 16; i++) h[i * 64 + lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (counts) {
+        const uint32_t base = (uint32_t)(uintptr_t)(lds_u32h *)h + ((lane & 3u) << 2);   // LDS byte address of this lane's copy of symbol 0
+        uint32_t run_at = base;                                                  // base + run * 256 (16 symbols x 4 copies x 4 bytes per run step)
+        const uint32_t zrl_row = base + 15u * 256u;
+        const uint32_t one = 1u;
+        auto add = [&](uint32_t addr) { __hip_atomic_fetch_add((lds_u32h *)(uintptr_t)addr, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+#pragma unroll
+        for (uint32_t k = 1; k < 64; k++) {
+            if (k > 1 && ((band_mask >> k) & 1u)) {                               // wave-uniform: a band starts here - close the previous one
+                if (run_at != base) add(base);                                   // EOB
+                run_at = base;
+            }
+            const int v = (k & 1u) ? (int)c[k >> 1] >> 16 : (int)(int16_t)(c[k >> 1] & 0xFFFFu);
+            if (v != 0) {
+                if (run_at > zrl_row) {
+#pragma nounroll
+                    do { add(base + 0xF0u * 16u); run_at -= 16u * 256u; } while (run_at > zrl_row);
+                }
+                const int a = v < 0 ? -v : v;
+                const uint32_t n = 32u - (uint32_t)__builtin_clz((uint32_t)a);
+                add(run_at + (n << 4));
+                run_at = base;
+            } else {
+                run_at += 256u;
+            }
+        }
+        if (run_at != base) add(base);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t sym = (uint32_t)i * 64u + lane;
+        const uint4 q = *reinterpret_cast<const uint4 *>(h + sym * 4u);
+        const uint32_t n = q.x + q.y + q.z + q.w;
+        if (n) atomicAdd(partial + sym, n);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                       // the staging area is reused right after
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The life of one wave over one group of 64 MCUs of frame `frm` (see the notes at the top of the file).
 template <int BPP, int SX, int SY, int VARIANT, bool CONV>
-__global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY <= 4 ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+__device__ __forceinline__ void block_wave(const BlockKernelParams &p, const ColourConsts &k, uint8_t *smem, const uint32_t grp, const uint32_t frm) {
 #ifdef JPEGENC_WAVE_TIMING
     const uint64_t tm0 = __builtin_readcyclecounter();
 #endif
@@ -243,12 +301,12 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
     const uint32_t order = H[11], units_x = Wv[3], limit = Wv[4], magic = Wv[5], shift = Wv[6];
     // Both block orders walk the image MCU by MCU - that is what makes the waves of a workgroup read the
     // same pixels; the order only decides where a block is stored (stage_and_store).
-    const uint32_t first_unit = blockIdx.x * 64u + Wv[1];
+    const uint32_t first_unit = grp * 64u + Wv[1];
     if (first_unit >= limit) return;                                // padding wave of the last group: nothing to do
     const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0], co_base = ((uint64_t)H[3] << 32) | H[2];
     const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4], co_stride = ((uint64_t)H[7] << 32) | H[6];
-    const gbytes frame = (gbytes)(uintptr_t)(px_base + (size_t)blockIdx.y * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]));
-    const gchunks frame_out = (gchunks)(uintptr_t)(co_base + (size_t)blockIdx.y * co_stride * 128u);
+    const gbytes frame = (gbytes)(uintptr_t)(px_base + (size_t)frm * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]));
+    const gchunks frame_out = (gchunks)(uintptr_t)(co_base + (size_t)frm * co_stride * 128u);
     const int width = (int)H[8], hlim = (int)H[9] - 1;
     const uint32_t pitch = H[10];                                   // frame bytes < 2^31 (checked by the launcher)
     const int sxc = sub ? SX : 1, syc = sub ? SY : 1;
@@ -338,6 +396,16 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
 #else
     fdct_quant_block<VARIANT>(rows, quant_table(qsel), packed);
 #endif
+    if (p.hist_partials && order != 0) {                                         // wave-uniform: optimised-Huffman statistics
+        const uint32_t wave_id = (grp * (blockDim.x >> 6) + wave) & (kHistCopies - 1u);
+        uint32_t *partial = p.hist_partials + (((size_t)frm * kHistCopies + wave_id) * 2u + (uint32_t)qsel) * 256u;
+        ac_histogram(packed, inside, smem + wave * kStageBytes, lane, p.hist_band_mask, partial);
+        if (inside) {
+            const uint32_t bx = (ux << lg) + sub_k, by = (uy << lgv) + vrow;
+            const uint64_t comp_off = ((uint64_t)Wv[8] << 32) | Wv[7];
+            p.dc_side[(size_t)frm * p.hist_total_blocks + comp_off + (size_t)by * Wv[2] + bx] = (int16_t)(packed[0] & 0xFFFFu);
+        }
+    }
 #if defined(JPEGENC_PROBE_MEMORY_ONLY) && JPEGENC_PROBE_MEMORY_ONLY == 4       // loads only
     uint32_t x = 0;
 #pragma unroll
@@ -364,13 +432,29 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
     __builtin_amdgcn_s_waitcnt(0);                             // stores retired (vmcnt 0): end of the wave's life
     const uint64_t tm4 = __builtin_readcyclecounter();
     if (p.timing && lane == 0) {       // one 32-byte record per wave, no atomics (they would dominate the kernel)
-        const size_t id = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave;
+        const size_t id = ((size_t)frm * p.groups + grp) * (blockDim.x >> 6) + wave;
         if (id < (1u << 20)) {
             uint32_t *tq = reinterpret_cast<uint32_t *>(p.timing) + id * 8;
             tq[0] = (uint32_t)(tm1 - tm0); tq[1] = (uint32_t)(tm2 - tm1); tq[2] = (uint32_t)(tm3 - tm2); tq[3] = (uint32_t)(tm4 - tm3);
             tq[4] = 1u + (uint32_t)(sub ? 1 : 0);      // class: full-resolution waves, decimated waves
         }
     }
+#endif
+}
+
+template <int BPP, int SX, int SY, int VARIANT, bool CONV>
+__global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY <= 4 ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef JPEGENC_PERSISTENT
+    // experiment: resident workgroups walk the (frame, group) items with a stride instead of one workgroup per item;
+    // waves never synchronise, so each wave simply loops (its staging area is its own)
+    const uint32_t total = p.groups * p.persistent_frames;
+    for (uint32_t item = blockIdx.x + blockIdx.y * gridDim.x; item < total * 1u; item += gridDim.x * gridDim.y) {
+        const uint32_t frm = item / p.groups;
+        block_wave<BPP, SX, SY, VARIANT, CONV>(p, k, smem, item - frm * p.groups, frm);
+    }
+#else
+    block_wave<BPP, SX, SY, VARIANT, CONV>(p, k, smem, blockIdx.x, blockIdx.y);
 #endif
 }
 
@@ -442,7 +526,14 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
                               hipStream_t stream) {
     BlockKernelParams q = p;
     if (!fill_fast_params(q, k, BPP, SX, SY, CONV)) return hipErrorInvalidValue;      // launch_blocks_fast checked the preconditions
+#ifdef JPEGENC_PERSISTENT
+    static const unsigned resident = [] { const char *e = getenv("JPEGENC_PERSISTENT_WGS"); return e ? (unsigned)atoi(e) : 768u; }();
+    const unsigned items = q.groups * (unsigned)num_frames;
+    const dim3 grid(items < resident ? items : resident, 1), block(q.per_group * 64u);
+    q.persistent_frames = (uint32_t)num_frames;
+#else
     const dim3 grid(q.groups, (unsigned)num_frames), block(q.per_group * 64u);          // <= 10 waves
+#endif
     size_t lds = (size_t)q.per_group * kStageBytes;
 #ifdef JPEGENC_WAVE_TIMING
     q.timing = wave_timing_buffer();

@@ -309,8 +309,16 @@ bool fused_supported(const BlockKernelParams &b) {
     if (b.bpm < 1 || b.bpm > 10 || b.total_mcus >= (1u << 26)) return false;
     if (b.h[1] != 1 || b.v[1] != 1 || b.h[2] != 1 || b.v[2] != 1) return false;
     if (b.h[0] != b.hmax || b.v[0] != b.vmax || b.hmax > 2 || b.vmax > 2) return false;
-    static const bool off = getenv("JPEGENC_NO_FUSED") != nullptr;
-    return !off;
+    return true;
+}
+
+// Whether the Encoder takes the fused kernel where the layout allows it.  Measured (profiles/README.md, r02): byte-
+// identical, but SLOWER than block kernel + k_block_code on every content - the pipeline is bound by instruction issue,
+// not by the coefficient round trip through HBM, and waves that hold several components pay ~20 % more instructions
+// than two role-uniform kernels - so it is opt-in (JPEGENC_FUSED=1); jpegenc_pixels_scan_device always takes it.
+bool fused_enabled() {
+    static const bool on = [] { const char *e = getenv("JPEGENC_FUSED"); return e && atoi(e) != 0; }();
+    return on;
 }
 
 uint32_t fused_run_blocks(const BlockKernelParams &b) { return (64u / b.bpm) * b.bpm; }

@@ -35,6 +35,7 @@ int build_block_params_planes(BlockKernelParams *p, const jpegenc_layout &L, int
 // block_kernels.hip
 hipError_t launch_blocks_generic(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream);
 hipError_t launch_histogram(const HistKernelParams &p, hipStream_t stream);
+hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream);
 // fast_kernels.hip: returns false when the configuration has no specialised kernel
 bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream,
                         hipError_t *err);
@@ -45,7 +46,8 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
 hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, hipStream_t stream, std::string *stored);
 // fused_kernels.hip: the Encoder's interleaved baseline scan coded straight from the pixels (no coefficients in HBM)
 struct FusedSource { const BlockKernelParams *blocks; int variant; };
-bool fused_supported(const BlockKernelParams &b);
+bool fused_supported(const BlockKernelParams &b);      // the layout has a fused kernel
+bool fused_enabled();                                    // the Encoder uses it (JPEGENC_FUSED=1; off by default, see fused_kernels.hip)
 uint32_t fused_run_blocks(const BlockKernelParams &b);
 uint32_t fused_runs(const BlockKernelParams &b);
 hipError_t launch_fused_code(const BlockKernelParams &b, const EntropyParams *d_params, int restart_interval, int frames, int variant,

@@ -243,6 +243,10 @@ struct DeviceCtx {
     int device = -1;
     hipStream_t stream = nullptr;
     void *d_pixels = nullptr, *d_coeffs = nullptr, *d_freq = nullptr;
+    // optimised tables: [freq 2x2x257 (padded to 4 KiB)][kHistCopies partial AC histograms] - cleared with one memset - and the DC side array
+    void *d_hist = nullptr, *d_dc_side = nullptr;
+    size_t d_dc_side_cap = 0;
+    static constexpr size_t kHistFreqBytes = 4352, kHistBytes = kHistFreqBytes + (size_t)kHistCopies * 2 * 256 * sizeof(uint32_t);
     const void *external_pixels = nullptr;   // device-resident input: use the caller's buffer, no upload
     size_t d_pixels_cap = 0, d_coeffs_cap = 0;
     int16_t *h_coeffs = nullptr;
@@ -288,6 +292,16 @@ struct DeviceCtx {
         JPEGENC_HIP(hipMalloc((void **)&d_scan_len, sizeof(uint32_t) * kMaxScans));
         JPEGENC_HIP(hipHostMalloc((void **)&h_scan_len, sizeof(uint32_t) * kMaxScans, hipHostMallocDefault));
         JPEGENC_HIP(hipMalloc(&d_lut, 4 * 256 * sizeof(uint32_t)));
+        return JPEGENC_OK;
+    }
+    int reserve_hist(size_t total_blocks) {            // optimised tables only
+        if (!d_hist) JPEGENC_HIP(hipMalloc(&d_hist, kHistBytes));
+        if (total_blocks * sizeof(int16_t) > d_dc_side_cap) {
+            if (d_dc_side) (void)hipFree(d_dc_side);
+            d_dc_side = nullptr; d_dc_side_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_dc_side, total_blocks * sizeof(int16_t)));
+            d_dc_side_cap = total_blocks * sizeof(int16_t);
+        }
         return JPEGENC_OK;
     }
     int reserve_host_coeffs(size_t coeff_bytes) {      // only the host entropy path needs the coefficients
@@ -365,6 +379,8 @@ struct DeviceCtx {
         if (d_pixels) (void)hipFree(d_pixels);
         if (d_coeffs) (void)hipFree(d_coeffs);
         if (d_freq) (void)hipFree(d_freq);
+        if (d_hist) (void)hipFree(d_hist);
+        if (d_dc_side) (void)hipFree(d_dc_side);
         if (h_coeffs) (void)hipHostFree(h_coeffs);
         if (h_pixels) (void)hipHostFree(h_pixels);
         if (h_freq) (void)hipHostFree(h_freq);
@@ -852,7 +868,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             if (w > ws) ws = w;
         }
         first_piece = out_total < DeviceCtx::kFirstPiece ? out_total : DeviceCtx::kFirstPiece;
-        fused = supported && mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_supported(p);
+        fused = supported && mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() && fused_supported(p);
         if (supported) {
             // The scans of a sequential / progressive frame are independent: coded in shared launches they cost
             // ~10 launches per 8 scans instead of ~10 per scan (a 4K progressive frame: 12 scans; such frames were
@@ -917,15 +933,53 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
         ~CaptureGuard() { if (active) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); } }
     } capture_guard{ctx.stream, how == CAPTURE};
     const bool enqueue = how != REPLAY;
+    bool hist_folded = false;                      // the tuned block kernel counted the symbols itself
+    if (optimize) {
+        // optimize_huffman_table's statistics (encoder.rs:1086-1200) are gathered by the block kernel while the
+        // coefficients are in registers; layouts only the generic kernel handles keep the separate pass over HBM
+        static const bool fold_off = getenv("JPEGENC_NO_FOLDED_HISTOGRAM") != nullptr;
+        rc = ctx.reserve_hist((size_t)L.total_blocks);
+        if (rc) return rc;
+        if (!fold_off && L.total_blocks < (1ull << 32)) {
+            p.hist_partials = (uint32_t *)((uint8_t *)ctx.d_hist + DeviceCtx::kHistFreqBytes);
+            p.dc_side = (int16_t *)ctx.d_dc_side;
+            p.hist_total_blocks = (uint32_t)L.total_blocks;
+            p.hist_band_mask = 0;
+            if (c.progressive_scans) {                                   // AC bands of encode_image_progressive (encoder.rs:1123-1134)
+                const int scans = c.progressive_scans - 1, per = 64 / scans;
+                for (int sidx = 1; sidx < scans; sidx++)
+                    if (sidx * per > 1 && sidx * per < 64) p.hist_band_mask |= 1ull << (sidx * per);
+            }
+        }
+    }
     if (enqueue && !fused) {
         hipError_t err = hipSuccess;
-        if (!launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, 1, c.fdct_variant, ctx.stream);
+        if (p.hist_partials) JPEGENC_HIP(hipMemsetAsync(ctx.d_hist, 0, DeviceCtx::kHistBytes, ctx.stream));
+        if (launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) {
+            hist_folded = p.hist_partials != nullptr;
+        } else {
+            err = launch_blocks_generic(p, 1, c.fdct_variant, ctx.stream);
+        }
         if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
     }
     if (optimize) {
-        rc = jpegenc_histogram_device(ctx.d_coeffs, &L, c.progressive_scans, ctx.d_freq, ctx.stream);
-        if (rc) return rc;
-        JPEGENC_HIP(hipMemcpyAsync(ctx.h_freq, ctx.d_freq, sizeof(uint32_t) * 2 * 2 * 257, hipMemcpyDeviceToHost, ctx.stream));
+        const void *d_freq = ctx.d_freq;
+        if (hist_folded) {
+            HistFinishParams hf;
+            memset(&hf, 0, sizeof hf);
+            hf.partials = p.hist_partials; hf.dc_side = p.dc_side; hf.freq = (uint32_t *)ctx.d_hist; hf.ncomp = L.num_components;
+            uint64_t off = 0;
+            for (int i = 0; i < L.num_components; i++) {
+                hf.nblocks[i] = (uint32_t)L.blocks[i]; hf.comp_off[i] = off; off += L.blocks[i]; hf.table[i] = L.table[i];
+            }
+            const hipError_t he = launch_hist_finish(hf, ctx.stream);
+            if (he != hipSuccess) return hip_fail(he, "histogram finish kernel launch");
+            d_freq = ctx.d_hist;
+        } else {
+            rc = jpegenc_histogram_device(ctx.d_coeffs, &L, c.progressive_scans, ctx.d_freq, ctx.stream);
+            if (rc) return rc;
+        }
+        JPEGENC_HIP(hipMemcpyAsync(ctx.h_freq, d_freq, sizeof(uint32_t) * 2 * 2 * 257, hipMemcpyDeviceToHost, ctx.stream));
     }
     // ---- entropy-code every scan on the device and fetch only the compressed bytes ----------------
     if (c.device_entropy && supported) {
@@ -1181,7 +1235,7 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         p.pixel_frame_stride = frame_stride;
         p.coeff_frame_stride = L.total_blocks;
         const FusedSource fused_src = {&p, c.fdct_variant};
-        const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_supported(p);
+        const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() && fused_supported(p);
         if (!fused) {
             hipError_t err = hipSuccess;
             if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, n, c.fdct_variant, ctx.stream);

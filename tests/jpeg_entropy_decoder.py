@@ -27,6 +27,7 @@ class _Bits:
 
     def _fill(self):
         d = self.d
+        self.acc &= (1 << self.n) - 1               # drop the consumed bits (Python ints are unbounded)
         while self.n <= 24:
             if self.pos >= len(d):
                 b = 0
@@ -60,6 +61,14 @@ class _Bits:
         self.n -= k
         return (self.acc >> self.n) & ((1 << k) - 1)
 
+    def peek16(self):
+        if self.n < 16:
+            self._fill()
+        return (self.acc >> (self.n - 16)) & 0xFFFF
+
+    def skip(self, k):
+        self.n -= k
+
     def align_and_expect_rst(self, index):
         """Discard the padding bits, then the RSTm marker must follow (F.2.2.5 / E.2.4)."""
         # bytes already pulled into the accumulator beyond the current byte boundary were real data only if n >= 8
@@ -75,7 +84,7 @@ class _Huff:
     """Decoder tables of Figure F.15 / F.16 from the BITS and HUFFVAL lists of a DHT segment (C.2, F.2.2.3)."""
 
     def __init__(self, counts, values):
-        self.mincode, self.maxcode, self.valptr, self.values = [0] * 17, [-1] * 18, [0] * 17, values
+        self.mincode, self.maxcode, self.valptr, self.values, self.fast = [0] * 17, [-1] * 18, [0] * 17, values, None
         code, k = 0, 0
         for length in range(1, 17):
             self.valptr[length] = k
@@ -88,12 +97,24 @@ class _Huff:
             raise JpegError("DHT: counts and values disagree")
 
     def decode(self, br):
-        code = 0
-        for length in range(1, 17):
-            code = (code << 1) | br.bit()
-            if self.maxcode[length] >= 0 and code <= self.maxcode[length] and code >= self.mincode[length]:
-                return self.values[self.valptr[length] + code - self.mincode[length]]
-        raise JpegError("invalid Huffman code")
+        """Figure F.16, through a table indexed by the next 16 bits (built on first use): entry = length << 8 | value."""
+        if self.fast is None:
+            fast = [0] * 65536
+            k = 0
+            for length in range(1, 17):
+                n = 0 if self.maxcode[length] < 0 else self.maxcode[length] - self.mincode[length] + 1
+                for i in range(n):
+                    code = self.mincode[length] + i
+                    lo = code << (16 - length)
+                    entry = (length << 8) | self.values[k]
+                    fast[lo:lo + (1 << (16 - length))] = [entry] * (1 << (16 - length))
+                    k += 1
+            self.fast = fast
+        e = self.fast[br.peek16()]
+        if e == 0:
+            raise JpegError("invalid Huffman code")
+        br.skip(e >> 8)
+        return e & 0xFF
 
 
 def _extend(v, t):                                   # Figure F.12

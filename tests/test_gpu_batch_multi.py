@@ -168,3 +168,46 @@ def test_pixels_scan_device_matches_the_two_kernel_path_and_the_oracle(binding, 
     for i in range(n):                                                  # the scan is the tail of the oracle's file: ... SOS header | scan | EOI
         ref = oracle.encode_jpeg(px[i], w, h, ct, 85, sampling=(hs, vs), restart_interval=restart)
         assert ref.endswith(outs[0][i] + b"\xff\xd9") and len(outs[0][i]) > 0
+
+
+def test_encoder_with_the_fused_kernel_enabled(binding, tmp_path):
+    """JPEGENC_FUSED=1 (read once per process, hence the child process): the Encoder codes its interleaved baseline scan
+    straight from the pixels - single frames (direct, captured and replayed launch sequences), restart intervals, 4-byte
+    pixels, the worker-pool batch and the device-resident batch - byte-identical to the oracle's files."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fused_child.py"
+    script.write_text(textwrap.dedent(f"""
+        import importlib, sys
+        sys.path.insert(0, {root!r})
+        import numpy as np, torch
+        import __graft_entry__ as ge
+        ge.load_package()
+        b = importlib.import_module("jpeg_encoder_amd.binding")
+        synth = importlib.import_module("jpeg_encoder_amd.synth")
+        from oracle import pyoracle as o
+        cases = [(b.RGB, 3, 258, 128, dict(quality=80)), (b.RGB, 3, 258, 128, dict(quality=100)), (b.RGB, 3, 515, 77, dict(quality=85, sampling=(2, 1))),
+                 (b.BGR, 3, 77, 515, dict(quality=70, sampling=(1, 2), restart_interval=3)), (b.RGBA, 4, 640, 360, dict(quality=90, sampling=(2, 2))),
+                 (b.BGRA, 4, 333, 201, dict(quality=60, restart_interval=1)), (b.RGB, 3, 1920, 1080, dict(quality=80)),
+                 (b.RGB, 3, 3840, 2160, dict(quality=90, sampling=(2, 2), restart_interval=240))]
+        for ct, bpp, w, h, kw in cases:
+            px = synth.lcg_image(w, h, bpp, 9)
+            px = (px.astype(np.int16) // 4 + np.add.outer(np.arange(h), np.arange(w))[..., None] // 3).clip(0, 255).astype(np.uint8)
+            e = b.Encoder(kw["quality"])
+            if "sampling" in kw: e.set_sampling_factor(b.sampling_factor(*kw["sampling"]))
+            if kw.get("restart_interval"): e.set_restart_interval(kw["restart_interval"])
+            want = o.encode_jpeg(px, w, h, ct, **kw)
+            for _ in range(4):                                   # direct, direct, capture, replay
+                assert e.encode(px, w, h, ct) == want, (ct, w, h, kw)
+            d = torch.from_numpy(np.stack([px, px[::-1].copy(), px])).cuda()
+            files = e.encode_batch_device(d.data_ptr(), w * h * bpp, 3, w, h, ct)
+            assert files[0] == want and files[2] == want and files[1] == o.encode_jpeg(px[::-1].copy(), w, h, ct, **kw)
+            assert e.encode_batch([px] * 5, w, h, ct) == [want] * 5
+        print("FUSED-OK")
+    """))
+    env = dict(os.environ, JPEGENC_FUSED="1")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FUSED-OK" in r.stdout, r.stderr[-3000:]
