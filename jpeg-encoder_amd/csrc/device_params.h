@@ -36,7 +36,7 @@ struct alignas(64) FastHeader {
     uint32_t width, height, pitch, order;
     uint32_t bpm;                     // blocks per MCU (MCU order)
     uint32_t mcu_w, mcu_h;            // 8 * hmax, 8 * vmax: MCU size in full-resolution samples
-    uint32_t reserved;
+    uint32_t group_mcus;              // MCUs per group (= workgroup): 64, or 32 / 16 where 64 MCUs would need more than 10 waves
 };
 struct alignas(64) FastWave {         // one per wave of a group, indexed by the wave's number in the workgroup
     uint32_t bits;                    // see FW_* below
@@ -60,6 +60,7 @@ enum : uint32_t {                     // FastWave::bits
     FW_VROW_SHIFT = 8,                // 3 bits: which block row inside the MCU
     FW_INVERT_SHIFT = 11,             // 1 bit: ROLE_BYTE sample = 255 - byte
     FW_LGV_SHIFT = 12,                // 2 bits: log2 of the component's block rows per MCU (= log2 v)
+    FW_COUNT_SHIFT = 14,              // 7 bits: MCUs this wave covers (64 >> lg, fewer when the group is smaller than that)
 };
 
 struct BlockKernelParams {

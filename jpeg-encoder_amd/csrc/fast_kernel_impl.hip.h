@@ -301,7 +301,8 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
     const uint32_t order = H[11], units_x = Wv[3], limit = Wv[4], magic = Wv[5], shift = Wv[6];
     // Both block orders walk the image MCU by MCU - that is what makes the waves of a workgroup read the
     // same pixels; the order only decides where a block is stored (stage_and_store).
-    const uint32_t first_unit = grp * 64u + Wv[1];
+    const uint32_t first_unit = grp * H[15] + Wv[1];
+    const uint32_t wave_mcus = (bits >> FW_COUNT_SHIFT) & 127u;   // MCUs this wave covers
     if (first_unit >= limit) return;                                // padding wave of the last group: nothing to do
     const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0], co_base = ((uint64_t)H[3] << 32) | H[2];
     const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4], co_stride = ((uint64_t)H[7] << 32) | H[6];
@@ -321,7 +322,7 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
         const uint32_t q = (uint32_t)(((uint64_t)ux * magic) >> shift);
         uy += q; ux -= q * units_x;
     }
-    bool inside = first_unit + dm < limit;
+    bool inside = first_unit + dm < limit && dm < wave_mcus;
     if (order != 0) inside = inside && (ux << lg) + sub_k < Wv[2] && (uy << lgv) + vrow < Wv[13];   // planar: the plane may end inside the last MCUs
     if (!inside) { ux = 0; uy = 0; }                                // such slots read block 0 and store nothing
     BlockRef me;
@@ -422,7 +423,7 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
     // planar order: a component with one block per MCU whose plane is as wide as the MCU grid stores 64
     // consecutive blocks (chroma of 4:2:0, everything in 4:4:4); the others map each slot through its MCU
     sm.order = order == 0 ? 0u : (lg == 0u && lgv == 0u && Wv[2] == units_x ? 1u : 2u);
-    sm.lg = lg; sm.first = first_unit; sm.limit = limit; sm.bpm = H[12];
+    sm.lg = lg; sm.first = first_unit; sm.limit = min(limit, first_unit + wave_mcus); sm.bpm = H[12];
     sm.out_base = ((uint64_t)Wv[8] << 32) | Wv[7];
     sm.units_x = units_x; sm.magic = magic; sm.shift = shift; sm.col0 = col0; sm.row0 = row0;
     sm.lgv = lgv; sm.vrow = vrow; sm.cols = Wv[2]; sm.rows = Wv[13];
@@ -464,29 +465,44 @@ unsigned long long *wave_timing_buffer();      // fast_kernels.hip
 
 // Host side of the prologue: the FastHeader / FastWave records of a launch.
 static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k, int bpp, int sx, int sy, bool conv) {
-    uint32_t waves = 0;
-    for (int c = 0; c < q.ncomp; c++) waves += (uint32_t)(q.h[c] * q.v[c]);
-    if (waves < 1 || waves > 10 || waves != q.wave_start[q.ncomp]) return false;
-    q.per_group = waves;                                          // both orders: the waves of 64 MCUs
-    q.groups = (q.total_mcus + 63u) / 64u;
+    // A group is 64 MCUs where that needs at most 10 waves (every layout of 1 - 3 components), else 32 or 16 MCUs
+    // (4-component layouts with 4x2 / 2x4 sampling: 11 or 18 waves per 64 MCUs).  A wave takes one row of a component's
+    // blocks inside the MCU from 64 / h MCUs - or from the whole group if that is smaller (its other lanes idle).
+    uint32_t group = 64, waves = 0, wave_first[5] = {0, 0, 0, 0, 0};
+    for (; group >= 16; group >>= 1) {
+        waves = 0;
+        for (int c = 0; c < q.ncomp; c++) {
+            const uint32_t per_wave = 64u / (uint32_t)q.h[c];
+            wave_first[c] = waves;
+            waves += ((group + per_wave - 1u) / per_wave) * (uint32_t)q.v[c];
+        }
+        wave_first[q.ncomp] = waves;
+        if (waves <= 10) break;
+    }
+    if (waves < 1 || waves > 10) return false;
+    q.per_group = waves;
+    q.groups = (q.total_mcus + group - 1u) / group;
     FastHeader &h = q.fast_hdr;
     memset(&h, 0, sizeof h);
     h.pixels = (uint64_t)(uintptr_t)q.pixels; h.coeffs = (uint64_t)(uintptr_t)q.coeffs;
     h.pixel_frame_stride = q.pixel_frame_stride; h.coeff_frame_stride = q.coeff_frame_stride;
     h.width = (uint32_t)q.width; h.height = (uint32_t)q.height; h.pitch = (uint32_t)q.width * (uint32_t)bpp;
     h.order = (uint32_t)q.order; h.bpm = q.bpm; h.mcu_w = 8u * (uint32_t)q.hmax; h.mcu_h = 8u * (uint32_t)q.vmax;
+    h.group_mcus = group;
     memset(q.fast_wave, 0, sizeof q.fast_wave);
     for (uint32_t w = 0; w < q.per_group; w++) {
         FastWave &f = q.fast_wave[w];
         int c = 0;
-        while (c + 1 < q.ncomp && w >= q.wave_start[c + 1]) c++;
-        const uint32_t in_comp = w - q.wave_start[c], hc = (uint32_t)q.h[c];
+        while (c + 1 < q.ncomp && w >= wave_first[c + 1]) c++;
+        const uint32_t in_comp = w - wave_first[c], hc = (uint32_t)q.h[c];
         // one row of the component's blocks inside the MCU from 64 / h MCUs (wave_tasks.hip.h), in both orders
         uint32_t lg = 0, lgv = 0;
         while ((1u << lg) < hc) lg++;
         while ((1u << lgv) < (uint32_t)q.v[c]) lgv++;
-        const uint32_t range = in_comp % hc, vrow = in_comp / hc;
-        f.first_off = range * (64u / hc);
+        const uint32_t per_wave = 64u / hc, ranges = (group + per_wave - 1u) / per_wave;
+        const uint32_t range = in_comp % ranges, vrow = in_comp / ranges;
+        f.first_off = range * per_wave;
+        const uint32_t count = group - f.first_off < per_wave ? group - f.first_off : per_wave;
         f.units_x = q.mcus_x; f.limit = q.total_mcus;
         if (q.order == 0) {
             const uint64_t ob = (uint64_t)q.comp_first[c] + (uint64_t)vrow * hc;
@@ -507,7 +523,7 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
         const int role = k.role[c];
         f.bits = ((uint32_t)c << FW_COMP_SHIFT) | ((uint32_t)role << FW_ROLE_SHIFT) | ((uint32_t)(q.qsel[c] & 1) << FW_QSEL_SHIFT) |
                  ((uint32_t)sub << FW_SUB_SHIFT) | (lg << FW_LG_SHIFT) | (vrow << FW_VROW_SHIFT) |
-                 ((uint32_t)(k.invert[c] != 0) << FW_INVERT_SHIFT) | (lgv << FW_LGV_SHIFT);
+                 ((uint32_t)(k.invert[c] != 0) << FW_INVERT_SHIFT) | (lgv << FW_LGV_SHIFT) | (count << FW_COUNT_SHIFT);
         if (conv && role == ROLE_Y) { f.conv[0] = k.y_lo; f.conv[1] = k.y_hi; }
         else if (conv && role != ROLE_BYTE) {
             const bool cb = role == ROLE_CB;

@@ -64,7 +64,6 @@ static bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx
 
 bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream, hipError_t *err) {
     if ((uint64_t)p.width * (uint64_t)p.height * (uint64_t)p.bpp >= (1ull << 31)) return false;   // 32-bit row offsets
-    if (p.wave_start[p.ncomp] * 64u > 640u) return false;          // more than 10 waves per 64 MCUs: generic kernel
     ColourConsts k;
     int sx, sy;
     if (!colour_consts(p, &k, &sx, &sy)) return false;

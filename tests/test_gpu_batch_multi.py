@@ -211,3 +211,30 @@ def test_encoder_with_the_fused_kernel_enabled(binding, tmp_path):
     env = dict(os.environ, JPEGENC_FUSED="1")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FUSED-OK" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("ct", [6, 7, 8], ids=["cmyk", "cmyk-as-ycck", "ycck"])
+@pytest.mark.parametrize("hs,vs", [(4, 2), (2, 4), (4, 1), (1, 4)])
+def test_four_component_layouts_with_factor_4_in_32_mcu_groups(binding, oracle, synth, ct, hs, vs):
+    """4-component layouts with 4x2 / 2x4 sampling need 11 or 18 waves per 64 MCUs: the tuned kernels take them in
+    groups of 32 MCUs (waves of a 1x1 component half full).  Sizes with several groups per MCU row, a ragged last
+    group and both edges padded; both block orders; a two-frame batch on the device."""
+    import torch
+    for w, h in ((1500, 260), (333, 517)):
+        px = synth.lcg_image(w, h, 4, 3 + ct + hs)
+        for order in (0, 1):
+            got = binding.blocks_host(px, w, h, ct, hs, vs, 88, order)
+            want = oracle.encode_blocks(px, w, h, ct, hs, vs, 88, order)
+            assert got.shape == want.shape and np.array_equal(got, want), (ct, hs, vs, w, h, order)
+    w, h = 515, 301
+    px = np.stack([synth.lcg_image(w, h, 4, 1), synth.lcg_image(w, h, 4, 2)])
+    d = torch.from_numpy(px).cuda()
+    L = binding.layout(w, h, ct, hs, vs, binding.ORDER_MCU)
+    n = int(L.total_blocks)
+    d_co = torch.zeros((2, n + 5, 64), dtype=torch.int16, device="cuda")
+    binding.blocks_device(d.data_ptr(), w * h * 4, 2, w, h, ct, hs, vs, binding.qtables(70), binding.ORDER_MCU, binding.FDCT_SIMD,
+                          d_co.data_ptr(), n + 5)
+    torch.cuda.synchronize()
+    for f in range(2):
+        want = oracle.encode_blocks(px[f], w, h, ct, hs, vs, 70, 0, variant=oracle.FDCT_SIMD)
+        assert np.array_equal(d_co[f, :n].cpu().numpy(), want) and not d_co[f, n:].any()
