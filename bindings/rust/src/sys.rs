@@ -57,6 +57,14 @@ pub struct jpegenc_scan {
     pub restart_interval: i32,
 }
 
+#[repr(C)]
+pub struct jpegenc_plane {
+    pub d_data: *const c_void,
+    pub pitch: usize,
+    pub pixel_stride: i32,
+    pub invert: i32,
+}
+
 pub enum jpegenc_encoder {}
 pub type jpegenc_write_fn = unsafe extern "C" fn(user: *mut c_void, data: *const u8, len: usize) -> c_int;
 pub type jpegenc_fill_row_fn = unsafe extern "C" fn(user: *mut c_void, y: u16, planes: *const *mut u8);
@@ -140,6 +148,9 @@ extern "C" {
     pub fn jpegenc_encoder_encode_image(e: *mut jpegenc_encoder, jpeg_color_type: c_int, width: c_int, height: c_int,
                                         fill_row: jpegenc_fill_row_fn, image_user: *mut c_void, sink: jpegenc_write_fn,
                                         sink_user: *mut c_void) -> c_int;
+    pub fn jpegenc_encoder_encode_planes_device(e: *mut jpegenc_encoder, jpeg_color_type: c_int, width: c_int, height: c_int,
+                                                planes: *const jpegenc_plane, planes_subsampled: c_int, sink: jpegenc_write_fn,
+                                                user: *mut c_void) -> c_int;
     pub fn jpegenc_encoder_encode_batch(e: *mut jpegenc_encoder, frames: *const *const u8, frame_len: usize, num_frames: c_int,
                                         width: c_int, height: c_int, color_type: c_int, sink: jpegenc_write_fn,
                                         users: *const *mut c_void) -> c_int;

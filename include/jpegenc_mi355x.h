@@ -312,6 +312,31 @@ typedef void (*jpegenc_fill_row_fn)(void *user, uint16_t y, uint8_t *const plane
 int  jpegenc_encoder_encode_image(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
                                   jpegenc_fill_row_fn fill_row, void *image_user,
                                   jpegenc_write_fn sink, void *sink_user);
+/* Encoder::encode_image for an image whose already-converted component planes live in DEVICE memory - the output of a
+ * video decoder, an ISP or a camera pipeline (planar YUV 4:4:4 / 4:2:2 / 4:2:0, NV12 / NV21, planar CMYK / YCCK ...) -
+ * described per component instead of produced by a host callback (the device counterpart of a user ImageBuffer,
+ * image_buffer.rs:86-98; no host code runs per row and nothing is uploaded).
+ *   planes[c]: sample (x, y) of component c is the byte at d_data + y * pitch + x * pixel_stride, optionally `255 - byte`
+ *     (CmykImage, image_buffer.rs:247-256); pixel_stride 1 = planar, 2 = one byte of an interleaved pair (NV12: Cb =
+ *     {uv, pitch, 2}, Cr = {uv + 1, pitch, 2}).  Components: 1 (J_LUMA), 3 (J_YCBCR) or 4 (J_CMYK, J_YCCK) as in
+ *     init_components (encoder.rs:569-619).
+ *   planes_subsampled = 0: every plane has width x height samples, like the rows fill_buffers delivers; the encoder
+ *     decimates by its sampling factor as get_block does (encoder.rs:1222-1242).
+ *   planes_subsampled = 1: a component the sampling factor decimates by (sx, sy) is given as ceil(width / sx) x
+ *     ceil(height / sy) samples (4:2:0 / 4:2:2 surfaces as decoders produce them).  Same bytes as an ImageBuffer that
+ *     repeats each such sample sx x sy times: get_block reads exactly one sample per repeat.
+ * The planes must stay valid and unmodified until the call returns.  Every Encoder mode applies (progressive,
+ * optimised tables, restart intervals ...).  Sampling factors of 4 are not taken for two-byte pixel strides. */
+typedef struct jpegenc_plane {
+    const void *d_data;
+    size_t pitch;
+    int32_t pixel_stride;
+    int32_t invert;
+} jpegenc_plane;
+int  jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
+                                          const jpegenc_plane planes[4], int planes_subsampled,
+                                          jpegenc_write_fn sink, void *user);
+
 /* Batch of same-geometry frames on this handle's device, double-buffered (H2D / kernel / D2H /
  * host entropy coding overlapped).  frames[i] -> sink(users[i], ...).
  * THREADING OF BATCH SINKS (every jpegenc_encoder_encode_batch* entry point): the library calls `sink` from its

@@ -54,6 +54,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_batch_device", "jpegenc_encoder_encode_batch_device_to_buffers", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_to_file",
     "jpegenc_encoder_encode_image", "jpegenc_encoder_block_order", "jpegenc_encoder_encode_coefficients",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
+    "jpegenc_encoder_encode_planes_device",
     "jpegenc_shard_frames", "jpegenc_encoder_encode_batch_multi", "jpegenc_encoder_encode_batch_multi_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
 ]
@@ -67,6 +68,10 @@ class Layout(C.Structure):
     _fields_ = [("num_components", C.c_int32), ("max_h", C.c_int32), ("max_v", C.c_int32),
                 ("h", C.c_int32 * 4), ("v", C.c_int32 * 4), ("table", C.c_int32 * 4),
                 ("blocks", C.c_uint64 * 4), ("total_blocks", C.c_uint64), ("mcus", C.c_uint64)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("d_data", C.c_void_p), ("pitch", C.c_size_t), ("pixel_stride", C.c_int32), ("invert", C.c_int32)]
 
 
 class Scan(C.Structure):
@@ -159,6 +164,7 @@ def lib():
         l.jpegenc_encoder_encode_batch_to_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_int,
                                                               C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                                               C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        l.jpegenc_encoder_encode_planes_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Plane), C.c_int, WRITE_FN, C.c_void_p]
         l.jpegenc_shard_frames.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
         l.jpegenc_encoder_encode_batch_multi_to_buffers.argtypes = [
             C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -444,6 +450,21 @@ class Encoder:
 
         cb = WRITE_FN(sink)
         check(lib().jpegenc_encoder_encode_device(self._h, d_pixels_ptr, width, height, color_type, cb, None))
+        return b"".join(chunks)
+
+    def encode_planes_device(self, jpeg_color_type, width, height, planes, planes_subsampled=False):
+        """jpegenc_encoder_encode_planes_device: planes = [(device_ptr, pitch, pixel_stride, invert), ...] per component."""
+        arr = (Plane * 4)()
+        for i, (ptr, pitch, stride, inv) in enumerate(planes):
+            arr[i] = Plane(ptr, pitch, stride, 1 if inv else 0)
+        chunks = []
+
+        def sink(_user, ptr, n):
+            chunks.append(C.string_at(ptr, n))
+            return 0
+
+        cb = WRITE_FN(sink)
+        check(lib().jpegenc_encoder_encode_planes_device(self._h, jpeg_color_type, width, height, arr, 1 if planes_subsampled else 0, cb, None))
         return b"".join(chunks)
 
     def encode_batch_device(self, d_frames_ptr, frame_stride, num_frames, width, height, color_type):

@@ -188,7 +188,6 @@ __global__ void __launch_bounds__(256) k_hist_finish(const HistFinishParams p) {
     if (n0) atomicAdd(&p.freq[257u + threadIdx.x], n0);                // table 0, AC
     if (n1) atomicAdd(&p.freq[514u + 257u + threadIdx.x], n1);         // table 1, AC
     // DC categories: component c's blocks in plane order, block b against block b - 1 (0 before the first)
-    uint64_t first = 0;
     for (int c = 0; c < p.ncomp; c++) {
         const uint32_t nb = p.nblocks[c];
         const int16_t *dcs = p.dc_side + p.comp_off[c];
@@ -197,7 +196,6 @@ __global__ void __launch_bounds__(256) k_hist_finish(const HistFinishParams p) {
             const int prev = b == 0 ? 0 : (int)dcs[b - 1];
             atomicAdd(&bins[nbits((int16_t)(dcs[b] - prev))], 1u);
         }
-        first += nb;
     }
     __syncthreads();
     if (threadIdx.x < 32) {

@@ -96,7 +96,13 @@ struct BlockKernelParams {
     int16_t *dc_side;                 // [frame][total planar blocks] DC of every block
     uint64_t hist_band_mask;          // bit k (2..63): a progressive AC band starts at zig-zag position k (encoder.rs:1123-1134)
     uint32_t hist_total_blocks;       // planar blocks per frame (stride of dc_side)
-    uint32_t hist_reserved;
+    // One launch per component plane of a device-resident planar source (jpegenc_encoder_encode_planes_device): only the
+    // waves of the components in comp_mask (0 = all), reading `pixels` as that plane with its own pitch; a plane that is
+    // already decimated has its own MCU size in plane samples.
+    uint32_t comp_mask;
+    uint32_t pitch_bytes;             // 0 = width * bpp
+    uint32_t plane_mcu_w, plane_mcu_h;   // 0 = 8 * hmax / 8 * vmax
+    uint32_t plane_byte_index, plane_invert;
     QuantDev q[2];
     FastHeader fast_hdr;
     FastWave fast_wave[10];

@@ -59,28 +59,16 @@ __device__ __forceinline__ uint32_t block_bit_offset(Params p, uint32_t f, uint3
     return s;
 }
 
-// Where a block's bits go.  The first walk of k_block_code only adds up lengths; the second shifts codes into
-// a 64-bit accumulator and ORs every completed 32-bit word (MSB-first byte order) into zeroed memory - the
-// wave's LDS window (ds_or_b32, no address-space guessing: the pointer type says LDS) or, for runs longer than
-// the window, the wave's slot in HBM.  OR-ing every word (not only the ones shared with a neighbouring
-// block) keeps a per-lane "is this my first word" flag and its branches out of the 63-symbol walk.
+// Where a block's bits go on the rare two-walk path (runs longer than the LDS window, blocks longer than a strip): codes
+// are shifted into a 64-bit accumulator and every completed 32-bit word (MSB-first byte order) is OR-ed into the wave's
+// zeroed slot in HBM.  OR-ing every word (not only the ones shared with a neighbouring block) keeps a per-lane "is this
+// my first word" flag and its branches out of the 63-symbol walk.
 typedef __attribute__((address_space(3))) uint32_t lds_word;
 typedef __attribute__((address_space(1))) uint32_t hbm_word;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte load from a 4-byte aligned address
 typedef __attribute__((address_space(1))) const u32x4 hbm_chunk;
 
-struct CountSink {
-    uint32_t total;
-    __device__ __forceinline__ void put(uint32_t, uint32_t len) { total += len; }
-};
-struct LdsWords {
-    lds_word *w;
-    __device__ __forceinline__ void or_next(uint32_t v) {
-        __hip_atomic_fetch_or(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        w++;
-    }
-};
 struct HbmWords {
     hbm_word *w;
     __device__ __forceinline__ void or_next(uint32_t v) {
@@ -106,8 +94,6 @@ struct PackSink {
     }
 };
 
-// lut: [table][0 = DC, 1 = AC][256] of (size << 16 | code), in LDS.
-// BASELINE = the scan codes DC and the whole band 1..63 (every non-progressive scan): no band tests in the walk.
 // All eight 16-byte pieces of the block are requested up front (the lane's 128-byte line is fetched once and
 // the other seven loads hit L1 while it is hot; walking piece by piece with the next one in flight re-missed
 // the line for every piece: 52 vs 39 us per 4K frame), so the walk is fully unrolled over registers.
@@ -141,44 +127,6 @@ __device__ __forceinline__ BlockPlace place_of(Params p, uint32_t b) {
     return q;
 }
 
-template <bool BASELINE, class Sink>
-__device__ __forceinline__ void walk_block(Params p, const uint32_t *lut, uint32_t table, int prev_dc, const BlockRegs &r, Sink &s) {
-    const uint32_t *dc_lut = lut + table * 512, *ac_lut = dc_lut + 256;
-    const uint32_t *c = r.c;
-    if (BASELINE || p.with_dc) {
-        const int prev = prev_dc;
-        const int dc = (int16_t)(c[0] & 0xFFFFu);
-        const int diff = (int16_t)(dc - prev);
-        const uint32_t n = bit_size(diff);
-        const uint32_t e = dc_lut[n];
-        const uint32_t mag = (uint32_t)(diff - (diff < 0)) & ((1u << n) - 1u);
-        s.put(((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
-    }
-    // AC: write_ac_block(block, start, end) (writer.rs:356-388)
-    if (!BASELINE && p.ac_end <= p.ac_start) return;
-    uint32_t run = 0;
-    const uint32_t zrl = ac_lut[0xF0];
-#pragma unroll
-    for (uint32_t k = 1; k < 64; k++) {
-        if (!BASELINE && (k < p.ac_start || k >= p.ac_end)) continue;
-        const int v = (k & 1u) ? (int)c[k >> 1] >> 16 : (int)(int16_t)(c[k >> 1] & 0xFFFFu);
-        if (v != 0) {
-            if (run > 15) {
-#pragma nounroll
-                do { s.put(zrl & 0xFFFFu, zrl >> 16); run -= 16; } while (run > 15);
-            }
-            const uint32_t n = bit_size(v);
-            const uint32_t e = ac_lut[(run << 4) | n];
-            const uint32_t mag = (uint32_t)(v - (v < 0)) & ((1u << n) - 1u);
-            s.put(((e & 0xFFFFu) << n) | mag, (e >> 16) + n);
-            run = 0;
-        } else {
-            run++;
-        }
-    }
-    if (run > 0) { const uint32_t e = ac_lut[0]; s.put(e & 0xFFFFu, e >> 16); }
-}
-
 // The code tables go to LDS in two steps: fetch (first in the load queue, so waiting for it waits for nothing
 // else), then the kernel requests its own data, then commit.  256 threads, 4 entries each.
 struct LutRegs { uint32_t v[4]; };
@@ -186,11 +134,6 @@ __device__ __forceinline__ void lut_fetch(Params p, LutRegs &l) {
     const hbm_word *src = (const hbm_word *)p.lut;
 #pragma unroll
     for (int i = 0; i < 4; i++) l.v[i] = src[i * 256 + threadIdx.x];
-}
-__device__ __forceinline__ void lut_commit(const LutRegs &l, uint32_t *lut) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) lut[i * 256 + threadIdx.x] = l.v[i];
-    __syncthreads();
 }
 
 __device__ __forceinline__ bool baseline_band(Params p) { return p.with_dc && p.ac_start == 1 && p.ac_end == 64; }

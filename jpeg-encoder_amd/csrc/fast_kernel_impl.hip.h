@@ -474,6 +474,7 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
         for (int c = 0; c < q.ncomp; c++) {
             const uint32_t per_wave = 64u / (uint32_t)q.h[c];
             wave_first[c] = waves;
+            if (q.comp_mask && !((q.comp_mask >> c) & 1u)) continue;          // per-plane launch: this component has no waves here
             waves += ((group + per_wave - 1u) / per_wave) * (uint32_t)q.v[c];
         }
         wave_first[q.ncomp] = waves;
@@ -486,14 +487,15 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
     memset(&h, 0, sizeof h);
     h.pixels = (uint64_t)(uintptr_t)q.pixels; h.coeffs = (uint64_t)(uintptr_t)q.coeffs;
     h.pixel_frame_stride = q.pixel_frame_stride; h.coeff_frame_stride = q.coeff_frame_stride;
-    h.width = (uint32_t)q.width; h.height = (uint32_t)q.height; h.pitch = (uint32_t)q.width * (uint32_t)bpp;
-    h.order = (uint32_t)q.order; h.bpm = q.bpm; h.mcu_w = 8u * (uint32_t)q.hmax; h.mcu_h = 8u * (uint32_t)q.vmax;
+    h.width = (uint32_t)q.width; h.height = (uint32_t)q.height; h.pitch = q.pitch_bytes ? q.pitch_bytes : (uint32_t)q.width * (uint32_t)bpp;
+    h.order = (uint32_t)q.order; h.bpm = q.bpm;
+    h.mcu_w = q.plane_mcu_w ? q.plane_mcu_w : 8u * (uint32_t)q.hmax; h.mcu_h = q.plane_mcu_h ? q.plane_mcu_h : 8u * (uint32_t)q.vmax;
     h.group_mcus = group;
     memset(q.fast_wave, 0, sizeof q.fast_wave);
     for (uint32_t w = 0; w < q.per_group; w++) {
         FastWave &f = q.fast_wave[w];
         int c = 0;
-        while (c + 1 < q.ncomp && w >= wave_first[c + 1]) c++;
+        while (c + 1 < q.ncomp && (w >= wave_first[c + 1] || (q.comp_mask && !((q.comp_mask >> c) & 1u)))) c++;
         const uint32_t in_comp = w - wave_first[c], hc = (uint32_t)q.h[c];
         // one row of the component's blocks inside the MCU from 64 / h MCUs (wave_tasks.hip.h), in both orders
         uint32_t lg = 0, lgv = 0;

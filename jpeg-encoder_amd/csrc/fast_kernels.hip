@@ -39,13 +39,17 @@ static bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx
             if (c < 3) k.role[c] = c == 0 ? ROLE_Y : c == 1 ? ROLE_CB : ROLE_CR;
             else { k.byte_index[c] = 3; k.invert[c] = 1; }
             break;
-        case XF_PLANES: k.byte_index[c] = 0; k.plane_offset[c] = (uint64_t)c * p.plane_stride; break;
+        case XF_PLANES:
+            if (p.comp_mask) { k.byte_index[c] = (int32_t)p.plane_byte_index; k.invert[c] = (int32_t)p.plane_invert; k.plane_offset[c] = 0; }
+            else { k.byte_index[c] = 0; k.plane_offset[c] = (uint64_t)c * p.plane_stride; }
+            break;
         default: return false;
         }
     }
     // every component is either full resolution or decimated by one common (SX, SY) in {1,2}^2
     int sx = 1, sy = 1;
     for (int c = 0; c < p.ncomp; c++) {
+        if (p.comp_mask && !((p.comp_mask >> c) & 1u)) continue;               // a per-plane launch looks at its own component only
         if (p.sx[c] > 4 || p.sy[c] > 4) return false;
         if (p.sx[c] > 1 || p.sy[c] > 1) {
             if ((sx > 1 || sy > 1) && (sx != p.sx[c] || sy != p.sy[c])) return false;
@@ -53,6 +57,7 @@ static bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx
         }
     }
     for (int c = 0; c < p.ncomp; c++) {
+        if (p.comp_mask && !((p.comp_mask >> c) & 1u)) continue;
         const bool sub = p.sx[c] > 1 || p.sy[c] > 1;
         if (k.role[c] == ROLE_Y && sub) return false;                          // luma is never decimated
         if (k.role[c] == ROLE_BYTE && sub && (p.xform == XF_RGB2YCC || p.xform == XF_CMYK2YCCK)) return false;
@@ -63,7 +68,8 @@ static bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx
 }
 
 bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream, hipError_t *err) {
-    if ((uint64_t)p.width * (uint64_t)p.height * (uint64_t)p.bpp >= (1ull << 31)) return false;   // 32-bit row offsets
+    const uint64_t pitch = p.pitch_bytes ? p.pitch_bytes : (uint64_t)p.width * (uint64_t)p.bpp;
+    if (pitch * (uint64_t)p.height >= (1ull << 31)) return false;                                   // 32-bit row offsets
     ColourConsts k;
     int sx, sy;
     if (!colour_consts(p, &k, &sx, &sy)) return false;
@@ -75,6 +81,39 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
 #undef JPEGENC_CASE
     if (sx == 4 || sy == 4) return launch_conv_s4(p, k, sx, sy, num_frames, variant, stream, err);
     return false;
+}
+
+// A device-resident planar source: one launch per component plane (its own base, pitch, pixel stride - 2 for an
+// interleaved UV plane - and resolution).  Planar input has no pixels shared between components, so nothing is lost by
+// not walking them together; each launch is the byte-plane kernel with only that component's waves.
+hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_plane planes[4], bool planes_subsampled, int variant,
+                                hipStream_t stream) {
+    for (int c = 0; c < base.ncomp; c++) {
+        BlockKernelParams q = base;
+        q.xform = XF_PLANES;
+        q.comp_mask = 1u << c;
+        q.plane_stride = 0;
+        uintptr_t ptr = (uintptr_t)planes[c].d_data;
+        q.bpp = planes[c].pixel_stride;
+        q.plane_byte_index = 0;
+        if (q.bpp == 2 && (ptr & 1u)) { ptr -= 1; q.plane_byte_index = 1; }       // second byte of an interleaved pair (NV12: Cr)
+        q.pixels = (const uint8_t *)ptr;
+        q.pitch_bytes = (uint32_t)planes[c].pitch;
+        q.plane_invert = planes[c].invert ? 1u : 0u;
+        if (planes_subsampled && (base.sx[c] > 1 || base.sy[c] > 1)) {
+            // the plane holds ceil(w / sx) x ceil(h / sy) samples: the image a fill_buffers that repeats each of them
+            // sx x sy times would deliver, of which get_block (encoder.rs:1222-1242) reads exactly these
+            q.width = (base.width + base.sx[c] - 1) / base.sx[c];
+            q.height = (base.height + base.sy[c] - 1) / base.sy[c];
+            q.sx[c] = q.sy[c] = 1;
+            q.plane_mcu_w = 8u * (uint32_t)base.h[c];
+            q.plane_mcu_h = 8u * (uint32_t)base.v[c];
+        }
+        hipError_t err = hipSuccess;
+        if (!launch_blocks_fast(q, 1, variant, stream, &err)) return hipErrorInvalidValue;
+        if (err != hipSuccess) return err;
+    }
+    return hipSuccess;
 }
 
 #ifdef JPEGENC_WAVE_TIMING

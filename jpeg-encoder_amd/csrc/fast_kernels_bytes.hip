@@ -8,6 +8,7 @@ bool launch_bytes_family(const BlockKernelParams &p, const ColourConsts &k, int 
                          hipStream_t stream, hipError_t *err) {
 #define JPEGENC_CASE(B, X, Y) if (p.bpp == B && sx == X && sy == Y) { *err = launch_fast<B, X, Y, false>(p, k, num_frames, variant, stream); return true; }
     JPEGENC_CASE(1, 1, 1) JPEGENC_CASE(1, 2, 1) JPEGENC_CASE(1, 1, 2) JPEGENC_CASE(1, 2, 2)
+    JPEGENC_CASE(2, 1, 1) JPEGENC_CASE(2, 2, 1) JPEGENC_CASE(2, 1, 2) JPEGENC_CASE(2, 2, 2)      // interleaved two-byte planes (NV12's UV)
     JPEGENC_CASE(3, 1, 1) JPEGENC_CASE(3, 2, 1) JPEGENC_CASE(3, 1, 2) JPEGENC_CASE(3, 2, 2)
     JPEGENC_CASE(4, 1, 1) JPEGENC_CASE(4, 2, 1) JPEGENC_CASE(4, 1, 2) JPEGENC_CASE(4, 2, 2)
 #undef JPEGENC_CASE

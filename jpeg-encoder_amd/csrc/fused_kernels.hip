@@ -123,17 +123,19 @@ __device__ __forceinline__ void fdct_quant_block_mixed(const uint32_t rows[8][4]
     for (int j = 0; j < 32; j++) out[j] = pack_hi(prod[kZigzag[2 * j]], prod[kZigzag[2 * j + 1]]);
 }
 
-// Register budget: 4 waves per SIMD (<= 128 VGPRs; left alone the compiler keeps every row load in flight and takes 232)
+// Register budget: 3 waves per SIMD (<= 168 VGPRs; left alone the compiler keeps every row load in flight and takes 232;
+// at 4 waves it cannot stay under 128 without spilling since the one-walk coder carries its accumulator through the walk)
 #ifndef JPEGENC_FUSED_WAVES
-#define JPEGENC_FUSED_WAVES 4
+#define JPEGENC_FUSED_WAVES 3
 #endif
 template <int BPP, int SX, int SY, int VARIANT>
 __global__ void __attribute__((amdgpu_waves_per_eu(JPEGENC_FUSED_WAVES))) __launch_bounds__(256) k_fused_code(const FusedParams fp, const ColourConsts k, const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
-    __shared__ uint32_t lut[4 * 256];
+    __shared__ u32x2 lut64[4 * 256];
     __shared__ __attribute__((aligned(16))) uint32_t qlds[2 * 128];
-    __shared__ __attribute__((aligned(16))) uint32_t window[4][kPackWindowWords];
-    qlds[threadIdx.x] = fused_quant_table(0)[threadIdx.x];                       // both tables (QuantDev q[2] is contiguous); visible after lut_commit's barrier
+    __shared__ __attribute__((aligned(16))) uint32_t window[4][kOnePassWindowWords];
+    __shared__ uint32_t strips[4][kPrivWords * 64];
+    qlds[threadIdx.x] = fused_quant_table(0)[threadIdx.x];                       // both tables (QuantDev q[2] is contiguous); visible after lut64_commit's barrier
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t f = blockIdx.y;
@@ -167,11 +169,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(JPEGENC_FUSED_WAVES))) __laun
     // One sample per lane, three or four components.  Not needed at the start of the frame or of a restart interval.
     int pred_first[4] = {0, 0, 0, 0};
     const bool need_pred = first_mcu != 0u && !(fp.interval_mcus && first_mcu % fp.interval_mcus == 0u);   // wave-uniform
-#ifdef EXP_NO_PRED
-    if (false) {
-#else
     if (need_pred) {
-#endif
         const uint32_t pm = first_mcu - 1u;
         const uint32_t pmy = (uint32_t)(((uint64_t)pm * fp.magic) >> fp.shift), pmx = pm - pmy * fp.mcus_x;
         uint32_t sample[4];
@@ -204,11 +202,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(JPEGENC_FUSED_WAVES))) __laun
     const uint32_t first = (uint32_t)y0 * pitch + (uint32_t)x0 * BPP;
     const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)x0 * BPP;
     uint32_t rows[8][4];
-#ifdef EXP_NO_EDGE
-    if (true) {
-#else
     if (x0 + 8 * sxc <= width) {
-#endif
         if ((SX > 1 || SY > 1) && sub) fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, LaneConv::kPack, conv, rows);
         else fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, LaneConv::kPack, conv, rows);
     } else {
@@ -226,15 +220,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(JPEGENC_FUSED_WAVES))) __laun
             rows[y][2] = v[7] | (v[6] << 16); rows[y][3] = v[4] | (v[5] << 16);
         }
     }
-    lut_commit(l, lut);                                                          // (__syncthreads: every wave of the workgroup gets here)
+    lut64_commit(l, lut64);                                                      // (__syncthreads: every wave of the workgroup gets here)
     if (run >= fp.nruns) return;
 
     BlockRegs r;
-#ifdef EXP_UNIFORM_TABLE
-    fdct_quant_block_mixed<VARIANT>(rows, qlds, r.c);
-#else
     fdct_quant_block_mixed<VARIANT>(rows, qlds + (second_table ? 128 : 0), r.c);
-#endif
 
     // ---- DC predecessor: previous block of the same component in scan order (write_dc, writer.rs:342-354) ---------------
     const int dc = (int)(int16_t)(r.c[0] & 0xFFFFu);
@@ -248,40 +238,28 @@ __global__ void __attribute__((amdgpu_waves_per_eu(JPEGENC_FUSED_WAVES))) __laun
     }
     const uint32_t table = second_table ? 1u : 0u;                              // quantisation = DC = AC table destination (encoder.rs:569-619)
 
-    // ---- from here on: k_block_code ----------------------------------------------------------------------------------------
-    uint32_t mine = 0;
+    // ---- from here on: k_block_code (one walk into a lane-private strip, prefix sum, strips into the window) ----------------
+    lds_word *strip = (lds_word *)strips[wave] + lane;
+    PrivSink ps = {strip, strip + (kPrivWords - 1u) * 64u, 0, 0, 0};
     if (valid) {
-#ifdef EXP_NO_WALK
-        uint32_t acc = prev_dc + table;
-        for (int i = 0; i < 32; i++) acc ^= r.c[i];
-        mine = acc & 255u;
-#else
-        CountSink cs = {0};
-        walk_block<true>(p, lut, table, prev_dc, r, cs);
-        mine = cs.total;
-#endif
-        p.bits[(size_t)f * p.nblocks + (size_t)mcu * bpm + pos] = mine;          // (interval offsets need them, k_interval_len)
+        walk_once<true>(p, lut64, table, prev_dc, r, ps);
+        ps.finish();
     }
+    const uint32_t mine = ps.bits();
+    if (valid) p.bits[(size_t)f * p.nblocks + (size_t)mcu * bpm + pos] = mine;   // (interval offsets need them, k_interval_len)
     const uint32_t upto = wave_inclusive(mine), at = upto - mine;               // bits of the run before this block
     const uint32_t total = (uint32_t)__shfl((int)upto, 63);
     if (lane == 0) p.wsum[(size_t)f * p.nwaves + run] = total;
     const uint32_t nwords = (total + 31u) >> 5;
     uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)run * p.slot_words;
     uint32_t *win = window[wave];
-    if (nwords + 4u <= p.window_words) {                                         // wave-uniform (+4: the zero word, 16-byte copies)
+    const bool strips_hold = __ballot(mine > kPrivWords * 32u) == 0;            // wave-uniform
+    if (strips_hold && nwords + 4u <= min(p.window_words, kOnePassWindowWords)) {   // wave-uniform (+4: the zero word, 16-byte copies)
         for (uint32_t i = lane; i <= nwords; i += 64u) win[i] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (valid) {
-            PackSink<LdsWords> ps = {LdsWords{(lds_word *)win + (at >> 5)}, 0, at & 31u};
-#ifdef EXP_NO_WALK
-            ps.put(r.c[3] & 1023u, 10);
-#else
-            walk_block<true>(p, lut, table, prev_dc, r, ps);
-#endif
-            ps.finish();
-        }
+        strip_to_window(strip, mine, at, (lds_word *)win);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -293,11 +271,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(JPEGENC_FUSED_WAVES))) __laun
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (valid) {
-            PackSink<HbmWords> ps = {HbmWords{(hbm_word *)slot + (at >> 5)}, 0, at & 31u};
-#ifndef EXP_NO_WALK
-            walk_block<true>(p, lut, table, prev_dc, r, ps);
-#endif
-            ps.finish();
+            PackSink<HbmWords> hs = {HbmWords{(hbm_word *)slot + (at >> 5)}, 0, at & 31u};
+            walk_once<true>(p, lut64, table, prev_dc, r, hs);
+            hs.finish();
         }
     }
 }

@@ -39,6 +39,9 @@ hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream);
 // fast_kernels.hip: returns false when the configuration has no specialised kernel
 bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream,
                         hipError_t *err);
+// fast_kernels.hip: a device-resident planar source, one launch per component plane (jpegenc_encoder_encode_planes_device)
+hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_plane planes[4], bool planes_subsampled, int variant,
+                                hipStream_t stream);
 
 // entropy_kernels.hip
 // stored: what the parameter blocks at d_params currently hold (nullptr: always store) - a caller that codes the same

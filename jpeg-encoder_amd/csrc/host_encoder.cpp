@@ -248,6 +248,8 @@ struct DeviceCtx {
     size_t d_dc_side_cap = 0;
     static constexpr size_t kHistFreqBytes = 4352, kHistBytes = kHistFreqBytes + (size_t)kHistCopies * 2 * 256 * sizeof(uint32_t);
     const void *external_pixels = nullptr;   // device-resident input: use the caller's buffer, no upload
+    const jpegenc_plane *external_planes = nullptr;   // device-resident planar input (jpegenc_encoder_encode_planes_device)
+    bool external_planes_subsampled = false;
     size_t d_pixels_cap = 0, d_coeffs_cap = 0;
     int16_t *h_coeffs = nullptr;
     size_t h_coeffs_cap = 0;
@@ -803,7 +805,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
 
     // ---- device: upload, fused kernel, [histogram], download ---------------------------------
     const size_t coeff_bytes = (size_t)L.total_blocks * 128;
-    rc = ctx.reserve(ctx.external_pixels ? 0 : pixel_bytes, coeff_bytes, color_type_or_planes >= 100);
+    rc = ctx.reserve(ctx.external_pixels || ctx.external_planes ? 0 : pixel_bytes, coeff_bytes, color_type_or_planes >= 100 && !ctx.external_planes);
     if (rc) return rc;
     rc = upload(ctx);
     if (rc) return rc;
@@ -888,7 +890,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     // single-scan frames use it.  (JPEGENC_NO_GRAPH=1 disables it.)
     static const bool graphs_off = getenv("JPEGENC_NO_GRAPH") != nullptr;
     enum { DIRECT, CAPTURE, REPLAY } how = DIRECT;
-    if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1) {
+    if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1 && !ctx.external_planes) {
         std::string key;
         auto put = [&](const void *v, size_t n) { key.append((const char *)v, n); };
         const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, ctx.d_gather, ctx.h_scan_out};
@@ -955,7 +957,11 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     if (enqueue && !fused) {
         hipError_t err = hipSuccess;
         if (p.hist_partials) JPEGENC_HIP(hipMemsetAsync(ctx.d_hist, 0, DeviceCtx::kHistBytes, ctx.stream));
-        if (launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) {
+        if (ctx.external_planes) {
+            err = launch_blocks_planes(p, ctx.external_planes, ctx.external_planes_subsampled, c.fdct_variant, ctx.stream);
+            if (err == hipErrorInvalidValue) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane layout not supported on the device (pixel stride 2 with a sampling factor of 4, or a plane of 2 GiB)");
+            hist_folded = p.hist_partials != nullptr;
+        } else if (launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) {
             hist_folded = p.hist_partials != nullptr;
         } else {
             err = launch_blocks_generic(p, 1, c.fdct_variant, ctx.stream);
@@ -1674,6 +1680,33 @@ int jpegenc_encoder_encode_image(jpegenc_encoder *e, int jct, int width, int hei
         return JPEGENC_OK;
     };
     return encode_frame(e->cfg, e->ctx, jct, width, height, 100 + jct, bytes, upload, sink, sink_user);
+}
+
+int jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jct, int width, int height, const jpegenc_plane planes[4],
+                                         int planes_subsampled, jpegenc_write_fn sink, void *user) {
+    REQUIRE(e);
+    if (!planes || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    if (jct < JPEGENC_J_LUMA || jct > JPEGENC_J_YCCK) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown JPEG colour type");
+    if (width < 0 || height < 0 || width > 65535 || height > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "width/height must fit u16");
+    if (width == 0 || height == 0) return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "Image dimensions must be non zero");
+    const int ncomp = jct == JPEGENC_J_LUMA ? 1 : jct == JPEGENC_J_YCBCR ? 3 : 4;
+    int hs, vs;
+    sampling_hv(e->cfg.sampling, &hs, &vs);
+    for (int i = 0; i < ncomp; i++) {
+        if (!planes[i].d_data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null plane");
+        if (planes[i].pixel_stride != 1 && planes[i].pixel_stride != 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "pixel_stride must be 1 or 2");
+        if (planes[i].pixel_stride == 2 && (hs == 4 || vs == 4) && !planes_subsampled)
+            return fail(JPEGENC_ERR_INVALID_ARGUMENT, "two-byte pixel strides are not decimated by 4 on the device");
+        if (planes[i].pitch > 0x7FFFFFFFu) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane pitch too large");
+    }
+    int rc = e->ctx.open(e->device);
+    if (rc) return rc;
+    e->ctx.external_planes = planes;
+    e->ctx.external_planes_subsampled = planes_subsampled != 0;
+    auto upload = [&](DeviceCtx &) -> int { return JPEGENC_OK; };
+    rc = encode_frame(e->cfg, e->ctx, jct, width, height, 100 + jct, (size_t)width * (size_t)height * (size_t)ncomp, upload, sink, user);
+    e->ctx.external_planes = nullptr;
+    return rc;
 }
 
 int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len, int num_frames,

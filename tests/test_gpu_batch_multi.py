@@ -238,3 +238,86 @@ def test_four_component_layouts_with_factor_4_in_32_mcu_groups(binding, oracle, 
     for f in range(2):
         want = oracle.encode_blocks(px[f], w, h, ct, hs, vs, 70, 0, variant=oracle.FDCT_SIMD)
         assert np.array_equal(d_co[f, :n].cpu().numpy(), want) and not d_co[f, n:].any()
+
+
+def _replicated(plane, sx, sy, w, h):
+    return np.repeat(np.repeat(plane, sy, axis=0), sx, axis=1)[:h, :w]
+
+
+@pytest.mark.parametrize("w,h", [(258, 128), (515, 301), (1920, 1080)])
+@pytest.mark.parametrize("kw", [dict(quality=80), dict(quality=90, sampling=(2, 1)), dict(quality=75, sampling=(1, 2), restart_interval=5),
+                                dict(quality=85, sampling=(2, 2), progressive_scans=4, optimize=True), dict(quality=95, sampling=(1, 1), optimize=True)],
+                         ids=["420", "422", "440-restart", "420-progressive-optimised", "444-optimised"])
+def test_encode_planes_device_yuv_surfaces(binding, oracle, synth, w, h, kw):
+    """Device-resident planar sources (jpegenc_encoder_encode_planes_device): I420-style planes (chroma already
+    decimated, padded pitches), NV12 (interleaved UV), and full-resolution planes - byte-identical to the oracle fed the
+    equivalent interleaved YCbCr image (chroma repeated sx x sy times: what the ImageBuffer of such a surface delivers)."""
+    import torch
+    hs, vs = kw.get("sampling", (2, 2) if kw["quality"] < 90 else (1, 1))
+    rng = np.random.default_rng(w * 7 + h)
+    cw, ch = -(-w // hs), -(-h // vs)
+    smooth = lambda a: (a.astype(np.int16) // 4 + np.add.outer(np.arange(a.shape[0]), np.arange(a.shape[1])) // 3).clip(0, 255).astype(np.uint8)
+    y = smooth(rng.integers(0, 256, (h, w), dtype=np.uint8))
+    cb = smooth(rng.integers(0, 256, (ch, cw), dtype=np.uint8))
+    cr = smooth(rng.integers(0, 256, (ch, cw), dtype=np.uint8))
+    full = np.stack([y, _replicated(cb, hs, vs, w, h), _replicated(cr, hs, vs, w, h)], axis=-1)
+    want = oracle.encode_jpeg(full, w, h, oracle.YCBCR, **kw)
+
+    def enc():
+        e = binding.Encoder(kw["quality"])
+        if "sampling" in kw:
+            e.set_sampling_factor(binding.sampling_factor(*kw["sampling"]))
+        if kw.get("progressive_scans"):
+            e.set_progressive_scans(kw["progressive_scans"])
+        if kw.get("restart_interval"):
+            e.set_restart_interval(kw["restart_interval"])
+        if kw.get("optimize"):
+            e.set_optimized_huffman_tables(True)
+        return e
+    # (1) I420-like: three planes, chroma decimated, every pitch padded (and odd for the chroma planes)
+    ypitch, cpitch = w + 13, cw + 7
+    d_y = torch.zeros((h, ypitch), dtype=torch.uint8, device="cuda"); d_y[:, :w] = torch.from_numpy(y).cuda()
+    d_cb = torch.zeros((ch, cpitch), dtype=torch.uint8, device="cuda"); d_cb[:, :cw] = torch.from_numpy(cb).cuda()
+    d_cr = torch.zeros((ch, cpitch), dtype=torch.uint8, device="cuda"); d_cr[:, :cw] = torch.from_numpy(cr).cuda()
+    got = enc().encode_planes_device(binding.J_YCBCR, w, h, [(d_y.data_ptr(), ypitch, 1, 0), (d_cb.data_ptr(), cpitch, 1, 0), (d_cr.data_ptr(), cpitch, 1, 0)],
+                                     planes_subsampled=True)
+    assert got == want
+    # (2) NV12-like: Y plane + one interleaved UV plane
+    uv = np.stack([cb, cr], axis=-1)
+    d_uv = torch.from_numpy(np.ascontiguousarray(uv)).cuda()
+    got = enc().encode_planes_device(binding.J_YCBCR, w, h, [(d_y.data_ptr(), ypitch, 1, 0), (d_uv.data_ptr(), cw * 2, 2, 0), (d_uv.data_ptr() + 1, cw * 2, 2, 0)],
+                                     planes_subsampled=True)
+    assert got == want
+    # (3) full-resolution planes (what fill_buffers delivers): the encoder decimates
+    d_full = torch.from_numpy(np.ascontiguousarray(full.transpose(2, 0, 1))).cuda()
+    got = enc().encode_planes_device(binding.J_YCBCR, w, h, [(d_full[c].data_ptr(), w, 1, 0) for c in range(3)])
+    assert got == want
+    # (4) the same from the interleaved image itself: three "planes" of pixel stride ... 3 is not a plane stride: rejected
+    with pytest.raises(binding.JpegEncError) as err:
+        enc().encode_planes_device(binding.J_YCBCR, w, h, [(d_y.data_ptr(), w * 3, 3, 0)] * 3)
+    assert err.value.status == binding.ERR_INVALID_ARGUMENT
+
+
+def test_encode_planes_device_luma_and_cmyk(binding, oracle, synth):
+    import torch
+    w, h = 333, 201
+    g = synth.test_img_gray(w, h)
+    d = torch.zeros((h, w + 3), dtype=torch.uint8, device="cuda"); d[:, :w] = torch.from_numpy(g).cuda()
+    with binding.Encoder(85) as e:
+        assert e.encode_planes_device(binding.J_LUMA, w, h, [(d.data_ptr(), w + 3, 1, 0)]) == oracle.encode_jpeg(g, w, h, oracle.LUMA, 85)
+    cmyk = synth.test_img_cmyk(w, h)
+    dp = torch.from_numpy(np.ascontiguousarray(cmyk.transpose(2, 0, 1))).cuda()
+    for kw in (dict(quality=90), dict(quality=70, sampling=(2, 2), restart_interval=9), dict(quality=80, sampling=(2, 1), optimize=True)):
+        e = binding.Encoder(kw["quality"])
+        if "sampling" in kw:
+            e.set_sampling_factor(binding.sampling_factor(*kw["sampling"]))
+        if kw.get("restart_interval"):
+            e.set_restart_interval(kw["restart_interval"])
+        if kw.get("optimize"):
+            e.set_optimized_huffman_tables(True)
+        # CmykImage inverts every channel (image_buffer.rs:247-256): planar CMYK with invert = 1 is ColorType::Cmyk
+        got = e.encode_planes_device(binding.J_CMYK, w, h, [(dp[c].data_ptr(), w, 1, 1) for c in range(4)])
+        assert got == oracle.encode_jpeg(cmyk, w, h, oracle.CMYK, **kw), kw
+        # and YCCK planes as they are = ColorType::Ycck
+        got = e.encode_planes_device(binding.J_YCCK, w, h, [(dp[c].data_ptr(), w, 1, 0) for c in range(4)])
+        assert got == oracle.encode_jpeg(cmyk, w, h, oracle.YCCK, **kw), kw
