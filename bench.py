@@ -617,7 +617,7 @@ def main():
                 return [outs3[i][:lens3[i]] for i in range(len(frames))]
             pool = batch.FramePool(synth)
             c3, mine = batch.run_sharded_batch(binding, encode_frames, pool, args.c3_frames, batch.C3_W, batch.C3_H, world, rank,
-                                               dist if distributed else None, warmup_frames=32)
+                                               dist if distributed else None, warmup_frames=32, device=dev)
             c3["what"] = (f"C3: {args.c3_frames} frames of 1920x1080 RGB q=80 4:2:0 sharded frame k -> rank k % {world} "
                           "(jpegenc_shard_frames), each rank: pageable host pixels -> complete JPEG files in host buffers through "
                           "jpegenc_encoder_encode_batch_to_buffers on its GPU; seconds = MAX over ranks; photo-like frames "

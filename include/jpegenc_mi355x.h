@@ -370,8 +370,9 @@ int  jpegenc_shard_frames(int num_frames, int num_shards, int shard, int *indice
 
 /* jpegenc_encoder_encode_batch over several GPUs of this node from ONE process: shard d = the frames
  * jpegenc_shard_frames(num_frames, num_devices, d) names, encoded on HIP device devices[d] by that device's own
- * worker threads, streams, pinned staging and device buffers (kept in the handle across calls); the threads feeding
- * a GPU are bound to the NUMA node of its PCIe root complex (best effort; JPEGENC_NO_NUMA_BIND=1 disables it).
+ * worker threads, streams, pinned staging and device buffers (kept in the handle across calls); with
+ * JPEGENC_NUMA_BIND=1 the threads feeding a GPU are bound to the NUMA node of its PCIe root complex (best effort;
+ * off by default: it lost throughput on the one two-socket host it was measured on).
  * A device may be listed more than once (several independent worker sets on it).  The reference has no
  * counterpart (it is single-threaded, encoder.rs:440-515); same bytes per frame as jpegenc_encoder_encode.
  * Sink threading: see jpegenc_encoder_encode_batch. */

@@ -4,8 +4,8 @@ GPUs of a node, one process (rank) per GPU.
 JPEG frames are independent: frame k belongs to shard k % world (`jpegenc_shard_frames`, the same C
 function the library's own multi-device batch uses), every rank encodes its own frames from pageable host
 memory to complete JPEG files in host buffers, and NO pixel or coefficient ever crosses ranks.  The only
-exchange is bookkeeping - frame counts, the slowest rank's wall time, per-frame digests - through
-`torch.distributed` object collectives, which run the same over RCCL (bench.py --gpus N) and gloo (the CPU
+exchange is bookkeeping - frame counts, the slowest rank's wall time, per-frame digests - through two small
+`torch.distributed` tensor all-reduces, which run the same over RCCL (bench.py --gpus N) and gloo (the CPU
 test, tests/test_batch_gloo.py, which injects the per-frame encoder and keeps everything else).
 """
 import hashlib
@@ -43,14 +43,16 @@ def _dist_ready(dist):
 
 
 def run_sharded_batch(binding, encode_frames, make_frame, num_frames, width, height, world=1, rank=0, dist=None,
-                      warmup_frames=0, digests=True):
+                      warmup_frames=0, digests=True, device=None):
     """One rank's share of a frame-sharded batch + the bookkeeping exchange.
 
     encode_frames(list of HxWx3 uint8 arrays) -> list of bytes : this rank's encoder (bench.py: the library's
         batch API on the rank's GPU; the gloo test: anything, e.g. the oracle).
     make_frame(k) -> pixels of frame k of the batch.
+    device: where the bookkeeping tensors live (the rank's GPU under RCCL, None = CPU under gloo).
     Returns a dict every rank agrees on: frames per rank, wall time of the slowest rank, aggregate rates, and -
-    with digests - a checksum of the per-frame checksums in frame order (independent of world size)."""
+    with digests - a checksum of the per-frame checksums in frame order (independent of world size).
+    The exchange is two small tensor all-reduces (no pixels, no coefficients, no files)."""
     mine = binding.shard_frames(num_frames, world, rank)
     frames = [make_frame(k) for k in mine]
     if warmup_frames and frames:
@@ -62,29 +64,34 @@ def run_sharded_batch(binding, encode_frames, make_frame, num_frames, width, hei
     seconds = time.perf_counter() - t0
     if len(files) != len(mine):
         raise RuntimeError(f"rank {rank}: {len(files)} files for {len(mine)} frames")
-    local = {"rank": rank, "frames": len(mine), "seconds": seconds, "bytes": sum(len(f) for f in files),
-             "digests": {k: hashlib.sha256(f).hexdigest()[:16] for k, f in zip(mine, files)} if digests else {}}
+    # per-rank slots (frames, seconds, bytes) and per-frame (owner count, 60 bits of SHA-256): every entry is written by
+    # exactly one rank, so a SUM all-reduce assembles the table on every rank
+    stats = np.zeros((world, 3), dtype=np.float64)
+    stats[rank] = (len(mine), seconds, sum(len(f) for f in files))
+    table = np.zeros((num_frames, 2), dtype=np.int64)
+    for k, f in zip(mine, files):
+        table[k, 0] = 1
+        if digests:
+            table[k, 1] = int.from_bytes(hashlib.sha256(f).digest()[:8], "big") >> 4
     if _dist_ready(dist):
-        parts = [None] * world
-        dist.all_gather_object(parts, local)
-    else:
-        parts = [local]
-    parts = sorted(parts, key=lambda p: p["rank"])
-    merged = {}
-    for p in parts:
-        for k, d in p["digests"].items():
-            if k in merged:
-                raise RuntimeError(f"frame {k} encoded by two ranks")
-            merged[k] = d
-    total = sum(p["frames"] for p in parts)
-    if total != num_frames or (digests and sorted(merged) != list(range(num_frames))):
+        import torch
+        t_stats = torch.from_numpy(stats).to(device) if device is not None else torch.from_numpy(stats)
+        t_table = torch.from_numpy(table).to(device) if device is not None else torch.from_numpy(table)
+        dist.all_reduce(t_stats)
+        dist.all_reduce(t_table)
+        stats, table = t_stats.cpu().numpy(), t_table.cpu().numpy()
+    if not np.array_equal(table[:, 0], np.ones(num_frames, dtype=np.int64)):
+        bad = np.flatnonzero(table[:, 0] != 1)
+        raise RuntimeError(f"sharding lost or duplicated frames, e.g. frame {int(bad[0])} encoded {int(table[bad[0], 0])} times")
+    total = int(stats[:, 0].sum())
+    if total != num_frames:
         raise RuntimeError(f"sharding lost frames: {total} of {num_frames}")
-    slowest = max(p["seconds"] for p in parts)
-    out = {"frames": total, "per_rank_frames": [p["frames"] for p in parts], "seconds": round(slowest, 6),
-           "per_rank_seconds": [round(p["seconds"], 6) for p in parts],
+    slowest = float(stats[:, 1].max())
+    out = {"frames": total, "per_rank_frames": [int(v) for v in stats[:, 0]], "seconds": round(slowest, 6),
+           "per_rank_seconds": [round(float(v), 6) for v in stats[:, 1]],
            "frames_per_s": round(total / slowest, 1) if slowest > 0 else None,
            "Mpixels_per_s": round(total * width * height / slowest / 1e6, 1) if slowest > 0 else None,
-           "jpeg_bytes_per_frame": int(sum(p["bytes"] for p in parts) / max(total, 1))}
+           "jpeg_bytes_per_frame": int(stats[:, 2].sum() / max(total, 1))}
     if digests:
-        out["digest"] = hashlib.sha256("".join(merged[k] for k in range(num_frames)).encode()).hexdigest()[:16]
+        out["digest"] = hashlib.sha256(b"".join(int(v).to_bytes(8, "big") for v in table[:, 1])).hexdigest()[:16]
     return out, dict(zip(mine, files))

@@ -17,6 +17,7 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -1381,6 +1382,64 @@ static int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint
     return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user);
 }
 
+// Host threads that feed a GPU should run on the NUMA node its PCIe root complex hangs off (pinned staging memory is
+// then first touched there and the uploads do not cross the socket interconnect) - what matters once eight ranks, or one
+// process driving eight GPUs, share a two-socket host.  Best effort: any failure leaves the thread where
+// it was.  The node's CPU list is read from sysfs once per device.  OPT-IN (JPEGENC_NUMA_BIND=1): on the one host it
+// could be measured on (2 x EPYC 9575F, one GPU) binding the 16 workers of a batch to the GPU's node LOST throughput
+// (1000 1080p frames: 4 800 vs 6 200 frames/s; the caller's pageable frames live wherever its own thread put them), and
+// an eight-GPU node was not available to show the opposite.
+static bool device_cpus(int device, cpu_set_t *out) {
+    static std::mutex mu;
+    static cpu_set_t sets[64];
+    static int state[64];              // 0 = unknown, 1 = known, -1 = none
+    if (device < 0 || device >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[device] == 0) {
+        state[device] = -1;
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device) == hipSuccess) {
+            for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+            char path[160];
+            snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+            int node = -1;
+            if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+            if (node >= 0) {
+                snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+                char list[4096] = {0};
+                size_t len = 0;
+                if (FILE *f = fopen(path, "r")) { len = fread(list, 1, sizeof list - 1, f); fclose(f); }
+                cpu_set_t want;
+                CPU_ZERO(&want);
+                for (const char *c = list; len && *c;) {                    // "0-31,128-159"
+                    char *end = nullptr;
+                    const long a = strtol(c, &end, 10);
+                    if (end == c) break;
+                    long b = a;
+                    c = end;
+                    if (*c == '-') { b = strtol(c + 1, &end, 10); c = end; }
+                    for (long i = a; i <= b && i < CPU_SETSIZE; i++) if (i >= 0) CPU_SET((int)i, &want);
+                    if (*c == ',') c++; else break;
+                }
+                if (CPU_COUNT(&want) > 0) { sets[device] = want; state[device] = 1; }
+            }
+        }
+    }
+    if (state[device] != 1) return false;
+    *out = sets[device];
+    return true;
+}
+
+static void bind_thread_near_device(int device) {
+    static const bool on = getenv("JPEGENC_NUMA_BIND") != nullptr;
+    if (!on) return;
+    cpu_set_t want, have, both;
+    if (!device_cpus(device, &want)) return;
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return;
+    CPU_AND(&both, &want, &have);
+    if (CPU_COUNT(&both) > 0) (void)sched_setaffinity(0, sizeof both, &both);
+}
+
 struct BufferSink {
     uint8_t *out;
     size_t cap, len;
@@ -1788,6 +1847,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
     const bool staged = getenv("JPEGENC_BATCH_PAGEABLE_H2D") == nullptr;
     auto body = [&](int w) {
+        if (w > 0) bind_thread_near_device(e->device);          // (JPEGENC_NUMA_BIND=1 only) spawned workers; the caller's own affinity is left alone
         DeviceCtx &ctx = *e->workers[(size_t)w];
         for (;;) {
             const int i = next.fetch_add(1);
@@ -1868,47 +1928,6 @@ int jpegenc_shard_frames(int num_frames, int num_shards, int shard, int *indices
 }  // extern "C"
 
 namespace jpegenc {
-
-// Host threads that feed a GPU should run on the NUMA node its PCIe root complex hangs off (pinned staging memory is
-// then first touched there and the uploads do not cross the socket interconnect).  Best effort: any failure leaves
-// the thread where it was.  JPEGENC_NO_NUMA_BIND=1 disables it.
-static void bind_thread_near_device(int device) {
-    static const bool off = getenv("JPEGENC_NO_NUMA_BIND") != nullptr;
-    if (off) return;
-    char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device) != hipSuccess) return;
-    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
-    char path[160];
-    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
-    FILE *f = fopen(path, "r");
-    if (!f) return;
-    int node = -1;
-    const int got = fscanf(f, "%d", &node);
-    fclose(f);
-    if (got != 1 || node < 0) return;
-    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
-    f = fopen(path, "r");
-    if (!f) return;
-    char list[4096] = {0};
-    const size_t len = fread(list, 1, sizeof list - 1, f);
-    fclose(f);
-    if (!len) return;
-    cpu_set_t want, have, both;
-    CPU_ZERO(&want);
-    for (const char *c = list; *c;) {                          // "0-31,128-159"
-        char *end = nullptr;
-        const long a = strtol(c, &end, 10);
-        if (end == c) break;
-        long b = a;
-        c = end;
-        if (*c == '-') { b = strtol(c + 1, &end, 10); c = end; }
-        for (long i = a; i <= b && i < CPU_SETSIZE; i++) if (i >= 0) CPU_SET((int)i, &want);
-        if (*c == ',') c++; else break;
-    }
-    if (sched_getaffinity(0, sizeof have, &have) != 0) return;
-    CPU_AND(&both, &want, &have);
-    if (CPU_COUNT(&both) > 0) (void)sched_setaffinity(0, sizeof both, &both);
-}
 
 static int encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_devices, const uint8_t *const *frames, size_t frame_len,
                               int num_frames, int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
