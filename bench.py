@@ -323,9 +323,22 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
+        import ctypes
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL: used for the barrier / max only
+        # RCCL prints a version banner to the C stdout when the first communicator is created; stdout must carry ONE JSON
+        # line, so fd 1 points at stderr until the communicator exists and the C buffer has been flushed
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL: used for the barrier / max / bookkeeping all-reduces only
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -617,7 +630,8 @@ def main():
                 return [outs3[i][:lens3[i]] for i in range(len(frames))]
             pool = batch.FramePool(synth)
             c3, mine = batch.run_sharded_batch(binding, encode_frames, pool, args.c3_frames, batch.C3_W, batch.C3_H, world, rank,
-                                               dist if distributed else None, warmup_frames=32, device=dev)
+                                               dist if distributed else None, warmup_frames=32, device=dev,
+                                               force_collectives=os.environ.get("JPEGENC_BENCH_FORCE_DIST") == "1")
             c3["what"] = (f"C3: {args.c3_frames} frames of 1920x1080 RGB q=80 4:2:0 sharded frame k -> rank k % {world} "
                           "(jpegenc_shard_frames), each rank: pageable host pixels -> complete JPEG files in host buffers through "
                           "jpegenc_encoder_encode_batch_to_buffers on its GPU; seconds = MAX over ranks; photo-like frames "

@@ -38,18 +38,19 @@ class FramePool:
         return self.cache[key]
 
 
-def _dist_ready(dist):
-    return dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+def _dist_ready(dist, force=False):
+    return dist is not None and dist.is_available() and dist.is_initialized() and (force or dist.get_world_size() > 1)
 
 
 def run_sharded_batch(binding, encode_frames, make_frame, num_frames, width, height, world=1, rank=0, dist=None,
-                      warmup_frames=0, digests=True, device=None):
+                      warmup_frames=0, digests=True, device=None, force_collectives=False):
     """One rank's share of a frame-sharded batch + the bookkeeping exchange.
 
     encode_frames(list of HxWx3 uint8 arrays) -> list of bytes : this rank's encoder (bench.py: the library's
         batch API on the rank's GPU; the gloo test: anything, e.g. the oracle).
     make_frame(k) -> pixels of frame k of the batch.
     device: where the bookkeeping tensors live (the rank's GPU under RCCL, None = CPU under gloo).
+    force_collectives: run the barrier and the all-reduces even with a single rank (a self-test of the RCCL path).
     Returns a dict every rank agrees on: frames per rank, wall time of the slowest rank, aggregate rates, and -
     with digests - a checksum of the per-frame checksums in frame order (independent of world size).
     The exchange is two small tensor all-reduces (no pixels, no coefficients, no files)."""
@@ -57,7 +58,7 @@ def run_sharded_batch(binding, encode_frames, make_frame, num_frames, width, hei
     frames = [make_frame(k) for k in mine]
     if warmup_frames and frames:
         encode_frames(frames[:warmup_frames])                      # buffers, page faults, clocks
-    if _dist_ready(dist):
+    if _dist_ready(dist, force_collectives):
         dist.barrier()
     t0 = time.perf_counter()
     files = encode_frames(frames) if frames else []
@@ -73,7 +74,7 @@ def run_sharded_batch(binding, encode_frames, make_frame, num_frames, width, hei
         table[k, 0] = 1
         if digests:
             table[k, 1] = int.from_bytes(hashlib.sha256(f).digest()[:8], "big") >> 4
-    if _dist_ready(dist):
+    if _dist_ready(dist, force_collectives):
         import torch
         t_stats = torch.from_numpy(stats).to(device) if device is not None else torch.from_numpy(stats)
         t_table = torch.from_numpy(table).to(device) if device is not None else torch.from_numpy(table)
