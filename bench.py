@@ -621,16 +621,16 @@ def main():
         try:
             batch = importlib.import_module("jpeg_encoder_amd.batch")
             enc3 = binding.Encoder(batch.C3_QUALITY, device=local_rank)         # q=80 -> default F_2_2 (encoder.rs:256-260)
-            cap3 = 4 << 20
+            cap3 = 1 << 20
             n_mine = len(binding.shard_frames(args.c3_frames, world, rank))
-            outs3 = [np.empty(cap3, dtype=np.uint8) for _ in range(n_mine)]      # caller-owned output buffers, reused
+            outs3 = [np.zeros(cap3, dtype=np.uint8) for _ in range(n_mine)]      # caller-owned output buffers, reused (and touched: no page faults in the timed pass)
 
             def encode_frames(frames):                                          # -> views of the files, no copies
                 lens3 = enc3.encode_batch_into(frames, batch.C3_W, batch.C3_H, binding.RGB, outs3)
                 return [outs3[i][:lens3[i]] for i in range(len(frames))]
             pool = batch.FramePool(synth)
             c3, mine = batch.run_sharded_batch(binding, encode_frames, pool, args.c3_frames, batch.C3_W, batch.C3_H, world, rank,
-                                               dist if distributed else None, warmup_frames=32, device=dev,
+                                               dist if distributed else None, warmup_frames=args.c3_frames, device=dev,     # one untimed pass over the rank's frames first
                                                force_collectives=os.environ.get("JPEGENC_BENCH_FORCE_DIST") == "1")
             c3["what"] = (f"C3: {args.c3_frames} frames of 1920x1080 RGB q=80 4:2:0 sharded frame k -> rank k % {world} "
                           "(jpegenc_shard_frames), each rank: pageable host pixels -> complete JPEG files in host buffers through "

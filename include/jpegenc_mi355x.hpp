@@ -128,6 +128,23 @@ public:
     void encode_coefficients(const int16_t *coeffs, size_t num_blocks, uint16_t width, uint16_t height, ColorType color_type) {
         check(jpegenc_encoder_encode_coefficients(h_, coeffs, num_blocks, width, height, (int)color_type, &sink, &w_));
     }
+    // a device-resident planar source (decoder / ISP output: I420, NV12, planar CMYK ...) described per component: the device
+    // counterpart of a user ImageBuffer, no host code per row (jpegenc_encoder_encode_planes_device)
+    void encode_planes_device(JpegColorType color, uint16_t width, uint16_t height, const jpegenc_plane planes[4], bool planes_subsampled) {
+        check(jpegenc_encoder_encode_planes_device(h_, (int)color, width, height, planes, planes_subsampled ? 1 : 0, &sink, &w_));
+    }
+    // A batch of same-geometry frames, frame k on devices[k % num_devices] (empty list: this encoder's own GPU); every frame
+    // into its own buffer.  The encoder's writer is not used.  lengths[i] = bytes frame i needs; throws on a short buffer.
+    void encode_batch_to_buffers(const int *devices, int num_devices, const uint8_t *const *frames, size_t frame_len, int num_frames,
+                                 uint16_t width, uint16_t height, ColorType color_type, uint8_t *const *outs, const size_t *capacities,
+                                 size_t *lengths) {
+        if (num_devices > 0)
+            check(jpegenc_encoder_encode_batch_multi_to_buffers(h_, devices, num_devices, frames, frame_len, num_frames, width, height,
+                                                                (int)color_type, outs, capacities, lengths));
+        else
+            check(jpegenc_encoder_encode_batch_to_buffers(h_, frames, frame_len, num_frames, width, height, (int)color_type, outs,
+                                                          capacities, lengths));
+    }
     // Encoder::encode_image, :505-515
     void encode_image(ImageBuffer &image) {
         check(jpegenc_encoder_encode_image(h_, (int)image.get_jpeg_color_type(), image.width(), image.height(), &fill_row, &image, &sink, &w_));

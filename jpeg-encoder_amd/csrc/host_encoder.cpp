@@ -1840,7 +1840,9 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     // one frame overlap the entropy coding of the others
     unsigned hw = std::thread::hardware_concurrency();
     int workers = (int)(hw ? hw : 4);
-    if (workers > e->max_batch_workers) workers = e->max_batch_workers;
+    static const int env_workers = [] { const char *v = getenv("JPEGENC_BATCH_WORKERS"); return v ? atoi(v) : 0; }();   // diagnosis: worker sweep
+    const int cap = env_workers > 0 && e->max_batch_workers == 16 ? env_workers : e->max_batch_workers;
+    if (workers > cap || env_workers > 0) workers = cap < (int)(hw ? hw : 4) ? cap : (int)(hw ? hw : 4);
     if (workers > num_frames) workers = num_frames;
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
