@@ -1073,7 +1073,12 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                 const Job &j = jobs[k];
                 write_scan_header(o, L, j.first, j.n, j.ss, j.se);
                 if (j.cap) {
-                    o.bytes(ctx.h_scan_out + at, scan_len[k]);
+                    if (scan_len[k] >= (64u << 10) && sink) {      // a large scan goes from the pinned buffer straight to the sink (one copy less)
+                        o.drain(true);
+                        if (!o.failed && sink(user, ctx.h_scan_out + at, scan_len[k]) != 0) o.failed = true;
+                    } else {
+                        o.bytes(ctx.h_scan_out + at, scan_len[k]);
+                    }
                     at += scan_len[k];
                 } else if (c.restart_interval) {
                     // empty band (progressive with > 33 scans, encoder.rs:927-944): no bits at all, but the
