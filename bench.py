@@ -199,7 +199,7 @@ def link_rates(torch, dev, nbytes=24_883_200, reps=24):
     out = {}
     for name, up, dn in (("h2d", 1, 0), ("d2h", 0, 1), ("both_each_direction", 1, 1)):
         run(up, dn, 4)
-        out[name] = round(run(up, dn, reps), 1)
+        out[name] = round(max(run(up, dn, reps) for _ in range(3)), 1)      # best of three: a peak, and the two-direction case is jittery
     out["what"] = f"pinned {nbytes / 1e6:.1f} MB copies measured by this run, GB/s"
     return out
 
