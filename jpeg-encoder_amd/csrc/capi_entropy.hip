@@ -73,7 +73,8 @@ static void plan_scan(uint64_t max_blocks, uint64_t bound, int frames, ScanPlan 
     pl->max_blocks = (uint32_t)max_blocks;
     pl->raw_stride = (max_blocks * (bound + 16) + 64 + 15) & ~15ull;
     pl->max_chunks = (uint32_t)(pl->raw_stride / 16);
-    pl->max_waves = pl->max_blocks / 60u + 2u;                 // runs of 64 blocks, or of the 60..64 a wave of the fused kernel holds
+    pl->max_waves = pl->max_blocks / 60u + 12u;                // runs of 64 blocks, or of the 60..64 a wave of the first fused kernel holds; the
+                                                               // second one's runs of 64 MCUs take bpm (<= 10) consecutive slots each
     pl->max_fftiles = (pl->max_chunks + 255u) / 256u;
     pl->max_tiles = (pl->max_blocks + 4095) / 4096 + 1;       // the largest scan is over restart intervals (<= blocks)
     size_t o = 0;
@@ -232,6 +233,8 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
             return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan cannot be coded by the fused kernel");
         p.run_blocks = fused_run_blocks(*fused->blocks);
         p.nwaves = fused_runs(*fused->blocks);
+        p.slot_words = fused_slot_words(*fused->blocks, pl.slot_words);
+        if ((uint64_t)p.nwaves * p.slot_words > (uint64_t)pl.max_waves * pl.slot_words) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "scan workspace too small for the fused kernel's runs");
         if (p.nwaves > pl.max_waves) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "scan workspace too small for the fused kernel's runs");
     }
     *d_params_out = (EntropyParams *)(ws + pl.off_params);

@@ -172,21 +172,23 @@ __device__ __forceinline__ uint32_t category_of(int t) { return 32u - min(sign_b
 struct PrivSink {                  // bits from bit 0 into words w[0], w[64], w[128] ... (one strip per lane, lane-interleaved)
     lds_word *w, *last;
     uint64_t acc;
-    uint32_t nacc, nwords;
+    uint32_t nacc, total;
+    // Branch-free: the word under construction is stored on EVERY put - left-aligned while it is partial, complete when the
+    // put fills it (then the pointer moves on and the surplus bits stay in the accumulator).  The walk is a chain of
+    // exec-masked regions; a "word full?" region inside each of them was a compare, two scalar mask operations and a
+    // branch per symbol, taken by some lane of the wave nearly every time.
     __device__ __forceinline__ void put(uint32_t bits, uint32_t len) {          // len <= 31
         acc = (acc << len) | bits;
-        nacc += len;
-        if (nacc >= 32) {
-            nacc -= 32;
-            *w = (uint32_t)(acc >> nacc);
-            w = min(w + 64, last);                                               // (a strip that overflows keeps overwriting its last word: the wave then takes the two-walk path)
-            nwords++;
-        }
+        const uint32_t t = nacc + len;                                           // valid low bits of acc, <= 62
+        *w = (uint32_t)((acc << ((64u - t) & 63u)) >> 32);                       // (t = 0: a word of stale bits that the next put or nothing replaces)
+        w = min(w + ((t >> 5) << 6), last);                                      // (a strip that overflows keeps overwriting its last word: the wave then takes the two-walk path)
+        nacc = t & 31u;
+        total += len;
     }
     __device__ __forceinline__ void finish() {
         if (nacc) *w = (uint32_t)(acc << (32u - nacc));
     }
-    __device__ __forceinline__ uint32_t bits() const { return nwords * 32u + nacc; }
+    __device__ __forceinline__ uint32_t bits() const { return total; }
 };
 
 // The table read of a symbol is issued where the symbol is found and consumed where the NEXT symbol is found (or at the
@@ -210,7 +212,10 @@ __device__ __forceinline__ void walk_once(Params p, const u32x2 *lut64, uint32_t
     }
     // AC: write_ac_block(block, start, end) (writer.rs:356-388)
     if (BASELINE || p.ac_end > p.ac_start) {
-        uint32_t run_at = ac_base;                 // address of the table row of the current zero run: ac_base + run * 128
+        // `row` = address of the table row of the current zero run (ac_base + run * 128).  It is advanced unconditionally
+        // after the non-zero region, which resets it to one row before the table: an if / else here costs every position a
+        // second exec-mask flip.  A run of 16 zeros cannot end before position 17.
+        uint32_t row = ac_base;
         const uint32_t zrl_row = ac_base + 15u * 128u;
         const u32x2 zrl = *(lut_ptr)(uintptr_t)(ac_base + 0xF0u * 8u), eob = *(lut_ptr)(uintptr_t)ac_base;
 #pragma unroll
@@ -219,21 +224,20 @@ __device__ __forceinline__ void walk_once(Params p, const u32x2 *lut64, uint32_t
             const int v = (k & 1u) ? (int)c[k >> 1] >> 16 : (int)(int16_t)(c[k >> 1] & 0xFFFFu);
             if (v != 0) {
                 s.put(pend.x | pend_mag, pend.y);
-                if (run_at > zrl_row) {
+                if (k > 16u && row > zrl_row) {
 #pragma nounroll
-                    do { s.put(zrl.x, zrl.y); run_at -= 16u * 128u; } while (run_at > zrl_row);
+                    do { s.put(zrl.x, zrl.y); row -= 16u * 128u; } while (row > zrl_row);
                 }
                 const int t = v + (v >> 31);
                 const uint32_t n = 32u - sign_bits(t);                           // v != 0: t is neither 0 nor -1
-                pend = *(lut_ptr)(uintptr_t)(run_at + (n << 3));
+                pend = *(lut_ptr)(uintptr_t)(row + (n << 3));
                 pend_mag = __builtin_amdgcn_ubfe((uint32_t)t, 0u, n);
-                run_at = ac_base;
-            } else {
-                run_at += 128u;
+                row = ac_base - 128u;
             }
+            row += 128u;
         }
         s.put(pend.x | pend_mag, pend.y);
-        if (run_at != ac_base) s.put(eob.x, eob.y);
+        if (row != ac_base) s.put(eob.x, eob.y);
     } else {
         s.put(pend.x | pend_mag, pend.y);
     }

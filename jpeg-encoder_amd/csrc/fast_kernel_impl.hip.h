@@ -279,11 +279,30 @@ __device__ __forceinline__ void ac_histogram(const uint32_t (&c)[32], bool count
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The life of one wave over one group of 64 MCUs of frame `frm` (see the notes at the top of the file).
-template <int BPP, int SX, int SY, int VARIANT, bool CONV>
-__device__ __forceinline__ void block_wave(const BlockKernelParams &p, const ColourConsts &k, uint8_t *smem, const uint32_t grp, const uint32_t frm) {
+// What a wave knows about itself after its prologue and block math (shared by k_blocks_fast, which stores the
+// coefficients, and the pixels -> bits kernel of fused_kernels.hip, which walks their symbols on the spot).
+struct WaveCtx {
+    u32x16 H, Wv;                      // FastHeader, the wave's FastWave record
+    uint32_t lane, wave, bits, order, lg, lgv, vrow;
+    uint32_t first_unit, wave_mcus, limit, units_x, magic, shift, col0, row0;
+    uint32_t dm, sub_k, ux, uy;        // this lane's block: MCU first_unit + dm = (ux, uy), block sub_k of the wave's block row in it
+    int c, role, qsel;
+    bool inside;                       // the lane has a block (slots past the frame's last MCU read block 0 and store nothing)
+    gbytes frame;                      // this frame's pixels (the component's plane for planar sources)
+    uint32_t pitch;
+    int width, hlim;
 #ifdef JPEGENC_WAVE_TIMING
-    const uint64_t tm0 = __builtin_readcyclecounter();
+    uint64_t tm0, tm1, tm2;
+#endif
+};
+
+// Prologue + fetch + conversion + FDCT + quantiser of one wave over one group of 64 MCUs of frame `frm` (see the notes
+// at the top of the file): packed[j] = zig-zag coefficients (2j, 2j + 1) of the lane's block.  false: a padding wave
+// of the last group (nothing computed).
+template <int BPP, int SX, int SY, int VARIANT, bool CONV>
+__device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint32_t grp, const uint32_t frm, WaveCtx &w, uint32_t (&packed)[32]) {
+#ifdef JPEGENC_WAVE_TIMING
+    w.tm0 = __builtin_readcyclecounter();
 #endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -303,11 +322,13 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
     // same pixels; the order only decides where a block is stored (stage_and_store).
     const uint32_t first_unit = grp * H[15] + Wv[1];
     const uint32_t wave_mcus = (bits >> FW_COUNT_SHIFT) & 127u;   // MCUs this wave covers
-    if (first_unit >= limit) return;                                // padding wave of the last group: nothing to do
-    const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0], co_base = ((uint64_t)H[3] << 32) | H[2];
-    const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4], co_stride = ((uint64_t)H[7] << 32) | H[6];
+    w.H = H; w.Wv = Wv; w.lane = lane; w.wave = wave; w.bits = bits; w.order = order; w.lg = lg; w.lgv = lgv; w.vrow = vrow;
+    w.first_unit = first_unit; w.wave_mcus = wave_mcus; w.limit = limit; w.units_x = units_x; w.magic = magic; w.shift = shift;
+    w.c = c; w.role = role; w.qsel = qsel;
+    if (first_unit >= limit) return false;                          // padding wave of the last group: nothing to do
+    const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0];
+    const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4];
     const gbytes frame = (gbytes)(uintptr_t)(px_base + (size_t)frm * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]));
-    const gchunks frame_out = (gchunks)(uintptr_t)(co_base + (size_t)frm * co_stride * 128u);
     const int width = (int)H[8], hlim = (int)H[9] - 1;
     const uint32_t pitch = H[10];                                   // frame bytes < 2^31 (checked by the launcher)
     const int sxc = sub ? SX : 1, syc = sub ? SY : 1;
@@ -325,6 +346,8 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
     bool inside = first_unit + dm < limit && dm < wave_mcus;
     if (order != 0) inside = inside && (ux << lg) + sub_k < Wv[2] && (uy << lgv) + vrow < Wv[13];   // planar: the plane may end inside the last MCUs
     if (!inside) { ux = 0; uy = 0; }                                // such slots read block 0 and store nothing
+    w.col0 = col0; w.row0 = row0; w.dm = dm; w.sub_k = sub_k; w.ux = ux; w.uy = uy; w.inside = inside;
+    w.frame = frame; w.pitch = pitch; w.width = width; w.hlim = hlim;
     BlockRef me;
     me.x0 = (int)(ux * H[13] + sub_k * 8u * (uint32_t)sxc);
     me.y0 = (int)(uy * H[14] + vrow * 8u * (uint32_t)syc);
@@ -334,7 +357,7 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
     uint32_t rows[8][4];
 #ifdef JPEGENC_WAVE_TIMING
     __builtin_amdgcn_sched_barrier(0);
-    const uint64_t tm1 = __builtin_readcyclecounter();        // prologue done: block origin and row offsets known
+    w.tm1 = __builtin_readcyclecounter();        // prologue done: block origin and row offsets known
     __builtin_amdgcn_sched_barrier(0);
 #endif
 
@@ -387,15 +410,35 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
 #ifdef JPEGENC_WAVE_TIMING
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" :: "v"(rows[7][3]), "v"(rows[0][0]));
-    const uint64_t tm2 = __builtin_readcyclecounter();        // rows loaded and converted
+    w.tm2 = __builtin_readcyclecounter();        // rows loaded and converted
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    uint32_t packed[32];
 #ifdef JPEGENC_PROBE_MEMORY_ONLY   // diagnostic build: same loads and stores, no block math
 #pragma unroll
     for (int j = 0; j < 32; j++) packed[j] = rows[j >> 2][j & 3];
 #else
     fdct_quant_block<VARIANT>(rows, quant_table(qsel), packed);
+#endif
+    return true;
+}
+
+// The life of one wave of the block kernel: compute, [count symbols], stage and store.
+template <int BPP, int SX, int SY, int VARIANT, bool CONV>
+__device__ __forceinline__ void block_wave(const BlockKernelParams &p, const ColourConsts &k, uint8_t *smem, const uint32_t grp, const uint32_t frm) {
+    WaveCtx w;
+    uint32_t packed[32];
+    if (!block_compute<BPP, SX, SY, VARIANT, CONV>(k, grp, frm, w, packed)) return;
+    const u32x16 H = w.H, Wv = w.Wv;
+    const uint32_t lane = w.lane, wave = w.wave, order = w.order, lg = w.lg, lgv = w.lgv, vrow = w.vrow, sub_k = w.sub_k, ux = w.ux, uy = w.uy;
+    const uint32_t first_unit = w.first_unit, wave_mcus = w.wave_mcus, limit = w.limit, units_x = w.units_x, magic = w.magic, shift = w.shift;
+    const uint32_t col0 = w.col0, row0 = w.row0;
+    const int qsel = w.qsel;
+    const bool inside = w.inside;
+    const uint64_t co_base = ((uint64_t)H[3] << 32) | H[2], co_stride = ((uint64_t)H[7] << 32) | H[6];
+    const gchunks frame_out = (gchunks)(uintptr_t)(co_base + (size_t)frm * co_stride * 128u);
+#ifdef JPEGENC_WAVE_TIMING
+    const uint64_t tm0 = w.tm0, tm1 = w.tm1, tm2 = w.tm2;
+    const bool sub = (w.bits >> FW_SUB_SHIFT) & 1u;
 #endif
     if (p.hist_partials && order != 0) {                                         // wave-uniform: optimised-Huffman statistics
         const uint32_t wave_id = (grp * (blockDim.x >> 6) + wave) & (kHistCopies - 1u);
@@ -564,6 +607,8 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
     return hipGetLastError();
 }
 
+// fast_kernels.hip: the colour constants of a launch + the one decimation (sx, sy) its subsampled components share
+bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx_out, int *sy_out);
 // fast_kernels_s4.hip / fast_kernels_bytes_s4.hip: the instantiations for a sampling factor of 4
 bool launch_conv_s4(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant,
                     hipStream_t stream, hipError_t *err);

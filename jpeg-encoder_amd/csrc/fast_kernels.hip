@@ -7,7 +7,7 @@
 
 namespace jpegenc {
 
-static bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx_out, int *sy_out) {
+bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx_out, int *sy_out) {
     ColourConsts k;
     memset(&k, 0, sizeof k);
     const int o_r = p.o[0], o_g = p.o[1], o_b = p.o[2];

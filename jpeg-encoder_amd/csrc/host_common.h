@@ -53,6 +53,7 @@ bool fused_supported(const BlockKernelParams &b);      // the layout has a fused
 bool fused_enabled();                                    // the Encoder uses it (JPEGENC_FUSED=1; off by default, see fused_kernels.hip)
 uint32_t fused_run_blocks(const BlockKernelParams &b);
 uint32_t fused_runs(const BlockKernelParams &b);
+uint32_t fused_slot_words(const BlockKernelParams &b, uint32_t slot_words_64);   // slot of a run, given the slot of 64 blocks
 hipError_t launch_fused_code(const BlockKernelParams &b, const EntropyParams *d_params, int restart_interval, int frames, int variant,
                              hipStream_t st);
 // fused != nullptr (one scan): the first kernel of the sequence reads pixels instead of coefficients

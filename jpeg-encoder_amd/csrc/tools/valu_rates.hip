@@ -53,6 +53,34 @@ RATE_KERNEL(k_mov, "v_mov_b32 %0, %1")
 RATE_KERNEL(k_bfi, "v_bfi_b32 %0, %1, %2, %0")
 RATE_KERNEL(k_lshlor, "v_lshl_or_b32 %0, %1, 16, %0")
 
+// 64-bit destination (the entropy walk's bit accumulator): a register pair per chain
+#define RATE_KERNEL64(NAME, ASM)                                                            \
+    __global__ void __launch_bounds__(256) NAME(uint32_t *out, uint32_t seed) {             \
+        uint64_t a[UNROLL];                                                                  \
+        uint32_t b = (seed * 2654435761u + threadIdx.x) & 31u, c = seed ^ 0x9E3779B9u;       \
+        for (int i = 0; i < UNROLL; i++) a[i] = ((uint64_t)seed << 32) + i * 7919u + threadIdx.x; \
+        for (int it = 0; it < ITERS; it++) {                                                 \
+            _Pragma("unroll") for (int i = 0; i < UNROLL; i++) asm volatile(ASM : "+v"(a[i]) : "v"(b), "v"(c)); \
+        }                                                                                    \
+        uint64_t r = 0;                                                                      \
+        for (int i = 0; i < UNROLL; i++) r ^= a[i];                                          \
+        if (r == 0x12345678u) out[threadIdx.x] = (uint32_t)r;                                \
+    }
+RATE_KERNEL64(k_lshl64, "v_lshlrev_b64 %0, %1, %0")
+RATE_KERNEL64(k_lshr64, "v_lshrrev_b64 %0, %1, %0")
+RATE_KERNEL(k_alignbit, "v_alignbit_b32 %0, %0, %1, %2")
+RATE_KERNEL(k_lshl32, "v_lshlrev_b32 %0, %1, %0")
+RATE_KERNEL(k_lshr32, "v_lshrrev_b32 %0, %1, %0")
+RATE_KERNEL(k_ffbh, "v_ffbh_i32 %0, %0")
+RATE_KERNEL(k_or3, "v_or3_b32 %0, %0, %1, %2")
+RATE_KERNEL(k_or, "v_or_b32 %0, %0, %1")
+RATE_KERNEL(k_min, "v_min_u32 %0, %0, %1")
+RATE_KERNEL(k_add3, "v_add3_u32 %0, %0, %1, %2")
+RATE_KERNEL(k_cmp, "v_cmp_ne_u32 vcc, %0, %1")
+RATE_KERNEL(k_bfe_v, "v_bfe_u32 %0, %0, %1, %2")
+RATE_KERNEL(k_bfe_i16, "v_bfe_i32 %0, %0, 16, 16")
+RATE_KERNEL(k_ashr_v, "v_ashrrev_i32 %0, %1, %0")
+
 __global__ void __launch_bounds__(256) k_copy(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
@@ -120,6 +148,20 @@ int main() {
     run_rate("mov_b32", k_mov, d_out, w, &clk);
     run_rate("bfi_b32", k_bfi, d_out, w, &clk);
     run_rate("lshl_or_b32", k_lshlor, d_out, w, &clk);
+    run_rate("lshlrev_b64", k_lshl64, d_out, w, &clk);
+    run_rate("lshrrev_b64", k_lshr64, d_out, w, &clk);
+    run_rate("alignbit_b32", k_alignbit, d_out, w, &clk);
+    run_rate("lshlrev_b32 v", k_lshl32, d_out, w, &clk);
+    run_rate("lshrrev_b32 v", k_lshr32, d_out, w, &clk);
+    run_rate("ashrrev_i32 v", k_ashr_v, d_out, w, &clk);
+    run_rate("ffbh_i32", k_ffbh, d_out, w, &clk);
+    run_rate("or3_b32", k_or3, d_out, w, &clk);
+    run_rate("or_b32", k_or, d_out, w, &clk);
+    run_rate("min_u32", k_min, d_out, w, &clk);
+    run_rate("add3_u32", k_add3, d_out, w, &clk);
+    run_rate("cmp_ne_u32", k_cmp, d_out, w, &clk);
+    run_rate("bfe_u32 v,v", k_bfe_v, d_out, w, &clk);
+    run_rate("bfe_i32 16,16", k_bfe_i16, d_out, w, &clk);
 
     // streaming copy: the practical HBM ceiling for a read-N-write-N kernel
     const size_t bytes = (size_t)1 << 30;

@@ -41,7 +41,10 @@ def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
     d_co = torch.empty((n, nblk * 64), dtype=torch.int16, device=dev)
     d_ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
+    only = os.environ.get("BENCH_FUSED_ONLY")               # e.g. "photo-like:fused" - one content, one way (for kernel traces)
     for kind in ("noise", "photo-like", "smooth"):
+        if only and only.split(":")[0] != kind:
+            continue
         d_px = frames_of(kind, n, w, h, dev)
         outs, lens = {}, {}
         res = {"content": kind, "frames": n, "size": f"{w}x{h}", "sampling": f"{hs}x{vs}", "quality": quality}
@@ -54,6 +57,8 @@ def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
             b.pixels_scan_device(d_px.data_ptr(), w * h * 3, n, w, h, b.RGB, hs, vs, q, d_out.data_ptr(), cap, d_len.data_ptr(),
                                  d_ws.data_ptr(), wsz, stream.cuda_stream)
         for name, fn in (("two_kernel", two_kernel), ("fused", fused)):
+            if only and only.split(":")[1] != name:
+                continue
             d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
             d_len = torch.zeros(n, dtype=torch.int32, device=dev)
             for _ in range(3):
@@ -70,6 +75,9 @@ def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
             res[name + "_Mpixels_per_s"] = round(n * w * h / ms / 1e3, 1)
             lens[name] = d_len.cpu()
             outs[name] = [d_out[i, :int(lens[name][i])].cpu() for i in range(n)]
+        if only:
+            print(json.dumps(res), flush=True)
+            continue
         res["scan_bytes_per_frame"] = int(lens["fused"].float().mean().item())
         res["identical"] = bool(torch.equal(lens["fused"], lens["two_kernel"]) and
                                 all(torch.equal(x, y) for x, y in zip(outs["fused"], outs["two_kernel"])))

@@ -33,7 +33,7 @@ for sub in ("sq", "sq2"):
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[(k, r["Counter_Name"])] += 1
     for k, v in acc.items():
-        if "fused" in k or "k_blocks_fast" in k or "k_block_code" in k:
+        if "fused" in k or "k_group" in k or "k_blocks_fast" in k or "k_block_code" in k:
             print("==", sub, k)
             for c, val in sorted(v.items()):
                 print(f"   {c:24s} per dispatch {val / max(cnt[(k, c)], 1):16.1f}")
