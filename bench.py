@@ -475,71 +475,54 @@ def main():
             d_len = torch.zeros(Fd, dtype=torch.int32, device=dev)
             d_ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
 
-            def full():
-                binding.blocks_device(d_px.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, HS, VS, q, binding.ORDER_MCU,
+            def two_kernels(px):           # the public coefficient interchange in between: jpegenc_blocks_device + jpegenc_scan_device
+                binding.blocks_device(px.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, HS, VS, q, binding.ORDER_MCU,
                                       binding.FDCT_SCALAR, d_co.data_ptr(), nblk, stream.cuda_stream)
                 binding.scan_device(d_co.data_ptr(), nblk, Fd, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(),
                                     d_ws.data_ptr(), wsz, stream.cuda_stream)
-            for _ in range(2):
-                full()
-            torch.cuda.synchronize()
+
+            def one_kernel(px):            # jpegenc_pixels_scan_device: pixels -> coded runs in ONE kernel (what the Encoder launches)
+                binding.pixels_scan_device(px.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, HS, VS, q, d_out.data_ptr(), cap,
+                                           d_len.data_ptr(), d_ws.data_ptr(), wsz, stream.cuda_stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(5):
-                full()
-            e1.record(stream)
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
+
+            def timed(fn, px, reps=10):
+                for _ in range(3):
+                    fn(px)
+                torch.cuda.synchronize()
+                e0.record(stream)
+                for _ in range(reps):
+                    fn(px)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps
+
             def full_roofline(ms_per_call, scan_bytes):
                 # algorithmic bytes of pixels -> scan: 3 B/px read + the scan bytes written; nothing else has to touch HBM.
                 # The path is bound by instruction issue (SQ counters, profiles/README.md), which is why frac is small.
                 algo = Fd * (W * H * 3.0 + scan_bytes)
                 ach = algo / (ms_per_call * 1e-3) / 1e9
                 return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                        "algorithmic_bytes_per_call": int(algo), "limited_by": "VALU issue of the symbol walk, not bytes"}
-            nbytes = int(d_len.float().mean().item())
-            result["device_resident_full_encode"] = {
-                "value": round(Fd * W * H / ms / 1e3, 1), "unit": "Mpixels/s",
-                "what": f"{Fd} 4K frames in HBM -> entropy-coded scan bytes in HBM (block kernel + one-walk device Huffman coder, "
-                        "noise frames = worst case for entropy coding)",
-                "scan_bytes_per_frame": nbytes, "us_per_frame": round(ms * 1e3 / Fd, 2), "roofline_full_encode": full_roofline(ms, nbytes)}
+                        "algorithmic_bytes_per_call": int(algo), "limited_by": "VALU issue of conversion + FDCT + symbol walk, not bytes"}
+
+            def leg(px):
+                ms = timed(one_kernel, px)
+                nbytes = int(d_len.float().mean().item())
+                ms2 = timed(two_kernels, px)
+                return {"value": round(Fd * W * H / ms / 1e3, 1), "unit": "Mpixels/s", "scan_bytes_per_frame": nbytes,
+                        "us_per_frame": round(ms * 1e3 / Fd, 2), "roofline_full_encode": full_roofline(ms, nbytes),
+                        "two_kernels": {"value": round(Fd * W * H / ms2 / 1e3, 1), "unit": "Mpixels/s", "us_per_frame": round(ms2 * 1e3 / Fd, 2),
+                                        "what": "jpegenc_blocks_device + jpegenc_scan_device (coefficients through HBM); same bytes"}}
+            result["device_resident_full_encode"] = dict(
+                leg(d_px), what=f"{Fd} 4K frames in HBM -> entropy-coded scan bytes in HBM, jpegenc_pixels_scan_device: ONE kernel from pixels to "
+                                "coded runs (one workgroup = 64 MCUs) + placement + 0xFF stuffing; noise frames = worst case for entropy coding")
             # the same on photo-like frames (gradient + a little noise): what entropy coding costs on realistic content
             base = torch.from_numpy(synth.test_img_rgb(W, H).reshape(-1)).to(dev)
             gen = torch.Generator(device=dev)
             gen.manual_seed(11)
             d_photo = torch.clamp(base.to(torch.int16)[None, :] + torch.randint(-6, 7, (Fd, base.numel()), dtype=torch.int16, device=dev, generator=gen),
                                   0, 255).to(torch.uint8)
-
-            def full_photo():
-                binding.blocks_device(d_photo.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, HS, VS, q, binding.ORDER_MCU,
-                                      binding.FDCT_SCALAR, d_co.data_ptr(), nblk, stream.cuda_stream)
-                binding.scan_device(d_co.data_ptr(), nblk, Fd, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(),
-                                    d_ws.data_ptr(), wsz, stream.cuda_stream)
-
-            def fused_photo():       # the ONE-kernel variant (jpegenc_pixels_scan_device): byte-identical, measured beside it
-                binding.pixels_scan_device(d_photo.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, HS, VS, q, d_out.data_ptr(), cap,
-                                           d_len.data_ptr(), d_ws.data_ptr(), wsz, stream.cuda_stream)
-
-            def timed(fn, reps=10):
-                for _ in range(3):
-                    fn()
-                torch.cuda.synchronize()
-                e0.record(stream)
-                for _ in range(reps):
-                    fn()
-                e1.record(stream)
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / reps
-            ms = timed(full_photo)
-            nbytes = int(d_len.float().mean().item())
-            result["device_resident_full_encode"]["photo_like"] = {
-                "value": round(Fd * W * H / ms / 1e3, 1), "unit": "Mpixels/s", "scan_bytes_per_frame": nbytes,
-                "us_per_frame": round(ms * 1e3 / Fd, 2), "roofline_full_encode": full_roofline(ms, nbytes)}
-            ms_f = timed(fused_photo)
-            result["device_resident_full_encode"]["photo_like"]["fused_one_kernel"] = {
-                "value": round(Fd * W * H / ms_f / 1e3, 1), "unit": "Mpixels/s", "us_per_frame": round(ms_f * 1e3 / Fd, 2),
-                "what": "jpegenc_pixels_scan_device: pixels -> coded runs in one kernel (no coefficients in HBM); same bytes; slower, "
-                        "so the Encoder keeps the two-kernel path (JPEGENC_FUSED=1 opts in)"}
+            result["device_resident_full_encode"]["photo_like"] = leg(d_photo)
             del d_out, d_ws, d_photo
         except Exception as exc:                                   # side figure only
             result["device_resident_full_encode"] = {"error": str(exc)}

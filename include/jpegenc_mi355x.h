@@ -220,11 +220,13 @@ int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num
  * encode_image_interleaved (encoder.rs:727-804) produces between the SOS header and EOI, for `num_frames` images
  * laid out as for jpegenc_blocks_device.  For the RGB family (Rgb / Rgba / Bgr / Bgra) ONE fused kernel goes from the
  * pixels to the coded runs - colour conversion, subsampling, FDCT, quantisation, zig-zag and write_block's bits
- * (writer.rs:331-388) without the coefficients ever reaching HBM (jpegenc_pixels_scan_fused returns 1; d_coeffs may
- * be NULL); other layouts run the block kernel into `d_coeffs` (coeff_frame_stride blocks per frame, 0 = total_blocks)
- * and code from there.  Workspace / output sizing: jpegenc_scan_workspace_size / jpegenc_scan_max_bytes with
- * jpegenc_scan{-1, 1, 1, 64, restart_interval} on the ORDER_MCU layout.  Same bytes as jpegenc_blocks_device followed
- * by jpegenc_scan_device; this is the path the Encoder takes.  Asynchronous on hip_stream. */
+ * (writer.rs:331-388) without the coefficients ever reaching HBM: a workgroup takes 64 consecutive MCUs with the block
+ * kernel's component-uniform waves and assembles their bits in scan order in LDS (jpegenc_pixels_scan_fused returns 1;
+ * d_coeffs may be NULL); other layouts run the block kernel into `d_coeffs` (coeff_frame_stride blocks per frame,
+ * 0 = total_blocks) and code from there.  Workspace / output sizing: jpegenc_scan_workspace_size /
+ * jpegenc_scan_max_bytes with jpegenc_scan{-1, 1, 1, 64, restart_interval} on the ORDER_MCU layout.  Same bytes as
+ * jpegenc_blocks_device followed by jpegenc_scan_device, and faster; this is the path the Encoder
+ * takes.  Asynchronous on hip_stream. */
 int jpegenc_pixels_scan_fused(int width, int height, int color_type, int h_sampling, int v_sampling);
 int jpegenc_pixels_scan_device(const void *d_pixels, size_t pixel_frame_stride, int num_frames, int width, int height,
                                int color_type, int h_sampling, int v_sampling, const jpegenc_qtable tables[2],

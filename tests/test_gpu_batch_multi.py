@@ -170,10 +170,15 @@ def test_pixels_scan_device_matches_the_two_kernel_path_and_the_oracle(binding, 
         assert ref.endswith(outs[0][i] + b"\xff\xd9") and len(outs[0][i]) > 0
 
 
-def test_encoder_with_the_fused_kernel_enabled(binding, tmp_path):
-    """JPEGENC_FUSED=1 (read once per process, hence the child process): the Encoder codes its interleaved baseline scan
-    straight from the pixels - single frames (direct, captured and replayed launch sequences), restart intervals, 4-byte
-    pixels, the worker-pool batch and the device-resident batch - byte-identical to the oracle's files."""
+@pytest.mark.parametrize("env", [{"JPEGENC_FUSED": "1"}, {"JPEGENC_FUSED": "0"}, {"JPEGENC_FUSED": "1", "JPEGENC_PACK_WINDOW_WORDS": "8"}],
+                         ids=["fused", "two-kernels", "fused-tiny-window"])
+def test_encoder_with_and_without_the_fused_kernel(binding, tmp_path, env):
+    """The Encoder codes its interleaved baseline scan of an RGB-family image straight from the pixels (one workgroup =
+    one run of 64 MCUs; JPEGENC_FUSED=0 keeps block kernel + coder; the switches are read once per process, hence the
+    child process): single frames (direct, captured and replayed launch sequences), restart intervals, 4-byte pixels,
+    blocks longer than a lane's strip (noise at quality 100) and runs longer than the window (forced by
+    JPEGENC_PACK_WINDOW_WORDS: the second-walk path), the worker-pool batch and the device-resident batch -
+    byte-identical to the oracle's files every way."""
     import os
     import subprocess
     import sys
@@ -192,13 +197,18 @@ def test_encoder_with_the_fused_kernel_enabled(binding, tmp_path):
         cases = [(b.RGB, 3, 258, 128, dict(quality=80)), (b.RGB, 3, 258, 128, dict(quality=100)), (b.RGB, 3, 515, 77, dict(quality=85, sampling=(2, 1))),
                  (b.BGR, 3, 77, 515, dict(quality=70, sampling=(1, 2), restart_interval=3)), (b.RGBA, 4, 640, 360, dict(quality=90, sampling=(2, 2))),
                  (b.BGRA, 4, 333, 201, dict(quality=60, restart_interval=1)), (b.RGB, 3, 1920, 1080, dict(quality=80)),
-                 (b.RGB, 3, 3840, 2160, dict(quality=90, sampling=(2, 2), restart_interval=240))]
-        for ct, bpp, w, h, kw in cases:
+                 (b.RGB, 3, 3840, 2160, dict(quality=90, sampling=(2, 2), restart_interval=240)),
+                 (b.RGB, 3, 1920, 1080, dict(quality=85, variant=o.FDCT_SIMD)), (b.BGRA, 4, 515, 301, dict(quality=95, sampling=(1, 1), variant=o.FDCT_SIMD)),
+                 (b.RGB, 3, 1030, 70, dict(quality=100, sampling=(1, 1))), (b.RGB, 3, 1000, 200, dict(quality=100, sampling=(2, 2), restart_interval=7)),
+                 (b.RGB, 3, 96, 80, dict(quality=95, variant=o.FDCT_SIMD))]
+        for i, (ct, bpp, w, h, kw) in enumerate(cases):
             px = synth.lcg_image(w, h, bpp, 9)
-            px = (px.astype(np.int16) // 4 + np.add.outer(np.arange(h), np.arange(w))[..., None] // 3).clip(0, 255).astype(np.uint8)
+            if i < len(cases) - 3:                               # (the last three stay pure noise: blocks of up to ~1 700 bits)
+                px = (px.astype(np.int16) // 4 + np.add.outer(np.arange(h), np.arange(w))[..., None] // 3).clip(0, 255).astype(np.uint8)
             e = b.Encoder(kw["quality"])
             if "sampling" in kw: e.set_sampling_factor(b.sampling_factor(*kw["sampling"]))
             if kw.get("restart_interval"): e.set_restart_interval(kw["restart_interval"])
+            if kw.get("variant"): e.set_fdct_variant(b.FDCT_SIMD)
             want = o.encode_jpeg(px, w, h, ct, **kw)
             for _ in range(4):                                   # direct, direct, capture, replay
                 assert e.encode(px, w, h, ct) == want, (ct, w, h, kw)
@@ -208,8 +218,7 @@ def test_encoder_with_the_fused_kernel_enabled(binding, tmp_path):
             assert e.encode_batch([px] * 5, w, h, ct) == [want] * 5
         print("FUSED-OK")
     """))
-    env = dict(os.environ, JPEGENC_FUSED="1")
-    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FUSED-OK" in r.stdout, r.stderr[-3000:]
 
 
