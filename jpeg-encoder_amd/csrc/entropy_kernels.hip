@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
     if (w >= p.nwaves) return;
     const uint32_t *wsum = p.wsum + (size_t)f * p.nwaves;
     uint32_t lo, hi, total_bits;
-    if (p.fused_prefix) {                        // few runs: every wave adds up the lengths itself, no scan launch before this kernel
+    if (p.fused_prefix & 1u) {                   // few runs: every wave adds up the lengths itself, no scan launch before this kernel
         uint32_t before = 0, all = 0;
         for (uint32_t i = lane; i < p.nwaves; i += 64u) { const uint32_t v = wsum[i]; all += v; if (i < w) before += v; }
         lo = wave_sum(before); total_bits = wave_sum(all);
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams *params) {
         const uint4 v = active ? reinterpret_cast<const uint4 *>(p.raw + (size_t)f * p.raw_stride)[q] : make_uint4(0, 0, 0, 0);
         uint32_t tile_ff;
         uint32_t tiles_before;
-        if (p.fused_prefix) {                    // few tiles: add up the counts of the tiles before this one here, no scan launch
+        if (p.fused_prefix & 2u) {               // few tiles: add up the counts of the tiles before this one here, no scan launch
             uint32_t sum = 0;
             for (uint32_t t = threadIdx.x; t < tile; t += 256u) sum += p.fftile[(size_t)f * p.max_fftiles + t];
             sum = wave_sum(sum);
@@ -748,17 +748,22 @@ static hipError_t scan(const EntropyParams *d_params, int which, uint32_t n_max,
 
 // njobs <= kMaxScansPerLaunch scans (same number of frames each) in one launch sequence; d_params: room
 // for njobs parameter blocks in device memory
-struct LaunchShape { uint32_t nblocks, nwaves, nintervals, fftiles; bool any_single, any_multi, fused_prefix; };
+struct LaunchShape { uint32_t nblocks, nwaves, nintervals, fftiles; bool any_single, any_multi; uint32_t fused_prefix; };
 static LaunchShape shape_of(const EntropyParams *jobs, int njobs) {
-    LaunchShape s = {0, 0, 0, 0, false, false, false};
+    LaunchShape s = {0, 0, 0, 0, false, false, 0};
     for (int j = 0; j < njobs; j++) {
         s.nblocks = max(s.nblocks, jobs[j].nblocks); s.nwaves = max(s.nwaves, jobs[j].nwaves);
         s.nintervals = max(s.nintervals, jobs[j].nintervals); s.fftiles = max(s.fftiles, jobs[j].max_fftiles);
         s.any_single = s.any_single || jobs[j].nintervals == 1; s.any_multi = s.any_multi || jobs[j].nintervals > 1;
     }
-    // few runs, few tiles, no restart markers (every frame up to about 1080p): the consumers of the two prefix sums
-    // compute them on the fly and the scan launches - pure launch latency at that size - are skipped
-    s.fused_prefix = !s.any_multi && s.nwaves <= kFusedPrefixMax && s.fftiles <= 4u * kFusedPrefixMax;   // (fftiles is the worst-case bound)
+    // no restart markers and few runs (bit 0) / few tiles (bit 1): the consumer of the prefix sum computes it on the fly - every
+    // wave of k_push adds up the run lengths before its own, every workgroup of k_stuff the 0xFF counts of the tiles before its
+    // own - and the scan launches (pure launch latency at that size, ~5 us each) are skipped.  Measured on 4K frames
+    // (tools/diag/prefix_ab.sh): the runs pay up to ~2 000 of them (the 2 040 runs of the pixels -> bits kernel: -0.2 us per
+    // frame; k_block_code's 3 038: +2-3 us); the tiles (worst-case bound 11 154) gain 0.5 us on photo-like frames and lose
+    // 0.8-1.6 us on noise, and per-64-tile counters kept by k_push to shorten the sum cost 2-3 us in contended atomics.
+    static const uint32_t allow = [] { const char *e = getenv("JPEGENC_FUSED_PREFIX_MASK"); return e ? (uint32_t)atoi(e) : 3u; }();   // diagnostic
+    if (!s.any_multi) s.fused_prefix = ((s.nwaves <= kFusedPrefixRuns ? 1u : 0u) | (s.fftiles <= kFusedPrefixTiles ? 2u : 0u)) & allow;
     return s;
 }
 
@@ -770,14 +775,14 @@ hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyPar
     if (stored) {            // (the blocks were zero-filled before their fields were set: comparable byte for byte)
         now.assign((const char *)&d_params, sizeof d_params);
         now.append((const char *)jobs, sizeof(EntropyParams) * (size_t)njobs);
-        now.push_back(shape.fused_prefix ? 1 : 0);
+        now.push_back((char)shape.fused_prefix);
         if (now == *stored) return hipSuccess;
         stored->clear();
     }
     for (int first = 0; first < njobs; first += (int)kScansPerStore) {
         ParamPack pack;
         pack.n = (uint32_t)min(njobs - first, (int)kScansPerStore);
-        for (uint32_t j = 0; j < pack.n; j++) { pack.p[j] = jobs[first + j]; pack.p[j].fused_prefix = shape.fused_prefix ? 1u : 0u; }
+        for (uint32_t j = 0; j < pack.n; j++) { pack.p[j] = jobs[first + j]; pack.p[j].fused_prefix = shape.fused_prefix; }
         hipLaunchKernelGGL(k_store_params, dim3(1), dim3(256), 0, st, pack, d_params + first);
     }
     if (stored) stored->swap(now);
@@ -791,7 +796,8 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
     if (e != hipSuccess) return e;
     const LaunchShape shape = shape_of(jobs, njobs);
     const uint32_t nblocks = shape.nblocks, nwaves = shape.nwaves, nintervals = shape.nintervals, fftiles = shape.fftiles;
-    const bool any_single = shape.any_single, any_multi = shape.any_multi, fused_prefix = shape.fused_prefix;
+    const bool any_single = shape.any_single, any_multi = shape.any_multi;
+    const bool fused_runs_prefix = shape.fused_prefix & 1u, fused_tiles_prefix = shape.fused_prefix & 2u;
     const uint32_t bgrid = (nblocks + 255u) / 256u;
     if (fused) {
         const int restart = jobs[0].nintervals > 1 ? (int)(jobs[0].interval_blocks / jobs[0].bpm) : 0;
@@ -800,7 +806,7 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
     } else {
         hipLaunchKernelGGL(k_block_code, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
     }
-    if (!fused_prefix) {
+    if (!fused_runs_prefix) {
         e = scan(d_params, SCAN_WAVES, nwaves, njobs, frames, st);
         if (e != hipSuccess) return e;
     }
@@ -815,7 +821,7 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
     if (any_single) hipLaunchKernelGGL(k_push, dim3((nwaves + 3u) / 4u, frames, njobs), dim3(256), 0, st, d_params);
     if (any_multi)
         hipLaunchKernelGGL(k_place, dim3(min((fftiles + kPlaceSub - 1u) / kPlaceSub, kChunkGrid), frames, njobs), dim3(256), 0, st, d_params);
-    if (!fused_prefix) {
+    if (!fused_tiles_prefix) {
         e = scan(d_params, SCAN_FFTILES, fftiles, njobs, frames, st);
         if (e != hipSuccess) return e;
     }

@@ -8,7 +8,7 @@ namespace jpegenc {
 #define JPEGENC_PACK_WINDOW 2048
 #endif
 constexpr uint32_t kPackWindowWords = JPEGENC_PACK_WINDOW;      // words of LDS per wave of the bit packer
-constexpr uint32_t kFusedPrefixMax = 2048;                       // runs / tiles up to which the prefix sums are folded into their consumers
+constexpr uint32_t kFusedPrefixRuns = 2048, kFusedPrefixTiles = 8192;   // runs / (worst-case) tiles up to which the prefix sums are folded into their consumers
 constexpr uint32_t kMaxScansPerLaunch = 16;                      // scans coded by one launch sequence (blockIdx.z)
 
 // k_gather_scans: the coded scans of one frame, collected behind a header of their lengths
@@ -69,7 +69,7 @@ struct EntropyParams {
     uint8_t *raw;                    // [frames][raw_stride]   unstuffed bits, every interval 16-byte aligned
     uint64_t raw_stride;             // bytes, multiple of 16
     uint32_t max_chunks;             // raw_stride / 16
-    uint32_t fused_prefix;           // 1: few runs and tiles, no restart markers - k_push and k_stuff add up the run lengths /
+    uint32_t fused_prefix;           // no restart markers and bit 0: few runs / bit 1: few tiles - k_push / k_stuff add up the run lengths /
                                      // tile counts before their own themselves and the two prefix-sum launches are skipped
     uint32_t window_words;           // bit-packer runs up to this many words go through the LDS window (<= kPackWindowWords;
                                      // JPEGENC_PACK_WINDOW_WORDS lowers it so that tests reach the direct path)
