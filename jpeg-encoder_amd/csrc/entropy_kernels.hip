@@ -216,7 +216,9 @@ __global__ void __launch_bounds__(256) k_scan_apply_fused(const EntropyParams *p
 // (strip_to_window) and the window goes to the wave's slot of the scratch buffer with coalesced stores, followed by one
 // zero word (k_place reads a word past the end of a run when it shifts).  Runs longer than the window or blocks longer
 // than a strip (pathological content; JPEGENC_PACK_WINDOW_WORDS forces it in tests) take a second walk that ORs the
-// bits straight into the zeroed slot.
+// bits straight into the zeroed slot.  (A workgroup's 256 blocks as ONE run - the pixels -> bits kernel's finding that k_push
+// likes few long runs - was tried: k_push 33 -> 14 us per 16 photo-like 4K frames, but the two barriers it takes cost
+// k_block_code as much: 21.6 vs 21.8 us per frame, noise 20.7 vs 20.2 for the coder alone; not kept.)
 __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
     __shared__ u32x2 lut64[4 * 256];
@@ -245,9 +247,9 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
         ps.finish();
     }
     const uint32_t mine = ps.bits();
-    if (valid) p.bits[(size_t)f * p.nblocks + b] = mine;                         // (interval offsets need them, k_interval_len)
     if (b < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + b] = 0;        // k_push adds its 0xFF counts to these
     const uint32_t upto = wave_inclusive(mine), at = upto - mine;               // bits of the run before this block
+    if (valid && p.nintervals > 1u) p.bits[(size_t)f * p.nblocks + b] = at;      // (interval offsets need them, k_interval_len)
     const uint32_t total = (uint32_t)__shfl((int)upto, 63);
     const uint32_t w = b >> 6;
     if (lane == 0) p.wsum[(size_t)f * p.nwaves + w] = total;

@@ -48,8 +48,8 @@ struct EntropyParams {
     // Huffman code tables: [destination][0 = DC, 1 = AC][symbol] = size << 16 | code
     const uint32_t *lut;
     // workspace (device), per frame
-    uint32_t *bits;                  // [frames][nblocks]      code length of each block
-    uint32_t run_blocks;             // blocks per run: 64 (k_block_code), or (64 / bpm) * bpm for the fused pixels -> bits kernel
+    uint32_t *bits;                  // [frames][nblocks]      bit offset of each block inside its run (written for scans with restart intervals)
+    uint32_t run_blocks;             // blocks per run: 64 (k_block_code: a wave), or 64 * bpm for the pixels -> bits kernel (64 MCUs)
     uint32_t nwaves;                 // runs per frame: ceil(nblocks / run_blocks); a run = the consecutive blocks one wave codes
     uint32_t *wsum;                  // [frames][nwaves]       code length of each wave's 64 blocks
     uint32_t *woff;                  // [frames][nwaves]       exclusive prefix sum of wsum = bit offset of the wave's run

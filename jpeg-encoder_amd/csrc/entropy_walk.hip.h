@@ -50,13 +50,10 @@ __device__ __forceinline__ uint32_t wg_exclusive(uint32_t x, uint32_t *part, uin
     return base + inc - x;
 }
 
-// bit offset of block b in the scan: its wave's offset + the lengths of the wave's earlier blocks
+// bit offset of block b in the scan: its run's offset + the block's offset inside the run (what the coder kernels leave in
+// `bits` for scans with restart intervals)
 __device__ __forceinline__ uint32_t block_bit_offset(Params p, uint32_t f, uint32_t b) {
-    const uint32_t run = b / p.run_blocks;            // 64 blocks per run, or what the fused kernel's waves hold
-    uint32_t s = p.woff[(size_t)f * p.nwaves + run];
-    const uint32_t *bits = p.bits + (size_t)f * p.nblocks;
-    for (uint32_t t = run * p.run_blocks; t < b; t++) s += bits[t];
-    return s;
+    return p.woff[(size_t)f * p.nwaves + b / p.run_blocks] + p.bits[(size_t)f * p.nblocks + b];
 }
 
 // Where a block's bits go on the rare two-walk path (runs longer than the LDS window, blocks longer than a strip): codes
