@@ -464,3 +464,21 @@ def test_frames_the_device_entropy_coder_declines(binding):
     assert ok[0] > 0 and ok[1] > 0
     ok = cap(7680, 4320, binding.CMYK, 1, 1)
     assert ok[0] > 0 and ok[1] > 0
+
+
+def test_which_layouts_take_the_one_kernel_path(binding):
+    """jpegenc_pixels_scan_fused (no GPU needed): the pixels -> bits kernel takes every ColorType whose MCU has at most 6
+    blocks at sampling factors 1 and 2 - what the Encoder's interleaved baseline scan runs through - and declines the rest
+    (4-component 2x2 layouts: 7 or 10 blocks per MCU; frames the device coder declines)."""
+    b = binding
+    yes = [(b.LUMA, 1, 1), (b.RGB, 1, 1), (b.RGB, 2, 1), (b.RGB, 1, 2), (b.RGB, 2, 2), (b.RGBA, 2, 2), (b.BGR, 2, 1), (b.BGRA, 1, 1),
+           (b.YCBCR, 2, 2), (b.YCBCR, 1, 1), (b.CMYK, 1, 1), (b.CMYK, 2, 1), (b.YCCK, 1, 1), (b.YCCK, 2, 1), (b.CMYK_AS_YCCK, 1, 1), (b.CMYK, 1, 2)]
+    no = [(b.CMYK, 2, 2), (b.YCCK, 2, 2), (b.CMYK_AS_YCCK, 2, 2)]
+    for ct, hs, vs in yes:
+        assert b.pixels_scan_fused(640, 360, ct, hs, vs), (ct, hs, vs)
+    for ct, hs, vs in no:
+        L = b.layout(640, 360, ct, hs, vs, b.ORDER_MCU)
+        assert int(L.total_blocks) // int(L.mcus) > 6
+        assert not b.pixels_scan_fused(640, 360, ct, hs, vs), (ct, hs, vs)
+    # (the device coder's 32-bit bit offsets end at about 2.45 M blocks: 96 Mpixel 4:2:0 frames pass, 128 Mpixel ones do not)
+    assert b.pixels_scan_fused(12000, 8000, b.RGB, 2, 2) and not b.pixels_scan_fused(16000, 8000, b.RGB, 2, 2)
