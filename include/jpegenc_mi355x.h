@@ -208,8 +208,9 @@ size_t jpegenc_scan_max_bytes(const jpegenc_layout *layout, const jpegenc_scan *
  * writer.rs:138-202, 331-388): coefficient blocks in HBM -> the scan's entropy-coded bytes (0xFF
  * stuffed, 1-padded, RSTn markers included) in HBM, byte-identical to the reference's.
  * tables[d][0] = DC, [d][1] = AC of destination d; NULL selects the Annex K.3 defaults of
- * Encoder::new (encoder.rs:240-249).  d_out receives each frame's segment at f * out_frame_stride,
- * d_out_lengths[f] its length.  Asynchronous on hip_stream. */
+ * Encoder::new (encoder.rs:240-249; their device code tables are built once per device by the first call
+ * that uses them, which waits for that build - so that call cannot be stream-captured).  d_out receives each
+ * frame's segment at f * out_frame_stride, d_out_lengths[f] its length.  Asynchronous on hip_stream. */
 int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num_frames,
                         const jpegenc_layout *layout, const jpegenc_scan *scan,
                         const jpegenc_huffman_spec (*tables)[2],

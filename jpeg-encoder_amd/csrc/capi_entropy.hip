@@ -2,6 +2,8 @@
 // "entropy coding of a baseline interleaved scan on the device") and the helper the Encoder uses.
 #include <string.h>
 
+#include <mutex>
+
 #include "host_common.h"
 #include "tables_data.inc"
 
@@ -137,6 +139,32 @@ int upload_huffman_luts(const jpegenc_huffman_spec (*tables)[2], void *d_lut, hi
     return JPEGENC_OK;
 }
 
+// The code tables of the Annex K.3 default Huffman tables (tables == NULL in the C ABI) on the current device: 4 KB, built by
+// the first call that needs them (which waits for the build once - later calls may come on any stream) and kept for the
+// life of the process.  A call with default tables otherwise spends a 6 us launch on them every time.
+static const uint32_t *default_luts(hipStream_t st) {
+    static std::mutex mu;
+    static uint32_t *per_device[64] = {};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hip_fail(hipErrorInvalidDevice, "hipGetDevice"); return nullptr; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[dev]) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (st && hipStreamIsCapturing(st, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+            (void)fail(JPEGENC_ERR_INVALID_ARGUMENT, "the first call with default Huffman tables on a device cannot be stream-captured");
+            return nullptr;
+        }
+        uint32_t *lut = nullptr;
+        hipError_t e = hipMalloc((void **)&lut, 4 * 256 * 4);
+        if (e != hipSuccess) { (void)hip_fail(e, "hipMalloc of the default code tables"); return nullptr; }
+        if (upload_huffman_luts(nullptr, lut, st) != JPEGENC_OK) { (void)hipFree(lut); return nullptr; }
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)hipFree(lut); (void)hip_fail(e, "building the default code tables"); return nullptr; }
+        per_device[dev] = lut;
+    }
+    return per_device[dev];
+}
+
 // Fills the parameter block of one scan (no launch).  d_lut == nullptr: the tables are built into the
 // workspace first (that one does launch).  *d_params_out = where this workspace keeps parameter blocks.
 static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
@@ -223,6 +251,10 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
     p.out_bytes = d_out_lengths;
     if (d_lut) {
         p.lut = (const uint32_t *)d_lut;
+    } else if (!tables) {                                      // Encoder::new's defaults: built once per device, not once per call
+        const uint32_t *lut = default_luts(st);
+        if (!lut) return JPEGENC_ERR_HIP;
+        p.lut = lut;
     } else {
         int rc = upload_huffman_luts(tables, ws + pl.off_lut, st);
         if (rc) return rc;
