@@ -834,6 +834,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap, ws_off, ws; };
     std::vector<Job> jobs;
     bool supported = false;
+    void *gather = nullptr;             // where a single scan is coded to: [length][bytes] in device memory, or in pinned host memory (small frames)
     size_t first_piece = 0;             // coded bytes fetched in the same copy as the scan lengths
     bool together = false;              // the frame's scans share launches (scan_device_multi), each with its own workspace
     if (c.device_entropy) {
@@ -880,8 +881,22 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             together = jobs.size() > 1 && !together_off && ws_sum <= ((size_t)3 << 30);
             rc = ctx.reserve_scan(together ? ws_sum : ws, out_total);
             if (rc) return rc;
+            // A small single-scan frame is coded STRAIGHT into the pinned host buffer the file is assembled from (the kernels'
+            // stores cross PCIe themselves; visible to the host once the stream has drained): the download - one more node
+            // of a sequence whose every node costs 6-10 us - disappears: 256x256 75 -> 68 us, 720p 122 -> 117, nothing beyond
+            // 1080p (tools/diag/zero_copy_ab.sh).  Frames above 1 MB of pixels keep the DMA: bulk copies are what it is good
+            // at, and sixteen batch workers storing 1.5 MB scans of 1080p frames across PCIe from their kernels ran at
+            // 5 300 instead of 8 400 frames/s.
+            static const size_t zero_copy_max = [] { const char *e = getenv("JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)1 << 20); }();
+            if (jobs.size() == 1 && jobs[0].cap && pixel_bytes <= zero_copy_max) {
+                rc = ctx.reserve_scan_host(kGatherHeader + jobs[0].cap);
+                if (rc) return rc;
+                gather = ctx.h_scan_out;
+            }
         }
     }
+    if (!gather) gather = ctx.d_gather;
+    const bool host_gather = gather != ctx.d_gather;
 
     // ---- launch sequence of the frame.  With fixed Huffman tables nothing in it depends on the image
     // content, so the second consecutive frame with identical parameters and buffers captures it into a
@@ -894,7 +909,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1 && !ctx.external_planes) {
         std::string key;
         auto put = [&](const void *v, size_t n) { key.append((const char *)v, n); };
-        const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, ctx.d_gather, ctx.h_scan_out};
+        const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, gather, ctx.h_scan_out};
         const int64_t vals[] = {width, height, color_type_or_planes, (int64_t)pixel_bytes, order, c.fdct_variant, c.sampling,
                                 c.progressive_scans, c.restart_interval, (int64_t)ctx.d_scan_ws_cap, (int64_t)jobs.size(), (int64_t)fused};
         put(ptrs, sizeof ptrs); put(vals, sizeof vals); put(t.q, sizeof t.q);
@@ -926,8 +941,8 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     // likewise the parameter block of a single scan: stored outside any capture (and only when it differs from what
     // the workspace holds), so that a replayed sequence finds it in place
     if (c.device_entropy && supported && !optimize && jobs.size() == 1 && jobs[0].cap) {
-        rc = scan_store_params(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, ctx.d_lut, (uint8_t *)ctx.d_gather + kGatherHeader, jobs[0].cap,
-                               (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params, fused ? &fused_src : nullptr);
+        rc = scan_store_params(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, ctx.d_lut, (uint8_t *)gather + kGatherHeader, jobs[0].cap,
+                               (uint32_t *)gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params, fused ? &fused_src : nullptr);
         if (rc) return rc;
     }
     if (how == CAPTURE) JPEGENC_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
@@ -1016,8 +1031,8 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                     if (rc) return rc;
                 } else if (jobs.size() == 1 && jobs[0].cap) {
                     // a single scan (every baseline frame) is coded straight into the gathered layout: [length][bytes]
-                    rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, nullptr, ctx.d_lut, (uint8_t *)ctx.d_gather + kGatherHeader,
-                                     jobs[0].cap, (uint32_t *)ctx.d_gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params,
+                    rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, nullptr, ctx.d_lut, (uint8_t *)gather + kGatherHeader,
+                                     jobs[0].cap, (uint32_t *)gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params,
                                      fused ? &fused_src : nullptr);
                     if (rc) return rc;
                 } else {
@@ -1037,7 +1052,8 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                     const hipError_t ge = launch_gather_scans(ga, ctx.d_scan_out, ctx.d_scan_len, ctx.d_gather, ctx.stream);
                     if (ge != hipSuccess) return hip_fail(ge, "gather kernel launch");
                 }
-                JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out, ctx.d_gather, kGatherHeader + first_piece, hipMemcpyDeviceToHost, ctx.stream));
+                if (!host_gather)
+                    JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out, ctx.d_gather, kGatherHeader + first_piece, hipMemcpyDeviceToHost, ctx.stream));
             }
             if (how == CAPTURE) {
                 hipGraph_t g = nullptr;
@@ -1056,7 +1072,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             size_t nbytes = 0;
             uint32_t scan_len[DeviceCtx::kMaxScans];                            // (the header may move if the buffer grows)
             for (size_t k = 0; k < jobs.size(); k++) { scan_len[k] = reinterpret_cast<const uint32_t *>(ctx.h_scan_out)[k]; nbytes += scan_len[k]; }
-            if (nbytes > first_piece) {                                         // the rest of a large file
+            if (nbytes > first_piece && !host_gather) {                         // the rest of a large file
                 rc = ctx.reserve_scan_host(kGatherHeader + nbytes, kGatherHeader + first_piece);
                 if (rc) return rc;
                 JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out + kGatherHeader + first_piece, (const uint8_t *)ctx.d_gather + kGatherHeader + first_piece,
@@ -1369,6 +1385,25 @@ static int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint
     rc = ctx.open(device);
     if (rc) return rc;
     const size_t bytes = (size_t)width * (size_t)height * (size_t)jpegenc_bytes_per_pixel(color_type);
+    // A small frame (up to 1 MB of pixels) is copied into this handle's pinned host buffer and the kernel reads it from
+    // there across PCIe: no DMA node in front of the launch sequence, 10-15 us of a 70-100 us call (256x256: 65 -> 54 us,
+    // 640x480: 99 -> 86).  Pinned host memory is not cached in L2 and every pixel is read by the waves of all three
+    // components, so it stops paying between 0.9 and 1.4 MB (800x600: 102 -> 112 us; 720p: 117 -> 148) - tools/diag/zero_copy_in_sizes.sh.
+    static const size_t zero_copy_in = [] { const char *e = getenv("JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)1 << 20); }();
+    if (!staged && bytes <= zero_copy_in && !ctx.external_pixels) {
+        if (bytes > ctx.h_pixels_cap) {
+            if (ctx.h_pixels) (void)hipHostFree(ctx.h_pixels);
+            ctx.h_pixels = nullptr; ctx.h_pixels_cap = 0;
+            JPEGENC_HIP(hipHostMalloc((void **)&ctx.h_pixels, bytes, hipHostMallocDefault));
+            ctx.h_pixels_cap = bytes;
+        }
+        memcpy(ctx.h_pixels, data, bytes);
+        ctx.external_pixels = ctx.h_pixels;
+        auto nothing = [&](DeviceCtx &) -> int { return JPEGENC_OK; };
+        rc = encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, nothing, sink, user);
+        ctx.external_pixels = nullptr;
+        return rc;
+    }
     auto upload = [&](DeviceCtx &cx) -> int {
         if (staged) {       // batch workers: copy into this worker's pinned buffer, then a true async DMA
             if (bytes > cx.h_pixels_cap) {

@@ -172,15 +172,18 @@ def test_pixels_scan_device_matches_the_two_kernel_path_and_the_oracle(binding, 
         assert ref.endswith(outs[0][i] + b"\xff\xd9") and len(outs[0][i]) > 0
 
 
-@pytest.mark.parametrize("env", [{"JPEGENC_FUSED": "1"}, {"JPEGENC_FUSED": "0"}, {"JPEGENC_FUSED": "1", "JPEGENC_PACK_WINDOW_WORDS": "8"}],
-                         ids=["fused", "two-kernels", "fused-tiny-window"])
+@pytest.mark.parametrize("env", [{"JPEGENC_FUSED": "1"}, {"JPEGENC_FUSED": "0"}, {"JPEGENC_FUSED": "1", "JPEGENC_PACK_WINDOW_WORDS": "8"},
+                                 {"JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES": "0", "JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES": "0"},
+                                 {"JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES": "100000000", "JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES": "100000000"}],
+                         ids=["fused", "two-kernels", "fused-tiny-window", "dma-both-ways", "zero-copy-both-ways-any-size"])
 def test_encoder_with_and_without_the_fused_kernel(binding, tmp_path, env):
     """The Encoder codes its interleaved baseline scan of an RGB-family image straight from the pixels (one workgroup =
     one run of 64 MCUs; JPEGENC_FUSED=0 keeps block kernel + coder; the switches are read once per process, hence the
     child process): single frames (direct, captured and replayed launch sequences), restart intervals, 4-byte pixels,
     blocks longer than a lane's strip (noise at quality 100) and runs longer than the window (forced by
     JPEGENC_PACK_WINDOW_WORDS: the second-walk path), the worker-pool batch and the device-resident batch -
-    byte-identical to the oracle's files every way."""
+    byte-identical to the oracle's files every way.  Small frames are read from and coded into pinned host memory by
+    the kernels themselves (no DMA nodes); the last two runs force the DMA path and the zero-copy path for every size."""
     import os
     import subprocess
     import sys

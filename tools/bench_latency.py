@@ -18,7 +18,10 @@ synth = importlib.import_module("jpeg_encoder_amd.synth")
 
 
 def main():
-    for w, h in ((256, 256), (1280, 720), (1920, 1080), (3840, 2160)):
+    sizes = ((256, 256), (1280, 720), (1920, 1080), (3840, 2160))
+    if os.environ.get("BENCH_LATENCY_SIZES"):                 # e.g. "384x384,512x512"
+        sizes = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["BENCH_LATENCY_SIZES"].split(","))
+    for w, h in sizes:
         px = synth.test_img_rgb(w, h)
         px = np.clip(px.astype(np.int16) + np.random.default_rng(1).integers(-5, 6, px.shape, dtype=np.int16), 0, 255).astype(np.uint8)
         for name, kw in (("baseline 4:2:0 q85", dict(q=85)), ("progressive+optimised q85", dict(q=85, prog=True, opt=True))):
