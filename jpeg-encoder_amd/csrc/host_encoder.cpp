@@ -834,7 +834,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap, ws_off, ws; };
     std::vector<Job> jobs;
     bool supported = false;
-    void *gather = nullptr;             // where a single scan is coded to: [length][bytes] in device memory, or in pinned host memory (small frames)
+    void *gather = nullptr;             // where a single scan is coded to / several are gathered: [lengths][bytes] in device memory, or in pinned host memory (small frames)
     size_t first_piece = 0;             // coded bytes fetched in the same copy as the scan lengths
     bool together = false;              // the frame's scans share launches (scan_device_multi), each with its own workspace
     if (c.device_entropy) {
@@ -888,8 +888,8 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             // at, and sixteen batch workers storing 1.5 MB scans of 1080p frames across PCIe from their kernels ran at
             // 5 300 instead of 8 400 frames/s.
             static const size_t zero_copy_max = [] { const char *e = getenv("JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)1 << 20); }();
-            if (jobs.size() == 1 && jobs[0].cap && pixel_bytes <= zero_copy_max) {
-                rc = ctx.reserve_scan_host(kGatherHeader + jobs[0].cap);
+            if (out_total && pixel_bytes <= zero_copy_max) {                  // (several scans: the gather kernel writes there)
+                rc = ctx.reserve_scan_host(kGatherHeader + out_total);
                 if (rc) return rc;
                 gather = ctx.h_scan_out;
             }
@@ -1049,7 +1049,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
                     GatherArgs ga;
                     ga.n = (uint32_t)jobs.size(); ga.reserved = 0;
                     for (size_t k = 0; k < jobs.size(); k++) ga.off[k] = jobs[k].off;
-                    const hipError_t ge = launch_gather_scans(ga, ctx.d_scan_out, ctx.d_scan_len, ctx.d_gather, ctx.stream);
+                    const hipError_t ge = launch_gather_scans(ga, ctx.d_scan_out, ctx.d_scan_len, gather, ctx.stream);
                     if (ge != hipSuccess) return hip_fail(ge, "gather kernel launch");
                 }
                 if (!host_gather)
