@@ -222,8 +222,7 @@ __global__ void __launch_bounds__(256) k_scan_apply_fused(const EntropyParams *p
 __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
     __shared__ u32x2 lut64[4 * 256];
-    __shared__ __attribute__((aligned(16))) uint32_t window[4][kOnePassWindowWords];
-    __shared__ uint32_t strips[4][kPrivWords * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t area[4][kOnePassWindowWords + kPrivWords * 64];   // per wave: window | strips (contiguous)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     const bool valid = b < p.nblocks;
@@ -240,7 +239,7 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
     if (__ballot(valid) == 0) return;                                            // whole wave past the end
     const int prev_dc = where.has_prev ? prev_raw : 0;
     const bool baseline = baseline_band(p);
-    lds_word *strip = (lds_word *)strips[wave] + lane;
+    lds_word *strip = (lds_word *)(area[wave] + kOnePassWindowWords) + lane;
     PrivSink ps = {strip, strip + (kPrivWords - 1u) * 64u, 0, 0, 0};
     if (valid) {
         if (baseline) walk_once<true>(p, lut64, where.table, prev_dc, r, ps); else walk_once<false>(p, lut64, where.table, prev_dc, r, ps);
@@ -255,7 +254,7 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
     if (lane == 0) p.wsum[(size_t)f * p.nwaves + w] = total;
     const uint32_t nwords = (total + 31u) >> 5;
     uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)w * p.slot_words;
-    uint32_t *win = window[wave];
+    uint32_t *win = area[wave];
     const bool strips_hold = __ballot(mine > kPrivWords * 32u) == 0;            // wave-uniform
     if (strips_hold && nwords + 4u <= min(p.window_words, kOnePassWindowWords)) {   // wave-uniform (+4: the zero word, 16-byte copies)
         for (uint32_t i = lane; i <= nwords; i += 64u) win[i] = 0;
@@ -267,6 +266,24 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // (the window was cleared one word past the run; up to three more stale words ride along - never read)
+        for (uint32_t i = lane * 4u; i <= nwords; i += 256u)
+            *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(win + i);
+    } else if (nwords + 4u <= (p.window_words >= kOnePassWindowWords ? kOnePassWindowWords + kPrivWords * 64u : 2u * p.window_words)) {
+        // a block longer than its strip (quality 95 and up), or a run longer than the window that fits window + strips (up to
+        // 1 024 bits per block on average): second walk, bits OR-ed into that zeroed LDS area - an LDS atomic per word
+        // instead of one to HBM (which made noise at quality 98 7 x slower)
+        for (uint32_t i = lane; i <= nwords; i += 64u) win[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (valid) {
+            PackSink<LdsWords> ls = {LdsWords{(lds_word *)win + (at >> 5)}, 0, at & 31u};
+            if (baseline) walk_once<true>(p, lut64, where.table, prev_dc, r, ls); else walk_once<false>(p, lut64, where.table, prev_dc, r, ls);
+            ls.finish();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (uint32_t i = lane * 4u; i <= nwords; i += 256u)
             *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(win + i);
     } else {

@@ -73,6 +73,13 @@ struct HbmWords {
         w++;
     }
 };
+struct LdsWords {                   // the same into a zeroed LDS area (blocks longer than a strip whose run still fits the workgroup's LDS)
+    lds_word *w;
+    __device__ __forceinline__ void or_next(uint32_t v) {
+        __hip_atomic_fetch_or(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        w++;
+    }
+};
 template <class Words>
 struct PackSink {
     Words words;          // next word to complete

@@ -148,15 +148,30 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     if (p.nintervals > 1u && mine_valid) p.bits[(size_t)f * p.nblocks + (size_t)group_first * bpm + s] = at;   // (interval offsets need them, k_interval_len)
     const uint32_t nwords = (total + 31u) >> 5;
     uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)grp * p.slot_words;
-    const bool fits = *flag == 0u && nwords + 4u <= min(p.window_words, kGWin) * bpm;   // workgroup-uniform (+4: the zero word, 16-byte copies)
+    const uint32_t window_cap = min(p.window_words, kGWin) * bpm;               // (p.window_words: the tests' way to the other paths)
+    const uint32_t both_cap = p.window_words >= kGWin ? window_cap + bpm * kGPriv * 64u : 2u * window_cap;   // window + strips: contiguous
+    const bool fits = *flag == 0u && nwords + 4u <= window_cap;                   // workgroup-uniform (+4: the zero word, 16-byte copies)
     if (fits) {
         strip_to_window(strip, mine, at, (lds_word *)window);
         __syncthreads();                                                         // (3) the run is complete
         for (uint32_t i = tid * 4u; i <= nwords; i += nthreads * 4u)
             *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(window + i);
+    } else if (nwords + 4u <= both_cap) {
+        // a block longer than its strip (quality 95 and up), or a run longer than the window that fits window + strips (up
+        // to 1 024 bits per block on average: noise at quality 100 has 710): second walk, bits OR-ed into that zeroed LDS
+        // area - an LDS atomic per word instead of one to HBM, which made such frames 7 x slower
+        for (uint32_t i = tid; i < bpm * kGPriv * 64u; i += nthreads) strips[i] = 0;     // (the window is still zero)
+        __syncthreads();
+        if (mine_valid) {
+            PackSink<LdsWords> ls = {LdsWords{(lds_word *)window + (at >> 5)}, 0, at & 31u};
+            walk_once<true>(p, lut64, table, prev_dc, r, ls);
+            ls.finish();
+        }
+        __syncthreads();
+        for (uint32_t i = tid * 4u; i <= nwords; i += nthreads * 4u)
+            *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(window + i);
     } else {
-        // a block longer than its strip or a run longer than the window (pathological content): second walk, bits OR-ed
-        // straight into the zeroed slot
+        // a run longer than the workgroup's LDS (pathological content): second walk, bits OR-ed straight into the zeroed slot
         for (uint32_t i = tid; i <= nwords; i += nthreads) slot[i] = 0;
         __threadfence();
         __syncthreads();

@@ -88,5 +88,7 @@ def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "1080p":
         main(n=32, w=1920, h=1080, quality=80)
+    elif len(sys.argv) > 1 and sys.argv[1].startswith("q"):      # e.g. q98: 4K frames at another quality (long blocks: the second-walk paths)
+        main(quality=int(sys.argv[1][1:]))
     else:
         main()
