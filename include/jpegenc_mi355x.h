@@ -219,8 +219,8 @@ int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num
 
 /* Pixels in HBM -> the entropy-coded interleaved baseline scan in HBM in one call: what the body of
  * encode_image_interleaved (encoder.rs:727-804) produces between the SOS header and EOI, for `num_frames` images
- * laid out as for jpegenc_blocks_device.  For every ColorType whose MCU has at most 6 blocks (all 1- and 3-component
- * layouts with sampling factors 1 and 2, 4-component layouts up to 2x1) ONE fused kernel goes from the
+ * laid out as for jpegenc_blocks_device.  For every ColorType whose MCU has 3 to 6 blocks (all 3-component layouts
+ * with sampling factors 1 and 2, 4-component layouts up to 2x1) ONE fused kernel goes from the
  * pixels to the coded runs - colour conversion, subsampling, FDCT, quantisation, zig-zag and write_block's bits
  * (writer.rs:331-388) without the coefficients ever reaching HBM: a workgroup takes 64 consecutive MCUs with the block
  * kernel's component-uniform waves and assembles their bits in scan order in LDS (jpegenc_pixels_scan_fused returns 1;

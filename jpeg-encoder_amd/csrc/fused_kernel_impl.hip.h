@@ -47,14 +47,12 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     uint32_t *flag = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);
     const uint32_t tid = threadIdx.x, grp = blockIdx.x, f = blockIdx.y;
 
-    // the code tables first in the load queue (1 024 entries over 192 / 256 / 384 threads; the single wave of a
-    // one-component image fetches them in a loop further down)
-    const bool lut_in_regs = nthreads >= 192u;                                   // workgroup-uniform
+    // the code tables first in the load queue (1 024 entries over 192 ... 384 threads: fused_supported admits 3 to 6 waves)
     uint32_t lutv[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const uint32_t idx = (uint32_t)i * nthreads + tid;
-        lutv[i] = lut_in_regs && idx < 1024u ? ((const hbm_word *)p.lut)[idx] : 0u;
+        lutv[i] = idx < 1024u ? ((const hbm_word *)p.lut)[idx] : 0u;
     }
     const uint32_t gid = grp * nthreads + tid;
     if (gid < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + gid] = 0;      // k_push adds its 0xFF counts to these
@@ -101,17 +99,10 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     }
     if (mcu_local < 64u) dcs[s] = mine_valid ? (int16_t)(r.c[0] & 0xFFFFu) : (int16_t)0;
     // code tables to LDS: entry (code << n, size + n), n = the symbol's size category (see lut64_commit)
-    if (lut_in_regs) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const uint32_t idx = (uint32_t)i * nthreads + tid;
-            if (idx < 1024u) { const uint32_t e = lutv[i], n = idx & 15u; lut64[idx] = u32x2{(e & 0xFFFFu) << n, (e >> 16) + n}; }
-        }
-    } else {
-        for (uint32_t idx = tid; idx < 1024u; idx += nthreads) {
-            const uint32_t e = ((const hbm_word *)p.lut)[idx], n = idx & 15u;
-            lut64[idx] = u32x2{(e & 0xFFFFu) << n, (e >> 16) + n};
-        }
+    for (int i = 0; i < 6; i++) {
+        const uint32_t idx = (uint32_t)i * nthreads + tid;
+        if (idx < 1024u) { const uint32_t e = lutv[i], n = idx & 15u; lut64[idx] = u32x2{(e & 0xFFFFu) << n, (e >> 16) + n}; }
     }
     __syncthreads();                                                             // (1) DCs and tables posted, window zeroed
 

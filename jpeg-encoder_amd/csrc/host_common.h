@@ -49,7 +49,7 @@ hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_pla
 hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, hipStream_t stream, std::string *stored);
 // fused_kernels.hip: the Encoder's interleaved baseline scan coded straight from the pixels (no coefficients in HBM)
 struct FusedSource { const BlockKernelParams *blocks; int variant; };
-bool fused_supported(const BlockKernelParams &b);      // the layout has a fused kernel (interleaved order, at most 6 blocks per MCU, sampling factors 1 and 2)
+bool fused_supported(const BlockKernelParams &b);      // the layout has a fused kernel (interleaved order, 3 to 6 blocks per MCU, sampling factors 1 and 2)
 bool fused_enabled();                                    // the Encoder uses it (default; JPEGENC_FUSED=0 keeps block kernel + k_block_code)
 uint32_t fused_run_blocks(const BlockKernelParams &b);
 uint32_t fused_runs(const BlockKernelParams &b);
