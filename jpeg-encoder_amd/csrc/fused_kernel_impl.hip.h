@@ -190,7 +190,7 @@ static hipError_t launch_group_t(const BlockKernelParams &b, const ColourConsts 
     return hipGetLastError();
 }
 
-// fused_kernels_bytes.hip: the byte-plane instantiations (Luma, Ycbcr, Cmyk, Ycck)
+// fused_kernels_bytes.hip: the byte-plane instantiations (Ycbcr, Cmyk, Ycck)
 hipError_t launch_group_bytes(const BlockKernelParams &b, const ColourConsts &k, int sx, int sy, const EntropyParams *d_params, int frames,
                               int variant, hipStream_t st);
 
