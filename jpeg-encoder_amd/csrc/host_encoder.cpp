@@ -23,10 +23,37 @@
 #include <utility>
 #include <vector>
 
+#include <immintrin.h>
+
 #include "host_common.h"
 #include "tables_data.inc"
 
 namespace jpegenc {
+
+// The staging copy of a frame (the caller's pageable pixels -> a worker's pinned buffer) with streaming stores: the
+// destination is only ever read by the DMA engine, so it should neither be fetched (a cached store first reads the
+// line it overwrites) nor pushed through the worker's cache.  Per frame byte the host memory then moves read + write +
+// DMA read = 3 instead of 4 - what matters when eight ranks stage 50 GB/s each through the two sockets' DRAM
+// (the host side is the limiter of the 8-GPU batch).  JPEGENC_PLAIN_STAGING_COPY=1 = memcpy.
+__attribute__((target("avx2"))) static void stream_copy_avx2(uint8_t *dst, const uint8_t *src, size_t n) {
+    size_t head = (size_t)(-(uintptr_t)dst & 31u);
+    if (head > n) head = n;
+    if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(src + i)), b = _mm256_loadu_si256((const __m256i *)(src + i + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i *)(src + i + 64)), d = _mm256_loadu_si256((const __m256i *)(src + i + 96));
+        _mm256_stream_si256((__m256i *)(dst + i), a); _mm256_stream_si256((__m256i *)(dst + i + 32), b);
+        _mm256_stream_si256((__m256i *)(dst + i + 64), c); _mm256_stream_si256((__m256i *)(dst + i + 96), d);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+static void staging_copy(void *dst, const void *src, size_t n) {
+    static const bool streaming = [] { return !getenv("JPEGENC_PLAIN_STAGING_COPY") && __builtin_cpu_supports("avx2"); }();
+    if (streaming && n >= ((size_t)256 << 10)) stream_copy_avx2((uint8_t *)dst, (const uint8_t *)src, n);
+    else memcpy(dst, src, n);
+}
 
 // T.81 Figure A.6 (writer.rs:64-68)
 static const uint8_t kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -884,9 +911,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             // A small single-scan frame is coded STRAIGHT into the pinned host buffer the file is assembled from (the kernels'
             // stores cross PCIe themselves; visible to the host once the stream has drained): the download - one more node
             // of a sequence whose every node costs 6-10 us - disappears: 256x256 75 -> 68 us, 720p 122 -> 117, nothing beyond
-            // 1080p (tools/diag/zero_copy_ab.sh).  Frames above 1 MB of pixels keep the DMA: bulk copies are what it is good
-            // at, and sixteen batch workers storing 1.5 MB scans of 1080p frames across PCIe from their kernels ran at
-            // 5 300 instead of 8 400 frames/s.
+            // 1080p (tools/diag/zero_copy_ab.sh).  Frames above 1 MB of pixels keep the DMA: bulk copies are what it is good at.
             static const size_t zero_copy_max = [] { const char *e = getenv("JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)1 << 20); }();
             if (out_total && pixel_bytes <= zero_copy_max) {                  // (several scans: the gather kernel writes there)
                 rc = ctx.reserve_scan_host(kGatherHeader + out_total);
@@ -1412,7 +1437,7 @@ static int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint
                 JPEGENC_HIP(hipHostMalloc((void **)&cx.h_pixels, bytes, hipHostMallocDefault));
                 cx.h_pixels_cap = bytes;
             }
-            memcpy(cx.h_pixels, data, bytes);
+            staging_copy(cx.h_pixels, data, bytes);
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, cx.h_pixels, bytes, hipMemcpyHostToDevice, cx.stream));
         } else {
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
@@ -1851,7 +1876,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
                     for (;;) {
                         const int i = nextf.fetch_add(1);
                         if (i >= hi) break;
-                        memcpy(sb.h[slot] + (size_t)i * frame_bytes, frames[first + i], frame_bytes);
+                        staging_copy(sb.h[slot] + (size_t)i * frame_bytes, frames[first + i], frame_bytes);
                     }
                 };
                 std::vector<std::thread> th;
