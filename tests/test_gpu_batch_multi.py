@@ -335,3 +335,40 @@ def test_encode_planes_device_luma_and_cmyk(binding, oracle, synth):
         # and YCCK planes as they are = ColorType::Ycck
         got = e.encode_planes_device(binding.J_YCCK, w, h, [(dp[c].data_ptr(), w, 1, 0) for c in range(4)])
         assert got == oracle.encode_jpeg(cmyk, w, h, oracle.YCCK, **kw), kw
+
+
+@pytest.mark.parametrize("quality,hs,vs", [(100, 1, 1), (100, 2, 2), (97, 2, 2)])
+def test_long_blocks_take_the_lds_second_walk(binding, oracle, synth, quality, hs, vs):
+    """Noise at quality 97-100: blocks of up to ~1 700 bits - longer than a lane's 512-bit strip - and runs longer than the
+    LDS window, i.e. the second walk into window + strips (and, for the longest runs, into the HBM slot), at a size with
+    hundreds of groups: jpegenc_pixels_scan_device against jpegenc_blocks_device + jpegenc_scan_device and the oracle."""
+    import torch
+    w, h, n = 1920, 1080, 2
+    rng = np.random.default_rng(quality + hs)
+    px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    px[1, :, : w // 2] = synth.test_img_rgb(w, h)[:, : w // 2]              # half of the second frame smooth: short and long runs side by side
+    d_px = torch.from_numpy(px).cuda()
+    L = binding.layout(w, h, binding.RGB, hs, vs, binding.ORDER_MCU)
+    scan = binding.baseline_scan()
+    cap, wsz = binding.scan_max_bytes(L, scan), binding.scan_workspace_size(L, scan, n)
+    q = binding.qtables(quality)
+    nblk = int(L.total_blocks)
+    d_co = torch.empty((n, nblk * 64), dtype=torch.int16, device="cuda")
+    d_ws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+    outs = []
+    for which in ("one-kernel", "two"):
+        d_out = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
+        d_len = torch.zeros(n, dtype=torch.int32, device="cuda")
+        if which == "one-kernel":
+            binding.pixels_scan_device(d_px.data_ptr(), w * h * 3, n, w, h, binding.RGB, hs, vs, q, d_out.data_ptr(), cap, d_len.data_ptr(),
+                                       d_ws.data_ptr(), wsz)
+        else:
+            binding.blocks_device(d_px.data_ptr(), w * h * 3, n, w, h, binding.RGB, hs, vs, q, binding.ORDER_MCU, binding.FDCT_SCALAR,
+                                  d_co.data_ptr(), nblk)
+            binding.scan_device(d_co.data_ptr(), nblk, n, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(), d_ws.data_ptr(), wsz)
+        torch.cuda.synchronize()
+        outs.append([bytes(d_out[i, :int(d_len[i])].cpu().numpy()) for i in range(n)])
+    assert outs[0] == outs[1]
+    for i in range(n):
+        ref = oracle.encode_jpeg(px[i], w, h, oracle.RGB, quality, sampling=(hs, vs))
+        assert ref.endswith(outs[0][i] + b"\xff\xd9") and len(outs[0][i]) > 1_000_000
