@@ -217,7 +217,10 @@ struct ByteConv {          // the sample is a byte of the pixel word itself
 #ifndef JPEGENC_MIN_WAVES
 #define JPEGENC_MIN_WAVES 5
 #endif
-#define JPEGENC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(JPEGENC_MIN_WAVES)))
+// The SIMD-variant instantiations of the byte-plane kernels spill ~19 SGPRs (the variant's extra constants), and at the
+// 5-wave budget some of them also spill VGPRs - the combination hipcc 7.2 got wrong in the pixels -> bits kernel
+// (fused_kernel_impl.hip.h).  These pass every test as compiled, but they get the 4-wave budget (no VGPR spills) anyway.
+#define JPEGENC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(VARIANT == 1 && !CONV ? 4 : JPEGENC_MIN_WAVES)))
 // CONV = the kernel carries the RGB -> YCbCr roles (RGB family, CmykAsYcck); otherwise byte planes only.
 // 3-byte RGB with sampling factors 1 and 2 has at most 6 waves per 64-MCU group; 4:1:0-style factors (4x2), CmykAsYcck
 // and 4-component layouts up to 10.

@@ -15,7 +15,9 @@ namespace jpegenc {
 // keeps every row load of a block in flight (104 VGPRs) and the kernel is 12 % slower - the block kernel's own finding.
 // The SIMD-variant instantiations stay at 4: their extra scalar constants push the kernel past the SGPR file, and at the
 // 5-wave budget the VGPRs that hold the spilled SGPRs are themselves spilled to scratch - code that hipcc 7.2 gets wrong
-// (scan bytes differ, memory faults; caught by test_encoder_simd_variant_file).  SGPR spills alone (4 waves) are fine.
+// (scan bytes differ, memory faults; caught by test_encoder_simd_variant_file).  SGPR spills alone (4 waves) are fine; the
+// byte-plane SIMD-variant instantiations need 3 waves (168 VGPRs) to keep their 40 spilled SGPRs in VGPRs that are not
+// spilled themselves.
 #ifndef JPEGENC_GROUP_WAVES
 #define JPEGENC_GROUP_WAVES 5
 #endif
@@ -34,7 +36,7 @@ __host__ __device__ inline uint32_t group_lds_bytes(uint32_t bpm) {
 }
 
 template <int BPP, int SX, int SY, int VARIANT, bool CONV>
-__global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 ? 4 : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
+__global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 ? (CONV ? 4 : 3) : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
 k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

@@ -9,9 +9,12 @@ run() {  # name, env..., then pytest -k expr
   ( env "$@" timeout 1500 python3 -m pytest tests/test_gpu_parity.py -q -x -k test_randomised_configurations 2>&1 | tail -3; echo "rc=$?" ) > $out/${tag}_soak_$name.log 2>&1
   tail -2 $out/${tag}_soak_$name.log
 }
-run small_a JPEGENC_FUZZ_SEED=101 JPEGENC_FUZZ_TRIALS=10000
-run small_b JPEGENC_FUZZ_SEED=202 JPEGENC_FUZZ_TRIALS=10000
-run large JPEGENC_FUZZ_SEED=303 JPEGENC_FUZZ_TRIALS=1200 JPEGENC_FUZZ_MAX_W=2100 JPEGENC_FUZZ_MAX_H=1300
-run two_kernels JPEGENC_FUSED=0 JPEGENC_FUZZ_SEED=404 JPEGENC_FUZZ_TRIALS=4000
+S=${SOAK_SEED:-100}
+run small_a JPEGENC_FUZZ_SEED=$((S + 1)) JPEGENC_FUZZ_TRIALS=20000
+run small_b JPEGENC_FUZZ_SEED=$((S + 2)) JPEGENC_FUZZ_TRIALS=20000
+run medium JPEGENC_FUZZ_SEED=$((S + 5)) JPEGENC_FUZZ_TRIALS=6000 JPEGENC_FUZZ_MAX_W=700 JPEGENC_FUZZ_MAX_H=500
+run large JPEGENC_FUZZ_SEED=$((S + 3)) JPEGENC_FUZZ_TRIALS=1500 JPEGENC_FUZZ_MAX_W=2100 JPEGENC_FUZZ_MAX_H=1300
+run two_kernels JPEGENC_FUSED=0 JPEGENC_FUZZ_SEED=$((S + 4)) JPEGENC_FUZZ_TRIALS=6000
+run dma_only JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES=0 JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES=0 JPEGENC_FUZZ_SEED=$((S + 6)) JPEGENC_FUZZ_TRIALS=6000
 ( JPEGENC_FUZZ_SEED=9 JPEGENC_GEOMETRY_TRIALS=1500 timeout 1200 python3 -m pytest tests/test_gpu_parity.py -q -x -k test_blocks_random_geometry 2>&1 | tail -2 ) > $out/${tag}_soak_geometry.log 2>&1
 tail -1 $out/${tag}_soak_geometry.log
