@@ -296,7 +296,8 @@ int  jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int
  * shares its launches (one fused block-encode launch, one launch sequence per scan for all frames);
  * only the compressed bytes come back.  With optimised Huffman tables (per-frame tables), the host
  * entropy coder, or frames too large for the device entropy coder (jpegenc_scan_max_bytes == 0: about
- * 2.45 M blocks and more) the frames are encoded one at a time - same bytes either way. */
+ * 2.45 M blocks and more) every frame takes the single-image path instead, up to 16 of them in flight on
+ * as many host workers (each with its own stream and buffers) - same bytes either way. */
 int  jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride,
                                          int num_frames, int width, int height, int color_type,
                                          jpegenc_write_fn sink, void *const *users);

@@ -1728,6 +1728,48 @@ int jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int 
     return rc;
 }
 
+// Device-resident frames one image at a time - every frame gets its own Huffman tables (optimised mode: a host step
+// between its statistics and its scans), or the host codes the entropy, or the device coder declines the geometry - but
+// sixteen at a time: one host worker per in-flight frame, each with its own stream and buffers, so the synchronisation
+// points of one frame are covered by the others (a batch of 8 optimised 4K frames: 283 us per frame one by one).
+static int encode_device_frames_pooled(jpegenc_encoder *e, const void *d_frames, size_t frame_stride, int num_frames, int width, int height,
+                                       int color_type, jpegenc_write_fn sink, void *const *users) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int workers = e->max_batch_workers < (int)(hw ? hw : 4) ? e->max_batch_workers : (int)(hw ? hw : 4);
+    if (workers > num_frames) workers = num_frames;
+    if (workers < 1) workers = 1;
+    while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
+    const size_t bytes = (size_t)width * (size_t)height * (size_t)jpegenc_bytes_per_pixel(color_type);
+    std::atomic<int> next(0), status(JPEGENC_OK);
+    std::vector<std::string> messages((size_t)workers);
+    auto body = [&](int w) {
+        if (w > 0) bind_thread_near_device(e->device);
+        DeviceCtx &ctx = *e->workers[(size_t)w];
+        int r = ctx.open(e->device);
+        while (r == JPEGENC_OK) {
+            const int i = next.fetch_add(1);
+            if (i >= num_frames || status.load() != JPEGENC_OK) break;
+            ctx.external_pixels = (const uint8_t *)d_frames + (size_t)i * frame_stride;
+            auto upload = [&](DeviceCtx &) -> int { return JPEGENC_OK; };
+            r = encode_frame(e->cfg, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, users[i]);
+            ctx.external_pixels = nullptr;
+        }
+        if (r != JPEGENC_OK) {
+            int expected = JPEGENC_OK;
+            if (status.compare_exchange_strong(expected, r)) messages[(size_t)w] = jpegenc_last_error();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < workers; w++) pool.emplace_back(body, w);
+    body(0);
+    for (auto &th : pool) th.join();
+    if (status.load() != JPEGENC_OK) {
+        for (const auto &m : messages) if (!m.empty()) { set_last_error(m); break; }
+        return status.load();
+    }
+    return JPEGENC_OK;
+}
+
 int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride, int num_frames,
                                         int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
     REQUIRE(e);
@@ -1739,21 +1781,12 @@ int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames
     if (num_frames == 0) return JPEGENC_OK;
     const bool per_frame_tables = e->cfg.optimize && select_mode(e->cfg) != MODE_INTERLEAVED;
     if (!e->cfg.device_entropy || per_frame_tables) {
-        // host entropy coding was asked for, or every frame gets its own Huffman tables: one image at a time
-        for (int i = 0; i < num_frames; i++) {
-            int rc = jpegenc_encoder_encode_device(e, (const uint8_t *)d_frames + (size_t)i * frame_stride, width, height, color_type,
-                                                   sink, users[i]);
-            if (rc) return rc;
-        }
-        return JPEGENC_OK;
+        // host entropy coding was asked for, or every frame gets its own Huffman tables: one image at a time per worker
+        return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
     }
     const int rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
     if (rc != kBatchNeedsPerFrame) return rc;
-    for (int i = 0; i < num_frames; i++) {
-        const int r = jpegenc_encoder_encode_device(e, (const uint8_t *)d_frames + (size_t)i * frame_stride, width, height, color_type, sink, users[i]);
-        if (r) return r;
-    }
-    return JPEGENC_OK;
+    return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
 }
 
 int jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len, int width, int height,
