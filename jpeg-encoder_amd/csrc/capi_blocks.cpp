@@ -3,6 +3,7 @@
 // entry points fail with JPEGENC_ERR_NO_DEVICE / JPEGENC_ERR_HIP when no MI355X is usable.
 #include <string.h>
 
+#include <chrono>
 #include <string>
 
 #include "host_common.h"
@@ -389,11 +390,21 @@ int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame
     if (rc) return rc;
 
     const size_t tile_bytes = (size_t)L.total_blocks * 128;
+    static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    double cb_seconds = 0;
     StreamPipe pipe;
     const int slots = num_frames < StreamPipe::kSlots ? num_frames : StreamPipe::kSlots;
-    JPEGENC_HIP(hipStreamCreateWithFlags(&pipe.s_up, hipStreamNonBlocking));
-    JPEGENC_HIP(hipStreamCreateWithFlags(&pipe.s_k, hipStreamNonBlocking));
-    JPEGENC_HIP(hipStreamCreateWithFlags(&pipe.s_dn, hipStreamNonBlocking));
+    // The three streams must sit on three different hardware queues or the two copy directions serialise (a process
+    // has 4 hardware queues per priority; streams are dealt onto them in creation order, so in a process that already
+    // holds a handful of streams - bench.py's - upload and download streams of equal priority landed on the same queue
+    // and the pipeline ran at 25 instead of 47 GB/s each way).  Each priority has its own queues: one stream per priority.
+    int prio_least = 0, prio_greatest = 0;
+    JPEGENC_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    const int prio_mid = (prio_least + prio_greatest) / 2;
+    JPEGENC_HIP(hipStreamCreateWithPriority(&pipe.s_up, hipStreamNonBlocking, prio_greatest));
+    JPEGENC_HIP(hipStreamCreateWithPriority(&pipe.s_dn, hipStreamNonBlocking, prio_mid != prio_greatest ? prio_mid : prio_least));
+    JPEGENC_HIP(hipStreamCreateWithPriority(&pipe.s_k, hipStreamNonBlocking, prio_least));
     bool all_pinned = true;
     for (int i = 0; i < num_frames && all_pinned; i++) all_pinned = is_pinned_host(frames[i]);
     for (int j = 0; j < slots; j++) {
@@ -423,10 +434,13 @@ int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame
     auto deliver = [&](int i) -> int {
         StreamSlot &x = pipe.slot[i % slots];
         JPEGENC_HIP(hipEventSynchronize(x.down));
+        const auto c0 = std::chrono::steady_clock::now();
         const int cb = callback(user, i, (const int16_t *)x.h_out, (size_t)L.total_blocks);
+        cb_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
         if (cb != 0) return fail(JPEGENC_ERR_WRITE, "tile callback returned " + std::to_string(cb));
         return JPEGENC_OK;
     };
+    const auto t_ready = std::chrono::steady_clock::now();
     const int ahead = slots > 2 ? 2 : 1;
     for (int i = 0; i < ahead && i < num_frames; i++)
         if ((rc = upload(i))) return rc;
@@ -445,6 +459,10 @@ int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame
     }
     for (int i = num_frames > slots ? num_frames - slots : 0; i < num_frames; i++)
         if ((rc = deliver(i))) return rc;
+    if (trace)
+        fprintf(stderr, "[jpegenc] blocks_stream: %d frames, %d slots, pinned input %d: setup %.2f ms, pipeline %.2f ms of which callbacks %.2f ms\n",
+                num_frames, slots, (int)all_pinned, std::chrono::duration<double>(t_ready - t_begin).count() * 1e3,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count() * 1e3, cb_seconds * 1e3);
     return JPEGENC_OK;
 }
 

@@ -266,6 +266,16 @@ struct Restart {
     }
 };
 
+// A side stream whose copies must overlap the work of a handle's main stream: created at the highest priority, because
+// every priority has its own hardware queues - two streams of equal priority may be dealt onto the SAME queue (4 per
+// process, in creation order) and then run one after the other (capi_blocks.cpp: jpegenc_blocks_stream lost half its rate so).
+static hipError_t create_side_stream(hipStream_t *s) {
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
 // ---------------------------------------------------------------------------------------------
 struct DeviceCtx {
     int device = -1;
@@ -454,7 +464,7 @@ struct SmallBatchBuffers {
     hipEvent_t done[2] = {nullptr, nullptr};
     int reserve(size_t bytes) {
         if (!up) {
-            JPEGENC_HIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+            JPEGENC_HIP(create_side_stream(&up));
             for (auto &ev : done) JPEGENC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         }
         if (bytes <= cap) return JPEGENC_OK;
@@ -503,7 +513,7 @@ struct BatchBuffers {
     hipEvent_t coded[2] = {nullptr, nullptr};
     int open_streams() {
         if (copy_stream) return JPEGENC_OK;
-        JPEGENC_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        JPEGENC_HIP(create_side_stream(&copy_stream));
         for (auto &e : coded) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         return JPEGENC_OK;
     }
