@@ -182,7 +182,9 @@ def link_rates(torch, dev, nbytes=24_883_200, reps=24):
     h_in = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
     h_out = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
     d = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-    s_up, s_dn = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    # (different priorities: each priority has its own hardware queues - two streams of equal priority can be dealt onto the
+    # same queue of the process, and then the two directions run one after the other: the 11.5 GB/s 'both' outliers of r02_b)
+    s_up, s_dn = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)
 
     def run(up, dn, n):
         torch.cuda.synchronize()
