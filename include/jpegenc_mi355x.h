@@ -330,6 +330,9 @@ int  jpegenc_encoder_encode_image(jpegenc_encoder *e, int jpeg_color_type, int w
  *   planes_subsampled = 1: a component the sampling factor decimates by (sx, sy) is given as ceil(width / sx) x
  *     ceil(height / sy) samples (4:2:0 / 4:2:2 surfaces as decoders produce them).  Same bytes as an ImageBuffer that
  *     repeats each such sample sx x sy times: get_block reads exactly one sample per repeat.
+ * One launch covers all planes - every wave reads its own plane (address, pitch, size and sample stride come from the
+ * wave's record) - and an interleaved baseline scan goes from the samples to the coded runs in ONE kernel, like the
+ * interleaved pixel formats; sampling factors of 4 take one block-kernel launch per plane.
  * The planes must stay valid and unmodified until the call returns.  Every Encoder mode applies (progressive,
  * optimised tables, restart intervals ...).  Sampling factors of 4 are not taken for two-byte pixel strides. */
 typedef struct jpegenc_plane {

@@ -8,7 +8,7 @@ bdir="${JPEGENC_BUILD_DIR:-${here}/build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-const-variable -Wno-unused-function
        -I"${here}/../../include")
-srcs=("${here}"/block_kernels.hip "${here}"/fast_kernels.hip "${here}"/fast_kernels_bytes.hip "${here}"/fast_kernels_s4.hip "${here}"/fast_kernels_bytes_s4.hip "${here}"/fused_kernels.hip "${here}"/fused_kernels_bytes.hip "${here}"/entropy_kernels.hip "${here}"/capi_entropy.hip "${here}"/capi_blocks.cpp "${here}"/host_encoder.cpp)
+srcs=("${here}"/block_kernels.hip "${here}"/fast_kernels.hip "${here}"/fast_kernels_bytes.hip "${here}"/fast_kernels_s4.hip "${here}"/fast_kernels_bytes_s4.hip "${here}"/fused_kernels.hip "${here}"/fused_kernels_bytes.hip "${here}"/fast_kernels_planes.hip "${here}"/entropy_kernels.hip "${here}"/capi_entropy.hip "${here}"/capi_blocks.cpp "${here}"/host_encoder.cpp)
 objs=()
 mkdir -p "${bdir}"
 pids=()

@@ -261,7 +261,8 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
         p.lut = (const uint32_t *)(ws + pl.off_lut);
     }
     if (fused) {             // runs = what a wave of the fused kernel holds: whole MCUs in scan order
-        if (sc.component >= 0 || !sc.with_dc || sc.ac_start != 1 || sc.ac_end != 64 || !fused_supported(*fused->blocks))
+        if (sc.component >= 0 || !sc.with_dc || sc.ac_start != 1 || sc.ac_end != 64 ||
+            !(fused->planes ? fused_planes_supported(*fused->blocks, fused->planes, fused->planes_subsampled) : fused_supported(*fused->blocks)))
             return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan cannot be coded by the fused kernel");
         p.run_blocks = fused_run_blocks(*fused->blocks);
         p.nwaves = fused_runs(*fused->blocks);
@@ -377,7 +378,7 @@ int jpegenc_pixels_scan_device(const void *d_pixels, size_t pixel_frame_stride, 
     const jpegenc_scan sc = {-1, 1, 1, 64, restart_interval};
     hipStream_t st = (hipStream_t)hip_stream;
     if (fused_supported(b)) {
-        const FusedSource src = {&b, fdct_variant};
+        const FusedSource src = {&b, fdct_variant, nullptr, false};
         return scan_device(d_coeffs, b.coeff_frame_stride, num_frames, L, sc, huffman, nullptr, d_out, out_frame_stride, d_out_lengths,
                            d_workspace, workspace_bytes, st, nullptr, &src);
     }

@@ -46,10 +46,12 @@ struct alignas(64) FastWave {         // one per wave of a group, indexed by the
     uint32_t limit;                   // MCUs of the frame
     uint32_t magic, shift;            // n / units_x == (n * magic) >> shift for every n < 2^26
     uint32_t out_base_lo, out_base_hi;   // MCU order: index of the wave's first block inside an MCU; planar: component offset
-    uint32_t conv[3];                 // the role's conversion constants (luma / chroma udot4: lo, hi, xor; chroma sdot2: sel, k, shift)
+    uint32_t conv[3];                 // the role's conversion constants (luma / chroma udot4: lo, hi, xor; chroma sdot2: sel, k, shift);
+                                      // PLANES kernels (one described plane per component): the plane's pitch, width | height << 16,
+                                      // MCU width | MCU height << 16 in its own samples
     uint32_t byte_pack;               // ROLE_BYTE: v_perm selector of the sample byte
     uint32_t rows;                    // planar order: block rows of this component's plane
-    uint32_t plane_lo, plane_hi;      // XF_PLANES: byte offset of the component's plane
+    uint32_t plane_lo, plane_hi;      // XF_PLANES: byte offset of the component's plane (PLANES kernels: its address, FastHeader::pixels = 0)
 };
 enum : uint32_t {                     // FastWave::bits
     FW_COMP_SHIFT = 0,                // 2 bits
@@ -61,6 +63,7 @@ enum : uint32_t {                     // FastWave::bits
     FW_INVERT_SHIFT = 11,             // 1 bit: ROLE_BYTE sample = 255 - byte
     FW_LGV_SHIFT = 12,                // 2 bits: log2 of the component's block rows per MCU (= log2 v)
     FW_COUNT_SHIFT = 14,              // 7 bits: MCUs this wave covers (64 >> lg, fewer when the group is smaller than that)
+    FW_BPP2_SHIFT = 21,               // 1 bit: described planes (PLANES kernels) - the samples of this component are two bytes apart
 };
 
 struct BlockKernelParams {

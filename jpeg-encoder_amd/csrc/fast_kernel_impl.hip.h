@@ -302,7 +302,10 @@ struct WaveCtx {
 // Prologue + fetch + conversion + FDCT + quantiser of one wave over one group of 64 MCUs of frame `frm` (see the notes
 // at the top of the file): packed[j] = zig-zag coefficients (2j, 2j + 1) of the lane's block.  false: a padding wave
 // of the last group (nothing computed).
-template <int BPP, int SX, int SY, int VARIANT, bool CONV>
+// PLANES: a device-resident planar surface described per component (jpegenc_plane: I420 / NV12 / planar CMYK ...) in ONE
+// launch - every wave takes its plane's address, pitch, size, MCU size and sample stride (1 or 2 bytes; BPP = 2 is then
+// the largest stride the kernel is built for) from its FastWave record instead of the frame-wide header.
+template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
 __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint32_t grp, const uint32_t frm, WaveCtx &w, uint32_t (&packed)[32]) {
 #ifdef JPEGENC_WAVE_TIMING
     w.tm0 = __builtin_readcyclecounter();
@@ -332,8 +335,11 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0];
     const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4];
     const gbytes frame = (gbytes)(uintptr_t)(px_base + (size_t)frm * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]));
-    const int width = (int)H[8], hlim = (int)H[9] - 1;
-    const uint32_t pitch = H[10];                                   // frame bytes < 2^31 (checked by the launcher)
+    const int width = PLANES ? (int)(Wv[10] & 0xFFFFu) : (int)H[8], hlim = (PLANES ? (int)(Wv[10] >> 16) : (int)H[9]) - 1;
+    const uint32_t pitch = PLANES ? Wv[9] : H[10];                  // frame bytes < 2^31 (checked by the launcher)
+    const uint32_t mcu_w = PLANES ? Wv[11] & 0xFFFFu : H[13], mcu_h = PLANES ? Wv[11] >> 16 : H[14];
+    const bool two_bytes = PLANES && ((bits >> FW_BPP2_SHIFT) & 1u);  // wave-uniform
+    const int bpp = PLANES ? (two_bytes ? 2 : 1) : BPP;
     const int sxc = sub ? SX : 1, syc = sub ? SY : 1;
 
     // this lane's block: MCU (ux, uy), then block sub_k of the wave's block row inside it
@@ -352,11 +358,11 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     w.col0 = col0; w.row0 = row0; w.dm = dm; w.sub_k = sub_k; w.ux = ux; w.uy = uy; w.inside = inside;
     w.frame = frame; w.pitch = pitch; w.width = width; w.hlim = hlim;
     BlockRef me;
-    me.x0 = (int)(ux * H[13] + sub_k * 8u * (uint32_t)sxc);
-    me.y0 = (int)(uy * H[14] + vrow * 8u * (uint32_t)syc);
+    me.x0 = (int)(ux * mcu_w + sub_k * 8u * (uint32_t)sxc);
+    me.y0 = (int)(uy * mcu_h + vrow * 8u * (uint32_t)syc);
     const bool aligned4 = (((uintptr_t)frame | pitch) & 3u) == 0;   // wave-uniform
-    const uint32_t first = (uint32_t)me.y0 * pitch + (uint32_t)me.x0 * BPP;
-    const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * BPP;
+    const uint32_t first = (uint32_t)me.y0 * pitch + (uint32_t)me.x0 * (uint32_t)bpp;
+    const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * (uint32_t)bpp;
     uint32_t rows[8][4];
 #ifdef JPEGENC_WAVE_TIMING
     __builtin_amdgcn_sched_barrier(0);
@@ -388,7 +394,15 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
             // byte b of each pixel word -> zero-extended 16-bit pair; `255 - v` as one packed subtract.
             // In the conversion kernels only CmykAsYcck's K plane (4-byte pixels, never decimated) gets here.
             const uint32_t pack = Wv[12];
-            if (!CONV && sub && (SX > 1 || SY > 1)) fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
+            if (PLANES) {                                           // the sample stride is the plane's (wave-uniform)
+                if (two_bytes) {
+                    if (sub && (SX > 1 || SY > 1)) fetch_rows<2, SX, SY>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
+                    else fetch_rows<2, 1, 1>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
+                } else {
+                    if (sub && (SX > 1 || SY > 1)) fetch_rows<1, SX, SY>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
+                    else fetch_rows<1, 1, 1>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
+                }
+            } else if (!CONV && sub && (SX > 1 || SY > 1)) fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
             else fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
             if ((bits >> FW_INVERT_SHIFT) & 1u) {
 #pragma unroll
@@ -405,7 +419,7 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
             const gbytes row = frame + (size_t)min(me.y0 + y * syc, hlim) * pitch;
             uint32_t v[8];
 #pragma unroll
-            for (int x = 0; x < 8; x++) v[x] = edge_sample(row + (size_t)min(me.x0 + x * sxc, width - 1) * BPP, role, c, k);
+            for (int x = 0; x < 8; x++) v[x] = edge_sample(row + (size_t)min(me.x0 + x * sxc, width - 1) * (size_t)bpp, role, c, k);
             rows[y][0] = v[0] | (v[1] << 16); rows[y][1] = v[3] | (v[2] << 16);
             rows[y][2] = v[7] | (v[6] << 16); rows[y][3] = v[4] | (v[5] << 16);
         }
@@ -426,11 +440,11 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
 }
 
 // The life of one wave of the block kernel: compute, [count symbols], stage and store.
-template <int BPP, int SX, int SY, int VARIANT, bool CONV>
+template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
 __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const ColourConsts &k, uint8_t *smem, const uint32_t grp, const uint32_t frm) {
     WaveCtx w;
     uint32_t packed[32];
-    if (!block_compute<BPP, SX, SY, VARIANT, CONV>(k, grp, frm, w, packed)) return;
+    if (!block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, frm, w, packed)) return;
     const u32x16 H = w.H, Wv = w.Wv;
     const uint32_t lane = w.lane, wave = w.wave, order = w.order, lg = w.lg, lgv = w.lgv, vrow = w.vrow, sub_k = w.sub_k, ux = w.ux, uy = w.uy;
     const uint32_t first_unit = w.first_unit, wave_mcus = w.wave_mcus, limit = w.limit, units_x = w.units_x, magic = w.magic, shift = w.shift;
@@ -489,7 +503,7 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
 #endif
 }
 
-template <int BPP, int SX, int SY, int VARIANT, bool CONV>
+template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
 __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY <= 4 ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef JPEGENC_PERSISTENT
@@ -498,10 +512,10 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
     const uint32_t total = p.groups * p.persistent_frames;
     for (uint32_t item = blockIdx.x + blockIdx.y * gridDim.x; item < total * 1u; item += gridDim.x * gridDim.y) {
         const uint32_t frm = item / p.groups;
-        block_wave<BPP, SX, SY, VARIANT, CONV>(p, k, smem, item - frm * p.groups, frm);
+        block_wave<BPP, SX, SY, VARIANT, CONV, PLANES>(p, k, smem, item - frm * p.groups, frm);
     }
 #else
-    block_wave<BPP, SX, SY, VARIANT, CONV>(p, k, smem, blockIdx.x, blockIdx.y);
+    block_wave<BPP, SX, SY, VARIANT, CONV, PLANES>(p, k, smem, blockIdx.x, blockIdx.y);
 #endif
 }
 
@@ -510,7 +524,10 @@ unsigned long long *wave_timing_buffer();      // fast_kernels.hip
 #endif
 
 // Host side of the prologue: the FastHeader / FastWave records of a launch.
-static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k, int bpp, int sx, int sy, bool conv) {
+// planes != nullptr: the PLANES kernels - component c is the described plane planes[c] (of ceil(width / sx) x ceil(height / sy)
+// samples when planes_subsampled and the sampling factor decimates it, else width x height).
+static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k, int bpp, int sx, int sy, bool conv,
+                                    const jpegenc_plane *planes = nullptr, bool planes_subsampled = false) {
     // A group is 64 MCUs where that needs at most 10 waves (every layout of 1 - 3 components), else 32 or 16 MCUs
     // (4-component layouts with 4x2 / 2x4 sampling: 11 or 18 waves per 64 MCUs).  A wave takes one row of a component's
     // blocks inside the MCU from 64 / h MCUs - or from the whole group if that is smaller (its other lanes idle).
@@ -531,8 +548,8 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
     q.groups = (q.total_mcus + group - 1u) / group;
     FastHeader &h = q.fast_hdr;
     memset(&h, 0, sizeof h);
-    h.pixels = (uint64_t)(uintptr_t)q.pixels; h.coeffs = (uint64_t)(uintptr_t)q.coeffs;
-    h.pixel_frame_stride = q.pixel_frame_stride; h.coeff_frame_stride = q.coeff_frame_stride;
+    h.pixels = planes ? 0u : (uint64_t)(uintptr_t)q.pixels; h.coeffs = (uint64_t)(uintptr_t)q.coeffs;
+    h.pixel_frame_stride = planes ? 0u : q.pixel_frame_stride; h.coeff_frame_stride = q.coeff_frame_stride;
     h.width = (uint32_t)q.width; h.height = (uint32_t)q.height; h.pitch = q.pitch_bytes ? q.pitch_bytes : (uint32_t)q.width * (uint32_t)bpp;
     h.order = (uint32_t)q.order; h.bpm = q.bpm;
     h.mcu_w = q.plane_mcu_w ? q.plane_mcu_w : 8u * (uint32_t)q.hmax; h.mcu_h = q.plane_mcu_h ? q.plane_mcu_h : 8u * (uint32_t)q.vmax;
@@ -567,7 +584,8 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
         while ((1u << l2) < f.units_x) l2++;
         f.shift = 26u + l2;
         f.magic = (uint32_t)((((uint64_t)1 << f.shift) + f.units_x - 1u) / f.units_x);
-        const bool sub = q.sx[c] > 1 || q.sy[c] > 1;
+        const bool decimated = q.sx[c] > 1 || q.sy[c] > 1;
+        const bool sub = decimated && !(planes && planes_subsampled);      // a subsampled plane is read sample by sample
         const int role = k.role[c];
         f.bits = ((uint32_t)c << FW_COMP_SHIFT) | ((uint32_t)role << FW_ROLE_SHIFT) | ((uint32_t)(q.qsel[c] & 1) << FW_QSEL_SHIFT) |
                  ((uint32_t)sub << FW_SUB_SHIFT) | (lg << FW_LG_SHIFT) | (vrow << FW_VROW_SHIFT) |
@@ -581,15 +599,23 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
         const uint32_t b = (uint32_t)k.byte_index[c];
         f.byte_pack = 0x0C040C00u | b | (b << 16);     // byte b of each pixel word -> zero-extended 16-bit pair
         f.plane_lo = (uint32_t)k.plane_offset[c]; f.plane_hi = (uint32_t)(k.plane_offset[c] >> 32);
+        if (planes) {
+            const bool own_size = planes_subsampled && decimated;
+            const uint32_t pw = own_size ? (uint32_t)((q.width + q.sx[c] - 1) / q.sx[c]) : (uint32_t)q.width;
+            const uint32_t ph = own_size ? (uint32_t)((q.height + q.sy[c] - 1) / q.sy[c]) : (uint32_t)q.height;
+            const uint32_t mw = own_size ? 8u * hc : 8u * (uint32_t)q.hmax, mh = own_size ? 8u * (uint32_t)q.v[c] : 8u * (uint32_t)q.vmax;
+            if (planes[c].pixel_stride == 2) f.bits |= 1u << FW_BPP2_SHIFT;
+            f.conv[0] = (uint32_t)planes[c].pitch; f.conv[1] = pw | (ph << 16); f.conv[2] = mw | (mh << 16);
+        }
     }
     return true;
 }
 
-template <int BPP, int SX, int SY, bool CONV>
+template <int BPP, int SX, int SY, bool CONV, bool PLANES = false>
 static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k, int num_frames, int variant,
-                              hipStream_t stream) {
+                              hipStream_t stream, const jpegenc_plane *planes = nullptr, bool planes_subsampled = false) {
     BlockKernelParams q = p;
-    if (!fill_fast_params(q, k, BPP, SX, SY, CONV)) return hipErrorInvalidValue;      // launch_blocks_fast checked the preconditions
+    if (!fill_fast_params(q, k, BPP, SX, SY, CONV, planes, planes_subsampled)) return hipErrorInvalidValue;      // launch_blocks_fast checked the preconditions
 #ifdef JPEGENC_PERSISTENT
     static const unsigned resident = [] { const char *e = getenv("JPEGENC_PERSISTENT_WGS"); return e ? (unsigned)atoi(e) : 768u; }();
     const unsigned items = q.groups * (unsigned)num_frames;
@@ -605,8 +631,8 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
     // diagnostic: extra dynamic LDS per workgroup lowers the number of resident workgroups per CU
     static const char *pad_env = getenv("JPEGENC_LDS_PAD_KB");
     if (pad_env) lds += (size_t)atoi(pad_env) * 1024u;
-    if (variant == 1) hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 1, CONV>), grid, block, lds, stream, q, k);
-    else hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 0, CONV>), grid, block, lds, stream, q, k);
+    if (variant == 1) hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 1, CONV, PLANES>), grid, block, lds, stream, q, k);
+    else hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 0, CONV, PLANES>), grid, block, lds, stream, q, k);
     return hipGetLastError();
 }
 

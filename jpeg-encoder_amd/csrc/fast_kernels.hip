@@ -88,6 +88,11 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
 // not walking them together; each launch is the byte-plane kernel with only that component's waves.
 hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_plane planes[4], bool planes_subsampled, int variant,
                                 hipStream_t stream) {
+    {   // sampling factors 1 and 2: ONE launch, every wave on its own plane (fast_kernels_planes.hip)
+        hipError_t once = hipSuccess;
+        static const bool per_plane = getenv("JPEGENC_PLANES_PER_PLANE_LAUNCHES") != nullptr;      // diagnostic / tests: the older path
+        if (!per_plane && launch_blocks_planes_once(base, planes, planes_subsampled, variant, stream, &once)) return once;
+    }
     for (int c = 0; c < base.ncomp; c++) {
         BlockKernelParams q = base;
         q.xform = XF_PLANES;

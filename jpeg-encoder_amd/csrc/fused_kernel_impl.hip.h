@@ -35,7 +35,7 @@ __host__ __device__ inline uint32_t group_lds_bytes(uint32_t bpm) {
     return kGroupLutBytes + bpm * kGWin * 4u + bpm * kGPriv * 64u * 4u + bpm * 64u * 4u + bpm * 64u * 2u + 16u;
 }
 
-template <int BPP, int SX, int SY, int VARIANT, bool CONV>
+template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 ? (CONV ? 4 : 3) : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
 k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
@@ -78,17 +78,23 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         const int csx = sub ? SX : 1, csy = sub ? SY : 1;
         const uint32_t pm = group_first - 1u;
         const uint32_t pmy = (uint32_t)(((uint64_t)pm * Wv[5]) >> Wv[6]), pmx = pm - pmy * Wv[3];
-        const int bx = (int)(pmx * H[13] + ((1u << lg) - 1u) * 8u * (uint32_t)csx) + (int)(lane & 7u) * csx;
-        const int by = (int)(pmy * H[14] + ((1u << lgv) - 1u) * 8u * (uint32_t)csy) + (int)(lane >> 3) * csy;
-        const gbytes frame = (gbytes)(uintptr_t)((((uint64_t)H[1] << 32) | H[0]) + (size_t)f * (((uint64_t)H[5] << 32) | H[4]));
+        // (PLANES: the component's own plane - address, pitch, size, MCU size and sample stride from the wave's record)
+        const uint32_t mcu_w = PLANES ? Wv[11] & 0xFFFFu : H[13], mcu_h = PLANES ? Wv[11] >> 16 : H[14];
+        const int pw = PLANES ? (int)(Wv[10] & 0xFFFFu) : (int)H[8], ph = PLANES ? (int)(Wv[10] >> 16) : (int)H[9];
+        const uint32_t ppitch = PLANES ? Wv[9] : H[10];
+        const size_t pbpp = PLANES ? (((wbits >> FW_BPP2_SHIFT) & 1u) ? 2u : 1u) : (size_t)BPP;
+        const int bx = (int)(pmx * mcu_w + ((1u << lg) - 1u) * 8u * (uint32_t)csx) + (int)(lane & 7u) * csx;
+        const int by = (int)(pmy * mcu_h + ((1u << lgv) - 1u) * 8u * (uint32_t)csy) + (int)(lane >> 3) * csy;
+        const gbytes frame = (gbytes)(uintptr_t)((((uint64_t)H[1] << 32) | H[0]) + (size_t)f * (((uint64_t)H[5] << 32) | H[4]) +
+                                                 (((uint64_t)Wv[15] << 32) | Wv[14]));
         const int c = (int)((wbits >> FW_COMP_SHIFT) & 3u), role = (int)((wbits >> FW_ROLE_SHIFT) & 3u);
-        pred_sample = edge_sample(frame + (size_t)min(by, (int)H[9] - 1) * H[10] + (size_t)min(bx, (int)H[8] - 1) * BPP, role, c, k);
+        pred_sample = edge_sample(frame + (size_t)min(by, ph - 1) * ppitch + (size_t)min(bx, pw - 1) * pbpp, role, c, k);
     }
 
     // ---- the block kernel's wave: this lane's 64 quantised zig-zag coefficients ----------------------------------------
     WaveCtx w;
     BlockRegs r;
-    const bool active = block_compute<BPP, SX, SY, VARIANT, CONV>(k, grp, f, w, r.c);
+    const bool active = block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, f, w, r.c);
     const bool mine_valid = active && w.inside;
     const uint32_t mcu_local = Wv[1] + (lane >> w.lg);                          // MCU of the group; (w.lg etc. are set for padding waves too)
     const uint32_t pos = Wv[7] + (lane & ((1u << w.lg) - 1u));                  // block position inside the MCU (FastWave::out_base of MCU order)
@@ -178,17 +184,17 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 
-template <int BPP, int SX, int SY, bool CONV>
+template <int BPP, int SX, int SY, bool CONV, bool PLANES = false>
 static hipError_t launch_group_t(const BlockKernelParams &b, const ColourConsts &k, const EntropyParams *d_params, int frames, int variant,
-                                 hipStream_t st) {
+                                 hipStream_t st, const jpegenc_plane *planes = nullptr, bool planes_subsampled = false) {
     BlockKernelParams q = b;
-    if (!fill_fast_params(q, k, BPP, SX, SY, CONV) || q.fast_hdr.group_mcus != 64u || q.per_group != q.bpm) return hipErrorInvalidValue;
+    if (!fill_fast_params(q, k, BPP, SX, SY, CONV, planes, planes_subsampled) || q.fast_hdr.group_mcus != 64u || q.per_group != q.bpm) return hipErrorInvalidValue;
     const dim3 grid(q.groups, (unsigned)frames), block(q.per_group * 64u);
     size_t lds = group_lds_bytes(q.bpm);
     static const char *pad_env = getenv("JPEGENC_GROUP_LDS_PAD_KB");               // diagnostic: fewer resident workgroups per CU
     if (pad_env) lds += (size_t)atoi(pad_env) * 1024u;
-    if (variant == 1) hipLaunchKernelGGL((k_group_code<BPP, SX, SY, 1, CONV>), grid, block, lds, st, q, k, d_params);
-    else hipLaunchKernelGGL((k_group_code<BPP, SX, SY, 0, CONV>), grid, block, lds, st, q, k, d_params);
+    if (variant == 1) hipLaunchKernelGGL((k_group_code<BPP, SX, SY, 1, CONV, PLANES>), grid, block, lds, st, q, k, d_params);
+    else hipLaunchKernelGGL((k_group_code<BPP, SX, SY, 0, CONV, PLANES>), grid, block, lds, st, q, k, d_params);
     return hipGetLastError();
 }
 

@@ -39,6 +39,12 @@ hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream);
 // fast_kernels.hip: returns false when the configuration has no specialised kernel
 bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream,
                         hipError_t *err);
+// fast_kernels_planes.hip: a described planar source in ONE launch (sampling factors 1 and 2); false = take the per-plane launches
+bool launch_blocks_planes_once(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, int variant, hipStream_t stream,
+                               hipError_t *err);
+bool fused_planes_supported(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled);
+hipError_t launch_group_planes(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, const EntropyParams *d_params,
+                               int variant, hipStream_t st);
 // fast_kernels.hip: a device-resident planar source, one launch per component plane (jpegenc_encoder_encode_planes_device)
 hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_plane planes[4], bool planes_subsampled, int variant,
                                 hipStream_t stream);
@@ -48,7 +54,7 @@ hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_pla
 // scan again and again (an Encoder fed frames of one geometry) skips the store launch
 hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, hipStream_t stream, std::string *stored);
 // fused_kernels.hip: the Encoder's interleaved baseline scan coded straight from the pixels (no coefficients in HBM)
-struct FusedSource { const BlockKernelParams *blocks; int variant; };
+struct FusedSource { const BlockKernelParams *blocks; int variant; const jpegenc_plane *planes; bool planes_subsampled; };   // planes: a described planar source (else null)
 bool fused_supported(const BlockKernelParams &b);      // the layout has a fused kernel (interleaved order, 3 to 6 blocks per MCU, sampling factors 1 and 2)
 bool fused_enabled();                                    // the Encoder uses it (default; JPEGENC_FUSED=0 keeps block kernel + k_block_code)
 uint32_t fused_run_blocks(const BlockKernelParams &b);

@@ -858,7 +858,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     const bool optimize = c.optimize && mode != MODE_INTERLEAVED;
     // interleaved baseline scan of an RGB-family image: ONE kernel goes from the pixels to the entropy-coded runs
     // (fused_kernels.hip); the coefficients never reach HBM
-    const FusedSource fused_src = {&p, c.fdct_variant};
+    const FusedSource fused_src = {&p, c.fdct_variant, ctx.external_planes, ctx.external_planes_subsampled};
     bool fused = false;
     static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -909,7 +909,8 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
             if (w > ws) ws = w;
         }
         first_piece = out_total < DeviceCtx::kFirstPiece ? out_total : DeviceCtx::kFirstPiece;
-        fused = supported && mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() && fused_supported(p);
+        fused = supported && mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() &&
+                (ctx.external_planes ? fused_planes_supported(p, ctx.external_planes, ctx.external_planes_subsampled) : fused_supported(p));
         if (supported) {
             // The scans of a sequential / progressive frame are independent: coded in shared launches they cost
             // ~10 launches per 8 scans instead of ~10 per scan (a 4K progressive frame: 12 scans; such frames were
@@ -941,13 +942,20 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
     // single-scan frames use it.  (JPEGENC_NO_GRAPH=1 disables it.)
     static const bool graphs_off = getenv("JPEGENC_NO_GRAPH") != nullptr;
     enum { DIRECT, CAPTURE, REPLAY } how = DIRECT;
-    if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1 && !ctx.external_planes) {
+    if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1) {
         std::string key;
         auto put = [&](const void *v, size_t n) { key.append((const char *)v, n); };
         const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, gather, ctx.h_scan_out};
         const int64_t vals[] = {width, height, color_type_or_planes, (int64_t)pixel_bytes, order, c.fdct_variant, c.sampling,
                                 c.progressive_scans, c.restart_interval, (int64_t)ctx.d_scan_ws_cap, (int64_t)jobs.size(), (int64_t)fused};
         put(ptrs, sizeof ptrs); put(vals, sizeof vals); put(t.q, sizeof t.q);
+        if (ctx.external_planes) {                                        // a described planar source: its descriptors are part of what the sequence bakes in
+            for (int i = 0; i < L.num_components; i++) {
+                const jpegenc_plane &pl = ctx.external_planes[i];
+                const int64_t d[] = {(int64_t)(uintptr_t)pl.d_data, (int64_t)pl.pitch, pl.pixel_stride, pl.invert, (int64_t)ctx.external_planes_subsampled};
+                put(d, sizeof d);
+            }
+        }
         if (ctx.graph_exec && key == ctx.graph_key) how = REPLAY;
         else if (key == ctx.last_key) how = CAPTURE;
         ctx.last_key.swap(key);
@@ -1297,7 +1305,7 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         p.coeffs = b.d_coeffs;
         p.pixel_frame_stride = frame_stride;
         p.coeff_frame_stride = L.total_blocks;
-        const FusedSource fused_src = {&p, c.fdct_variant};
+        const FusedSource fused_src = {&p, c.fdct_variant, nullptr, false};
         const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() && fused_supported(p);
         if (!fused) {
             hipError_t err = hipSuccess;

@@ -312,6 +312,19 @@ def test_encode_planes_device_yuv_surfaces(binding, oracle, synth, w, h, kw):
     assert err.value.status == binding.ERR_INVALID_ARGUMENT
 
 
+def test_planes_per_plane_launch_path_still_matches(binding):
+    """The described planar sources take ONE launch (every wave on its own plane) and, for interleaved baseline scans, the
+    one-kernel pixels -> bits path; sampling factors of 4 keep one block-kernel launch per plane.  That older path is
+    forced here for every planes test (the switches are read once per process: a child pytest)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, JPEGENC_PLANES_PER_PLANE_LAUNCHES="1", JPEGENC_FUSED="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "encode_planes_device"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_encode_planes_device_luma_and_cmyk(binding, oracle, synth):
     import torch
     w, h = 333, 201
