@@ -321,7 +321,11 @@ class Encoder:
             lib().jpegenc_encoder_free(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except TypeError:          # interpreter shutdown: module globals are already gone
+            pass
 
     def __enter__(self):
         return self
