@@ -151,6 +151,10 @@ extern "C" {
     pub fn jpegenc_encoder_encode_planes_device(e: *mut jpegenc_encoder, jpeg_color_type: c_int, width: c_int, height: c_int,
                                                 planes: *const jpegenc_plane, planes_subsampled: c_int, sink: jpegenc_write_fn,
                                                 user: *mut c_void) -> c_int;
+    // a pool of such surfaces (planes: num_frames x 4 descriptors, frame-major), the batch sharing its launches
+    pub fn jpegenc_encoder_encode_planes_batch_device(e: *mut jpegenc_encoder, jpeg_color_type: c_int, width: c_int, height: c_int,
+                                                      planes: *const jpegenc_plane, num_frames: c_int, planes_subsampled: c_int,
+                                                      sink: jpegenc_write_fn, users: *const *mut c_void) -> c_int;
     pub fn jpegenc_encoder_encode_batch(e: *mut jpegenc_encoder, frames: *const *const u8, frame_len: usize, num_frames: c_int,
                                         width: c_int, height: c_int, color_type: c_int, sink: jpegenc_write_fn,
                                         users: *const *mut c_void) -> c_int;

@@ -344,6 +344,15 @@ typedef struct jpegenc_plane {
 int  jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
                                           const jpegenc_plane planes[4], int planes_subsampled,
                                           jpegenc_write_fn sink, void *user);
+/* A batch of such surfaces of one geometry (a decoder's or camera pipeline's frame pool): planes = num_frames x 4
+ * descriptors, frame-major (frame f, component c at planes[4 * f + c]), the surfaces anywhere in device memory.  Frame
+ * f -> sink(users[f], ...), one complete file each (sink threading: see jpegenc_encoder_encode_batch).  The device
+ * work of the whole batch shares its launches as in jpegenc_encoder_encode_batch_device when the descriptors of each
+ * component agree in pitch, pixel_stride and invert over the frames; otherwise - and with optimised Huffman tables, the
+ * host entropy coder or sampling factors of 4 - the frames are encoded one at a time.  Same bytes either way. */
+int  jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
+                                                const jpegenc_plane *planes, int num_frames, int planes_subsampled,
+                                                jpegenc_write_fn sink, void *const *users);
 
 /* Batch of same-geometry frames on this handle's device, double-buffered (H2D / kernel / D2H /
  * host entropy coding overlapped).  frames[i] -> sink(users[i], ...).

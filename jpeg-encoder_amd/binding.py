@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_batch_device", "jpegenc_encoder_encode_batch_device_to_buffers", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_to_file",
     "jpegenc_encoder_encode_image", "jpegenc_encoder_block_order", "jpegenc_encoder_encode_coefficients",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
-    "jpegenc_encoder_encode_planes_device",
+    "jpegenc_encoder_encode_planes_device", "jpegenc_encoder_encode_planes_batch_device",
     "jpegenc_shard_frames", "jpegenc_encoder_encode_batch_multi", "jpegenc_encoder_encode_batch_multi_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
 ]
@@ -470,6 +470,27 @@ class Encoder:
         cb = WRITE_FN(sink)
         check(lib().jpegenc_encoder_encode_planes_device(self._h, jpeg_color_type, width, height, arr, 1 if planes_subsampled else 0, cb, None))
         return b"".join(chunks)
+
+    def encode_planes_batch_device(self, jpeg_color_type, width, height, frames, planes_subsampled=False):
+        """jpegenc_encoder_encode_planes_batch_device: frames = [[(device_ptr, pitch, pixel_stride, invert), ...] per frame]
+        -> list of bytes."""
+        n = len(frames)
+        arr = (Plane * (4 * max(n, 1)))()
+        for f, planes in enumerate(frames):
+            for i, (ptr, pitch, stride, inv) in enumerate(planes):
+                arr[4 * f + i] = Plane(ptr, pitch, stride, 1 if inv else 0)
+        outs = [[] for _ in range(n)]
+
+        def sink(user, ptr, nbytes):
+            outs[(user or 0)].append(C.string_at(ptr, nbytes))
+            return 0
+
+        cb = WRITE_FN(sink)
+        users = (C.c_void_p * max(n, 1))(*[i for i in range(n)])
+        fn = lib().jpegenc_encoder_encode_planes_batch_device
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Plane), C.c_int, C.c_int, WRITE_FN, C.POINTER(C.c_void_p)]
+        check(fn(self._h, jpeg_color_type, width, height, arr, n, 1 if planes_subsampled else 0, cb, users))
+        return [b"".join(o) for o in outs]
 
     def encode_batch_device(self, d_frames_ptr, frame_stride, num_frames, width, height, color_type):
         """Device-resident batch (raw pointer, frames `frame_stride` bytes apart) -> list of bytes."""

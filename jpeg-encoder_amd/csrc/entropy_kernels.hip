@@ -820,7 +820,7 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
     const uint32_t bgrid = (nblocks + 255u) / 256u;
     if (fused) {
         const int restart = jobs[0].nintervals > 1 ? (int)(jobs[0].interval_blocks / jobs[0].bpm) : 0;
-        e = fused->planes ? launch_group_planes(*fused->blocks, fused->planes, fused->planes_subsampled, d_params, fused->variant, st)
+        e = fused->planes ? launch_group_planes(*fused->blocks, fused->planes, fused->planes_subsampled, d_params, frames, fused->variant, st)
                           : launch_fused_code(*fused->blocks, d_params, restart, frames, fused->variant, st);
         if (e != hipSuccess) return e;
     } else {

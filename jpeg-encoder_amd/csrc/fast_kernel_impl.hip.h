@@ -302,6 +302,22 @@ struct WaveCtx {
 // Prologue + fetch + conversion + FDCT + quantiser of one wave over one group of 64 MCUs of frame `frm` (see the notes
 // at the top of the file): packed[j] = zig-zag coefficients (2j, 2j + 1) of the lane's block.  false: a padding wave
 // of the last group (nothing computed).
+// Where a wave's samples start: frame `frm` of the launch + the component's plane.  PLANES kernels of a BATCH of described
+// surfaces (a pixel_frame_stride of all ones) look the plane's address up in a device table [frame][4] instead - surfaces
+// from a decoder's pool lie anywhere.
+constexpr uint64_t kPlaneTableStride = ~0ull;
+template <bool PLANES>
+__device__ __forceinline__ gbytes frame_base(const u32x16 &H, const u32x16 &Wv, uint32_t frm, uint32_t c) {
+    const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0];
+    const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4];
+    if (PLANES && px_stride == kPlaneTableStride) {
+        const uint64_t __attribute__((address_space(1))) *table = (const uint64_t __attribute__((address_space(1))) *)(uintptr_t)px_base;
+        const uint64_t addr = table[(size_t)frm * 4u + c];
+        return (gbytes)(uintptr_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)addr));
+    }
+    return (gbytes)(uintptr_t)(px_base + (size_t)frm * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]));
+}
+
 // PLANES: a device-resident planar surface described per component (jpegenc_plane: I420 / NV12 / planar CMYK ...) in ONE
 // launch - every wave takes its plane's address, pitch, size, MCU size and sample stride (1 or 2 bytes; BPP = 2 is then
 // the largest stride the kernel is built for) from its FastWave record instead of the frame-wide header.
@@ -332,9 +348,7 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     w.first_unit = first_unit; w.wave_mcus = wave_mcus; w.limit = limit; w.units_x = units_x; w.magic = magic; w.shift = shift;
     w.c = c; w.role = role; w.qsel = qsel;
     if (first_unit >= limit) return false;                          // padding wave of the last group: nothing to do
-    const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0];
-    const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4];
-    const gbytes frame = (gbytes)(uintptr_t)(px_base + (size_t)frm * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]));
+    const gbytes frame = frame_base<PLANES>(H, Wv, frm, (uint32_t)c);
     const int width = PLANES ? (int)(Wv[10] & 0xFFFFu) : (int)H[8], hlim = (PLANES ? (int)(Wv[10] >> 16) : (int)H[9]) - 1;
     const uint32_t pitch = PLANES ? Wv[9] : H[10];                  // frame bytes < 2^31 (checked by the launcher)
     const uint32_t mcu_w = PLANES ? Wv[11] & 0xFFFFu : H[13], mcu_h = PLANES ? Wv[11] >> 16 : H[14];
@@ -548,8 +562,10 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
     q.groups = (q.total_mcus + group - 1u) / group;
     FastHeader &h = q.fast_hdr;
     memset(&h, 0, sizeof h);
-    h.pixels = planes ? 0u : (uint64_t)(uintptr_t)q.pixels; h.coeffs = (uint64_t)(uintptr_t)q.coeffs;
-    h.pixel_frame_stride = planes ? 0u : q.pixel_frame_stride; h.coeff_frame_stride = q.coeff_frame_stride;
+    // (described planes: one surface - addresses in the wave records, base 0 - or a batch - q.pixels = the device table of plane addresses)
+    const bool plane_table = planes && q.pixel_frame_stride == kPlaneTableStride;
+    h.pixels = planes && !plane_table ? 0u : (uint64_t)(uintptr_t)q.pixels; h.coeffs = (uint64_t)(uintptr_t)q.coeffs;
+    h.pixel_frame_stride = planes && !plane_table ? 0u : q.pixel_frame_stride; h.coeff_frame_stride = q.coeff_frame_stride;
     h.width = (uint32_t)q.width; h.height = (uint32_t)q.height; h.pitch = q.pitch_bytes ? q.pitch_bytes : (uint32_t)q.width * (uint32_t)bpp;
     h.order = (uint32_t)q.order; h.bpm = q.bpm;
     h.mcu_w = q.plane_mcu_w ? q.plane_mcu_w : 8u * (uint32_t)q.hmax; h.mcu_h = q.plane_mcu_h ? q.plane_mcu_h : 8u * (uint32_t)q.vmax;

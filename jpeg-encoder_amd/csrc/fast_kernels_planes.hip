@@ -31,14 +31,14 @@ static bool planes_consts(const BlockKernelParams &p, const jpegenc_plane planes
     return true;
 }
 
-bool launch_blocks_planes_once(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, int variant, hipStream_t stream,
-                               hipError_t *err) {
+bool launch_blocks_planes_once(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, int num_frames, int variant,
+                               hipStream_t stream, hipError_t *err) {
     ColourConsts k;
     int sx, sy;
     if (!planes_consts(p, planes, planes_subsampled, &k, &sx, &sy)) return false;
     BlockKernelParams probe = p;
     if (!fill_fast_params(probe, k, 2, sx, sy, false, planes, planes_subsampled)) return false;
-#define JPEGENC_CASE(X, Y) if (sx == X && sy == Y) { *err = launch_fast<2, X, Y, false, true>(p, k, 1, variant, stream, planes, planes_subsampled); return true; }
+#define JPEGENC_CASE(X, Y) if (sx == X && sy == Y) { *err = launch_fast<2, X, Y, false, true>(p, k, num_frames, variant, stream, planes, planes_subsampled); return true; }
     JPEGENC_CASE(1, 1) JPEGENC_CASE(2, 1) JPEGENC_CASE(1, 2) JPEGENC_CASE(2, 2)
 #undef JPEGENC_CASE
     return false;
@@ -56,11 +56,11 @@ bool fused_planes_supported(const BlockKernelParams &p, const jpegenc_plane plan
 }
 
 hipError_t launch_group_planes(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, const EntropyParams *d_params,
-                               int variant, hipStream_t st) {
+                               int frames, int variant, hipStream_t st) {
     ColourConsts k;
     int sx, sy;
     if (!planes_consts(p, planes, planes_subsampled, &k, &sx, &sy)) return hipErrorInvalidValue;
-#define JPEGENC_CASE(X, Y) if (sx == X && sy == Y) return launch_group_t<2, X, Y, false, true>(p, k, d_params, 1, variant, st, planes, planes_subsampled);
+#define JPEGENC_CASE(X, Y) if (sx == X && sy == Y) return launch_group_t<2, X, Y, false, true>(p, k, d_params, frames, variant, st, planes, planes_subsampled);
     JPEGENC_CASE(1, 1) JPEGENC_CASE(2, 1) JPEGENC_CASE(1, 2) JPEGENC_CASE(2, 2)
 #undef JPEGENC_CASE
     return hipErrorInvalidValue;

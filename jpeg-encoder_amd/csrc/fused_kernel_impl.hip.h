@@ -85,9 +85,8 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         const size_t pbpp = PLANES ? (((wbits >> FW_BPP2_SHIFT) & 1u) ? 2u : 1u) : (size_t)BPP;
         const int bx = (int)(pmx * mcu_w + ((1u << lg) - 1u) * 8u * (uint32_t)csx) + (int)(lane & 7u) * csx;
         const int by = (int)(pmy * mcu_h + ((1u << lgv) - 1u) * 8u * (uint32_t)csy) + (int)(lane >> 3) * csy;
-        const gbytes frame = (gbytes)(uintptr_t)((((uint64_t)H[1] << 32) | H[0]) + (size_t)f * (((uint64_t)H[5] << 32) | H[4]) +
-                                                 (((uint64_t)Wv[15] << 32) | Wv[14]));
         const int c = (int)((wbits >> FW_COMP_SHIFT) & 3u), role = (int)((wbits >> FW_ROLE_SHIFT) & 3u);
+        const gbytes frame = frame_base<PLANES>(H, Wv, f, (uint32_t)c);
         pred_sample = edge_sample(frame + (size_t)min(by, ph - 1) * ppitch + (size_t)min(bx, pw - 1) * pbpp, role, c, k);
     }
 

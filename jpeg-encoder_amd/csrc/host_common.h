@@ -40,11 +40,13 @@ hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream);
 bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream,
                         hipError_t *err);
 // fast_kernels_planes.hip: a described planar source in ONE launch (sampling factors 1 and 2); false = take the per-plane launches
-bool launch_blocks_planes_once(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, int variant, hipStream_t stream,
-                               hipError_t *err);
+bool launch_blocks_planes_once(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, int num_frames, int variant,
+                               hipStream_t stream, hipError_t *err);
+// (a batch of described surfaces: p.pixels = device table [frame][4] of plane addresses, p.pixel_frame_stride = kPlaneTableStrideHost)
+constexpr uint64_t kPlaneTableStrideHost = ~0ull;
 bool fused_planes_supported(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled);
 hipError_t launch_group_planes(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, const EntropyParams *d_params,
-                               int variant, hipStream_t st);
+                               int frames, int variant, hipStream_t st);
 // fast_kernels.hip: a device-resident planar source, one launch per component plane (jpegenc_encoder_encode_planes_device)
 hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_plane planes[4], bool planes_subsampled, int variant,
                                 hipStream_t stream);

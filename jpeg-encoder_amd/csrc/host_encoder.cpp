@@ -508,6 +508,16 @@ struct BatchBuffers {
         *cap = need;
         return JPEGENC_OK;
     }
+    void *d_plane_table = nullptr;        // batches of described planar surfaces: [frame][4] plane addresses
+    size_t plane_table_cap = 0;
+    int reserve_plane_table(size_t bytes) {
+        if (bytes <= plane_table_cap) return JPEGENC_OK;
+        if (d_plane_table) (void)hipFree(d_plane_table);
+        d_plane_table = nullptr; plane_table_cap = 0;
+        JPEGENC_HIP(hipMalloc(&d_plane_table, bytes));
+        plane_table_cap = bytes;
+        return JPEGENC_OK;
+    }
     // d_out, d_len and h_len hold TWO rounds (halves): one is downloaded while the next is coded
     hipStream_t copy_stream = nullptr;
     hipEvent_t coded[2] = {nullptr, nullptr};
@@ -550,6 +560,7 @@ struct BatchBuffers {
         if (d_out) (void)hipFree(d_out);
         if (d_ws) (void)hipFree(d_ws);
         if (d_packed) (void)hipFree(d_packed);
+        if (d_plane_table) (void)hipFree(d_plane_table);
         if (d_pos) (void)hipFree(d_pos);
         if (d_len) (void)hipFree(d_len);
         if (h_len) (void)hipHostFree(h_len);
@@ -1196,12 +1207,18 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
 // hands such scans to the host coder - same bytes.
 constexpr int kBatchNeedsPerFrame = -1000;
 
+// A batch of described planar surfaces (jpegenc_encoder_encode_planes_batch_device): every frame's planes share pitch, sample
+// stride and inversion (planes = frame 0's descriptors); where each frame's planes start is a device table [frame][4].
+struct PlaneBatch { const jpegenc_plane *planes; bool subsampled; const uint64_t *d_table; int jct; };
+
 static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b, int device, const void *d_frames,
                                size_t frame_stride, int num_frames, int width, int height, int color_type,
-                               jpegenc_write_fn sink, void *const *users) {
-    const int bpp = jpegenc_bytes_per_pixel(color_type);
-    const size_t bytes = (size_t)width * (size_t)height * (size_t)bpp;
-    if (frame_stride < bytes) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "frame stride smaller than a frame");
+                               jpegenc_write_fn sink, void *const *users, const PlaneBatch *pb = nullptr) {
+    if (!pb) {
+        const int bpp = jpegenc_bytes_per_pixel(color_type);
+        const size_t bytes = (size_t)width * (size_t)height * (size_t)bpp;
+        if (frame_stride < bytes) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "frame stride smaller than a frame");
+    }
     int rc = ctx.open(device);
     if (rc) return rc;
     Tables t;
@@ -1213,10 +1230,10 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
     int hs, vs;
     sampling_hv(c.sampling, &hs, &vs);
     const Mode mode = select_mode(c);
-    const int jct = jpeg_color_type_of(color_type);
+    const int jct = pb ? pb->jct : jpeg_color_type_of(color_type);
     const int order = mode == MODE_INTERLEAVED ? JPEGENC_ORDER_MCU : JPEGENC_ORDER_PLANAR;
     jpegenc_layout L;
-    rc = jpegenc_layout_init(&L, width, height, color_type, hs, vs, order);
+    rc = jpegenc_layout_init(&L, width, height, pb ? 100 + pb->jct : color_type, hs, vs, order);
     if (rc) return rc;
 
     struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap, ws_off, ws; };
@@ -1299,17 +1316,22 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         const int f0 = r * per_round, half = r & 1;
         const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
         BlockKernelParams p;
-        int e = build_block_params(&p, L, width, height, color_type, t.q, order);
+        int e = pb ? build_block_params_planes(&p, L, width, height, t.q, order) : build_block_params(&p, L, width, height, color_type, t.q, order);
         if (e) return e;
-        p.pixels = (const uint8_t *)d_frames + (size_t)f0 * frame_stride;
+        p.pixels = pb ? (const uint8_t *)(pb->d_table + (size_t)f0 * 4u) : (const uint8_t *)d_frames + (size_t)f0 * frame_stride;
         p.coeffs = b.d_coeffs;
-        p.pixel_frame_stride = frame_stride;
+        p.pixel_frame_stride = pb ? kPlaneTableStrideHost : frame_stride;
         p.coeff_frame_stride = L.total_blocks;
-        const FusedSource fused_src = {&p, c.fdct_variant, nullptr, false};
-        const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() && fused_supported(p);
+        const FusedSource fused_src = {&p, c.fdct_variant, pb ? pb->planes : nullptr, pb ? pb->subsampled : false};
+        const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() &&
+                           (pb ? fused_planes_supported(p, pb->planes, pb->subsampled) : fused_supported(p));
         if (!fused) {
             hipError_t err = hipSuccess;
-            if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) err = launch_blocks_generic(p, n, c.fdct_variant, ctx.stream);
+            if (pb) {
+                if (!launch_blocks_planes_once(p, pb->planes, pb->subsampled, n, c.fdct_variant, ctx.stream, &err)) return kBatchNeedsPerFrame;   // (sampling factors of 4)
+            } else if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) {
+                err = launch_blocks_generic(p, n, c.fdct_variant, ctx.stream);
+            }
             if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
         }
         uint32_t *d_len = b.d_len + (size_t)half * nlen;
@@ -1805,6 +1827,61 @@ int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames
     const int rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
     if (rc != kBatchNeedsPerFrame) return rc;
     return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
+}
+
+// A batch of described planar surfaces (decoder / camera pools of I420 or NV12 frames): the launches of the whole batch are
+// shared like those of jpegenc_encoder_encode_batch_device.  planes: num_frames x 4 descriptors, frame-major; the
+// descriptors of one component must agree in pitch, pixel_stride and invert across frames (only d_data differs).
+int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int width, int height, const jpegenc_plane *planes,
+                                               int num_frames, int planes_subsampled, jpegenc_write_fn sink, void *const *users) {
+    REQUIRE(e);
+    if (num_frames < 0 || (num_frames && (!planes || !users)) || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
+    if (jct < JPEGENC_J_LUMA || jct > JPEGENC_J_YCCK) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown JPEG colour type");
+    if (width < 0 || height < 0 || width > 65535 || height > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "width/height must fit u16");
+    if (width == 0 || height == 0) return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "Image dimensions must be non zero");
+    if (num_frames == 0) return JPEGENC_OK;
+    const int ncomp = jct == JPEGENC_J_LUMA ? 1 : jct == JPEGENC_J_YCBCR ? 3 : 4;
+    int hs, vs;
+    sampling_hv(e->cfg.sampling, &hs, &vs);
+    bool uniform = true;
+    for (int f = 0; f < num_frames; f++)
+        for (int i = 0; i < ncomp; i++) {
+            const jpegenc_plane &pl = planes[(size_t)f * 4 + i], &p0 = planes[i];
+            if (!pl.d_data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null plane");
+            if (pl.pixel_stride != 1 && pl.pixel_stride != 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "pixel_stride must be 1 or 2");
+            if (pl.pitch > 0x7FFFFFFFu) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane pitch too large");
+            if (pl.pitch != p0.pitch || pl.pixel_stride != p0.pixel_stride || (pl.invert != 0) != (p0.invert != 0) ||
+                (pl.pixel_stride == 2 && (((uintptr_t)pl.d_data ^ (uintptr_t)p0.d_data) & 1u)))
+                uniform = false;
+        }
+    auto one_by_one = [&]() -> int {
+        for (int f = 0; f < num_frames; f++) {
+            const int r = jpegenc_encoder_encode_planes_device(e, jct, width, height, planes + (size_t)f * 4, planes_subsampled, sink, users[f]);
+            if (r) return r;
+        }
+        return JPEGENC_OK;
+    };
+    const bool per_frame_tables = e->cfg.optimize && select_mode(e->cfg) != MODE_INTERLEAVED;
+    if (!uniform || !e->cfg.device_entropy || per_frame_tables || hs == 4 || vs == 4 || num_frames == 1) return one_by_one();
+    int rc = e->ctx.open(e->device);
+    if (rc) return rc;
+    // where every frame's planes start (the second byte of an interleaved pair is addressed through its pair: the kernels
+    // pick byte 1 of each two-byte sample, as jpegenc_encoder_encode_planes_device does)
+    std::vector<uint64_t> table((size_t)num_frames * 4, 0);
+    for (int f = 0; f < num_frames; f++)
+        for (int i = 0; i < ncomp; i++) {
+            const jpegenc_plane &pl = planes[(size_t)f * 4 + i];
+            const uintptr_t ptr = (uintptr_t)pl.d_data;
+            table[(size_t)f * 4 + i] = (uint64_t)(ptr - (pl.pixel_stride == 2 ? (ptr & 1u) : 0u));
+        }
+    rc = e->batch.reserve_plane_table(table.size() * sizeof(uint64_t));
+    if (rc) return rc;
+    JPEGENC_HIP(hipMemcpyAsync(e->batch.d_plane_table, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, e->ctx.stream));
+    JPEGENC_HIP(hipStreamSynchronize(e->ctx.stream));                           // (`table` is pageable and leaves scope)
+    const PlaneBatch pb = {planes, planes_subsampled != 0, (const uint64_t *)e->batch.d_plane_table, jct};
+    rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, nullptr, 0, num_frames, width, height, 0, sink, users, &pb);
+    if (rc != kBatchNeedsPerFrame) return rc;
+    return one_by_one();
 }
 
 int jpegenc_encoder_encode_to_buffer(jpegenc_encoder *e, const uint8_t *data, size_t len, int width, int height,

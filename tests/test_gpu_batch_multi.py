@@ -385,3 +385,53 @@ def test_long_blocks_take_the_lds_second_walk(binding, oracle, synth, quality, h
     for i in range(n):
         ref = oracle.encode_jpeg(px[i], w, h, oracle.RGB, quality, sampling=(hs, vs))
         assert ref.endswith(outs[0][i] + b"\xff\xd9") and len(outs[0][i]) > 1_000_000
+
+
+@pytest.mark.parametrize("kw", [dict(quality=80), dict(quality=90, sampling=(2, 1), restart_interval=4), dict(quality=85, sampling=(2, 2), progressive_scans=4),
+                                dict(quality=88, sampling=(2, 2), optimize=True), dict(quality=70, sampling=(4, 1))],
+                         ids=["420", "422-rst4", "420-progressive", "420-optimised-one-by-one", "411-one-by-one"])
+def test_encode_planes_batch_device(binding, oracle, synth, kw):
+    """jpegenc_encoder_encode_planes_batch_device: a pool of I420 surfaces anywhere in device memory (padded pitches) and a
+    pool of NV12 surfaces, five frames per call sharing their launches (plane addresses through a device table) - each file
+    byte-identical to the oracle fed the equivalent interleaved YCbCr image; a frame whose pitch differs from the others'
+    sends the batch down the one-frame-at-a-time path, same bytes."""
+    import torch
+    w, h, n = 515, 301, 5
+    hs, vs = kw.get("sampling", (2, 2) if kw["quality"] < 90 else (1, 1))
+    cw, ch = -(-w // hs), -(-h // vs)
+    rng = np.random.default_rng(11)
+    smooth = lambda a: (a.astype(np.int16) // 4 + np.add.outer(np.arange(a.shape[0]), np.arange(a.shape[1])) // 3).clip(0, 255).astype(np.uint8)
+    okw = dict(kw)
+    e = binding.Encoder(kw["quality"])
+    if "sampling" in kw:
+        e.set_sampling_factor(binding.sampling_factor(*kw["sampling"]))
+    if kw.get("progressive_scans"):
+        e.set_progressive_scans(kw["progressive_scans"])
+    if kw.get("restart_interval"):
+        e.set_restart_interval(kw["restart_interval"])
+    if kw.get("optimize"):
+        e.set_optimized_huffman_tables(True)
+    ypitch, cpitch = w + 13, cw + 7
+    keep, i420, nv12, want = [], [], [], []
+    for f in range(n):
+        y, cb, cr = (smooth(rng.integers(0, 256, s, dtype=np.uint8)) for s in ((h, w), (ch, cw), (ch, cw)))
+        full = np.stack([y, _replicated(cb, hs, vs, w, h), _replicated(cr, hs, vs, w, h)], axis=-1)
+        want.append(oracle.encode_jpeg(full, w, h, oracle.YCBCR, **okw))
+        d_y = torch.zeros((h, ypitch), dtype=torch.uint8, device="cuda"); d_y[:, :w] = torch.from_numpy(y).cuda()
+        d_cb = torch.zeros((ch, cpitch), dtype=torch.uint8, device="cuda"); d_cb[:, :cw] = torch.from_numpy(cb).cuda()
+        d_cr = torch.zeros((ch, cpitch), dtype=torch.uint8, device="cuda"); d_cr[:, :cw] = torch.from_numpy(cr).cuda()
+        d_uv = torch.from_numpy(np.ascontiguousarray(np.stack([cb, cr], axis=-1))).cuda()
+        keep += [d_y, d_cb, d_cr, d_uv]
+        i420.append([(d_y.data_ptr(), ypitch, 1, 0), (d_cb.data_ptr(), cpitch, 1, 0), (d_cr.data_ptr(), cpitch, 1, 0)])
+        nv12.append([(d_y.data_ptr(), ypitch, 1, 0), (d_uv.data_ptr(), cw * 2, 2, 0), (d_uv.data_ptr() + 1, cw * 2, 2, 0)])
+    assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, i420, planes_subsampled=True) == want
+    assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, nv12, planes_subsampled=True) == want
+    assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, i420[:1], planes_subsampled=True) == want[:1]
+    assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, [], planes_subsampled=True) == []
+    # one frame with another luma pitch: not a uniform pool any more
+    y3 = torch.zeros((h, w + 64), dtype=torch.uint8, device="cuda"); y3[:, :w] = keep[4 * 3][:, :w]
+    odd = [list(fr) for fr in i420]
+    odd[3][0] = (y3.data_ptr(), w + 64, 1, 0)
+    assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, odd, planes_subsampled=True) == want
+    with pytest.raises(binding.JpegEncError):
+        e.encode_planes_batch_device(binding.J_YCBCR, w, h, [[(0, ypitch, 1, 0)] * 3] * 2, planes_subsampled=True)
