@@ -313,7 +313,8 @@ __device__ __forceinline__ gbytes frame_base(const u32x16 &H, const u32x16 &Wv, 
     if (PLANES && px_stride == kPlaneTableStride) {
         const uint64_t __attribute__((address_space(1))) *table = (const uint64_t __attribute__((address_space(1))) *)(uintptr_t)px_base;
         const uint64_t addr = table[(size_t)frm * 4u + c];
-        return (gbytes)(uintptr_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)addr));
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(addr >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);   // (wave-uniform -> scalar registers)
+        return (gbytes)(uintptr_t)(((uint64_t)hi << 32) | lo);
     }
     return (gbytes)(uintptr_t)(px_base + (size_t)frm * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]));
 }

@@ -435,3 +435,64 @@ def test_encode_planes_batch_device(binding, oracle, synth, kw):
     assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, odd, planes_subsampled=True) == want
     with pytest.raises(binding.JpegEncError):
         e.encode_planes_batch_device(binding.J_YCBCR, w, h, [[(0, ypitch, 1, 0)] * 3] * 2, planes_subsampled=True)
+
+
+def test_randomised_planar_sources(binding, oracle, synth):
+    """Fuzz-style sweep over described planar sources: size, sampling factor (1, 2 and 4), subsampled or full-resolution
+    planes, I420-like or NV12-like chroma, padded pitches, quality, scan mode, restart interval, FDCT build, one surface
+    at a time and as a pool - every file byte-identical to the oracle fed the equivalent interleaved YCbCr image.
+    (JPEGENC_FUZZ_TRIALS / JPEGENC_FUZZ_SEED: soak length.)"""
+    import os
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("JPEGENC_FUZZ_SEED", "4242")))
+    samplings = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (1, 4)]
+    for trial in range(int(os.environ.get("JPEGENC_FUZZ_TRIALS", "40"))):
+        w, h = int(rng.integers(1, 700)), int(rng.integers(1, 400))
+        hs, vs = samplings[int(rng.integers(0, len(samplings)))]
+        subsampled = bool(rng.integers(0, 2))
+        nv12 = bool(rng.integers(0, 2)) and (subsampled or (hs < 4 and vs < 4))
+        kw = dict(quality=int(rng.integers(1, 101)), sampling=(hs, vs))
+        mode = int(rng.integers(0, 4))
+        if mode == 1:
+            kw["progressive_scans"] = int(rng.integers(2, 12))
+        elif mode == 2:
+            kw["optimize"] = True
+        if rng.integers(0, 3) == 0:
+            kw["restart_interval"] = int(rng.integers(1, 40))
+        variant = oracle.FDCT_SIMD if rng.integers(0, 4) == 0 else oracle.FDCT_SCALAR
+        nframes = int(rng.integers(1, 4))
+        cw, ch = (-(-w // hs), -(-h // vs)) if subsampled else (w, h)
+        e = binding.Encoder(kw["quality"])
+        e.set_sampling_factor(binding.sampling_factor(hs, vs))
+        if kw.get("progressive_scans"):
+            e.set_progressive_scans(kw["progressive_scans"])
+        if kw.get("optimize"):
+            e.set_optimized_huffman_tables(True)
+        if kw.get("restart_interval"):
+            e.set_restart_interval(kw["restart_interval"])
+        if variant == oracle.FDCT_SIMD:
+            e.set_fdct_variant(binding.FDCT_SIMD)
+        ypad, cpad = int(rng.integers(0, 40)), int(rng.integers(0, 9))
+        frames, want, keep = [], [], []
+        for f in range(nframes):
+            noisy = trial % 3 != 0
+            mk = (lambda s: rng.integers(0, 256, s, dtype=np.uint8)) if noisy else (lambda s: (np.add.outer(np.arange(s[0]), np.arange(s[1])) // 3 + f).astype(np.uint8))
+            y, cb, cr = mk((h, w)), mk((ch, cw)), mk((ch, cw))
+            full = np.stack([y, _replicated(cb, hs, vs, w, h) if subsampled else cb, _replicated(cr, hs, vs, w, h) if subsampled else cr], axis=-1)
+            want.append(oracle.encode_jpeg(np.ascontiguousarray(full), w, h, oracle.YCBCR, variant=variant, **kw))
+            d_y = torch.zeros((h, w + ypad), dtype=torch.uint8, device="cuda"); d_y[:, :w] = torch.from_numpy(y).cuda()
+            if nv12:
+                d_uv = torch.zeros((ch, 2 * cw + 2 * cpad), dtype=torch.uint8, device="cuda")
+                d_uv[:, 0:2 * cw:2] = torch.from_numpy(cb).cuda(); d_uv[:, 1:2 * cw:2] = torch.from_numpy(cr).cuda()
+                keep += [d_y, d_uv]
+                frames.append([(d_y.data_ptr(), w + ypad, 1, 0), (d_uv.data_ptr(), 2 * cw + 2 * cpad, 2, 0), (d_uv.data_ptr() + 1, 2 * cw + 2 * cpad, 2, 0)])
+            else:
+                d_cb = torch.zeros((ch, cw + cpad), dtype=torch.uint8, device="cuda"); d_cb[:, :cw] = torch.from_numpy(cb).cuda()
+                d_cr = torch.zeros((ch, cw + cpad), dtype=torch.uint8, device="cuda"); d_cr[:, :cw] = torch.from_numpy(cr).cuda()
+                keep += [d_y, d_cb, d_cr]
+                frames.append([(d_y.data_ptr(), w + ypad, 1, 0), (d_cb.data_ptr(), cw + cpad, 1, 0), (d_cr.data_ptr(), cw + cpad, 1, 0)])
+        what = (trial, w, h, hs, vs, subsampled, nv12, kw, variant, nframes)
+        if os.environ.get("JPEGENC_FUZZ_VERBOSE"):
+            print(what, flush=True)
+        assert e.encode_planes_device(binding.J_YCBCR, w, h, frames[0], planes_subsampled=subsampled) == want[0], what
+        assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, frames, planes_subsampled=subsampled) == want, what

@@ -16,5 +16,7 @@ run medium JPEGENC_FUZZ_SEED=$((S + 5)) JPEGENC_FUZZ_TRIALS=6000 JPEGENC_FUZZ_MA
 run large JPEGENC_FUZZ_SEED=$((S + 3)) JPEGENC_FUZZ_TRIALS=1500 JPEGENC_FUZZ_MAX_W=2100 JPEGENC_FUZZ_MAX_H=1300
 run two_kernels JPEGENC_FUSED=0 JPEGENC_FUZZ_SEED=$((S + 4)) JPEGENC_FUZZ_TRIALS=6000
 run dma_only JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES=0 JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES=0 JPEGENC_FUZZ_SEED=$((S + 6)) JPEGENC_FUZZ_TRIALS=6000
+( JPEGENC_FUZZ_SEED=$((S + 7)) JPEGENC_FUZZ_TRIALS=4000 timeout 1200 python3 -m pytest tests/test_gpu_batch_multi.py -q -x -k test_randomised_planar_sources 2>&1 | tail -2 ) > $out/${tag}_soak_planar.log 2>&1
+tail -1 $out/${tag}_soak_planar.log
 ( JPEGENC_FUZZ_SEED=9 JPEGENC_GEOMETRY_TRIALS=1500 timeout 1200 python3 -m pytest tests/test_gpu_parity.py -q -x -k test_blocks_random_geometry 2>&1 | tail -2 ) > $out/${tag}_soak_geometry.log 2>&1
 tail -1 $out/${tag}_soak_geometry.log
