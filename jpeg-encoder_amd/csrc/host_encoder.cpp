@@ -1982,7 +1982,8 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     if (!small_off && frame_bytes <= ((size_t)2 << 20) && num_frames >= 16 && e->cfg.device_entropy && !per_frame_tables) {
         for (int i = 0; i < num_frames; i++)
             if (!frames[i]) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
-        int per_round = (int)(((size_t)64 << 20) / frame_bytes);
+        static const size_t round_mb = [] { const char *v = getenv("JPEGENC_SMALL_BATCH_ROUND_MB"); return v && atoi(v) > 0 ? (size_t)atoi(v) : (size_t)64; }();   // (diagnostic sweep)
+        int per_round = (int)((round_mb << 20) / frame_bytes);
         if (per_round > 1024) per_round = 1024;
         if (per_round > num_frames) per_round = num_frames;
         JPEGENC_HIP(hipSetDevice(e->device));
