@@ -496,3 +496,37 @@ def test_randomised_planar_sources(binding, oracle, synth):
             print(what, flush=True)
         assert e.encode_planes_device(binding.J_YCBCR, w, h, frames[0], planes_subsampled=subsampled) == want[0], what
         assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, frames, planes_subsampled=subsampled) == want, what
+
+
+def test_planar_source_launch_sequence_is_replayed_correctly(binding, oracle, synth):
+    """One encoder, the same I420 surface several times in a row: the single-scan launch sequence is captured on the second
+    identical call and replayed from the third (hipGraph) - the plane descriptors are part of what it bakes in.  New pixels
+    in the same surface must come out of a replay, a surface at another address or with NV12 chroma must not be served by
+    the old sequence."""
+    import torch
+    w, h = 640, 360
+    rng = np.random.default_rng(5)
+    cw, ch = w // 2, h // 2
+
+    def surface():
+        y, cb, cr = (rng.integers(0, 256, s, dtype=np.uint8) // 3 + 60 for s in ((h, w), (ch, cw), (ch, cw)))
+        full = np.stack([y, _replicated(cb, 2, 2, w, h), _replicated(cr, 2, 2, w, h)], axis=-1)
+        return y, cb, cr, oracle.encode_jpeg(np.ascontiguousarray(full), w, h, oracle.YCBCR, 80, sampling=(2, 2))
+    e = binding.Encoder(80)
+    e.set_sampling_factor(binding.F_2_2)
+    y, cb, cr, want = surface()
+    d_y, d_cb, d_cr = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (y, cb, cr))
+    planes = [(d_y.data_ptr(), w, 1, 0), (d_cb.data_ptr(), cw, 1, 0), (d_cr.data_ptr(), cw, 1, 0)]
+    for _ in range(5):                                             # direct, direct (keys match: capture), replay, replay, replay
+        assert e.encode_planes_device(binding.J_YCBCR, w, h, planes, planes_subsampled=True) == want
+    y2, cb2, cr2, want2 = surface()                                # new content, same surface: the replayed sequence reads it
+    d_y.copy_(torch.from_numpy(np.ascontiguousarray(y2))); d_cb.copy_(torch.from_numpy(np.ascontiguousarray(cb2))); d_cr.copy_(torch.from_numpy(np.ascontiguousarray(cr2)))
+    torch.cuda.synchronize()
+    for _ in range(2):
+        assert e.encode_planes_device(binding.J_YCBCR, w, h, planes, planes_subsampled=True) == want2
+    d_uv = torch.from_numpy(np.ascontiguousarray(np.stack([cb, cr], axis=-1))).cuda()          # another chroma layout and address
+    d_y3 = torch.from_numpy(np.ascontiguousarray(y)).cuda()
+    nv12 = [(d_y3.data_ptr(), w, 1, 0), (d_uv.data_ptr(), cw * 2, 2, 0), (d_uv.data_ptr() + 1, cw * 2, 2, 0)]
+    for _ in range(4):
+        assert e.encode_planes_device(binding.J_YCBCR, w, h, nv12, planes_subsampled=True) == want
+    assert e.encode_planes_device(binding.J_YCBCR, w, h, planes, planes_subsampled=True) == want2
