@@ -636,6 +636,28 @@ def main():
                 dtm = time.perf_counter() - t1
                 c3["multi_api_one_device"] = {"frames": len(some), "frames_per_s": round(len(some) / dtm, 1),
                                               "identical_files": all(outs3[k][:lens_m[k]].tobytes() == first[k] for k in range(len(some)))}
+                # the same 1000-frame batch with the frames in page-locked memory (jpegenc_host_alloc): uploaded in place,
+                # no staging copy by the workers - what a caller with a pinned capture ring / frame pool gets
+                try:
+                    fb = batch.C3_W * batch.C3_H * 3
+                    pinned = binding.HostBuffer(batch.POOL * fb)
+                    pframes = []
+                    for k in range(batch.POOL):
+                        pinned.array[k * fb:(k + 1) * fb] = pool(k).reshape(-1)
+                        pframes.append(pinned.array[k * fb:(k + 1) * fb])
+                    pf = [pframes[k % batch.POOL] for k in range(args.c3_frames)]
+                    enc3.encode_batch_into(pf[:64], batch.C3_W, batch.C3_H, binding.RGB, outs3)
+                    t1 = time.perf_counter()
+                    lens_p = enc3.encode_batch_into(pf, batch.C3_W, batch.C3_H, binding.RGB, outs3)
+                    dtp = time.perf_counter() - t1
+                    c3["pinned_frames"] = {"frames": len(pf), "frames_per_s": round(len(pf) / dtp, 1), "seconds": round(dtp, 6),
+                                           "identical_files": all(outs3[k][:lens_p[k]].tobytes() == first[k] for k in range(len(some))),
+                                           "roofline": pcie_roofline("pcie_h2d", len(pf) * fb, dtp, link) if link else None,
+                                           "what": "the same batch, frames in page-locked host memory (jpegenc_host_alloc): DMA reads them in place, no staging copy"}
+                    del pf, pframes
+                    pinned.close()
+                except Exception as exc:
+                    c3["pinned_frames"] = {"error": repr(exc)}
                 ks = [0, len(some) // 2]                                      # checked against the oracle by the cpu_baseline leg
                 c3_samples = [(pool(k), batch.C3_W, batch.C3_H, batch.C3_QUALITY, first[k]) for k in ks]
             result["c3_batch"] = c3

@@ -165,6 +165,10 @@ extern "C" {
                                                           num_frames: c_int, width: c_int, height: c_int, color_type: c_int,
                                                           outs: *const *mut u8, capacities: *const usize, lengths: *mut usize) -> c_int;
 
+    pub fn jpegenc_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn jpegenc_host_free(p: *mut c_void) -> c_int;
+    pub fn jpegenc_host_register(p: *mut c_void, bytes: usize) -> c_int;
+    pub fn jpegenc_host_unregister(p: *mut c_void) -> c_int;
     pub fn jpegenc_shard_frames(num_frames: c_int, num_shards: c_int, shard: c_int, indices: *mut c_int, capacity: c_int) -> c_int;
     pub fn jpegenc_encoder_encode_batch_multi(e: *mut jpegenc_encoder, devices: *const c_int, num_devices: c_int,
                                               frames: *const *const u8, frame_len: usize, num_frames: c_int, width: c_int,

@@ -365,6 +365,19 @@ int  jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *fram
                                   int num_frames, int width, int height, int color_type,
                                   jpegenc_write_fn sink, void *const *users);
 
+/* Page-locked ("pinned") host memory.  The batch entry points above and below stage pageable frames through the
+ * workers' own pinned buffers (one host copy per frame); a frame that already lies in page-locked memory - from
+ * jpegenc_host_alloc, registered in place with jpegenc_host_register, or from HIP's own hipHostMalloc /
+ * hipHostRegister - is uploaded in place by the DMA engine, with no host copy (large frames; frames of at most 2 MB in
+ * batches of 16 or more are gathered into shared uploads either way).  What that saves is host work and host DRAM
+ * traffic (three bytes moved per frame byte), the limiter once eight GPUs share one host; on one GPU the
+ * batch is bound by the PCIe link with or without it.  Registering costs about as much as copying the range once: it
+ * pays for buffers that are reused (capture rings, decoder output pools).  No counterpart in the reference. */
+int  jpegenc_host_alloc(size_t bytes, void **out);
+int  jpegenc_host_free(void *p);
+int  jpegenc_host_register(void *p, size_t bytes);
+int  jpegenc_host_unregister(void *p);
+
 /* Same batch, each frame into its own caller buffer (no callbacks): outs[i] has capacities[i]
  * bytes, lengths[i] receives the size frame i needs; a frame that does not fit makes the call
  * return JPEGENC_ERR_BUFFER_TOO_SMALL after all frames have been attempted. */

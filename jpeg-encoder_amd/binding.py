@@ -55,6 +55,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_encode_image", "jpegenc_encoder_block_order", "jpegenc_encoder_encode_coefficients",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
     "jpegenc_encoder_encode_planes_device", "jpegenc_encoder_encode_planes_batch_device",
+    "jpegenc_host_alloc", "jpegenc_host_free", "jpegenc_host_register", "jpegenc_host_unregister",
     "jpegenc_shard_frames", "jpegenc_encoder_encode_batch_multi", "jpegenc_encoder_encode_batch_multi_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
 ]
@@ -166,6 +167,10 @@ def lib():
                                                               C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         l.jpegenc_encoder_encode_planes_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Plane), C.c_int, WRITE_FN, C.c_void_p]
         l.jpegenc_shard_frames.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+        l.jpegenc_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        l.jpegenc_host_free.argtypes = [C.c_void_p]
+        l.jpegenc_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        l.jpegenc_host_unregister.argtypes = [C.c_void_p]
         l.jpegenc_encoder_encode_batch_multi_to_buffers.argtypes = [
             C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
@@ -185,6 +190,39 @@ def check(status):
 
 def device_count():
     return lib().jpegenc_device_count()
+
+
+class HostBuffer:
+    """jpegenc_host_alloc: page-locked host memory as a numpy uint8 array (`.array`); frames handed to the batch entry
+    points from such memory are uploaded in place, without the workers' staging copy.  Freed by close() / at collection."""
+
+    def __init__(self, nbytes):
+        import numpy as np
+        self._ptr = C.c_void_p()
+        check(lib().jpegenc_host_alloc(nbytes, C.byref(self._ptr)))
+        self.nbytes = nbytes
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self._ptr.value)) if nbytes else np.zeros(0, np.uint8)
+
+    def close(self):
+        if getattr(self, "_ptr", None) is not None and self._ptr.value:
+            self.array = None
+            lib().jpegenc_host_free(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown
+            pass
+
+
+def host_register(array):
+    """jpegenc_host_register on a writable C-contiguous numpy array: its pages stay locked until host_unregister(array)."""
+    check(lib().jpegenc_host_register(array.ctypes.data, array.nbytes))
+
+
+def host_unregister(array):
+    check(lib().jpegenc_host_unregister(array.ctypes.data))
 
 
 def shard_frames(num_frames, num_shards, shard):

@@ -154,6 +154,14 @@ int build_block_params_planes(BlockKernelParams *p, const jpegenc_layout &L, int
 
 }  // namespace jpegenc
 
+namespace jpegenc {
+bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+}  // namespace jpegenc
+
 using namespace jpegenc;
 
 extern "C" {
@@ -360,11 +368,6 @@ struct StreamPipe {
         if (s_dn) (void)hipStreamDestroy(s_dn);
     }
 };
-bool is_pinned_host(const void *p) {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
-}
 }  // namespace
 
 int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame_len, int num_frames,

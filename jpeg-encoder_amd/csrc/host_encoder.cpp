@@ -1472,7 +1472,11 @@ static int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint
         return rc;
     }
     auto upload = [&](DeviceCtx &cx) -> int {
-        if (staged) {       // batch workers: copy into this worker's pinned buffer, then a true async DMA
+        if (staged && is_pinned_host(data)) {
+            // the caller's frame is page-locked already (jpegenc_host_alloc / jpegenc_host_register, or HIP's own calls):
+            // the DMA engine reads it in place - no staging copy, no host DRAM traffic beside the DMA's own read
+            JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
+        } else if (staged) {       // batch workers: copy into this worker's pinned buffer, then a true async DMA
             if (bytes > cx.h_pixels_cap) {
                 if (cx.h_pixels) (void)hipHostFree(cx.h_pixels);
                 cx.h_pixels = nullptr; cx.h_pixels_cap = 0;
@@ -2114,6 +2118,30 @@ int jpegenc_encoder_encode_batch_device_to_buffers(jpegenc_encoder *e, const voi
 
 
 // ---- multi-GPU batches (frame k -> GPU k mod N, no collective) ---------------------------------
+// Page-locked host memory for frames (and outputs): what the batch entry points upload without a staging copy.
+int jpegenc_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null result pointer");
+    *out = nullptr;
+    if (bytes == 0) return JPEGENC_OK;
+    JPEGENC_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return JPEGENC_OK;
+}
+int jpegenc_host_free(void *p) {
+    if (!p) return JPEGENC_OK;
+    JPEGENC_HIP(hipHostFree(p));
+    return JPEGENC_OK;
+}
+int jpegenc_host_register(void *p, size_t bytes) {
+    if (!p || bytes == 0) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "nothing to register");
+    JPEGENC_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return JPEGENC_OK;
+}
+int jpegenc_host_unregister(void *p) {
+    if (!p) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null pointer");
+    JPEGENC_HIP(hipHostUnregister(p));
+    return JPEGENC_OK;
+}
+
 int jpegenc_shard_frames(int num_frames, int num_shards, int shard, int *indices, int capacity) {
     if (num_frames < 0 || num_shards < 1 || shard < 0 || shard >= num_shards)
         return -fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad shard arguments");

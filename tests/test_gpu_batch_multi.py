@@ -57,6 +57,38 @@ def test_run_sharded_batch_on_the_gpu(binding, c3):
         assert bytes(f) == want[k % batch.POOL]
 
 
+def test_batch_frames_in_page_locked_memory_are_uploaded_in_place(binding, c3):
+    """Frames from jpegenc_host_alloc, from a registered numpy array and from pageable memory in ONE batch (the workers
+    stage only the pageable ones); single- and multi-device entry points; unregistering returns the range to pageable."""
+    batch, pool, want = c3
+    fb = batch.C3_W * batch.C3_H * 3
+    hb = binding.HostBuffer(8 * fb)
+    reg = np.empty(8 * fb + 4096, dtype=np.uint8)[37:37 + 8 * fb]        # an unaligned range of the caller's own memory
+    binding.host_register(reg)
+    try:
+        frames = []
+        for k in range(48):
+            src = pool(k).reshape(-1)
+            if k % 3 == 0:
+                v = hb.array[(k % 8) * fb:(k % 8 + 1) * fb]; v[:] = pool(k % 8).reshape(-1); src = v
+            elif k % 3 == 1:
+                v = reg[(k % 8) * fb:(k % 8 + 1) * fb]; v[:] = pool(k % 8).reshape(-1); src = v
+            frames.append(src)
+        keys = [k % 8 if k % 3 != 2 else k % batch.POOL for k in range(48)]
+        with binding.Encoder(batch.C3_QUALITY) as enc:
+            outs = [np.empty(2 << 20, dtype=np.uint8) for _ in frames]
+            for devices in (None, [0, 0]):
+                lens = enc.encode_batch_into(frames, batch.C3_W, batch.C3_H, binding.RGB, outs, devices=devices)
+                for i, key in enumerate(keys):
+                    assert outs[i][:lens[i]].tobytes() == want[key], f"frame {i} devices {devices}"
+    finally:
+        binding.host_unregister(reg)
+        hb.close()
+    with pytest.raises(binding.JpegEncError):
+        binding.host_unregister(reg)                                      # not registered any more
+    assert binding.lib().jpegenc_host_free(None) == 0
+
+
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
 def test_encode_batch_multi_shards(binding, c3, devices):
     """jpegenc_encoder_encode_batch_multi_to_buffers: frame k -> devices[k % n]; same files as the oracle whatever
