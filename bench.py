@@ -623,43 +623,66 @@ def main():
                           "jpegenc_encoder_encode_batch_to_buffers on its GPU; seconds = MAX over ranks; photo-like frames "
                           f"({batch.POOL} distinct, frame k = pool[k % {batch.POOL}]); digest = checksum of the per-frame SHA-256s in frame order")
             c3["scaling"] = "strong"
+            idx = binding.shard_frames(args.c3_frames, world, rank)
+            first = [bytes(mine[k]) for k in idx[:64]]                         # (outs3 is reused by the legs below)
             if rank == 0 and world == 1 and link:
                 c3["roofline"] = pcie_roofline("pcie_h2d", args.c3_frames * batch.C3_W * batch.C3_H * 3, c3["seconds"], link)
             if rank == 0 and world == 1:
                 # the same batch through the library's own multi-device entry point (one process driving the listed GPUs;
                 # here only this rank's GPU, so it measures the API's overhead, not scaling) - same files
                 some = [pool(k) for k in range(min(args.c3_frames, 64))]
-                first = [bytes(mine[k]) for k in range(len(some))]            # (outs3 is reused below)
                 enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])     # warm-up: the shard's buffers
                 t1 = time.perf_counter()
                 lens_m = enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])
                 dtm = time.perf_counter() - t1
                 c3["multi_api_one_device"] = {"frames": len(some), "frames_per_s": round(len(some) / dtm, 1),
                                               "identical_files": all(outs3[k][:lens_m[k]].tobytes() == first[k] for k in range(len(some)))}
-                # the same 1000-frame batch with the frames in page-locked memory (jpegenc_host_alloc): uploaded in place,
-                # no staging copy by the workers - what a caller with a pinned capture ring / frame pool gets
-                try:
-                    fb = batch.C3_W * batch.C3_H * 3
-                    pinned = binding.HostBuffer(batch.POOL * fb)
-                    pframes = []
-                    for k in range(batch.POOL):
-                        pinned.array[k * fb:(k + 1) * fb] = pool(k).reshape(-1)
-                        pframes.append(pinned.array[k * fb:(k + 1) * fb])
-                    pf = [pframes[k % batch.POOL] for k in range(args.c3_frames)]
+                ks = [0, len(some) // 2]                                      # checked against the oracle by the cpu_baseline leg
+                c3_samples = [(pool(k), batch.C3_W, batch.C3_H, batch.C3_QUALITY, first[k]) for k in ks]
+            # the same batch with the frames in page-locked memory (jpegenc_host_alloc): uploaded in place, no staging copy
+            # by the workers - what a caller with a pinned capture ring / frame pool gets.  Every rank runs it on its shard;
+            # the two all-reduces below are unconditional (a rank whose leg failed contributes -1), so ranks cannot part ways.
+            dtp, same, err_p = -1.0, True, None
+            try:
+                fb = batch.C3_W * batch.C3_H * 3
+                keep = min(len(idx), 32)
+                pinned = binding.HostBuffer(batch.POOL * fb)
+                pframes = []
+                for k in range(batch.POOL):
+                    pinned.array[k * fb:(k + 1) * fb] = pool(k).reshape(-1)
+                    pframes.append(pinned.array[k * fb:(k + 1) * fb])
+                pf = [pframes[k % batch.POOL] for k in idx]
+                if pf:
                     enc3.encode_batch_into(pf[:64], batch.C3_W, batch.C3_H, binding.RGB, outs3)
+            except Exception as exc:
+                err_p, pf = repr(exc), None
+            if distributed:
+                dist.barrier()
+            if pf is not None:
+                try:
                     t1 = time.perf_counter()
-                    lens_p = enc3.encode_batch_into(pf, batch.C3_W, batch.C3_H, binding.RGB, outs3)
+                    lens_p = enc3.encode_batch_into(pf, batch.C3_W, batch.C3_H, binding.RGB, outs3) if pf else []
                     dtp = time.perf_counter() - t1
-                    c3["pinned_frames"] = {"frames": len(pf), "frames_per_s": round(len(pf) / dtp, 1), "seconds": round(dtp, 6),
-                                           "identical_files": all(outs3[k][:lens_p[k]].tobytes() == first[k] for k in range(len(some))),
-                                           "roofline": pcie_roofline("pcie_h2d", len(pf) * fb, dtp, link) if link else None,
-                                           "what": "the same batch, frames in page-locked host memory (jpegenc_host_alloc): DMA reads them in place, no staging copy"}
+                    same = all(outs3[i][:lens_p[i]].tobytes() == first[i] for i in range(keep))
                     del pf, pframes
                     pinned.close()
                 except Exception as exc:
-                    c3["pinned_frames"] = {"error": repr(exc)}
-                ks = [0, len(some) // 2]                                      # checked against the oracle by the cpu_baseline leg
-                c3_samples = [(pool(k), batch.C3_W, batch.C3_H, batch.C3_QUALITY, first[k]) for k in ks]
+                    err_p, dtp = repr(exc), -1.0
+            if distributed:
+                t_hi = torch.tensor([dtp, 0.0 if same else 1.0], dtype=torch.float64, device=dev)
+                t_lo = torch.tensor([dtp], dtype=torch.float64, device=dev)
+                dist.all_reduce(t_hi, op=dist.ReduceOp.MAX)
+                dist.all_reduce(t_lo, op=dist.ReduceOp.MIN)
+                dtp, same = (float(t_hi[0]) if float(t_lo[0]) > 0 else -1.0), float(t_hi[1]) == 0.0
+            if dtp > 0:
+                c3["pinned_frames"] = {"frames": args.c3_frames, "frames_per_s": round(args.c3_frames / dtp, 1), "seconds": round(dtp, 6),
+                                       "identical_files": same,
+                                       "what": "the same sharded batch, frames in page-locked host memory (jpegenc_host_alloc): DMA reads them in "
+                                               "place, no staging copy by the workers; seconds = MAX over ranks"}
+                if rank == 0 and world == 1 and link:
+                    c3["pinned_frames"]["roofline"] = pcie_roofline("pcie_h2d", args.c3_frames * fb, dtp, link)
+            else:
+                c3["pinned_frames"] = {"error": err_p or "failed on another rank"}
             result["c3_batch"] = c3
         except Exception as exc:                                   # never lose the headline line to a side leg
             result["c3_batch"] = {"error": repr(exc)}

@@ -160,6 +160,9 @@ bool is_pinned_host(const void *p) {
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
 }
+bool is_pinned_host_range(const void *p, size_t bytes) {        // first and last byte: a registration may end inside the frame
+    return p && bytes && is_pinned_host(p) && is_pinned_host((const uint8_t *)p + bytes - 1);
+}
 }  // namespace jpegenc
 
 using namespace jpegenc;
@@ -409,7 +412,7 @@ int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame
     JPEGENC_HIP(hipStreamCreateWithPriority(&pipe.s_dn, hipStreamNonBlocking, prio_mid != prio_greatest ? prio_mid : prio_least));
     JPEGENC_HIP(hipStreamCreateWithPriority(&pipe.s_k, hipStreamNonBlocking, prio_least));
     bool all_pinned = true;
-    for (int i = 0; i < num_frames && all_pinned; i++) all_pinned = is_pinned_host(frames[i]);
+    for (int i = 0; i < num_frames && all_pinned; i++) all_pinned = is_pinned_host_range(frames[i], required);
     for (int j = 0; j < slots; j++) {
         StreamSlot &x = pipe.slot[j];
         if (!all_pinned) JPEGENC_HIP(hipHostMalloc(&x.h_in, required, hipHostMallocDefault));

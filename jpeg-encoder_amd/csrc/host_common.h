@@ -94,6 +94,7 @@ size_t scan_workspace_size(const jpegenc_layout &L, const jpegenc_scan &sc, int 
 size_t scan_max_bytes(const jpegenc_layout &L, const jpegenc_scan &sc);
 
 int ensure_device_ready(int device);
+bool is_pinned_host_range(const void *p, size_t bytes);
 bool is_pinned_host(const void *p);      // page-locked host memory (hipHostMalloc / hipHostRegister / jpegenc_host_*): DMA reads it in place
 
 }  // namespace jpegenc

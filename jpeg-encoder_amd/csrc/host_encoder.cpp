@@ -1472,7 +1472,7 @@ static int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint
         return rc;
     }
     auto upload = [&](DeviceCtx &cx) -> int {
-        if (staged && is_pinned_host(data)) {
+        if (staged && is_pinned_host_range(data, bytes)) {
             // the caller's frame is page-locked already (jpegenc_host_alloc / jpegenc_host_register, or HIP's own calls):
             // the DMA engine reads it in place - no staging copy, no host DRAM traffic beside the DMA's own read
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));

@@ -84,6 +84,17 @@ def test_batch_frames_in_page_locked_memory_are_uploaded_in_place(binding, c3):
     finally:
         binding.host_unregister(reg)
         hb.close()
+    # a registration that ends inside the frame: treated as pageable (staged), same bytes
+    half = np.empty(fb, dtype=np.uint8)
+    half[:] = pool(3).reshape(-1)
+    binding.host_register(half[:fb // 2])
+    try:
+        with binding.Encoder(batch.C3_QUALITY) as enc:
+            outs = [np.empty(2 << 20, dtype=np.uint8) for _ in range(4)]
+            lens = enc.encode_batch_into([half] * 4, batch.C3_W, batch.C3_H, binding.RGB, outs)
+            assert all(outs[i][:lens[i]].tobytes() == want[3] for i in range(4))
+    finally:
+        binding.host_unregister(half[:fb // 2])
     with pytest.raises(binding.JpegEncError):
         binding.host_unregister(reg)                                      # not registered any more
     assert binding.lib().jpegenc_host_free(None) == 0
