@@ -348,7 +348,7 @@ int  jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jpeg_color_typ
  * descriptors, frame-major (frame f, component c at planes[4 * f + c]), the surfaces anywhere in device memory.  Frame
  * f -> sink(users[f], ...), one complete file each (sink threading: see jpegenc_encoder_encode_batch).  The device
  * work of the whole batch shares its launches as in jpegenc_encoder_encode_batch_device when the descriptors of each
- * component agree in pitch, pixel_stride and invert over the frames; otherwise - and with optimised Huffman tables, the
+ * component agree in pixel_stride and invert over the frames (address and pitch are per frame); otherwise - and with optimised Huffman tables, the
  * host entropy coder or sampling factors of 4 - the frames are encoded one at a time.  Same bytes either way. */
 int  jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
                                                 const jpegenc_plane *planes, int num_frames, int planes_subsampled,

@@ -17,6 +17,7 @@ void set_last_error(const std::string &msg) { g_last_error = msg; }
 int fail(int status, const std::string &msg) { g_last_error = msg; return status; }
 int hip_fail(hipError_t e, const char *what) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();       // reported: HIP's per-thread sticky error must not fail the next call's launch checks
     return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? JPEGENC_ERR_NO_DEVICE : JPEGENC_ERR_HIP;
 }
 

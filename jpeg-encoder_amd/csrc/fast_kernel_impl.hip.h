@@ -303,17 +303,18 @@ struct WaveCtx {
 // at the top of the file): packed[j] = zig-zag coefficients (2j, 2j + 1) of the lane's block.  false: a padding wave
 // of the last group (nothing computed).
 // Where a wave's samples start: frame `frm` of the launch + the component's plane.  PLANES kernels of a BATCH of described
-// surfaces (a pixel_frame_stride of all ones) look the plane's address up in a device table [frame][4] instead - surfaces
-// from a decoder's pool lie anywhere.
+// surfaces (a pixel_frame_stride of all ones) look the plane's address AND pitch up in a device table
+// [frame][8] = {4 addresses, 4 pitches} instead - surfaces from a decoder's pool lie anywhere, and pools mix pitches.
 constexpr uint64_t kPlaneTableStride = ~0ull;
 template <bool PLANES>
-__device__ __forceinline__ gbytes frame_base(const u32x16 &H, const u32x16 &Wv, uint32_t frm, uint32_t c) {
+__device__ __forceinline__ gbytes frame_base(const u32x16 &H, const u32x16 &Wv, uint32_t frm, uint32_t c, uint32_t &pitch) {
     const uint64_t px_base = ((uint64_t)H[1] << 32) | H[0];
     const uint64_t px_stride = ((uint64_t)H[5] << 32) | H[4];
     if (PLANES && px_stride == kPlaneTableStride) {
         const uint64_t __attribute__((address_space(1))) *table = (const uint64_t __attribute__((address_space(1))) *)(uintptr_t)px_base;
-        const uint64_t addr = table[(size_t)frm * 4u + c];
+        const uint64_t addr = table[(size_t)frm * 8u + c], pt = table[(size_t)frm * 8u + 4u + c];
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(addr >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr);   // (wave-uniform -> scalar registers)
+        pitch = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pt);
         return (gbytes)(uintptr_t)(((uint64_t)hi << 32) | lo);
     }
     return (gbytes)(uintptr_t)(px_base + (size_t)frm * px_stride + (((uint64_t)Wv[15] << 32) | Wv[14]));
@@ -349,9 +350,9 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     w.first_unit = first_unit; w.wave_mcus = wave_mcus; w.limit = limit; w.units_x = units_x; w.magic = magic; w.shift = shift;
     w.c = c; w.role = role; w.qsel = qsel;
     if (first_unit >= limit) return false;                          // padding wave of the last group: nothing to do
-    const gbytes frame = frame_base<PLANES>(H, Wv, frm, (uint32_t)c);
+    uint32_t pitch = PLANES ? Wv[9] : H[10];                        // frame bytes < 2^31 (checked by the launcher)
+    const gbytes frame = frame_base<PLANES>(H, Wv, frm, (uint32_t)c, pitch);
     const int width = PLANES ? (int)(Wv[10] & 0xFFFFu) : (int)H[8], hlim = (PLANES ? (int)(Wv[10] >> 16) : (int)H[9]) - 1;
-    const uint32_t pitch = PLANES ? Wv[9] : H[10];                  // frame bytes < 2^31 (checked by the launcher)
     const uint32_t mcu_w = PLANES ? Wv[11] & 0xFFFFu : H[13], mcu_h = PLANES ? Wv[11] >> 16 : H[14];
     const bool two_bytes = PLANES && ((bits >> FW_BPP2_SHIFT) & 1u);  // wave-uniform
     const int bpp = PLANES ? (two_bytes ? 2 : 1) : BPP;

@@ -81,12 +81,12 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         // (PLANES: the component's own plane - address, pitch, size, MCU size and sample stride from the wave's record)
         const uint32_t mcu_w = PLANES ? Wv[11] & 0xFFFFu : H[13], mcu_h = PLANES ? Wv[11] >> 16 : H[14];
         const int pw = PLANES ? (int)(Wv[10] & 0xFFFFu) : (int)H[8], ph = PLANES ? (int)(Wv[10] >> 16) : (int)H[9];
-        const uint32_t ppitch = PLANES ? Wv[9] : H[10];
+        uint32_t ppitch = PLANES ? Wv[9] : H[10];
         const size_t pbpp = PLANES ? (((wbits >> FW_BPP2_SHIFT) & 1u) ? 2u : 1u) : (size_t)BPP;
         const int bx = (int)(pmx * mcu_w + ((1u << lg) - 1u) * 8u * (uint32_t)csx) + (int)(lane & 7u) * csx;
         const int by = (int)(pmy * mcu_h + ((1u << lgv) - 1u) * 8u * (uint32_t)csy) + (int)(lane >> 3) * csy;
         const int c = (int)((wbits >> FW_COMP_SHIFT) & 3u), role = (int)((wbits >> FW_ROLE_SHIFT) & 3u);
-        const gbytes frame = frame_base<PLANES>(H, Wv, f, (uint32_t)c);
+        const gbytes frame = frame_base<PLANES>(H, Wv, f, (uint32_t)c, ppitch);
         pred_sample = edge_sample(frame + (size_t)min(by, ph - 1) * ppitch + (size_t)min(bx, pw - 1) * pbpp, role, c, k);
     }
 

@@ -42,7 +42,7 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
 // fast_kernels_planes.hip: a described planar source in ONE launch (sampling factors 1 and 2); false = take the per-plane launches
 bool launch_blocks_planes_once(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, int num_frames, int variant,
                                hipStream_t stream, hipError_t *err);
-// (a batch of described surfaces: p.pixels = device table [frame][4] of plane addresses, p.pixel_frame_stride = kPlaneTableStrideHost)
+// (a batch of described surfaces: p.pixels = device table [frame][8] of plane addresses and pitches, p.pixel_frame_stride = kPlaneTableStrideHost)
 constexpr uint64_t kPlaneTableStrideHost = ~0ull;
 bool fused_planes_supported(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled);
 hipError_t launch_group_planes(const BlockKernelParams &p, const jpegenc_plane planes[4], bool planes_subsampled, const EntropyParams *d_params,

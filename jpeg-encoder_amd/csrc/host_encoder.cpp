@@ -508,7 +508,7 @@ struct BatchBuffers {
         *cap = need;
         return JPEGENC_OK;
     }
-    void *d_plane_table = nullptr;        // batches of described planar surfaces: [frame][4] plane addresses
+    void *d_plane_table = nullptr;        // batches of described planar surfaces: [frame][8] = 4 plane addresses + 4 pitches
     size_t plane_table_cap = 0;
     int reserve_plane_table(size_t bytes) {
         if (bytes <= plane_table_cap) return JPEGENC_OK;
@@ -1208,7 +1208,7 @@ static int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int
 constexpr int kBatchNeedsPerFrame = -1000;
 
 // A batch of described planar surfaces (jpegenc_encoder_encode_planes_batch_device): every frame's planes share pitch, sample
-// stride and inversion (planes = frame 0's descriptors); where each frame's planes start is a device table [frame][4].
+// stride and inversion (planes = frame 0's descriptors with each component's largest pitch); every frame's plane addresses and pitches are a device table [frame][8].
 struct PlaneBatch { const jpegenc_plane *planes; bool subsampled; const uint64_t *d_table; int jct; };
 
 static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b, int device, const void *d_frames,
@@ -1320,7 +1320,7 @@ static int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b,
         BlockKernelParams p;
         int e = pb ? build_block_params_planes(&p, L, width, height, t.q, order) : build_block_params(&p, L, width, height, color_type, t.q, order);
         if (e) return e;
-        p.pixels = pb ? (const uint8_t *)(pb->d_table + (size_t)f0 * 4u) : (const uint8_t *)d_frames + (size_t)f0 * frame_stride;
+        p.pixels = pb ? (const uint8_t *)(pb->d_table + (size_t)f0 * 8u) : (const uint8_t *)d_frames + (size_t)f0 * frame_stride;
         p.coeffs = b.d_coeffs;
         p.pixel_frame_stride = pb ? kPlaneTableStrideHost : frame_stride;
         p.coeff_frame_stride = L.total_blocks;
@@ -1837,7 +1837,7 @@ int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames
 
 // A batch of described planar surfaces (decoder / camera pools of I420 or NV12 frames): the launches of the whole batch are
 // shared like those of jpegenc_encoder_encode_batch_device.  planes: num_frames x 4 descriptors, frame-major; the
-// descriptors of one component must agree in pitch, pixel_stride and invert across frames (only d_data differs).
+// descriptors of one component must agree in pixel_stride and invert across frames (d_data and pitch may differ).
 int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int width, int height, const jpegenc_plane *planes,
                                                int num_frames, int planes_subsampled, jpegenc_write_fn sink, void *const *users) {
     REQUIRE(e);
@@ -1856,7 +1856,7 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
             if (!pl.d_data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null plane");
             if (pl.pixel_stride != 1 && pl.pixel_stride != 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "pixel_stride must be 1 or 2");
             if (pl.pitch > 0x7FFFFFFFu) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane pitch too large");
-            if (pl.pitch != p0.pitch || pl.pixel_stride != p0.pixel_stride || (pl.invert != 0) != (p0.invert != 0) ||
+            if (pl.pixel_stride != p0.pixel_stride || (pl.invert != 0) != (p0.invert != 0) ||
                 (pl.pixel_stride == 2 && (((uintptr_t)pl.d_data ^ (uintptr_t)p0.d_data) & 1u)))
                 uniform = false;
         }
@@ -1873,18 +1873,26 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
     if (rc) return rc;
     // where every frame's planes start (the second byte of an interleaved pair is addressed through its pair: the kernels
     // pick byte 1 of each two-byte sample, as jpegenc_encoder_encode_planes_device does)
-    std::vector<uint64_t> table((size_t)num_frames * 4, 0);
+    // table[frame][8] = {4 plane addresses, 4 pitches}: the frames of a pool may differ in both (what they share - sample
+    // stride, inversion, byte of the pair - is in the launch's wave records, set up from `rep`: frame 0's descriptors with
+    // the LARGEST pitch of each component, which is what the launchers' 32-bit offset checks look at)
+    std::vector<uint64_t> table((size_t)num_frames * 8, 0);
+    jpegenc_plane rep[4];
+    memset(rep, 0, sizeof rep);
+    for (int i = 0; i < ncomp; i++) rep[i] = planes[i];
     for (int f = 0; f < num_frames; f++)
         for (int i = 0; i < ncomp; i++) {
             const jpegenc_plane &pl = planes[(size_t)f * 4 + i];
             const uintptr_t ptr = (uintptr_t)pl.d_data;
-            table[(size_t)f * 4 + i] = (uint64_t)(ptr - (pl.pixel_stride == 2 ? (ptr & 1u) : 0u));
+            table[(size_t)f * 8 + i] = (uint64_t)(ptr - (pl.pixel_stride == 2 ? (ptr & 1u) : 0u));
+            table[(size_t)f * 8 + 4 + i] = (uint64_t)pl.pitch;
+            if (pl.pitch > rep[i].pitch) rep[i].pitch = pl.pitch;
         }
     rc = e->batch.reserve_plane_table(table.size() * sizeof(uint64_t));
     if (rc) return rc;
     JPEGENC_HIP(hipMemcpyAsync(e->batch.d_plane_table, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, e->ctx.stream));
     JPEGENC_HIP(hipStreamSynchronize(e->ctx.stream));                           // (`table` is pageable and leaves scope)
-    const PlaneBatch pb = {planes, planes_subsampled != 0, (const uint64_t *)e->batch.d_plane_table, jct};
+    const PlaneBatch pb = {rep, planes_subsampled != 0, (const uint64_t *)e->batch.d_plane_table, jct};
     rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, nullptr, 0, num_frames, width, height, 0, sink, users, &pb);
     if (rc != kBatchNeedsPerFrame) return rc;
     return one_by_one();

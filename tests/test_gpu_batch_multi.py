@@ -437,7 +437,8 @@ def test_encode_planes_batch_device(binding, oracle, synth, kw):
     """jpegenc_encoder_encode_planes_batch_device: a pool of I420 surfaces anywhere in device memory (padded pitches) and a
     pool of NV12 surfaces, five frames per call sharing their launches (plane addresses through a device table) - each file
     byte-identical to the oracle fed the equivalent interleaved YCbCr image; a frame whose pitch differs from the others'
-    sends the batch down the one-frame-at-a-time path, same bytes."""
+    stays in the shared launches (addresses AND pitches are per frame in the table), one whose sample stride differs sends
+    the batch down the one-frame-at-a-time path - same bytes."""
     import torch
     w, h, n = 515, 301, 5
     hs, vs = kw.get("sampling", (2, 2) if kw["quality"] < 90 else (1, 1))
@@ -471,11 +472,19 @@ def test_encode_planes_batch_device(binding, oracle, synth, kw):
     assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, nv12, planes_subsampled=True) == want
     assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, i420[:1], planes_subsampled=True) == want[:1]
     assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, [], planes_subsampled=True) == []
-    # one frame with another luma pitch: not a uniform pool any more
+    # one frame with another luma pitch and one with other chroma pitches: per-frame pitches in the table
     y3 = torch.zeros((h, w + 64), dtype=torch.uint8, device="cuda"); y3[:, :w] = keep[4 * 3][:, :w]
+    cb1 = torch.zeros((ch, cw + 1), dtype=torch.uint8, device="cuda"); cb1[:, :cw] = keep[4 * 1 + 1][:, :cw]
+    cr1 = torch.zeros((ch, cw + 33), dtype=torch.uint8, device="cuda"); cr1[:, :cw] = keep[4 * 1 + 2][:, :cw]
     odd = [list(fr) for fr in i420]
     odd[3][0] = (y3.data_ptr(), w + 64, 1, 0)
+    odd[1][1] = (cb1.data_ptr(), cw + 1, 1, 0)
+    odd[1][2] = (cr1.data_ptr(), cw + 33, 1, 0)
     assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, odd, planes_subsampled=True) == want
+    # an NV12 surface in an I420 pool (sample stride differs): one frame at a time
+    mixed = [list(fr) for fr in i420]
+    mixed[2] = nv12[2]
+    assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, mixed, planes_subsampled=True) == want
     with pytest.raises(binding.JpegEncError):
         e.encode_planes_batch_device(binding.J_YCBCR, w, h, [[(0, ypitch, 1, 0)] * 3] * 2, planes_subsampled=True)
 
@@ -516,8 +525,11 @@ def test_randomised_planar_sources(binding, oracle, synth):
         if variant == oracle.FDCT_SIMD:
             e.set_fdct_variant(binding.FDCT_SIMD)
         ypad, cpad = int(rng.integers(0, 40)), int(rng.integers(0, 9))
+        mixed_pitches = bool(rng.integers(0, 2))                      # a pool whose surfaces differ in pitch (per-frame pitch table)
         frames, want, keep = [], [], []
         for f in range(nframes):
+            if mixed_pitches and f:
+                ypad, cpad = int(rng.integers(0, 40)), int(rng.integers(0, 9))
             noisy = trial % 3 != 0
             mk = (lambda s: rng.integers(0, 256, s, dtype=np.uint8)) if noisy else (lambda s: (np.add.outer(np.arange(s[0]), np.arange(s[1])) // 3 + f).astype(np.uint8))
             y, cb, cr = mk((h, w)), mk((ch, cw)), mk((ch, cw))
