@@ -509,12 +509,15 @@ struct BatchBuffers {
         return JPEGENC_OK;
     }
     void *d_plane_table = nullptr;        // batches of described planar surfaces: [frame][8] = 4 plane addresses + 4 pitches
+    uint64_t *h_plane_table = nullptr;    // its page-locked source: uploaded in stream order, no synchronisation (the batch call ends only when its work has)
     size_t plane_table_cap = 0;
     int reserve_plane_table(size_t bytes) {
         if (bytes <= plane_table_cap) return JPEGENC_OK;
         if (d_plane_table) (void)hipFree(d_plane_table);
-        d_plane_table = nullptr; plane_table_cap = 0;
+        if (h_plane_table) (void)hipHostFree(h_plane_table);
+        d_plane_table = nullptr; h_plane_table = nullptr; plane_table_cap = 0;
         JPEGENC_HIP(hipMalloc(&d_plane_table, bytes));
+        JPEGENC_HIP(hipHostMalloc((void **)&h_plane_table, bytes, hipHostMallocDefault));
         plane_table_cap = bytes;
         return JPEGENC_OK;
     }
@@ -561,6 +564,7 @@ struct BatchBuffers {
         if (d_ws) (void)hipFree(d_ws);
         if (d_packed) (void)hipFree(d_packed);
         if (d_plane_table) (void)hipFree(d_plane_table);
+        if (h_plane_table) (void)hipHostFree(h_plane_table);
         if (d_pos) (void)hipFree(d_pos);
         if (d_len) (void)hipFree(d_len);
         if (h_len) (void)hipHostFree(h_len);
@@ -1871,27 +1875,27 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
     if (!uniform || !e->cfg.device_entropy || per_frame_tables || hs == 4 || vs == 4 || num_frames == 1) return one_by_one();
     int rc = e->ctx.open(e->device);
     if (rc) return rc;
-    // where every frame's planes start (the second byte of an interleaved pair is addressed through its pair: the kernels
-    // pick byte 1 of each two-byte sample, as jpegenc_encoder_encode_planes_device does)
+    // (the second byte of an interleaved pair is addressed through its pair: the kernels pick byte 1 of each two-byte sample,
+    // as jpegenc_encoder_encode_planes_device does)
     // table[frame][8] = {4 plane addresses, 4 pitches}: the frames of a pool may differ in both (what they share - sample
     // stride, inversion, byte of the pair - is in the launch's wave records, set up from `rep`: frame 0's descriptors with
     // the LARGEST pitch of each component, which is what the launchers' 32-bit offset checks look at)
-    std::vector<uint64_t> table((size_t)num_frames * 8, 0);
+    rc = e->batch.reserve_plane_table((size_t)num_frames * 8 * sizeof(uint64_t));
+    if (rc) return rc;
+    uint64_t *table = e->batch.h_plane_table;
     jpegenc_plane rep[4];
     memset(rep, 0, sizeof rep);
     for (int i = 0; i < ncomp; i++) rep[i] = planes[i];
     for (int f = 0; f < num_frames; f++)
-        for (int i = 0; i < ncomp; i++) {
+        for (int i = 0; i < 4; i++) {
+            if (i >= ncomp) { table[(size_t)f * 8 + i] = table[(size_t)f * 8 + 4 + i] = 0; continue; }
             const jpegenc_plane &pl = planes[(size_t)f * 4 + i];
             const uintptr_t ptr = (uintptr_t)pl.d_data;
             table[(size_t)f * 8 + i] = (uint64_t)(ptr - (pl.pixel_stride == 2 ? (ptr & 1u) : 0u));
             table[(size_t)f * 8 + 4 + i] = (uint64_t)pl.pitch;
             if (pl.pitch > rep[i].pitch) rep[i].pitch = pl.pitch;
         }
-    rc = e->batch.reserve_plane_table(table.size() * sizeof(uint64_t));
-    if (rc) return rc;
-    JPEGENC_HIP(hipMemcpyAsync(e->batch.d_plane_table, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, e->ctx.stream));
-    JPEGENC_HIP(hipStreamSynchronize(e->ctx.stream));                           // (`table` is pageable and leaves scope)
+    JPEGENC_HIP(hipMemcpyAsync(e->batch.d_plane_table, table, (size_t)num_frames * 8 * sizeof(uint64_t), hipMemcpyHostToDevice, e->ctx.stream));
     const PlaneBatch pb = {rep, planes_subsampled != 0, (const uint64_t *)e->batch.d_plane_table, jct};
     rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, nullptr, 0, num_frames, width, height, 0, sink, users, &pb);
     if (rc != kBatchNeedsPerFrame) return rc;

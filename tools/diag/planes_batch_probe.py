@@ -16,8 +16,15 @@ rng = np.random.default_rng(2)
 frames, keep, rgbs = [], [], []
 for f in range(n):
     px = np.clip(rgb.astype(np.int16) + rng.integers(-6, 7, rgb.shape, dtype=np.int16), 0, 255).astype(np.uint8)
-    y = torch.from_numpy(np.ascontiguousarray(px[:, :, 1])).cuda()
-    cb = torch.from_numpy(np.ascontiguousarray(px[::2, ::2, 0])).cuda(); cr = torch.from_numpy(np.ascontiguousarray(px[::2, ::2, 2])).cuda()
+    # the I420 surface a camera / decoder would hand over for this RGB frame (image_buffer.rs:9-31 + 2x2 averaging), so both
+    # ways code the same picture and their files have the same size
+    r_, g_, b_ = (px[:, :, i].astype(np.int64) for i in range(3))
+    yy = (19595 * r_ + 38470 * g_ + 7471 * b_ + 32767) >> 16
+    cbf = (-11059 * r_ - 21709 * g_ + 32768 * b_ + (128 << 16) + 32767) >> 16
+    crf = (32768 * r_ - 27439 * g_ - 5329 * b_ + (128 << 16) + 32767) >> 16
+    avg = lambda a: ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    y = torch.from_numpy(np.ascontiguousarray(yy.astype(np.uint8))).cuda()
+    cb = torch.from_numpy(np.ascontiguousarray(avg(cbf))).cuda(); cr = torch.from_numpy(np.ascontiguousarray(avg(crf))).cuda()
     keep += [y, cb, cr]
     frames.append([(y.data_ptr(), w, 1, 0), (cb.data_ptr(), w // 2, 1, 0), (cr.data_ptr(), w // 2, 1, 0)])
     rgbs.append(px)
@@ -53,4 +60,5 @@ def each():
 t_each = timed(each)
 e2 = b.Encoder(85); e2.set_sampling_factor(b.F_2_2)
 t_rgb = timed(lambda: b.check(fb(e2._h, d_rgb.data_ptr(), w * h * 3, n, w, h, b.RGB, cb_, users)))
-print(f"{n} 4K frames q85 4:2:0 in HBM -> files ({mb:.2f} MB each): I420 batch {t_batch * 1e6 / n:6.1f} us/frame, I420 one call per frame {t_each * 1e6 / n:6.1f}, interleaved RGB batch {t_rgb * 1e6 / n:6.1f}")
+mb_rgb = nbytes[0] / n / 1e6
+print(f"{n} 4K frames q85 4:2:0 in HBM -> files: I420 batch ({mb:.2f} MB each) {t_batch * 1e6 / n:6.1f} us/frame, I420 one call per frame {t_each * 1e6 / n:6.1f}, interleaved RGB batch ({mb_rgb:.2f} MB each) {t_rgb * 1e6 / n:6.1f}")
