@@ -62,6 +62,100 @@ __global__ void __launch_bounds__(384) k_tile(const uint8_t *px, uint8_t *out, u
     if (acc == 0x12345678u) sink[t] = acc;
 }
 
+
+// ---- per-WAVE tiles (no workgroup barrier): the six waves of a 4:2:0 group as in the block kernel - four luma waves (32 MCUs x
+// one block row: 8 pixel rows x 1 536 bytes) and two chroma waves (64 MCUs: the 8 even rows x 3 072 bytes - the reference point-samples -, both reading the same pixels).
+// MODE 4: rows brought into the wave's own 12 KB of LDS by coalesced LDS DMA (chroma in two pieces of 4 rows), lanes then read
+//         their block's bytes from LDS;  MODE 5: the shipped kernel's pattern - every lane loads its block's row bytes itself
+//         (16 + 8 bytes at a lane stride of 24, or 3 x 16 at a stride of 48).  Both write 8 KB per wave with streaming stores.
+__device__ __forceinline__ uint32_t mcu_offset(int u) {            // byte offset of MCU u's first pixel row
+    u = u < MCUS_X * MCU_ROWS ? u : MCUS_X * MCU_ROWS - 1;
+    const int my = u / MCUS_X, mx = u - my * MCUS_X;
+    return (uint32_t)(my * 16) * PITCH + (uint32_t)mx * 48u;
+}
+template <int MODE>
+__global__ void __launch_bounds__(384) k_wave_tiles(const uint8_t *px, uint8_t *out, uint32_t *sink) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];                          // 6 x 12 KB
+    const int g = blockIdx.x, f = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint8_t *frame = px + (size_t)f * PITCH * H;
+    uint8_t *mine = lds + wave * 12288;
+    uint32_t acc = 0;
+    if (wave < 4) {
+        const int first = g * 64 + (wave & 1) * 32, vrow = wave >> 1;
+        if (MODE == 4) {
+            uint32_t off[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int c = lane + 64 * j, rr = c >= 96, col = c - 96 * rr, m = col / 3, part = col - 3 * m;
+                off[j] = mcu_offset(first + m) + (uint32_t)(vrow * 8 + rr) * PITCH + (uint32_t)part * 16u;
+            }
+#pragma unroll
+            for (int rp = 0; rp < 4; rp++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    __builtin_amdgcn_global_load_lds((gvec *)(frame + off[j] + (uint32_t)(rp * 2) * PITCH), (lds_void *)(mine + rp * 3072 + j * 1024), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint64_t *q = (const uint64_t *)(mine + r * 1536 + (lane >> 1) * 48 + (lane & 1) * 24);
+                const uint64_t a = q[0] ^ q[1] ^ q[2];
+                acc ^= (uint32_t)a ^ (uint32_t)(a >> 32);
+            }
+        } else {
+            const uint32_t o = mcu_offset(first + (lane >> 1)) + (uint32_t)(vrow * 8) * PITCH + (uint32_t)(lane & 1) * 24u;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x4 a = *(gvec *)(frame + o + (uint32_t)r * PITCH);
+                const u32x2 b = *(__attribute__((address_space(1))) const u32x2 *)(frame + o + (uint32_t)r * PITCH + 16);
+                acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y;
+            }
+        }
+    } else {
+        const int first = g * 64;
+        if (MODE == 4) {
+            uint32_t off[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int c = lane + 64 * j, m = c / 3, part = c - 3 * m;
+                off[j] = mcu_offset(first + m) + (uint32_t)part * 16u;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {                                            // (the reference point-samples: even rows only)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++)
+                        __builtin_amdgcn_global_load_lds((gvec *)(frame + off[j] + (uint32_t)(ch * 8 + r * 2) * PITCH), (lds_void *)(mine + r * 3072 + j * 1024), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const u32x4 *q = (const u32x4 *)(mine + r * 3072 + lane * 48);
+                    const u32x4 a = q[0], b = q[1], c2 = q[2];
+                    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c2.x ^ c2.y ^ c2.z ^ c2.w;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // reads done before the next piece overwrites
+            }
+        } else {
+            const uint32_t o = mcu_offset(first + lane);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const u32x4 a = *(gvec *)(frame + o + (uint32_t)r * PITCH), b = *(gvec *)(frame + o + (uint32_t)r * PITCH + 16),
+                            c2 = *(gvec *)(frame + o + (uint32_t)r * PITCH + 32);
+                acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c2.x ^ c2.y ^ c2.z ^ c2.w;
+            }
+        }
+    }
+    uint8_t *dst = out + ((size_t)f * GROUPS + g) * 49152 + (size_t)wave * 8192;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const u32x4 v = {acc, acc + it, acc ^ 5u, (uint32_t)lane};
+        __builtin_nontemporal_store(v, (u32x4 *)(dst + (size_t)(it * 64 + lane) * 16));
+    }
+    if (acc == 0x12345678u) sink[t] = acc;
+}
+
 template <int MODE>
 static int run(const char *name, const uint8_t *px, uint8_t *out, uint32_t *sink, int frames, double bytes) {
     hipEvent_t a, b;
@@ -72,6 +166,25 @@ static int run(const char *name, const uint8_t *px, uint8_t *out, uint32_t *sink
     for (int r = 0; r < 10; r++) {
         CHECK(hipEventRecord(a));
         hipLaunchKernelGGL(k_tile<MODE>, dim3(GROUPS, frames), dim3(384), 49152, 0, px, out, sink);
+        CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+        float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    printf("%-44s %8.3f ms  %6.2f TB/s\n", name, best, bytes / (best * 1e-3) / 1e12);
+    return 0;
+}
+
+template <int MODE>
+static int run_waves(const char *name, const uint8_t *px, uint8_t *out, uint32_t *sink, int frames, double bytes) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    CHECK(hipFuncSetAttribute((const void *)k_wave_tiles<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 12288));
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_wave_tiles<MODE>, dim3(GROUPS, frames), dim3(384), MODE == 4 ? 6 * 12288 : 49152, 0, px, out, sink);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 10; r++) {
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL(k_wave_tiles<MODE>, dim3(GROUPS, frames), dim3(384), MODE == 4 ? 6 * 12288 : 49152, 0, px, out, sink);
         CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
         float ms; CHECK(hipEventElapsedTime(&ms, a, b));
         if (ms < best) best = ms;
@@ -92,5 +205,7 @@ int main() {
     run<1>("tile in by register loads, 48 KB out", px, out, sink, frames, both);
     run<2>("tile in by LDS DMA only", px, out, sink, frames, in);
     run<3>("tile in by register loads only", px, out, sink, frames, in);
+    run_waves<4>("per-wave tiles by LDS DMA, 8 KB out per wave", px, out, sink, frames, both);
+    run_waves<5>("per-lane row loads (shipped pattern), 8 KB out", px, out, sink, frames, both);
     return 0;
 }
