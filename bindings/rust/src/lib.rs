@@ -624,6 +624,89 @@ impl<W: JfifWrite> Encoder<W> {
     }
 }
 
+/// A frame buffer in page-locked host memory (`jpegenc_host_alloc`): batches built from such frames are uploaded in place
+/// by the DMA engine, without the workers' staging copy.  Derefs to `[u8]`, so `&*frame` goes where `&[u8]` frames go
+/// (`encode_batch`, `encode_batch_multi`).  No counterpart in the crate.
+pub struct PinnedFrame {
+    ptr: *mut u8,
+    len: usize,
+}
+
+// the buffer is plain bytes owned by this value
+unsafe impl Send for PinnedFrame {}
+unsafe impl Sync for PinnedFrame {}
+
+impl PinnedFrame {
+    /// `len` zero-initialised page-locked bytes.
+    pub fn new(len: usize) -> Result<PinnedFrame, EncodingError> {
+        let mut p: *mut core::ffi::c_void = core::ptr::null_mut();
+        let status = unsafe { sys::jpegenc_host_alloc(len, &mut p) };
+        if status != sys::JPEGENC_OK || (p.is_null() && len != 0) {
+            return Err(EncodingError::Write(alloc::string::String::from("page-locked allocation failed")));
+        }
+        if len != 0 {
+            unsafe { core::ptr::write_bytes(p as *mut u8, 0, len) };
+        }
+        Ok(PinnedFrame { ptr: p as *mut u8, len })
+    }
+
+    /// A page-locked copy of `pixels`.
+    pub fn from_slice(pixels: &[u8]) -> Result<PinnedFrame, EncodingError> {
+        let mut f = PinnedFrame::new(pixels.len())?;
+        f.copy_from_slice(pixels);
+        Ok(f)
+    }
+}
+
+impl core::ops::Deref for PinnedFrame {
+    type Target = [u8];
+    fn deref(&self) -> &[u8] {
+        if self.len == 0 { &[] } else { unsafe { core::slice::from_raw_parts(self.ptr, self.len) } }
+    }
+}
+
+impl core::ops::DerefMut for PinnedFrame {
+    fn deref_mut(&mut self) -> &mut [u8] {
+        if self.len == 0 { &mut [] } else { unsafe { core::slice::from_raw_parts_mut(self.ptr, self.len) } }
+    }
+}
+
+impl Drop for PinnedFrame {
+    fn drop(&mut self) {
+        if !self.ptr.is_null() {
+            unsafe { sys::jpegenc_host_free(self.ptr as *mut core::ffi::c_void) };
+        }
+    }
+}
+
+/// Page-locks a buffer the caller keeps (a capture ring, a reused `Vec<u8>`) for as long as the guard lives: frames inside
+/// it are uploaded in place.  Registering costs about one copy of the range - it pays for buffers that are reused.
+pub struct PinnedRegistration<'a> {
+    range: &'a mut [u8],
+}
+
+impl<'a> PinnedRegistration<'a> {
+    pub fn new(range: &'a mut [u8]) -> Result<PinnedRegistration<'a>, EncodingError> {
+        let status = unsafe { sys::jpegenc_host_register(range.as_mut_ptr() as *mut core::ffi::c_void, range.len()) };
+        if status != sys::JPEGENC_OK {
+            return Err(EncodingError::Write(alloc::string::String::from("page-locking the range failed")));
+        }
+        Ok(PinnedRegistration { range })
+    }
+    pub fn as_slice(&self) -> &[u8] {
+        self.range
+    }
+    pub fn as_mut_slice(&mut self) -> &mut [u8] {
+        self.range
+    }
+}
+
+impl<'a> Drop for PinnedRegistration<'a> {
+    fn drop(&mut self) {
+        unsafe { sys::jpegenc_host_unregister(self.range.as_mut_ptr() as *mut core::ffi::c_void) };
+    }
+}
+
 #[cfg(feature = "std")]
 impl Encoder<std::io::BufWriter<std::fs::File>> {
     /// Create a new encoder that writes into a file (encoder.rs:1204-1219)
