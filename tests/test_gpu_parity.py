@@ -658,6 +658,47 @@ def test_handles_are_independent_across_threads(binding, oracle, synth):
         assert out[i] == oracle.encode_jpeg(px, w, h, oracle.RGB, **kw), i
 
 
+def test_many_threads_many_frames(binding, oracle, synth):
+    """Thread stress: twelve threads, each with its own handles, encode random frames of random settings at once - small
+    frames read from pinned host memory by the kernels, larger ones uploaded, captured launch sequences replayed per
+    handle, the shared per-device code-table cache hit from every thread.  Expected files are made up front (serially).
+    JPEGENC_THREAD_TRIALS: encodes per thread (soak length)."""
+    import os
+    import threading
+    nthreads, per_thread = 12, int(os.environ.get("JPEGENC_THREAD_TRIALS", "12"))
+    rng = np.random.default_rng(int(os.environ.get("JPEGENC_FUZZ_SEED", "77")))
+    modes = [dict(), dict(sampling=(2, 2)), dict(progressive_scans=4), dict(optimize=True), dict(restart_interval=5), dict(sampling=(2, 1))]
+    work = []
+    for t in range(nthreads):
+        kw = dict(modes[t % len(modes)], quality=int(rng.integers(30, 100)))
+        sizes = [(int(rng.integers(1, 700)), int(rng.integers(1, 500))) for _ in range(4)]
+        frames = [np.ascontiguousarray(synth.lcg_image(w, h, 3, 1000 + 17 * t + i)) for i, (w, h) in enumerate(sizes)]
+        want = [oracle.encode_jpeg(f, w, h, oracle.RGB, **kw) for f, (w, h) in zip(frames, sizes)]
+        work.append((kw, sizes, frames, want))
+    errs = []
+
+    def run(t):
+        try:
+            kw, sizes, frames, want = work[t]
+            enc = _encoder(binding, kw, device_entropy=t % 4 != 3)
+            for i in range(per_thread):
+                j = (i * 7 + t) % len(frames)
+                if i % 5 == 4:
+                    enc = _encoder(binding, kw, device_entropy=t % 4 != 3)          # a fresh handle now and then
+                got = enc.encode(frames[j], sizes[j][0], sizes[j][1], binding.RGB)
+                if got != want[j]:
+                    errs.append((t, i, sizes[j], kw))
+                    return
+        except Exception as exc:                                  # surfaced below
+            errs.append((t, exc))
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs[:3]
+
+
 @pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned"])
 def test_blocks_stream_tiles_in_order(binding, oracle, synth, pinned):
     """jpegenc_blocks_stream: eleven frames through the upload / kernel / download pipeline (more frames
