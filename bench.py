@@ -303,6 +303,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-frames", type=int, default=32, help="frames for the end-to-end (JPEG bytes) side figure; 0 disables")
     ap.add_argument("--c3-frames", type=int, default=1000, help="frames of the config-3 batch (whole job, all ranks); 0 disables")
+    ap.add_argument("--numa-bind", type=int, default=0, choices=(0, 1),
+                    help="headline variant of the config-3 leg: batch worker threads bound to the NUMA node of the rank's GPU "
+                         "(jpegenc_encoder_set_numa_bind); the other setting is timed beside it (c3_batch.variants)")
+    ap.add_argument("--pinned-frames", action="store_true",
+                    help="headline variant of the config-3 leg: the rank's frames in page-locked host memory (uploaded in place); "
+                         "the pageable variant is timed beside it (c3_batch.variants)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the side figures, so that every launch of the fused kernel in the process is the "
                          "headline launch (what tools/profile_round.sh runs under rocprofv3)")
@@ -399,15 +405,21 @@ def main():
     algo_bytes = F * W * H * ALGO_BYTES_PER_PIXEL
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM bytes per launch come from separate `rocprofv3 --pmc` passes over this same command (tools/profile_round.sh):
-    # counters cannot be read from inside the timed process, so the line says where the number was measured and on
-    # which build - a stale file (kernel sources newer than it) is reported as such, not silently reused
-    traffic, traffic_source = None, None
+    # counters cannot be read from inside the timed process, so the line says where the number was measured and on which
+    # build.  The file carries the SHA-256 of the kernel sources it was measured on (jpeg_encoder_amd/srchash.py); when the
+    # tree this run uses hashes differently the figure is reported as stale, not silently reused.
+    traffic, traffic_source, traffic_stale = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             traffic = rec.get("hbm_bytes_per_launch")
-            traffic_source = ("profiles/pmc_traffic.json - static, NOT measured by this run: " + str(rec.get("collected", "rocprofv3 --pmc passes"))[:160])
+            srchash = importlib.import_module("jpeg_encoder_amd.srchash")
+            now, then = srchash.kernel_sources_sha256(), rec.get("csrc_sha256")
+            traffic_stale = then is None or then != now
+            traffic_source = ("profiles/pmc_traffic.json - static, NOT measured by this run; measured on kernel sources "
+                              f"{(then or 'unrecorded')[:12]} (git {str(rec.get('git_head_at_reduction', 'unrecorded'))[:12]}), this run's sources: "
+                              f"{now[:12]}; " + str(rec.get("collected", "rocprofv3 --pmc passes"))[:160])
         except Exception:
             traffic = None
 
@@ -423,7 +435,8 @@ def main():
                                f"pixels and coefficients resident in HBM; {F} frames per launch per GPU",
                    "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
+                     "traffic_source": traffic_source,
                      "kernel": "fused colour+subsample+FDCT+quant+zigzag", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": int(algo_bytes),
                      "read_only_frac": round(achieved / 2 / HBM_PEAK_GBPS, 4)},
@@ -602,35 +615,84 @@ def main():
         except Exception as exc:                                   # side figure only
             result["criterion_workloads"] = {"error": str(exc)}
     # ---- BASELINE config 3 on every rank: the frame-sharded 1000-frame batch, pageable host pixels -> JPEG files in
-    # host buffers (jpeg_encoder_amd/batch.py; no data-path collective, MAX over ranks of the wall time)
+    # host buffers (jpeg_encoder_amd/batch.py; no data-path collective, MAX over ranks of the wall time).  Every frame of
+    # the batch is distinct (seeded 42 + k) and a rank only materialises its own shard.  Besides the headline variant
+    # (pageable frames, threads unbound) the leg times the two host-side levers an 8-rank host is expected to need - frames
+    # in page-locked memory (no staging copy) and worker threads bound to the GPU's NUMA node - and every rank reports its
+    # own upload rate against the link rate it measured itself, all ranks copying at once.
     if args.c3_frames > 0 and not args.headline_only:
         try:
             batch = importlib.import_module("jpeg_encoder_amd.batch")
             enc3 = binding.Encoder(batch.C3_QUALITY, device=local_rank)         # q=80 -> default F_2_2 (encoder.rs:256-260)
+            enc3.set_numa_bind(bool(args.numa_bind))
             cap3 = 1 << 20
-            n_mine = len(binding.shard_frames(args.c3_frames, world, rank))
+            fb = batch.C3_W * batch.C3_H * 3
+            idx = binding.shard_frames(args.c3_frames, world, rank)
+            n_mine = len(idx)
             outs3 = [np.zeros(cap3, dtype=np.uint8) for _ in range(n_mine)]      # caller-owned output buffers, reused (and touched: no page faults in the timed pass)
 
             def encode_frames(frames):                                          # -> views of the files, no copies
                 lens3 = enc3.encode_batch_into(frames, batch.C3_W, batch.C3_H, binding.RGB, outs3)
                 return [outs3[i][:lens3[i]] for i in range(len(frames))]
-            pool = batch.FramePool(synth)
-            c3, mine = batch.run_sharded_batch(binding, encode_frames, pool, args.c3_frames, batch.C3_W, batch.C3_H, world, rank,
-                                               dist if distributed else None, warmup_frames=args.c3_frames, device=dev,     # one untimed pass over the rank's frames first
-                                               force_collectives=os.environ.get("JPEGENC_BENCH_FORCE_DIST") == "1")
-            c3["what"] = (f"C3: {args.c3_frames} frames of 1920x1080 RGB q=80 4:2:0 sharded frame k -> rank k % {world} "
-                          "(jpegenc_shard_frames), each rank: pageable host pixels -> complete JPEG files in host buffers through "
-                          "jpegenc_encoder_encode_batch_to_buffers on its GPU; seconds = MAX over ranks; photo-like frames "
-                          f"({batch.POOL} distinct, frame k = pool[k % {batch.POOL}]); digest = checksum of the per-frame SHA-256s in frame order")
+            pool = batch.ShardFrames(synth, torch=torch, device=dev)
+            pool.materialise(idx)
+            force = os.environ.get("JPEGENC_BENCH_FORCE_DIST") == "1"
+            ddist = dist if distributed else None
+            # what this rank's link delivers while every rank copies (the peak of its own upload figure)
+            if ddist is not None:
+                ddist.barrier()
+            try:
+                my_link = link if (link and "h2d" in link) else link_rates(torch, dev, reps=12)
+            except Exception:
+                my_link = {}
+            pinned_first = bool(args.pinned_frames)
+            pageable = [pool(k) for k in idx]
+            pinned_buf, pinned = None, None
+            try:
+                pinned_buf = binding.HostBuffer(max(n_mine, 1) * fb)
+                for i, k in enumerate(idx):
+                    pinned_buf.array[i * fb:(i + 1) * fb] = pool(k).reshape(-1)
+                pinned = [pinned_buf.array[i * fb:(i + 1) * fb] for i in range(n_mine)]
+            except Exception as exc:
+                pinned_err = repr(exc)
+            primary_frames = pinned if (pinned_first and pinned is not None) else pageable
+            lookup = {id(f): f for f in primary_frames}
+
+            c3, mine = batch.run_sharded_batch(binding, encode_frames, lambda k: primary_frames[idx.index(k)], args.c3_frames, batch.C3_W, batch.C3_H,
+                                               world, rank, ddist, warmup_frames=args.c3_frames, device=dev,     # one untimed pass over the rank's frames first
+                                               force_collectives=force)
+            c3["what"] = (f"C3: {args.c3_frames} DISTINCT frames of 1920x1080 RGB q=80 4:2:0 (gradient shifted by 16 k columns + noise seeded 42 + k) "
+                          f"sharded frame k -> rank k % {world} (jpegenc_shard_frames), each rank materialises and encodes only its own shard: "
+                          f"{'page-locked' if primary_frames is pinned else 'pageable'} host pixels -> complete JPEG files in host buffers through "
+                          "jpegenc_encoder_encode_batch_to_buffers on its GPU; seconds = MAX over ranks; digest = checksum of the per-frame "
+                          "SHA-256s in frame order")
             c3["scaling"] = "strong"
-            idx = binding.shard_frames(args.c3_frames, world, rank)
-            first = [bytes(mine[k]) for k in idx[:64]]                         # (outs3 is reused by the legs below)
-            if rank == 0 and world == 1 and link:
-                c3["roofline"] = pcie_roofline("pcie_h2d", args.c3_frames * batch.C3_W * batch.C3_H * 3, c3["seconds"], link)
+            c3["numa_bind"] = bool(args.numa_bind)
+            c3["frames_in"] = "page-locked memory" if primary_frames is pinned else "pageable memory"
+            first = [bytes(mine[k]) for k in idx[:64]]                         # (outs3 is reused by the variants below)
+
+            def per_rank_report(seconds_mine):
+                """every rank's frames / s and upload GB/s against the h2d rate it measured with all ranks copying at once"""
+                t = batch.per_rank_table(ddist, [n_mine, seconds_mine, float(my_link.get("h2d") or 0.0)], world, rank, dev, force)
+                rows = []
+                for r in range(world):
+                    fr, sec, lk = t[r]
+                    gbps = fr * fb / sec / 1e9 if sec > 0 else None
+                    rows.append({"rank": r, "frames": int(fr), "seconds": round(float(sec), 6),
+                                 "frames_per_s": round(fr / sec, 1) if sec > 0 else None,
+                                 "h2d_GBps": round(gbps, 2) if gbps else None, "link_h2d_GBps": round(float(lk), 1) if lk else None,
+                                 "frac": round(gbps / lk, 4) if gbps and lk else None})
+                fps = [x["frames_per_s"] for x in rows if x["frames_per_s"]]
+                fracs = [x["frac"] for x in rows if x["frac"]]
+                return rows, {"frames_per_s_min": min(fps) if fps else None, "frames_per_s_max": max(fps) if fps else None,
+                              "frac_min": min(fracs) if fracs else None, "frac_max": max(fracs) if fracs else None}
+            c3["per_rank"], c3["per_rank_min_max"] = per_rank_report(c3["per_rank_seconds"][rank])
+            if world == 1 and my_link:
+                c3["roofline"] = pcie_roofline("pcie_h2d", args.c3_frames * fb, c3["seconds"], my_link)
             if rank == 0 and world == 1:
-                # the same batch through the library's own multi-device entry point (one process driving the listed GPUs;
+                # the same frames through the library's own multi-device entry point (one process driving the listed GPUs;
                 # here only this rank's GPU, so it measures the API's overhead, not scaling) - same files
-                some = [pool(k) for k in range(min(args.c3_frames, 64))]
+                some = pageable[:64]
                 enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])     # warm-up: the shard's buffers
                 t1 = time.perf_counter()
                 lens_m = enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])
@@ -638,54 +700,62 @@ def main():
                 c3["multi_api_one_device"] = {"frames": len(some), "frames_per_s": round(len(some) / dtm, 1),
                                               "identical_files": all(outs3[k][:lens_m[k]].tobytes() == first[k] for k in range(len(some)))}
                 ks = [0, len(some) // 2]                                      # checked against the oracle by the cpu_baseline leg
-                c3_samples = [(pool(k), batch.C3_W, batch.C3_H, batch.C3_QUALITY, first[k]) for k in ks]
-            # the same batch with the frames in page-locked memory (jpegenc_host_alloc): uploaded in place, no staging copy
-            # by the workers - what a caller with a pinned capture ring / frame pool gets.  Every rank runs it on its shard;
-            # the two all-reduces below are unconditional (a rank whose leg failed contributes -1), so ranks cannot part ways.
-            dtp, same, err_p = -1.0, True, None
-            try:
-                fb = batch.C3_W * batch.C3_H * 3
-                keep = min(len(idx), 32)
-                pinned = binding.HostBuffer(batch.POOL * fb)
-                pframes = []
-                for k in range(batch.POOL):
-                    pinned.array[k * fb:(k + 1) * fb] = pool(k).reshape(-1)
-                    pframes.append(pinned.array[k * fb:(k + 1) * fb])
-                pf = [pframes[k % batch.POOL] for k in idx]
-                if pf:
-                    enc3.encode_batch_into(pf[:64], batch.C3_W, batch.C3_H, binding.RGB, outs3)
-            except Exception as exc:
-                err_p, pf = repr(exc), None
-            if distributed:
-                dist.barrier()
-            if pf is not None:
-                try:
-                    t1 = time.perf_counter()
-                    lens_p = enc3.encode_batch_into(pf, batch.C3_W, batch.C3_H, binding.RGB, outs3) if pf else []
-                    dtp = time.perf_counter() - t1
-                    same = all(outs3[i][:lens_p[i]].tobytes() == first[i] for i in range(keep))
-                    del pf, pframes
-                    pinned.close()
-                except Exception as exc:
-                    err_p, dtp = repr(exc), -1.0
-            if distributed:
-                t_hi = torch.tensor([dtp, 0.0 if same else 1.0], dtype=torch.float64, device=dev)
-                t_lo = torch.tensor([dtp], dtype=torch.float64, device=dev)
-                dist.all_reduce(t_hi, op=dist.ReduceOp.MAX)
-                dist.all_reduce(t_lo, op=dist.ReduceOp.MIN)
-                dtp, same = (float(t_hi[0]) if float(t_lo[0]) > 0 else -1.0), float(t_hi[1]) == 0.0
-            if dtp > 0:
-                c3["pinned_frames"] = {"frames": args.c3_frames, "frames_per_s": round(args.c3_frames / dtp, 1), "seconds": round(dtp, 6),
-                                       "identical_files": same,
-                                       "what": "the same sharded batch, frames in page-locked host memory (jpegenc_host_alloc): DMA reads them in "
-                                               "place, no staging copy by the workers; seconds = MAX over ranks"}
-                if rank == 0 and world == 1 and link:
-                    c3["pinned_frames"]["roofline"] = pcie_roofline("pcie_h2d", args.c3_frames * fb, dtp, link)
-            else:
-                c3["pinned_frames"] = {"error": err_p or "failed on another rank"}
+                c3_samples = [(pageable[k], batch.C3_W, batch.C3_H, batch.C3_QUALITY, first[k]) for k in ks]
+            # ---- the other three corners of {pageable, page-locked} x {unbound, NUMA-bound}: every rank runs every variant
+            # on its shard; the bookkeeping all-reduce inside per_rank_report is unconditional (a rank whose variant failed
+            # contributes a negative time), so ranks cannot part ways
+            variants = {}
+            for v_pinned in (False, True):
+                for v_bind in (False, True):
+                    name = ("pinned" if v_pinned else "pageable") + ("_numa_bind" if v_bind else "")
+                    is_primary = (v_pinned == (primary_frames is pinned)) and (v_bind == bool(args.numa_bind))
+                    frames_v = pinned if v_pinned else pageable
+                    dtv, same, err_v = -1.0, True, None
+                    if is_primary:
+                        dtv = c3["per_rank_seconds"][rank]
+                    elif frames_v is None:
+                        err_v = "no page-locked copy of the shard"
+                    else:
+                        try:
+                            enc3.set_numa_bind(v_bind)
+                            if frames_v:
+                                enc3.encode_batch_into(frames_v[:64], batch.C3_W, batch.C3_H, binding.RGB, outs3)   # warm-up
+                        except Exception as exc:
+                            err_v = repr(exc)
+                    if ddist is not None:
+                        ddist.barrier()
+                    if not is_primary and err_v is None:
+                        try:
+                            t1 = time.perf_counter()
+                            lens_v = enc3.encode_batch_into(frames_v, batch.C3_W, batch.C3_H, binding.RGB, outs3) if frames_v else []
+                            dtv = time.perf_counter() - t1
+                            same = all(outs3[i][:lens_v[i]].tobytes() == first[i] for i in range(min(n_mine, 32)))
+                        except Exception as exc:
+                            err_v, dtv = repr(exc), -1.0
+                    rows, mm = per_rank_report(dtv if dtv > 0 else -1.0)
+                    ok = all(x["seconds"] > 0 for x in rows if x["frames"] > 0)
+                    t_same = batch.per_rank_table(ddist, [0.0 if same else 1.0], world, rank, dev, force)
+                    slowest = max(x["seconds"] for x in rows)
+                    variants[name] = ({"frames_per_s": round(args.c3_frames / slowest, 1), "seconds": round(slowest, 6),
+                                       "identical_files": bool(t_same.sum() == 0), "per_rank": rows, **mm, "is_headline_variant": is_primary}
+                                      if ok and slowest > 0 else {"error": err_v or "failed on another rank"})
+            enc3.set_numa_bind(bool(args.numa_bind))
+            c3["variants"] = variants
+            c3["variants_what"] = ("the same sharded batch with the frames in pageable / page-locked host memory (jpegenc_host_alloc: DMA reads them in place, "
+                                   "no staging copy by the workers) and the batch worker threads unbound / bound to the NUMA node of the rank's GPU "
+                                   "(jpegenc_encoder_set_numa_bind); seconds = MAX over ranks; per_rank.frac = the rank's upload rate over the h2d rate "
+                                   "it measured for plain pinned copies while every rank was copying")
+            if "pinned" in variants and "error" not in variants["pinned"]:
+                c3["pinned_frames"] = {k: variants["pinned"][k] for k in ("frames_per_s", "seconds", "identical_files")}
+                if world == 1 and my_link:
+                    c3["pinned_frames"]["roofline"] = pcie_roofline("pcie_h2d", args.c3_frames * fb, variants["pinned"]["seconds"], my_link)
+            if pinned_buf is not None:
+                del pinned, primary_frames
+                pinned_buf.close()
             result["c3_batch"] = c3
         except Exception as exc:                                   # never lose the headline line to a side leg
-            result["c3_batch"] = {"error": repr(exc)}
+            import traceback
+            result["c3_batch"] = {"error": repr(exc), "trace": traceback.format_exc()[-600:]}
     if rank == 0 and world == 1 and not args.headline_only and args.cpu_seconds >= 2.0:
         try:
             extras = cpu_baseline_extras(synth, result.get("criterion_workloads"), criterion_files, c3_samples)

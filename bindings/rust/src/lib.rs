@@ -326,17 +326,44 @@ fn last_error() -> String {
 struct SinkState<'a, W: JfifWrite> {
     w: &'a mut W,
     err: Option<EncodingError>,
+    panic: Option<Box<dyn core::any::Any + Send + 'static>>,
+}
+
+/// A panic of the caller's writer / `ImageBuffer` must not unwind through the library's C++ frames: with `std` it is
+/// caught here, the call fails with a non-zero status and the payload is re-raised once the FFI call has returned
+/// (`Encoder::finish`); without `std` there is no unwinding to contain (panic = abort).
+#[cfg(feature = "std")]
+fn contain<R>(f: impl FnOnce() -> R) -> Result<R, Box<dyn core::any::Any + Send + 'static>> {
+    std::panic::catch_unwind(std::panic::AssertUnwindSafe(f))
+}
+#[cfg(not(feature = "std"))]
+fn contain<R>(f: impl FnOnce() -> R) -> Result<R, Box<dyn core::any::Any + Send + 'static>> {
+    Ok(f())
+}
+/// Re-raises a panic caught inside a callback, now that no C++ frame is on the stack.
+fn resume(payload: Option<Box<dyn core::any::Any + Send + 'static>>) {
+    #[cfg(feature = "std")]
+    if let Some(p) = payload {
+        std::panic::resume_unwind(p);
+    }
+    #[cfg(not(feature = "std"))]
+    let _ = payload;
 }
 
 unsafe extern "C" fn sink_trampoline<W: JfifWrite>(user: *mut c_void, data: *const u8, len: usize) -> c_int {
     let st = &mut *(user as *mut SinkState<'_, W>);
-    if st.err.is_some() {
+    if st.err.is_some() || st.panic.is_some() {
         return 1;
     }
-    match st.w.write_all(core::slice::from_raw_parts(data, len)) {
-        Ok(()) => 0,
-        Err(e) => {
+    let w = &mut *st.w;
+    match contain(|| w.write_all(core::slice::from_raw_parts(data, len))) {
+        Ok(Ok(())) => 0,
+        Ok(Err(e)) => {
             st.err = Some(e);
+            1
+        }
+        Err(payload) => {
+            st.panic = Some(payload);
             1
         }
     }
@@ -347,14 +374,22 @@ struct FillState<'a, I: ImageBuffer> {
     bufs: [Vec<u8>; 4],
     planes: usize,
     width: usize,
+    panic: Option<Box<dyn core::any::Any + Send + 'static>>,
 }
 
 unsafe extern "C" fn fill_trampoline<I: ImageBuffer>(user: *mut c_void, y: u16, planes: *const *mut u8) {
     let st = &mut *(user as *mut FillState<'_, I>);
+    if st.panic.is_some() {
+        return;                                                              // (the rows after a panic stay as they are; the panic is resumed after the call)
+    }
     for b in st.bufs.iter_mut() {
         b.clear();
     }
-    st.image.fill_buffers(y, &mut st.bufs);
+    let (image, bufs) = (st.image, &mut st.bufs);
+    if let Err(payload) = contain(|| image.fill_buffers(y, bufs)) {
+        st.panic = Some(payload);
+        return;
+    }
     for i in 0..st.planes {
         let n = core::cmp::min(st.width, st.bufs[i].len());
         core::ptr::copy_nonoverlapping(st.bufs[i].as_ptr(), *planes.add(i), n);
@@ -530,11 +565,12 @@ impl<W: JfifWrite> Encoder<W> {
     pub fn encode(mut self, data: &[u8], width: u16, height: u16, color_type: ColorType) -> Result<(), EncodingError> {
         let required = width as usize * height as usize * color_type.get_bytes_per_pixel();
         let h = self.h;
-        let mut st = SinkState { w: &mut self.w, err: None };
+        let mut st = SinkState { w: &mut self.w, err: None, panic: None };
         let status = unsafe {
             sys::jpegenc_encoder_encode(h, data.as_ptr(), data.len(), width as c_int, height as c_int, color_type as c_int,
                                         sink_trampoline::<W>, &mut st as *mut SinkState<'_, W> as *mut c_void)
         };
+        resume(st.panic.take());
         let err = st.err.take();
         Self::finish(status, err, data.len(), required, width, height)
     }
@@ -550,13 +586,15 @@ impl<W: JfifWrite> Encoder<W> {
             JpegColorType::Ycck => (3, 4),
         };
         let h = self.h;
-        let mut fill = FillState { image: &image, bufs: [Vec::new(), Vec::new(), Vec::new(), Vec::new()], planes, width: width as usize };
-        let mut st = SinkState { w: &mut self.w, err: None };
+        let mut fill = FillState { image: &image, bufs: [Vec::new(), Vec::new(), Vec::new(), Vec::new()], planes, width: width as usize, panic: None };
+        let mut st = SinkState { w: &mut self.w, err: None, panic: None };
         let status = unsafe {
             sys::jpegenc_encoder_encode_image(h, jct, width as c_int, height as c_int, fill_trampoline::<I>,
                                               &mut fill as *mut FillState<'_, I> as *mut c_void, sink_trampoline::<W>,
                                               &mut st as *mut SinkState<'_, W> as *mut c_void)
         };
+        resume(fill.panic.take());
+        resume(st.panic.take());
         let err = st.err.take();
         Self::finish(status, err, 0, 0, width, height)
     }
@@ -571,6 +609,11 @@ impl<W: JfifWrite> Encoder<W> {
     /// `false`: coefficients come back over PCIe and are Huffman-coded on the host (same bytes).
     pub fn set_device_entropy(&mut self, enable: bool) {
         unsafe { sys::jpegenc_encoder_set_device_entropy(self.h, enable as c_int) };
+    }
+
+    /// `true`: the host threads of the batch calls run on the NUMA node of the encoder's GPU (off by default).
+    pub fn set_numa_bind(&mut self, enable: bool) {
+        unsafe { sys::jpegenc_encoder_set_numa_bind(self.h, enable as c_int) };
     }
 
     /// Number of usable MI355X devices (0: `encode` will fail, keep the CPU crate as the fallback).
@@ -590,6 +633,7 @@ impl<W: JfifWrite> Encoder<W> {
         let required = width as usize * height as usize * color_type.get_bytes_per_pixel();
         let ptrs: Vec<*const u8> = frames.iter().map(|f| f.as_ptr()).collect();
         let mut cap = required / 2 + (1 << 16);
+        let mut retried = false;
         loop {
             let mut outs: Vec<Vec<u8>> = (0..n).map(|_| Vec::with_capacity(cap)).collect();
             let out_ptrs: Vec<*mut u8> = outs.iter_mut().map(|o| o.as_mut_ptr()).collect();
@@ -606,8 +650,12 @@ impl<W: JfifWrite> Encoder<W> {
                                                                        out_ptrs.as_ptr(), caps.as_ptr(), lens.as_mut_ptr())
                 }
             };
-            if status == sys::JPEGENC_ERR_BUFFER_TOO_SMALL {
-                cap = lens.iter().copied().max().unwrap_or(cap) + 4096;      // every needed size is known now
+            if status == sys::JPEGENC_ERR_BUFFER_TOO_SMALL && !retried && lens.iter().zip(caps.iter()).any(|(l, c)| l > c) {
+                // some output buffer was too small and the library reported the size it needs: once more with room for the
+                // largest.  (The same status also means "scan workspace too small" - then no length exceeds its capacity
+                // and a retry could not help: it is reported, never looped on.)
+                cap = lens.iter().copied().max().unwrap_or(cap) + 4096;
+                retried = true;
                 continue;
             }
             Self::finish(status, None, frame_len, required, width, height)?;

@@ -250,6 +250,11 @@ int  jpegenc_encoder_set_fdct_variant(jpegenc_encoder *e, int variant);  /* defa
 /* 1 (default): every scan is entropy-coded on the GPU and only compressed bytes cross PCIe;
  * 0: coefficients come back and the host codes them.  The emitted bytes are identical either way. */
 int  jpegenc_encoder_set_device_entropy(jpegenc_encoder *e, int enable);
+/* 1: the host threads the batch calls spawn for this handle (and for its per-device children in
+ * jpegenc_encoder_encode_batch_multi) run on the NUMA node of the device's PCIe root complex - their pinned staging
+ * memory is then first touched there and uploads do not cross the socket interconnect.  Best effort (sysfs), the
+ * caller's own thread is left alone.  Default 0, or 1 when JPEGENC_NUMA_BIND is set in the environment. */
+int  jpegenc_encoder_set_numa_bind(jpegenc_encoder *e, int enable);
 
 int  jpegenc_encoder_set_density(jpegenc_encoder *e, int unit, uint16_t x, uint16_t y);   /* :280 */
 int  jpegenc_encoder_density(const jpegenc_encoder *e, int *unit, uint16_t *x, uint16_t *y);

@@ -1,7 +1,7 @@
 """BASELINE config 3: a 1000-frame batch of 1920x1080 RGB q=80 4:2:0 frames sharded frame-wise over the
 GPUs of a node, one process (rank) per GPU.
 
-JPEG frames are independent: frame k belongs to shard k % world (`jpegenc_shard_frames`, the same C
+JPEG frames are independent and all distinct (frame k seeded 42 + k): frame k belongs to shard k % world (`jpegenc_shard_frames`, the same C
 function the library's own multi-device batch uses), every rank encodes its own frames from pageable host
 memory to complete JPEG files in host buffers, and NO pixel or coefficient ever crosses ranks.  The only
 exchange is bookkeeping - frame counts, the slowest rank's wall time, per-frame digests - through two small
@@ -14,19 +14,56 @@ import time
 import numpy as np
 
 C3_W, C3_H, C3_QUALITY, C3_FRAMES = 1920, 1080, 80, 1000      # BASELINE.json configs[2]; q=80 -> default F_2_2 (encoder.rs:256-260)
-POOL = 25                                                       # distinct frames; frame k of the batch = pool[k % POOL]
 
 
 def photo_like_frame(synth, k, w=C3_W, h=C3_H):
-    """Frame k of the batch: the reference's test gradient (lib.rs:81-98) scaled to the frame size, shifted by k
-    and carrying +-6 of noise seeded 42 + k (frame k seeded 42+k) - entropy-codes like a photograph."""
-    g = np.roll(synth.test_img_rgb(w, h), 16 * (k % POOL), axis=1).astype(np.int16)
-    rng = np.random.default_rng(42 + (k % POOL))
+    """Frame k of the batch (numpy form): the reference's test gradient (lib.rs:81-98) scaled to the frame size, shifted by
+    16 k columns and carrying +-6 of noise seeded 42 + k (frame k seeded 42+k) - entropy-codes like a
+    photograph.  All frames of a batch are distinct."""
+    g = np.roll(synth.test_img_rgb(w, h), (16 * k) % w, axis=1).astype(np.int16)
+    rng = np.random.default_rng(42 + k)
     return np.clip(g + rng.integers(-6, 7, g.shape, dtype=np.int16), 0, 255).astype(np.uint8)
 
 
+class ShardFrames:
+    """make_frame(k) for the frames of ONE rank's shard: every frame of the batch is distinct (gradient shifted by 16 k
+    columns + noise seeded 42 + k), a rank only ever materialises the frames it owns (6.2 GB / N for config 3), and they
+    stay resident in pageable host memory.  With a torch device the frames are generated there (seconds for a thousand
+    1080p frames instead of most of a minute in numpy) and copied to the host; the two generators draw different noise, so
+    a digest is comparable between runs of the same kind only."""
+
+    def __init__(self, synth, w=C3_W, h=C3_H, torch=None, device=None):
+        self.synth, self.w, self.h, self.torch, self.device, self.cache = synth, w, h, torch, device, {}
+        self._base = None
+
+    def _device_frame(self, k):
+        torch = self.torch
+        if self._base is None:
+            self._base = torch.from_numpy(self.synth.test_img_rgb(self.w, self.h)).to(self.device).to(torch.int16)
+            self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(42 + k)
+        g = torch.roll(self._base, shifts=(16 * k) % self.w, dims=1)
+        noise = torch.randint(-6, 7, g.shape, dtype=torch.int16, device=self.device, generator=self._gen)
+        return np.ascontiguousarray(torch.clamp(g + noise, 0, 255).to(torch.uint8).cpu().numpy())
+
+    def materialise(self, ks):
+        for k in ks:
+            self(k)
+        self._base = None                                          # (device memory is not needed any more)
+
+    def __call__(self, k):
+        if k not in self.cache:
+            self.cache[k] = self._device_frame(k) if self.torch is not None and self.device is not None else \
+                np.ascontiguousarray(photo_like_frame(self.synth, k, self.w, self.h))
+        return self.cache[k]
+
+
+POOL = 25        # tests/test_gpu_batch_multi.py: a cycling pool, so that the oracle has 25 files to produce instead of 1000
+
+
 class FramePool:
-    """make_frame(k) with the POOL distinct frames generated once (a 1000-frame batch is 6.2 GB of pixels)."""
+    """make_frame(k) = distinct frame k % POOL: for the parity tests, which need the oracle's file of every distinct frame.
+    bench.py's c3_batch leg uses ShardFrames (every frame distinct)."""
 
     def __init__(self, synth, w=C3_W, h=C3_H):
         self.synth, self.w, self.h, self.cache = synth, w, h, {}
@@ -36,6 +73,19 @@ class FramePool:
         if key not in self.cache:
             self.cache[key] = np.ascontiguousarray(photo_like_frame(self.synth, key, self.w, self.h))
         return self.cache[key]
+
+
+def per_rank_table(dist, values, world, rank, device=None, force=False):
+    """[world][len(values)] with row `rank` = values on every rank: one SUM all-reduce of a table every rank writes one row of
+    (the same bookkeeping exchange run_sharded_batch uses; no pixels, no files)."""
+    table = np.zeros((world, len(values)), dtype=np.float64)
+    table[rank] = values
+    if _dist_ready(dist, force):
+        import torch
+        t = torch.from_numpy(table).to(device) if device is not None else torch.from_numpy(table)
+        dist.all_reduce(t)
+        table = t.cpu().numpy()
+    return table
 
 
 def _dist_ready(dist, force=False):

@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "host_common.h"
+#include "entropy_loop.hip.h"
 #include "tables_data.inc"
 
 namespace jpegenc {
@@ -24,20 +25,26 @@ __global__ void __launch_bounds__(1024) k_build_lut(const LutSpecs specs, uint32
     const uint8_t __attribute__((address_space(4))) *s =
         (const uint8_t __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + id * sizeof(jpegenc_huffman_spec);
     const uint32_t num_values = *(const uint32_t __attribute__((address_space(4))) *)(s + __builtin_offsetof(jpegenc_huffman_spec, num_values));
-    if (k >= num_values) return;
-    uint32_t code = 0, first = 0;
+    if (k < num_values) {
+        uint32_t code = 0, first = 0;
 #pragma unroll
-    for (uint32_t len = 1; len <= 16; len++) {
-        const uint32_t n = s[__builtin_offsetof(jpegenc_huffman_spec, bits) + len - 1];
-        if (k < first + n) {
-            const uint32_t sym = s[__builtin_offsetof(jpegenc_huffman_spec, values) + k];
-            lut[id * 256u + sym] = (len << 16) | (code + (k - first));
-            return;
+        for (uint32_t len = 1; len <= 16; len++) {
+            const uint32_t n = s[__builtin_offsetof(jpegenc_huffman_spec, bits) + len - 1];
+            if (k < first + n) {
+                const uint32_t sym = s[__builtin_offsetof(jpegenc_huffman_spec, values) + k];
+                lut[id * 256u + sym] = (len << 16) | (code + (k - first));
+                break;
+            }
+            code = (code + n) << 1;
+            first += n;
         }
-        code = (code + n) << 1;
-        first += n;
     }
+    // the same tables in the layout the pixels -> bits kernel copies into LDS (entropy_loop.hip.h), behind the first form
+    __syncthreads();
+    if (threadIdx.x < kLoopLutEntries)
+        reinterpret_cast<u32x2 *>(lut + kLutWords)[threadIdx.x] = loop_lut_entry(threadIdx.x, lut[loop_lut_source(threadIdx.x)]);
 }
+static_assert(kLoopLutBytes == kLutCompactBytes, "entropy_params.h sizes the compact tables");
 
 struct ScanPlan {
     uint32_t max_blocks, max_chunks, max_tiles, max_waves, max_fftiles, slot_words;
@@ -83,7 +90,7 @@ static void plan_scan(uint64_t max_blocks, uint64_t bound, int frames, ScanPlan 
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     const size_t F = (size_t)frames;
     pl->off_params = take(kMaxScansPerLaunch * sizeof(EntropyParams));      // the parameter blocks of a launch live in the first scan's workspace
-    pl->off_lut = take(4 * 256 * 4);
+    pl->off_lut = take(kLutDeviceBytes);
     pl->off_bits = take(F * pl->max_blocks * 4);
     pl->off_wsum = take(F * pl->max_waves * 4);
     pl->off_woff = take(F * pl->max_waves * 4);
@@ -155,7 +162,7 @@ static const uint32_t *default_luts(hipStream_t st) {
             return nullptr;
         }
         uint32_t *lut = nullptr;
-        hipError_t e = hipMalloc((void **)&lut, 4 * 256 * 4);
+        hipError_t e = hipMalloc((void **)&lut, kLutDeviceBytes);
         if (e != hipSuccess) { (void)hip_fail(e, "hipMalloc of the default code tables"); return nullptr; }
         if (upload_huffman_luts(nullptr, lut, st) != JPEGENC_OK) { (void)hipFree(lut); return nullptr; }
         e = hipStreamSynchronize(st);

@@ -10,6 +10,12 @@ namespace jpegenc {
 constexpr uint32_t kPackWindowWords = JPEGENC_PACK_WINDOW;      // words of LDS per wave of the bit packer
 constexpr uint32_t kFusedPrefixRuns = 2048, kFusedPrefixTiles = 8192;   // runs / (worst-case) tiles up to which the prefix sums are folded into their consumers
 constexpr uint32_t kMaxScansPerLaunch = 16;                      // scans coded by one launch sequence (blockIdx.z)
+// Device memory of one set of Huffman code tables (k_build_lut): [destination][0 = DC, 1 = AC][256 symbols] = size << 16 | code,
+// followed by the same tables the way the pixels -> bits kernel keeps them in LDS (entropy_loop.hip.h: 2 x (16 + 256) entries
+// of (code << n, -(size + n)), slots ordered for the walk) so that its workgroups copy instead of deriving them.
+constexpr uint32_t kLutWords = 4u * 256u;
+constexpr uint32_t kLutCompactBytes = 2u * (16u + 256u) * 8u;
+constexpr uint32_t kLutDeviceBytes = kLutWords * 4u + kLutCompactBytes;
 
 // k_gather_scans: the coded scans of one frame, collected behind a header of their lengths
 constexpr uint32_t kGatherMaxScans = 256;

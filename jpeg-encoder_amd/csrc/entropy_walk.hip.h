@@ -37,6 +37,21 @@ __device__ __forceinline__ uint32_t wave_inclusive(uint32_t x) {
     }
     return x;
 }
+// The same in seven v_add_u32 with DPP operands instead of six ds_bpermute round trips (row_shr within rows of 16 lanes, then
+// row_bcast:15 / row_bcast:31 carry the row totals across; lanes a step does not reach keep their value: old = 0 is added).
+__device__ __forceinline__ uint32_t wave_inclusive_dpp(uint32_t x) {
+#define JPEGENC_DPP(v, ctrl, rows, banks) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rows, banks, true)
+    uint32_t v = x;
+    v += JPEGENC_DPP(x, 0x111, 0xF, 0xF);      // row_shr:1
+    v += JPEGENC_DPP(x, 0x112, 0xF, 0xF);      // row_shr:2
+    v += JPEGENC_DPP(x, 0x113, 0xF, 0xF);      // row_shr:3: sums of up to four neighbours
+    v += JPEGENC_DPP(v, 0x114, 0xF, 0xE);      // row_shr:4 into banks 1-3
+    v += JPEGENC_DPP(v, 0x118, 0xF, 0xC);      // row_shr:8 into banks 2-3: inclusive within each row
+    v += JPEGENC_DPP(v, 0x142, 0xA, 0xF);      // row_bcast:15 into rows 1 and 3
+    v += JPEGENC_DPP(v, 0x143, 0xC, 0xF);      // row_bcast:31 into rows 2 and 3
+#undef JPEGENC_DPP
+    return v;
+}
 // 256 threads; part[4] in LDS; the caller separates consecutive uses with __syncthreads()
 __device__ __forceinline__ uint32_t wg_exclusive(uint32_t x, uint32_t *part, uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;

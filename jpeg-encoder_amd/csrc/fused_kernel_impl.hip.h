@@ -6,7 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "entropy_walk.hip.h"
+#include "entropy_loop.hip.h"
 #include "fast_kernel_impl.hip.h"
 
 namespace jpegenc {
@@ -17,61 +17,95 @@ namespace jpegenc {
 // 5-wave budget the VGPRs that hold the spilled SGPRs are themselves spilled to scratch - code that hipcc 7.2 gets wrong
 // (scan bytes differ, memory faults; caught by test_encoder_simd_variant_file).  SGPR spills alone (4 waves) are fine; the
 // byte-plane SIMD-variant instantiations need 3 waves (168 VGPRs) to keep their 40 spilled SGPRs in VGPRs that are not
-// spilled themselves.
+// spilled themselves.  build.sh checks the combination after every build (tools/check_spills.py).
 #ifndef JPEGENC_GROUP_WAVES
 #define JPEGENC_GROUP_WAVES 5
 #endif
-constexpr uint32_t kGroupLutBytes = 4u * 256u * 8u;
 #ifndef JPEGENC_GROUP_PRIV_WORDS
 #define JPEGENC_GROUP_PRIV_WORDS 16
 #endif
-#ifndef JPEGENC_GROUP_WINDOW_WORDS
-#define JPEGENC_GROUP_WINDOW_WORDS 1024
-#endif
-constexpr uint32_t kGPriv = JPEGENC_GROUP_PRIV_WORDS, kGWin = JPEGENC_GROUP_WINDOW_WORDS;   // words of a lane's strip / of the window per wave
+constexpr uint32_t kGPriv = JPEGENC_GROUP_PRIV_WORDS;     // words of a lane's strip: word 0 = the DC code (right-aligned), AC bits from bit 32
+constexpr uint32_t kGImageWords = 2048;                  // a wave's coefficient image (64 lanes x 32 pairs) = its share of the window later
+constexpr uint32_t kGWin = kGImageWords;
+constexpr uint32_t kGDcBits = 27;                        // longest DC code + magnitude bits (16 + 11)
 
+constexpr uint32_t kGSpillBytes = 256;
+static_assert(kGPriv == 16, "StripOr finds a strip's word with a 4-bit field of the cursor");
 __host__ __device__ inline uint32_t group_lds_bytes(uint32_t bpm) {
-    // code tables | window (1 024 words per wave) | strips (kGPriv per lane) | lengths | DCs | flag
-    return kGroupLutBytes + bpm * kGWin * 4u + bpm * kGPriv * 64u * 4u + bpm * 64u * 4u + bpm * 64u * 2u + 16u;
+    // strips (16 words per lane: 4 KiB per wave, 4 KiB-aligned) | one row that takes what the last wave's overflowing strips spill |
+    // coefficient images, then the run's window (2 048 words per wave) | code tables | lengths | DCs | flags
+    return bpm * kGPriv * 64u * 4u + kGSpillBytes + bpm * kGImageWords * 4u + kLoopLutBytes + bpm * 64u * 2u + bpm * 64u * 2u + 16u;
 }
 
 template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 ? (CONV ? 4 : 3) : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
 k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    extern __shared__ __attribute__((aligned(4096))) uint8_t smem[];              // (the kernel has no static LDS: the dynamic part starts at 0)
     const uint32_t nthreads = blockDim.x, bpm = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);   // one wave per block position of the MCU
-    u32x2 *lut64 = reinterpret_cast<u32x2 *>(smem);
-    uint32_t *window = reinterpret_cast<uint32_t *>(smem + kGroupLutBytes);
-    uint32_t *strips = window + bpm * kGWin;
-    uint32_t *lens = strips + bpm * kGPriv * 64u;
+    uint32_t *strips = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *window = strips + bpm * kGPriv * 64u + kGSpillBytes / 4u;          // first: every wave's coefficient image
+    uint8_t *lut_bytes = reinterpret_cast<uint8_t *>(window + bpm * kGImageWords);
+    u32x2 *lut = reinterpret_cast<u32x2 *>(lut_bytes);
+    uint16_t *lens = reinterpret_cast<uint16_t *>(lut_bytes + kLoopLutBytes);
     int16_t *dcs = reinterpret_cast<int16_t *>(lens + bpm * 64u);
-    uint32_t *flag = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);
+    uint32_t *flags = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);              // [0]: a block outgrew its strip, [1]: bits of the run (only summed for a lowered window)
     const uint32_t tid = threadIdx.x, grp = blockIdx.x, f = blockIdx.y;
-
-    // the code tables first in the load queue (1 024 entries over 192 ... 384 threads: fused_supported admits 3 to 6 waves)
-    uint32_t lutv[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const uint32_t idx = (uint32_t)i * nthreads + tid;
-        lutv[i] = idx < 1024u ? ((const hbm_word *)p.lut)[idx] : 0u;
-    }
-    const uint32_t gid = grp * nthreads + tid;
-    if (gid < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + gid] = 0;      // k_push adds its 0xFF counts to these
-    // the window starts out zeroed (the strips are OR-ed in): 16 words per thread
-#pragma unroll
-    for (uint32_t i = 0; i < kGWin / 256u; i++) reinterpret_cast<uint4 *>(window)[i * nthreads + tid] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) *flag = 0;
-
-    // ---- DC predecessor of the group's first MCU: one sample of the component's last block in the MCU before it ---------
-    const u32x16 H = kernarg16(__builtin_offsetof(BlockKernelParams, fast_hdr));
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
-    const u32x16 Wv = kernarg16(__builtin_offsetof(BlockKernelParams, fast_wave) + (size_t)wave_id * sizeof(FastWave));
+
+    // ---- (0) the code tables (k_build_lut leaves them in LDS form behind the first one: 544 entries of 8 bytes over 192 ... 384
+    // threads), zeroed strips ---------------------------------------------------------------------------------------------
+    {
+        typedef const __attribute__((address_space(1))) u32x2 *hbm_entries;
+        const hbm_entries compact = (hbm_entries)(p.lut + kLutWords);
+        u32x2 lutv[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const uint32_t e = (uint32_t)i * nthreads + tid;
+            lutv[i] = compact[min(e, kLoopLutEntries - 1u)];
+        }
+        const uint32_t gid = grp * nthreads + tid;
+        if (gid < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + gid] = 0;      // k_push adds its 0xFF counts to these
+#pragma unroll
+        for (uint32_t i = 0; i < kGPriv / 4u; i++) reinterpret_cast<uint4 *>(strips)[i * nthreads + tid] = make_uint4(0, 0, 0, 0);
+        if (tid < 2u) flags[tid] = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const uint32_t e = (uint32_t)i * nthreads + tid;
+            if (e < kLoopLutEntries) lut[e] = lutv[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- the block kernel's wave: this lane's 64 quantised zig-zag coefficients -> LDS image + non-zero mask -------------
+    typedef __attribute__((address_space(3))) uint8_t *lds_bytes;
+    WaveCtx w;
+    uint64_t mask;
+    bool mine_valid;
+    int my_dc;
+    uint32_t *image = window + wave_id * kGImageWords;
+    {
+        BlockRegs r;
+        const bool active = block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, f, w, r.c);
+        mine_valid = active && w.inside;
+        stage_block(r.c, image, lane);
+        mask = mine_valid ? nonzero_mask(r.c) : 0ull;
+        my_dc = mine_valid ? (int)(int16_t)(r.c[0] & 0xFFFFu) : 0;
+    }
+    const u32x16 Wv = w.Wv;
+    const uint32_t mcu_local = Wv[1] + (lane >> w.lg);                          // MCU of the group; (w.lg etc. are set for padding waves too)
+    const uint32_t pos = Wv[7] + (lane & ((1u << w.lg) - 1u));                  // block position inside the MCU (FastWave::out_base of MCU order)
+    const uint32_t s = mcu_local * bpm + pos;                                   // the block's place in the run (scan order)
+    if (mcu_local < 64u) dcs[s] = (int16_t)my_dc;
+
+    // ---- DC predecessor of the group's first MCU: one sample of the component's last block in the MCU before it, requested
+    // here and added up after the AC walk ------------------------------------------------------------------------------------
     const uint32_t interval_mcus = p.nintervals > 1 ? p.interval_blocks / p.bpm : 0u;
     const uint32_t group_first = grp * 64u;
     const bool need_pred = Wv[1] == 0u && group_first != 0u && !(interval_mcus && group_first % interval_mcus == 0u);   // wave-uniform
     uint32_t pred_sample = 0;
     if (need_pred) {
+        const u32x16 H = w.H;
         const uint32_t wbits = Wv[0];
         const bool sub = (wbits >> FW_SUB_SHIFT) & 1u;
         const uint32_t lg = (wbits >> FW_LG_SHIFT) & 3u, lgv = (wbits >> FW_LGV_SHIFT) & 3u;
@@ -90,30 +124,40 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         pred_sample = edge_sample(frame + (size_t)min(by, ph - 1) * ppitch + (size_t)min(bx, pw - 1) * pbpp, role, c, k);
     }
 
-    // ---- the block kernel's wave: this lane's 64 quantised zig-zag coefficients ----------------------------------------
-    WaveCtx w;
-    BlockRegs r;
-    const bool active = block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, f, w, r.c);
-    const bool mine_valid = active && w.inside;
-    const uint32_t mcu_local = Wv[1] + (lane >> w.lg);                          // MCU of the group; (w.lg etc. are set for padding waves too)
-    const uint32_t pos = Wv[7] + (lane & ((1u << w.lg) - 1u));                  // block position inside the MCU (FastWave::out_base of MCU order)
-    const uint32_t s = mcu_local * bpm + pos;                                   // the block's place in the run (scan order)
+    // ---- the AC symbols of the block, into the lane's strip from bit 32 (before the barrier: the other waves still fetch) ----
+    const uint32_t table = (uint32_t)w.qsel;                                    // quantisation = DC = AC table destination (encoder.rs:569-619)
+    const uint32_t dc_table = (uint32_t)(uintptr_t)(lds_bytes)lut_bytes + table * kLoopLutPerTable * 8u, ac_table = dc_table + 16u * 8u;
+    const uint32_t image_at = (uint32_t)(uintptr_t)(lds_bytes)(smem) + bpm * kGPriv * 256u + kGSpillBytes + wave_id * kGImageWords * 4u + lane * 4u;
+    lds_word *strip = (lds_word *)(strips + wave_id * kGPriv * 64u) + lane;
+    uint32_t ac_bits = 0;
+    if (mine_valid) {
+        StripOr so = {(uint32_t)(uintptr_t)strip, 32u * 8u};
+        walk_nonzeros(mask, 1u, 64u, image_at, ac_table, so);
+        ac_bits = so.bits() - 32u;
+    }
+    if (ac_bits > (kGPriv - 1u) * 32u) __hip_atomic_fetch_or((lds_word *)flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const bool lowered_window = p.window_words < kGWin;                          // (the tests' way to the second walk: then the run's length matters too)
+    if (lowered_window) {
+        const uint32_t wave_bits = wave_sum(ac_bits);
+        if (lane == 0) __hip_atomic_fetch_add((lds_word *)(flags + 1), wave_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     int pred_first = 0;
     if (need_pred) {
         const int v = (int)wave_sum(pred_sample) - 8192;
         const qconst_ptr qc = quant_table(w.qsel);
         pred_first = __builtin_amdgcn_readfirstlane(dot2((uint32_t)v, qc[0], (int)qc[1]) >> 16);   // natural coefficient 0
     }
-    if (mcu_local < 64u) dcs[s] = mine_valid ? (int16_t)(r.c[0] & 0xFFFFu) : (int16_t)0;
-    // code tables to LDS: entry (code << n, size + n), n = the symbol's size category (see lut64_commit)
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const uint32_t idx = (uint32_t)i * nthreads + tid;
-        if (idx < 1024u) { const uint32_t e = lutv[i], n = idx & 15u; lut64[idx] = u32x2{(e & 0xFFFFu) << n, (e >> 16) + n}; }
-    }
-    __syncthreads();                                                             // (1) DCs and tables posted, window zeroed
+    __syncthreads();                                                             // (1) DCs posted, every AC walk done: the images are dead
 
-    // ---- DC predecessor: previous block of the same component in scan order ---------------------------------------------
+    // whether the run goes through the window: decided here (workgroup-uniform) because the window takes the images' place
+    // (a run whose strips all hold cannot outgrow the full window: at most 15 * 32 + 27 of its 1 024 bits per block)
+    const bool fits = flags[0] == 0u && (!lowered_window || ((flags[1] + 64u * bpm * kGDcBits + 31u) >> 5) + 4u <= p.window_words * bpm);   // (+4: the zero word, 16-byte copies)
+    if (fits) {
+#pragma unroll
+        for (uint32_t i = 0; i < kGImageWords / 256u; i++) reinterpret_cast<uint4 *>(window)[i * nthreads + tid] = make_uint4(0, 0, 0, 0);
+    }
+
+    // ---- DC: previous block of the same component in scan order ------------------------------------------------------------
     const bool prev_in_mcu = (p.pos_delta_bits >> pos) & 1u;
     int prev_dc;
     if (prev_in_mcu) {
@@ -123,22 +167,21 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         prev_dc = mcu_local ? (int)dcs[(mcu_local - 1u) * bpm + last_pos] : pred_first;
         if (interval_mcus && (group_first + mcu_local) % interval_mcus == 0u) prev_dc = 0;   // predictors reset at a restart boundary
     }
-    const uint32_t table = (uint32_t)w.qsel;                                    // quantisation = DC = AC table destination (encoder.rs:569-619)
-    lds_word *strip = (lds_word *)(strips + wave_id * kGPriv * 64u) + lane;
-    PrivSink ps = {strip, strip + (kGPriv - 1u) * 64u, 0, 0, 0};
+    uint32_t mine = 0, from = 32u, head = 0;
     if (mine_valid) {
-        walk_once<true>(p, lut64, table, prev_dc, r, ps);
-        ps.finish();
+        const u32x2 dc = dc_code(dc_table, my_dc, prev_dc);
+        head = dc.x;                                                             // right-aligned in the head word
+        from = 32u - dc.y;
+        mine = dc.y + ac_bits;
     }
-    const uint32_t mine = ps.bits();
-    if (mcu_local < 64u) lens[s] = mine;
-    if (mine > kGPriv * 32u) __hip_atomic_fetch_or((lds_word *)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __syncthreads();                                                             // (2) lengths posted
+    strip[0] = head;                                                             // (stored, not OR-ed: a neighbour's overflowing strip may have spilt into it)
+    if (mcu_local < 64u) lens[s] = (uint16_t)mine;
+    __syncthreads();                                                             // (2) lengths posted, window zeroed
 
     // ---- bit offset of every block in the run: each wave adds up the MCUs itself (lane = MCU) ----------------------------
     uint32_t mcu_bits = 0;
     for (uint32_t j = 0; j < bpm; j++) mcu_bits += lens[lane * bpm + j];
-    const uint32_t upto = wave_inclusive(mcu_bits);
+    const uint32_t upto = wave_inclusive_dpp(mcu_bits);
     const uint32_t total = (uint32_t)__shfl((int)upto, 63);
     uint32_t at = (uint32_t)__shfl((int)(upto - mcu_bits), (int)(mcu_local & 63u));
     for (uint32_t j = 0; j < bpm; j++) { const uint32_t v = lens[(mcu_local & 63u) * bpm + j]; if (j < pos) at += v; }
@@ -146,37 +189,31 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     if (p.nintervals > 1u && mine_valid) p.bits[(size_t)f * p.nblocks + (size_t)group_first * bpm + s] = at;   // (interval offsets need them, k_interval_len)
     const uint32_t nwords = (total + 31u) >> 5;
     uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)grp * p.slot_words;
-    const uint32_t window_cap = min(p.window_words, kGWin) * bpm;               // (p.window_words: the tests' way to the other paths)
-    const uint32_t both_cap = p.window_words >= kGWin ? window_cap + bpm * kGPriv * 64u : 2u * window_cap;   // window + strips: contiguous
-    const bool fits = *flag == 0u && nwords + 4u <= window_cap;                   // workgroup-uniform (+4: the zero word, 16-byte copies)
     if (fits) {
-        strip_to_window(strip, mine, at, (lds_word *)window);
+        strip_to_window_from(strip, from, mine, at, (lds_word *)window);
         __syncthreads();                                                         // (3) the run is complete
         for (uint32_t i = tid * 4u; i <= nwords; i += nthreads * 4u)
             *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(window + i);
-    } else if (nwords + 4u <= both_cap) {
-        // a block longer than its strip (quality 95 and up), or a run longer than the window that fits window + strips (up
-        // to 1 024 bits per block on average: noise at quality 100 has 710): second walk, bits OR-ed into that zeroed LDS
-        // area - an LDS atomic per word instead of one to HBM, which made such frames 7 x slower
-        for (uint32_t i = tid; i < bpm * kGPriv * 64u; i += nthreads) strips[i] = 0;     // (the window is still zero)
-        __syncthreads();
-        if (mine_valid) {
-            PackSink<LdsWords> ls = {LdsWords{(lds_word *)window + (at >> 5)}, 0, at & 31u};
-            walk_once<true>(p, lut64, table, prev_dc, r, ls);
-            ls.finish();
-        }
-        __syncthreads();
-        for (uint32_t i = tid * 4u; i <= nwords; i += nthreads * 4u)
-            *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(window + i);
     } else {
-        // a run longer than the workgroup's LDS (pathological content): second walk, bits OR-ed straight into the zeroed slot
-        for (uint32_t i = tid; i <= nwords; i += nthreads) slot[i] = 0;
-        __threadfence();
-        __syncthreads();
-        if (mine_valid) {
-            PackSink<HbmWords> hs = {HbmWords{(hbm_word *)slot + (at >> 5)}, 0, at & 31u};
-            walk_once<true>(p, lut64, table, prev_dc, r, hs);
-            hs.finish();
+        // A block longer than its strip (quality 95 and up) or a run longer than the window: the images are still there, so
+        // the run is coded again chunk by chunk - every lane whose block reaches into the chunk walks its symbols a second
+        // time and ORs them at their final place into the zeroed chunk (the strips' area), which then goes to the slot.
+        const uint32_t chunk_words = (max(min(p.window_words, kGPriv * 64u), 4u) & ~3u) * bpm, chunk_bits = chunk_words * 32u;   // (a multiple of 16 bytes)
+        for (uint32_t w0 = 0; w0 <= nwords; w0 += chunk_words) {                 // (word nwords = the zero word after the run)
+            for (uint32_t i = tid; i < chunk_words; i += nthreads) strips[i] = 0;
+            __syncthreads();
+            const uint32_t c0 = w0 * 32u;
+            if (mine_valid && at < c0 + chunk_bits && at + mine > c0) {
+                ChunkOr co = {(lds_word *)strips, (int32_t)(at - c0), chunk_words};
+                const u32x2 dc = dc_code(dc_table, my_dc, prev_dc);
+                co.put(dc.x, 0u - dc.y);
+                walk_nonzeros(mask, 1u, 64u, image_at, ac_table, co);
+            }
+            __syncthreads();
+            const uint32_t n = min(chunk_words, nwords + 1u - w0);
+            for (uint32_t i = tid * 4u; i < n; i += nthreads * 4u)
+                *reinterpret_cast<uint4 *>(slot + w0 + i) = *reinterpret_cast<const uint4 *>(strips + i);
+            __syncthreads();
         }
     }
 }
@@ -192,7 +229,18 @@ static hipError_t launch_group_t(const BlockKernelParams &b, const ColourConsts 
     size_t lds = group_lds_bytes(q.bpm);
     static const char *pad_env = getenv("JPEGENC_GROUP_LDS_PAD_KB");               // diagnostic: fewer resident workgroups per CU
     if (pad_env) lds += (size_t)atoi(pad_env) * 1024u;
-    if (variant == 1) hipLaunchKernelGGL((k_group_code<BPP, SX, SY, 1, CONV, PLANES>), grid, block, lds, st, q, k, d_params);
+    // (more than 64 KiB of dynamic LDS per workgroup has to be allowed once per kernel and device)
+    static thread_local int allowed_device[2] = {-1, -1};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    const int vi = variant == 1 ? 1 : 0;
+    if (allowed_device[vi] != dev) {
+        const void *fn = vi ? (const void *)k_group_code<BPP, SX, SY, 1, CONV, PLANES> : (const void *)k_group_code<BPP, SX, SY, 0, CONV, PLANES>;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)group_lds_bytes(6u) + 64 * 1024);
+        if (e != hipSuccess) return e;
+        allowed_device[vi] = dev;
+    }
+    if (vi) hipLaunchKernelGGL((k_group_code<BPP, SX, SY, 1, CONV, PLANES>), grid, block, lds, st, q, k, d_params);
     else hipLaunchKernelGGL((k_group_code<BPP, SX, SY, 0, CONV, PLANES>), grid, block, lds, st, q, k, d_params);
     return hipGetLastError();
 }

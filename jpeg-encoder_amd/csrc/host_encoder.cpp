@@ -331,7 +331,7 @@ struct DeviceCtx {
         JPEGENC_HIP(hipHostMalloc((void **)&h_freq, sizeof(uint32_t) * 2 * 2 * 257, hipHostMallocDefault));
         JPEGENC_HIP(hipMalloc((void **)&d_scan_len, sizeof(uint32_t) * kMaxScans));
         JPEGENC_HIP(hipHostMalloc((void **)&h_scan_len, sizeof(uint32_t) * kMaxScans, hipHostMallocDefault));
-        JPEGENC_HIP(hipMalloc(&d_lut, 4 * 256 * sizeof(uint32_t)));
+        JPEGENC_HIP(hipMalloc(&d_lut, kLutDeviceBytes));
         return JPEGENC_OK;
     }
     int reserve_hist(size_t total_blocks) {            // optimised tables only
@@ -574,6 +574,12 @@ struct BatchBuffers {
     }
 };
 
+// JPEGENC_NUMA_BIND=1: the default of jpegenc_encoder_set_numa_bind (see bind_thread_near_device)
+static bool numa_bind_default() {
+    static const bool on = getenv("JPEGENC_NUMA_BIND") != nullptr;
+    return on;
+}
+
 }  // namespace jpegenc
 
 using namespace jpegenc;
@@ -586,6 +592,7 @@ struct jpegenc_encoder {
     BatchBuffers batch;                                  // device-resident batch API
     SmallBatchBuffers small;                             // batches of small frames
     int max_batch_workers = 16;                          // host threads of jpegenc_encoder_encode_batch
+    bool numa_bind = jpegenc::numa_bind_default();      // those threads run on the NUMA node of the device (jpegenc_encoder_set_numa_bind)
     // jpegenc_encoder_encode_batch_multi: one child encoder per entry of `devices` (its own workers, streams,
     // pinned staging and device buffers), kept across calls
     std::vector<std::unique_ptr<jpegenc_encoder>> shards;
@@ -1545,8 +1552,7 @@ static bool device_cpus(int device, cpu_set_t *out) {
     return true;
 }
 
-static void bind_thread_near_device(int device) {
-    static const bool on = getenv("JPEGENC_NUMA_BIND") != nullptr;
+static void bind_thread_near_device(int device, bool on) {
     if (!on) return;
     cpu_set_t want, have, both;
     if (!device_cpus(device, &want)) return;
@@ -1592,6 +1598,12 @@ int jpegenc_encoder_set_device(jpegenc_encoder *e, int device) {
 int jpegenc_encoder_set_device_entropy(jpegenc_encoder *e, int enable) {
     REQUIRE(e);
     e->cfg.device_entropy = enable != 0;
+    return JPEGENC_OK;
+}
+
+int jpegenc_encoder_set_numa_bind(jpegenc_encoder *e, int enable) {
+    REQUIRE(e);
+    e->numa_bind = enable != 0;
     return JPEGENC_OK;
 }
 
@@ -1793,7 +1805,7 @@ static int encode_device_frames_pooled(jpegenc_encoder *e, const void *d_frames,
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)workers);
     auto body = [&](int w) {
-        if (w > 0) bind_thread_near_device(e->device);
+        if (w > 0) bind_thread_near_device(e->device, e->numa_bind);
         DeviceCtx &ctx = *e->workers[(size_t)w];
         int r = ctx.open(e->device);
         while (r == JPEGENC_OK) {
@@ -2061,7 +2073,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
     const bool staged = getenv("JPEGENC_BATCH_PAGEABLE_H2D") == nullptr;
     auto body = [&](int w) {
-        if (w > 0) bind_thread_near_device(e->device);          // (JPEGENC_NUMA_BIND=1 only) spawned workers; the caller's own affinity is left alone
+        if (w > 0) bind_thread_near_device(e->device, e->numa_bind);   // (opt-in) spawned workers; the caller's own affinity is left alone
         DeviceCtx &ctx = *e->workers[(size_t)w];
         for (;;) {
             const int i = next.fetch_add(1);
@@ -2196,11 +2208,12 @@ static int encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_de
         }
         child->cfg = e->cfg;
         child->max_batch_workers = per_shard;
+        child->numa_bind = e->numa_bind;
     }
     std::vector<int> status((size_t)num_devices, JPEGENC_OK);
     std::vector<std::string> messages((size_t)num_devices);
     auto shard_body = [&](int d) {
-        bind_thread_near_device(devices[d]);                                // the workers this thread spawns inherit the mask
+        bind_thread_near_device(devices[d], e->numa_bind);                  // the workers this thread spawns inherit the mask
         const int n = jpegenc_shard_frames(num_frames, num_devices, d, nullptr, 0);
         if (n <= 0) { status[(size_t)d] = n < 0 ? -n : JPEGENC_OK; return; }
         std::vector<int> idx((size_t)n);

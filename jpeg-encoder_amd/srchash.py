@@ -1,0 +1,21 @@
+"""SHA-256 over the kernel sources of the library (csrc/*.hip, *.hip.h, *.h, *.inc, *.cpp, build.sh): how a measurement file
+(profiles/pmc_traffic.json) names the build it was taken on and how bench.py notices that the tree has moved on."""
+import glob
+import hashlib
+import os
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+
+
+def kernel_sources_sha256(csrc=CSRC):
+    files = sorted(p for pat in ("*.hip", "*.h", "*.inc", "*.cpp", "build.sh") for p in glob.glob(os.path.join(csrc, pat)))
+    h = hashlib.sha256()
+    for p in files:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    return h.hexdigest()
+
+
+if __name__ == "__main__":
+    print(kernel_sources_sha256())

@@ -45,11 +45,12 @@ def build(force=False, extra_cflags=None, out_path=None):
     out = out_path or _LIB_PATH
     src = os.path.join(_HERE, "jpegenc_oracle.c")
     src_avx2 = os.path.join(_HERE, "jpegenc_oracle_avx2.c")
-    deps = [src, src_avx2, os.path.join(_HERE, "jpegenc_oracle.h"), os.path.join(_HERE, "orc_tables.h")]
+    src_hw = os.path.join(_HERE, "fdct_avx2_hw.c")
+    deps = [src, src_avx2, src_hw, os.path.join(_HERE, "jpegenc_oracle.h"), os.path.join(_HERE, "orc_tables.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     flags = extra_cflags or ["-mavx2"]
-    subprocess.check_call(["gcc", "-O3", "-fPIC", "-std=gnu11", *flags, "-shared", "-o", out, src, src_avx2])
+    subprocess.check_call(["gcc", "-O3", "-fPIC", "-std=gnu11", *flags, "-shared", "-o", out, src, src_avx2, src_hw])
     return out
 
 
@@ -72,6 +73,10 @@ def _bind(l):
     l.orc_rgb_to_ycbcr.argtypes = [C.c_uint8] * 3 + [u8p]
     l.orc_cmyk_to_ycck.argtypes = [C.c_uint8] * 4 + [u8p]
     l.orc_fdct.argtypes = [i16p, C.c_int]
+    l.orc_fdct_avx2_hw.argtypes = [i16p]
+    l.orc_fdct_avx2_hw_many.argtypes = [C.c_void_p, C.c_long]
+    l.orc_fdct_avx2_hw_compare.argtypes = [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_long)]
+    l.orc_fdct_avx2_hw_compare.restype = C.c_long
     l.orc_qtable_init.argtypes = [C.POINTER(QTable), C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int]
     l.orc_quantize.argtypes = [C.POINTER(QTable), C.c_int16, C.c_int]
     l.orc_quantize.restype = C.c_int16

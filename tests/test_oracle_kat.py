@@ -125,7 +125,7 @@ def test_sampling_factors(kats):
 def test_simd_fdct_variant(oracle):
     """The `simd` feature's FDCT (src/avx2/fdct.rs) differs from the scalar one only at natural
     positions 1,3,5,7 and 33,35,37,39, by 0 or -1 (rounding constant built with 32-bit lanes).
-    Vectors: lane-accurate emulation, see tests/golden/README.md."""
+    Vectors: the intrinsic sequence executed with AVX2 (tests/golden/make_simd_fdct_vectors.py), see tests/golden/README.md."""
     with open(os.path.join(GOLDEN, "simd_fdct_vectors.json")) as f:
         vectors = json.load(f)["vectors"]
     quirk = {1, 3, 5, 7, 33, 35, 37, 39}
@@ -140,6 +140,51 @@ def test_simd_fdct_variant(oracle):
                 assert i in quirk and b == a - 1
                 differing += 1
     assert differing > 0
+
+
+def test_simd_fdct_pinned_by_executing_the_intrinsic_sequence(oracle):
+    """SURVEY 8 row a6': what `fdct_avx2` (src/avx2/fdct.rs:62-468) produces is no longer this project's reading of the
+    source but the x86 instructions themselves: oracle/fdct_avx2_hw.c issues the same _mm256_* sequence (gcc -mavx2) on
+    this machine, and ORC_FDCT_SIMD - the scalar behavioural model the GPU's VARIANT 1 is tested against - must equal
+    it on (a) the 64 committed vectors, (b) 1.2 million random legal blocks (-128..127), (c) the saturating / wrapping
+    corners: constant, checkerboard, impulse and full-range i16 blocks (legal input never wraps a 16-bit lane; the
+    model's wrap16 / sat16 are only reached out of range)."""
+    import ctypes as C
+    lib = oracle.lib()
+    if not lib.orc_fdct_avx2_hw_available():
+        pytest.skip("host CPU has no AVX2")
+    with open(os.path.join(GOLDEN, "simd_fdct_vectors.json")) as f:
+        vectors = json.load(f)["vectors"]
+    assert len(vectors) == 64
+    for v in vectors:
+        blk = np.array(v["input"], dtype=np.int16)
+        lib.orc_fdct_avx2_hw(blk.ctypes.data_as(C.POINTER(C.c_int16)))
+        assert blk.tolist() == v["simd"]
+
+    def differing(blocks, variant=oracle.FDCT_SIMD):
+        blocks = np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, 64)
+        first = C.c_long()
+        return int(lib.orc_fdct_avx2_hw_compare(blocks.ctypes.data, len(blocks), variant, C.byref(first))), first.value
+    rng = np.random.default_rng(2026)
+    legal = rng.integers(-128, 128, (1_200_000, 64), dtype=np.int16)
+    assert differing(legal) == (0, -1)
+    # ... and it is NOT the scalar transform (fdct.rs:107-238): nearly every random block differs somewhere
+    n_scalar, _ = differing(legal[:20000], oracle.FDCT_SCALAR)
+    assert n_scalar > 19000
+    y, x = np.mgrid[0:8, 0:8]
+    corners = [np.full(64, v) for v in (-128, 127, 0, -1, 1)]
+    corners += [np.where((x + y) % 2 == 0, a, b).reshape(64) for a, b in ((-128, 127), (127, -128))]
+    corners += [np.where(x % 2 == 0, -128, 127).reshape(64), np.where(y % 2 == 0, 127, -128).reshape(64)]
+    for pos in range(64):
+        for v in (-128, 127):
+            e = np.zeros(64, dtype=np.int64)
+            e[pos] = v
+            corners.append(e)
+    assert differing(np.array(corners)) == (0, -1)
+    for lo, hi, n in ((-32768, 32768, 300_000), (-2048, 2048, 200_000), (-300, 300, 200_000)):
+        assert differing(rng.integers(lo, hi, (n, 64), dtype=np.int16)) == (0, -1), (lo, hi)
+    extremes = rng.choice(np.array([-32768, -32767, -1, 0, 1, 32767], dtype=np.int16), (100_000, 64))
+    assert differing(extremes) == (0, -1)
 
 
 def test_huffman_default_tables_are_prefix_codes(oracle):

@@ -4,7 +4,7 @@
 set -u
 tag=${1:-rXX}; way=${2:-fused}
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p "$out"
-export TMPDIR=/tmp BENCH_FUSED_ONLY=photo-like:$way
+export TMPDIR=/tmp BENCH_FUSED_ONLY=${CONTENT:-photo-like}:$way
 cd /tmp
 pass() {   # name, counters...
   local name=$1; shift

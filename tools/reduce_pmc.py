@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--alg-bytes", type=int, required=True, help="algorithmic bytes per launch (DESIGN.md)")
     ap.add_argument("--workload", default="32 frames 3840x2160 RGB q=90 4:2:0 per launch (bench.py)")
     ap.add_argument("--out", default="profiles/pmc_traffic.json")
+    ap.add_argument("--srchash-file", default=None, help="<tag>_srchash.txt written by tools/profile_round.sh on the GPU box: SHA-256 of the "
+                                                         "kernel sources the measured library was built from")
     ap.add_argument("dirs", nargs="+")
     a = ap.parse_args()
 
@@ -70,6 +72,16 @@ def main():
         "collected": "separate rocprofv3 --pmc passes (one directory each: " + ", ".join(os.path.basename(os.path.normpath(d)) for d in a.dirs)
                      + "), each: rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --steps 20 --warmup 5 --settle-ms 0 --cpu-seconds 0.2 --headline-only; reduced by tools/reduce_pmc.py",
     }
+    # which build this is a measurement of: bench.py reports `traffic_stale` when the tree's sources hash differently
+    if a.srchash_file and os.path.exists(a.srchash_file):
+        doc["csrc_sha256"] = open(a.srchash_file).read().strip()
+    try:
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        doc["git_head_at_reduction"] = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], text=True).strip()
+        doc["git_dirty_at_reduction"] = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "jpeg-encoder_amd/csrc"], text=True).strip())
+    except Exception:
+        pass
     d = {}
     if "SQ_WAVES" in counters and counters["SQ_WAVES"]:
         w = counters["SQ_WAVES"]
