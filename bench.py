@@ -103,6 +103,29 @@ def cpu_baseline(seconds_budget, synth, gpu_frame=None, gpu_coeffs=None):
     if avx2 is not None:
         base["scalar"] = {"value": round(ns * W * H / dts / 1e6, 2), "unit": "Mpixels/s", "cores": 1,
                           "sample": f"{ns} frames in {dts:.1f} s with the scalar port (oracle/jpegenc_oracle.c)"}
+    # the reference's two micro-benchmarks on the ports (oracle/criterion_micro.c): one 8x8 block through the FDCT
+    # (criterion/benches/fdct.rs:6-42) and the 1001x500 pattern through the row colour conversion (ycbcr.rs:6-100)
+    try:
+        lib.orc_bench_fdct_ns.restype = C.c_double
+        lib.orc_bench_fdct_ns.argtypes = [C.c_int, C.c_double]
+        lib.orc_bench_ycbcr_ms.restype = C.c_double
+        lib.orc_bench_ycbcr_ms.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int]
+        img = np.ascontiguousarray(synth.criterion_pattern(1001, 500))
+        slice_s = max(0.05, min(0.5, seconds_budget / 20))
+        has_avx2 = bool(lib.orc_fdct_avx2_hw_available())
+        ycc_avx2 = lib.orc_bench_ycbcr_ms(1, slice_s, img.ctypes.data, 1001, 500) if has_avx2 else -1.0
+        base["criterion_micro"] = {
+            "fdct": {"default_ns": round(lib.orc_bench_fdct_ns(0, slice_s), 1),
+                     "avx2_ns": round(lib.orc_bench_fdct_ns(1, slice_s), 1) if has_avx2 else None,
+                     "what": "criterion/benches/fdct.rs:6-42: one block (INPUT1) per call; default = scalar port, avx2 = the crate's intrinsic "
+                             "sequence executed (oracle/fdct_avx2_hw.c)"},
+            "ycbcr": {"default_ms": round(lib.orc_bench_ycbcr_ms(0, slice_s, img.ctypes.data, 1001, 500), 3),
+                      "avx2_ms": round(ycc_avx2, 3) if ycc_avx2 > 0 else None,
+                      "what": "criterion/benches/ycbcr.rs:6-100: RgbImage::fill_buffers over the 500 rows of the 1001x500 pattern, per pass; "
+                              "default = scalar port, avx2 = the 8-pixel row of oracle/jpegenc_oracle_avx2.c"},
+            "cores": 1}
+    except Exception as exc:                                    # side figure only
+        base["criterion_micro"] = {"error": str(exc)}
     # the same port through to the file (block path + Huffman coding + markers), one core: the CPU figure
     # comparable with `end_to_end`
     try:

@@ -616,6 +616,11 @@ impl<W: JfifWrite> Encoder<W> {
         unsafe { sys::jpegenc_encoder_set_numa_bind(self.h, enable as c_int) };
     }
 
+    /// Upper bound on the frames of a device-resident batch in flight together (0 = sized by device memory footprint).
+    pub fn set_batch_round_frames(&mut self, frames: u32) {
+        unsafe { sys::jpegenc_encoder_set_batch_round_frames(self.h, frames as c_int) };
+    }
+
     /// Number of usable MI355X devices (0: `encode` will fail, keep the CPU crate as the fallback).
     pub fn device_count() -> i32 {
         unsafe { sys::jpegenc_device_count() as i32 }

@@ -255,6 +255,10 @@ int  jpegenc_encoder_set_device_entropy(jpegenc_encoder *e, int enable);
  * memory is then first touched there and uploads do not cross the socket interconnect.  Best effort (sysfs), the
  * caller's own thread is left alone.  Default 0, or 1 when JPEGENC_NUMA_BIND is set in the environment. */
 int  jpegenc_encoder_set_numa_bind(jpegenc_encoder *e, int enable);
+/* Upper bound on the frames of a device-resident batch (jpegenc_encoder_encode_batch_device and the calls built on it) whose
+ * device work is in flight together: a round of n frames occupies n x (coefficients + worst-case scan bytes) of device
+ * memory.  0 (default): rounds are sized for a 6 GiB footprint, at most 1024 frames.  The files do not depend on it. */
+int  jpegenc_encoder_set_batch_round_frames(jpegenc_encoder *e, int frames);
 
 int  jpegenc_encoder_set_density(jpegenc_encoder *e, int unit, uint16_t x, uint16_t y);   /* :280 */
 int  jpegenc_encoder_density(const jpegenc_encoder *e, int *unit, uint16_t *x, uint16_t *y);

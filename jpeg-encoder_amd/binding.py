@@ -11,6 +11,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # JPEGENC_LIB: a diagnostic variant build (tools/diag/ab_bench.sh) instead of the in-tree library
 LIB_PATH = os.environ.get("JPEGENC_LIB") or os.path.join(_HERE, "libjpegenc_mi355x.so")
+# the -DJPEGENC_DIAG build of the same sources (csrc/diag_env.h): the only library that reads the diagnostic switches
+# (JPEGENC_FUSED, JPEGENC_PACK_WINDOW_WORDS, ...); tests that force a rare path start a child process with JPEGENC_LIB = this
+DIAG_LIB_PATH = os.path.join(_HERE, "libjpegenc_mi355x_diag.so")
 
 # enum jpegenc_color_type == reference `enum ColorType` order (src/encoder.rs:72-99)
 LUMA, RGB, RGBA, BGR, BGRA, YCBCR, CMYK, CMYK_AS_YCCK, YCCK = range(9)
@@ -41,7 +44,7 @@ ABI_SYMBOLS = [
     "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_histogram_device",
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
     "jpegenc_pixels_scan_fused", "jpegenc_pixels_scan_device",
-    "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_numa_bind",
+    "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_numa_bind", "jpegenc_encoder_set_batch_round_frames",
     "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
     "jpegenc_encoder_set_fdct_variant", "jpegenc_encoder_set_density", "jpegenc_encoder_density",
     "jpegenc_encoder_set_sampling_factor", "jpegenc_encoder_sampling_factor",
@@ -138,7 +141,7 @@ def lib():
         l.jpegenc_pixels_scan_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.POINTER(QTable), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-        for name in ("set_device", "set_device_entropy", "set_numa_bind", "set_fdct_variant", "set_sampling_factor", "set_progressive",
+        for name in ("set_device", "set_device_entropy", "set_numa_bind", "set_batch_round_frames", "set_fdct_variant", "set_sampling_factor", "set_progressive",
                      "set_progressive_scans", "set_optimized_huffman_tables"):
             getattr(l, "jpegenc_encoder_" + name).argtypes = [C.c_void_p, C.c_int]
         for name in ("sampling_factor", "progressive_scans", "restart_interval", "optimized_huffman_tables"):
@@ -420,6 +423,9 @@ class Encoder:
 
     def set_device_entropy(self, enable):
         check(lib().jpegenc_encoder_set_device_entropy(self._h, 1 if enable else 0))
+
+    def set_batch_round_frames(self, frames):
+        check(lib().jpegenc_encoder_set_batch_round_frames(self._h, int(frames)))
 
     def set_numa_bind(self, enable):
         check(lib().jpegenc_encoder_set_numa_bind(self._h, 1 if enable else 0))

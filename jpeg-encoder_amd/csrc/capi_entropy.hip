@@ -4,6 +4,7 @@
 
 #include <mutex>
 
+#include "diag_env.h"
 #include "host_common.h"
 #include "entropy_loop.hip.h"
 #include "tables_data.inc"
@@ -217,7 +218,7 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
     p.coeff_frame_stride = coeff_frame_stride;
     p.nblocks = (uint32_t)nblocks;
     static const uint32_t window_words = [] {
-        const char *e = getenv("JPEGENC_PACK_WINDOW_WORDS");
+        const char *e = JPEGENC_DIAG_ENV("JPEGENC_PACK_WINDOW_WORDS");
         const long v = e ? atol(e) : (long)kPackWindowWords;
         return (uint32_t)(v < 0 ? 0 : v > (long)kPackWindowWords ? kPackWindowWords : v);
     }();

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <string>
 
+#include "diag_env.h"
 #include "entropy_params.h"
 #include "entropy_walk.hip.h"
 #include "host_common.h"
@@ -752,7 +753,7 @@ static hipError_t scan(const EntropyParams *d_params, int which, uint32_t n_max,
     const uint32_t tiles = (n_max + kScanTile - 1) / kScanTile;
     // up to this many tiles every workgroup can afford to add up the tile sums before its own (tests lower it
     // to reach the three-kernel form, which real scans need only beyond 8.4 M elements)
-    static const uint32_t fused_max = [] { const char *e = getenv("JPEGENC_SCAN_FUSED_MAX_TILES"); return e ? (uint32_t)atol(e) : 2048u; }();
+    static const uint32_t fused_max = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_SCAN_FUSED_MAX_TILES"); return e ? (uint32_t)atol(e) : 2048u; }();
     const bool fused = tiles <= fused_max;
     if (tiles > 1 || !fused)   // a single tile has no tiles before it: the fused kernel alone is the scan
         hipLaunchKernelGGL(k_scan_reduce, dim3(tiles ? tiles : 1, frames, njobs), dim3(256), 0, st, d_params, which);
@@ -781,7 +782,7 @@ static LaunchShape shape_of(const EntropyParams *jobs, int njobs) {
     // (tools/diag/prefix_ab.sh): the runs pay up to ~2 000 of them (the 2 040 runs of the pixels -> bits kernel: -0.2 us per
     // frame; k_block_code's 3 038: +2-3 us); the tiles (worst-case bound 11 154) gain 0.5 us on photo-like frames and lose
     // 0.8-1.6 us on noise, and per-64-tile counters kept by k_push to shorten the sum cost 2-3 us in contended atomics.
-    static const uint32_t allow = [] { const char *e = getenv("JPEGENC_FUSED_PREFIX_MASK"); return e ? (uint32_t)atoi(e) : 3u; }();   // diagnostic
+    static const uint32_t allow = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_FUSED_PREFIX_MASK"); return e ? (uint32_t)atoi(e) : 3u; }();   // diagnostic
     if (!s.any_multi) s.fused_prefix = ((s.nwaves <= kFusedPrefixRuns ? 1u : 0u) | (s.fftiles <= kFusedPrefixTiles ? 2u : 0u)) & allow;
     return s;
 }

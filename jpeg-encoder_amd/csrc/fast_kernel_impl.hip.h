@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "diag_env.h"
 #include "fdct_quant.hip.h"
 #include "host_common.h"
 #include "wave_tasks.hip.h"
@@ -635,7 +636,7 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
     BlockKernelParams q = p;
     if (!fill_fast_params(q, k, BPP, SX, SY, CONV, planes, planes_subsampled)) return hipErrorInvalidValue;      // launch_blocks_fast checked the preconditions
 #ifdef JPEGENC_PERSISTENT
-    static const unsigned resident = [] { const char *e = getenv("JPEGENC_PERSISTENT_WGS"); return e ? (unsigned)atoi(e) : 768u; }();
+    static const unsigned resident = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_PERSISTENT_WGS"); return e ? (unsigned)atoi(e) : 768u; }();
     const unsigned items = q.groups * (unsigned)num_frames;
     const dim3 grid(items < resident ? items : resident, 1), block(q.per_group * 64u);
     q.persistent_frames = (uint32_t)num_frames;
@@ -647,7 +648,7 @@ static hipError_t launch_fast(const BlockKernelParams &p, const ColourConsts &k,
     q.timing = wave_timing_buffer();
 #endif
     // diagnostic: extra dynamic LDS per workgroup lowers the number of resident workgroups per CU
-    static const char *pad_env = getenv("JPEGENC_LDS_PAD_KB");
+    static const char *pad_env = JPEGENC_DIAG_ENV("JPEGENC_LDS_PAD_KB");
     if (pad_env) lds += (size_t)atoi(pad_env) * 1024u;
     if (variant == 1) hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 1, CONV, PLANES>), grid, block, lds, stream, q, k);
     else hipLaunchKernelGGL((k_blocks_fast<BPP, SX, SY, 0, CONV, PLANES>), grid, block, lds, stream, q, k);

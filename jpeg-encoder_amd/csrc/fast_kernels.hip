@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "diag_env.h"
 #include "fast_kernel_impl.hip.h"
 
 namespace jpegenc {
@@ -90,7 +91,7 @@ hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_pla
                                 hipStream_t stream) {
     {   // sampling factors 1 and 2: ONE launch, every wave on its own plane (fast_kernels_planes.hip)
         hipError_t once = hipSuccess;
-        static const bool per_plane = getenv("JPEGENC_PLANES_PER_PLANE_LAUNCHES") != nullptr;      // diagnostic / tests: the older path
+        static const bool per_plane = JPEGENC_DIAG_ENV("JPEGENC_PLANES_PER_PLANE_LAUNCHES") != nullptr;      // diagnostic / tests: the older path
         if (!per_plane && launch_blocks_planes_once(base, planes, planes_subsampled, 1, variant, stream, &once)) return once;
     }
     for (int c = 0; c < base.ncomp; c++) {

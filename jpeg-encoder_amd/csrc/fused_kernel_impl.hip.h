@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "diag_env.h"
 #include "entropy_loop.hip.h"
 #include "fast_kernel_impl.hip.h"
 
@@ -227,7 +228,7 @@ static hipError_t launch_group_t(const BlockKernelParams &b, const ColourConsts 
     if (!fill_fast_params(q, k, BPP, SX, SY, CONV, planes, planes_subsampled) || q.fast_hdr.group_mcus != 64u || q.per_group != q.bpm) return hipErrorInvalidValue;
     const dim3 grid(q.groups, (unsigned)frames), block(q.per_group * 64u);
     size_t lds = group_lds_bytes(q.bpm);
-    static const char *pad_env = getenv("JPEGENC_GROUP_LDS_PAD_KB");               // diagnostic: fewer resident workgroups per CU
+    static const char *pad_env = JPEGENC_DIAG_ENV("JPEGENC_GROUP_LDS_PAD_KB");               // diagnostic: fewer resident workgroups per CU
     if (pad_env) lds += (size_t)atoi(pad_env) * 1024u;
     // (more than 64 KiB of dynamic LDS per workgroup has to be allowed once per kernel and device)
     static thread_local int allowed_device[2] = {-1, -1};

@@ -23,6 +23,7 @@
 //     in the group's zeroed window, which goes to the group's slot with coalesced stores.
 // Three barriers per workgroup.  Runs are 64 * bpm blocks long (EntropyParams::run_blocks); k_push / k_place / k_stuff
 // take them as they take k_block_code's (and k_push likes them better: a third of the time for a sixth of the runs).
+#include "diag_env.h"
 #include "fused_kernel_impl.hip.h"
 
 namespace jpegenc {
@@ -48,7 +49,7 @@ bool fused_supported(const BlockKernelParams &b) {
 // k_block_code).  Measured on 4K 4:2:0 frames (profiles/README.md, r02): the workgroup-per-run form is byte-identical
 // and faster on every content - 19.3 vs 21.8 us per photo-like frame, 16.9 vs 19.6 smooth, 31.3 vs 33.3 noise.
 bool fused_enabled() {
-    static const bool on = [] { const char *e = getenv("JPEGENC_FUSED"); return !e || atoi(e) != 0; }();
+    static const bool on = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_FUSED"); return !e || atoi(e) != 0; }();
     return on;
 }
 

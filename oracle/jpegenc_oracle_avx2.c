@@ -70,6 +70,13 @@ AVX2 static void convert_row(const uint8_t *px, int width, int bpp, int ir, int 
     }
 }
 
+/* one RGB row through the 8-pixel conversion above (criterion_micro.c: the reference's "ycbcr avx2" workload); -1 without AVX2 */
+int orc_avx2_convert_rgb_row(const uint8_t *px, int width, uint8_t *y, uint8_t *cb, uint8_t *cr) {
+    if (!__builtin_cpu_supports("avx2")) return -1;
+    convert_row(px, width, 3, 0, 1, 2, y, cb, cr);
+    return 0;
+}
+
 /* ---- 8x8 forward DCT, eight 1-D transforms per pass in 16-bit lanes (fdct.rs:107-238) ------------------ */
 AVX2 static inline void transpose8(__m128i r[8]) {
     const __m128i a0 = _mm_unpacklo_epi16(r[0], r[1]), a1 = _mm_unpackhi_epi16(r[0], r[1]);

@@ -46,11 +46,12 @@ def build(force=False, extra_cflags=None, out_path=None):
     src = os.path.join(_HERE, "jpegenc_oracle.c")
     src_avx2 = os.path.join(_HERE, "jpegenc_oracle_avx2.c")
     src_hw = os.path.join(_HERE, "fdct_avx2_hw.c")
-    deps = [src, src_avx2, src_hw, os.path.join(_HERE, "jpegenc_oracle.h"), os.path.join(_HERE, "orc_tables.h")]
+    src_micro = os.path.join(_HERE, "criterion_micro.c")
+    deps = [src, src_avx2, src_hw, src_micro, os.path.join(_HERE, "jpegenc_oracle.h"), os.path.join(_HERE, "orc_tables.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     flags = extra_cflags or ["-mavx2"]
-    subprocess.check_call(["gcc", "-O3", "-fPIC", "-std=gnu11", *flags, "-shared", "-o", out, src, src_avx2, src_hw])
+    subprocess.check_call(["gcc", "-O3", "-fPIC", "-std=gnu11", *flags, "-shared", "-o", out, src, src_avx2, src_hw, src_micro])
     return out
 
 
@@ -77,6 +78,10 @@ def _bind(l):
     l.orc_fdct_avx2_hw_many.argtypes = [C.c_void_p, C.c_long]
     l.orc_fdct_avx2_hw_compare.argtypes = [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_long)]
     l.orc_fdct_avx2_hw_compare.restype = C.c_long
+    l.orc_bench_fdct_ns.argtypes = [C.c_int, C.c_double]
+    l.orc_bench_fdct_ns.restype = C.c_double
+    l.orc_bench_ycbcr_ms.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int]
+    l.orc_bench_ycbcr_ms.restype = C.c_double
     l.orc_qtable_init.argtypes = [C.POINTER(QTable), C.c_int, C.POINTER(C.c_uint16), C.c_int, C.c_int]
     l.orc_quantize.argtypes = [C.POINTER(QTable), C.c_int16, C.c_int]
     l.orc_quantize.restype = C.c_int16

@@ -483,3 +483,23 @@ def test_which_layouts_take_the_one_kernel_path(binding):
         assert not b.pixels_scan_fused(640, 360, ct, hs, vs), (ct, hs, vs)
     # (the device coder's 32-bit bit offsets end at about 2.45 M blocks: 96 Mpixel 4:2:0 frames pass, 128 Mpixel ones do not)
     assert b.pixels_scan_fused(12000, 8000, b.RGB, 2, 2) and not b.pixels_scan_fused(16000, 8000, b.RGB, 2, 2)
+
+
+def test_shipping_library_reads_no_diagnostic_switches(pkg):
+    """The shipping library's behaviour must not depend on the caller's environment: the diagnostic switches
+    (JPEGENC_FUSED, JPEGENC_PACK_WINDOW_WORDS, ... - INTEGRATION.md section 6) are compiled into the -DJPEGENC_DIAG build
+    only (csrc/diag_env.h).  What is left in libjpegenc_mi355x.so: JPEGENC_TRACE and JPEGENC_NUMA_BIND."""
+    import importlib
+    import re
+    b = importlib.import_module("jpeg_encoder_amd.binding")
+    default = os.path.join(os.path.dirname(b.DIAG_LIB_PATH), "libjpegenc_mi355x.so")
+    names = lambda path: set(m.decode() for m in re.findall(rb"JPEGENC_[A-Z0-9_]{3,}", open(path, "rb").read()))
+    assert names(default) <= {"JPEGENC_TRACE", "JPEGENC_NUMA_BIND"}, sorted(names(default))
+    assert os.path.exists(b.DIAG_LIB_PATH), "build.sh builds the diagnostic library beside the shipping one"
+    diag = names(b.DIAG_LIB_PATH)
+    assert {"JPEGENC_FUSED", "JPEGENC_PACK_WINDOW_WORDS", "JPEGENC_SCANS_ONE_BY_ONE", "JPEGENC_TRACE"} <= diag
+    # same exported entry points
+    import subprocess
+    syms = lambda path: set(l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", path], text=True).splitlines()
+                            if " T " in l and "jpegenc_" in l)
+    assert syms(default) == syms(b.DIAG_LIB_PATH)

@@ -120,6 +120,47 @@ def test_encode_batch_multi_shards(binding, c3, devices):
         assert f == pyoracle.encode_jpeg(px, 200, 120, pyoracle.RGB, batch.C3_QUALITY, progressive_scans=4, optimize=True)
 
 
+def test_encode_batch_multi_on_distinct_devices(binding, c3):
+    """One process driving SEVERAL GPUs (skipped on the one-GPU boxes): every device of the node gets its own child encoder,
+    worker set, streams, pinned staging and default code tables (jpegenc_encoder_encode_batch_multi, host_encoder.cpp) - the
+    125-frame shard size of config 3 per device, the files compared with the oracle's, twice (the second pass replays the
+    captured launch sequences of every device), then with the worker threads bound to each device's NUMA node."""
+    n_dev = min(binding.device_count(), 8)
+    if n_dev < 2:
+        pytest.skip("needs at least two GPUs in one process")
+    batch, pool, want = c3
+    devices = list(range(n_dev))
+    frames = [pool(k) for k in range(125 * n_dev if n_dev <= 2 else 64 * n_dev)]
+    with binding.Encoder(batch.C3_QUALITY) as enc:
+        for bind in (False, False, True):
+            enc.set_numa_bind(bind)
+            files = enc.encode_batch_multi_to_buffers(devices, frames, batch.C3_W, batch.C3_H, binding.RGB, 2 << 20)
+            assert [f == want[k % batch.POOL] for k, f in enumerate(files)] == [True] * len(frames)
+        # a device list in another order, and with a device twice: frame k -> devices[k % n] whatever the list says
+        for devs in (devices[::-1], devices + devices[:1]):
+            files = enc.encode_batch_multi_to_buffers(devs, frames[:37], batch.C3_W, batch.C3_H, binding.RGB, 2 << 20)
+            assert [f == want[k % batch.POOL] for k, f in enumerate(files)] == [True] * 37
+    # every device on its own, from its own handle and thread, at the same time (the one-process-per-GPU shape inside one process)
+    import threading
+    errors = []
+
+    def one(dev):
+        try:
+            with binding.Encoder(batch.C3_QUALITY, device=dev) as e:
+                outs = [np.empty(2 << 20, dtype=np.uint8) for _ in range(32)]
+                lens = e.encode_batch_into(frames[:32], batch.C3_W, batch.C3_H, binding.RGB, outs)
+                for i in range(32):
+                    assert outs[i][:lens[i]].tobytes() == want[i % batch.POOL], (dev, i)
+        except Exception as exc:                                       # noqa: BLE001 - reported below
+            errors.append((dev, repr(exc)))
+    threads = [threading.Thread(target=one, args=(d,)) for d in devices]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_encode_batch_multi_sink_and_errors(binding, c3, synth):
     import ctypes as C
     batch, pool, want = c3
@@ -266,7 +307,7 @@ def test_encoder_with_and_without_the_fused_kernel(binding, tmp_path, env):
             assert e.encode_batch([px] * 5, w, h, ct) == [want] * 5
         print("FUSED-OK")
     """))
-    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, JPEGENC_LIB=binding.DIAG_LIB_PATH, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FUSED-OK" in r.stdout, r.stderr[-3000:]
 
 
@@ -362,7 +403,7 @@ def test_planes_per_plane_launch_path_still_matches(binding):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, JPEGENC_PLANES_PER_PLANE_LAUNCHES="1", JPEGENC_FUSED="0")
+    env = dict(os.environ, JPEGENC_PLANES_PER_PLANE_LAUNCHES="1", JPEGENC_FUSED="0", JPEGENC_LIB=binding.DIAG_LIB_PATH)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "encode_planes_device"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

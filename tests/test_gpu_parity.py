@@ -801,14 +801,10 @@ def test_encode_batch_device_resident(binding, oracle, synth, kw):
     buf = torch.zeros(n * stride, dtype=torch.uint8, device="cuda:0")
     for i in range(n):
         buf[i * stride:i * stride + w * h * 3] = torch.from_numpy(frames[i].reshape(-1).copy()).to("cuda:0")
-    import os
-    for on, round_frames in ((True, "64"), (True, None), (False, None)):     # 64: the batch takes two rounds
-        if round_frames:
-            os.environ["JPEGENC_BATCH_ROUND_FRAMES"] = round_frames
-        try:
-            got = _encoder(binding, kw, on).encode_batch_device(buf.data_ptr(), stride, n, w, h, binding.RGB)
-        finally:
-            os.environ.pop("JPEGENC_BATCH_ROUND_FRAMES", None)
+    for on, round_frames in ((True, 64), (True, 0), (False, 0)):             # 64: the batch takes two rounds
+        enc = _encoder(binding, kw, on)
+        enc.set_batch_round_frames(round_frames)
+        got = enc.encode_batch_device(buf.data_ptr(), stride, n, w, h, binding.RGB)
         assert len(got) == n
         for i in (0, 1, 2, 33, 63, 64, 69):
             assert got[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, **kw), (i, on)
@@ -906,13 +902,10 @@ def test_device_batch_sink_failure_in_a_later_round(binding, oracle, synth):
     users = (C.c_void_p * n)(*range(n))
     fn = binding.lib().jpegenc_encoder_encode_batch_device
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, binding.WRITE_FN, C.POINTER(C.c_void_p)]
-    os.environ["JPEGENC_BATCH_ROUND_FRAMES"] = "8"
-    try:
-        rc = fn(e._h, d.data_ptr(), w * h * 3, n, w, h, binding.RGB, cb, users)
-        assert rc == binding.ERR_WRITE and 19 in seen
-        got = e.encode_batch_device(d.data_ptr(), w * h * 3, n, w, h, binding.RGB)          # five rounds, all fine now
-    finally:
-        del os.environ["JPEGENC_BATCH_ROUND_FRAMES"]
+    e.set_batch_round_frames(8)
+    rc = fn(e._h, d.data_ptr(), w * h * 3, n, w, h, binding.RGB, cb, users)
+    assert rc == binding.ERR_WRITE and 19 in seen
+    got = e.encode_batch_device(d.data_ptr(), w * h * 3, n, w, h, binding.RGB)          # five rounds, all fine now
     for i in (0, 7, 8, 19, 39):
         assert got[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, 85), i
 
@@ -972,7 +965,7 @@ def test_device_entropy_pack_window_overflow_path(binding, oracle, synth):
         "    assert e.encode(px, w, h, b.RGB) == o.encode_jpeg(px, w, h, o.RGB, **kw), kw\n"
         "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for words in ("0", "16"):
-        env = dict(os.environ, JPEGENC_PACK_WINDOW_WORDS=words)
+        env = dict(os.environ, JPEGENC_PACK_WINDOW_WORDS=words, JPEGENC_LIB=binding.DIAG_LIB_PATH)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
@@ -1048,10 +1041,10 @@ def test_scans_coded_together_and_one_by_one_agree(binding, oracle, synth):
         "    if kw.get('optimize'): e.set_optimized_huffman_tables(True)\n"
         "    assert e.encode(px, w, h, b.RGB) == o.encode_jpeg(px, w, h, o.RGB, **kw), kw\n"
         "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cases)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JPEGENC_SCANS_ONE_BY_ONE="1"), capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JPEGENC_SCANS_ONE_BY_ONE="1", JPEGENC_LIB=binding.DIAG_LIB_PATH), capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
     # the three-kernel form of the prefix sums (real scans need it only beyond 8.4 M elements)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JPEGENC_SCAN_FUSED_MAX_TILES="0"), capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JPEGENC_SCAN_FUSED_MAX_TILES="0", JPEGENC_LIB=binding.DIAG_LIB_PATH), capture_output=True, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
