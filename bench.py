@@ -635,6 +635,16 @@ def main():
                                     "roofline": pcie_roofline("pcie_h2d", n * frame_bytes, dt, link)}
         try:
             result["criterion_workloads"], criterion_files = criterion_workloads(binding, synth, local_rank)
+            # each call moves 10.8 MB of pixels up and the file down, one after the other (a scan can only come back once the
+            # whole frame is coded): the floor is the SUM of the two copies at this box's link rates
+            if link and link.get("h2d") and link.get("d2h"):
+                for name, rec in result["criterion_workloads"].items():
+                    if isinstance(rec, dict) and "jpeg_bytes" in rec:
+                        up, down = 2000 * 1800 * 3, rec["jpeg_bytes"]
+                        floor_ms = (up / link["h2d"] + down / link["d2h"]) / 1e6
+                        rec["roofline"] = {"bound": "pcie_serial", "achieved": round((up + down) / rec["gpu_ms"] / 1e6, 1), "unit": "GB/s",
+                                           "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / rec["gpu_ms"], 4),
+                                           "peak_source": "h2d + d2h of this run's link_rates, one after the other"}
         except Exception as exc:                                   # side figure only
             result["criterion_workloads"] = {"error": str(exc)}
     # ---- BASELINE config 3 on every rank: the frame-sharded 1000-frame batch, pageable host pixels -> JPEG files in

@@ -358,7 +358,9 @@ int  jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jpeg_color_typ
  * f -> sink(users[f], ...), one complete file each (sink threading: see jpegenc_encoder_encode_batch).  The device
  * work of the whole batch shares its launches as in jpegenc_encoder_encode_batch_device when the descriptors of each
  * component agree in pixel_stride and invert over the frames (address and pitch are per frame); otherwise - and with optimised Huffman tables, the
- * host entropy coder or sampling factors of 4 - the frames are encoded one at a time.  Same bytes either way. */
+ * host entropy coder or sampling factors of 4 - the frames are encoded ONE AT A TIME on the handle's own stream, strictly in
+ * sequence (no worker pool as for pixel frames: expect ~280 us per 4K frame instead of ~30; a sink error returns with the
+ * earlier frames already delivered).  Same bytes either way. */
 int  jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
                                                 const jpegenc_plane *planes, int num_frames, int planes_subsampled,
                                                 jpegenc_write_fn sink, void *const *users);

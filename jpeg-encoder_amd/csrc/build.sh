@@ -9,7 +9,7 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-const-variable -Wno-unused-function
        -I"${here}/../../include")
-srcs=("${here}"/block_kernels.hip "${here}"/fast_kernels.hip "${here}"/fast_kernels_bytes.hip "${here}"/fast_kernels_s4.hip "${here}"/fast_kernels_bytes_s4.hip "${here}"/fused_kernels.hip "${here}"/fused_kernels_bytes.hip "${here}"/fast_kernels_planes.hip "${here}"/entropy_kernels.hip "${here}"/capi_entropy.hip "${here}"/capi_blocks.cpp "${here}"/host_encoder.cpp)
+srcs=("${here}"/block_kernels.hip "${here}"/fast_kernels.hip "${here}"/fast_kernels_bytes.hip "${here}"/fast_kernels_s4.hip "${here}"/fast_kernels_bytes_s4.hip "${here}"/fused_kernels.hip "${here}"/fused_kernels_bytes.hip "${here}"/fast_kernels_planes.hip "${here}"/entropy_kernels.hip "${here}"/capi_entropy.hip "${here}"/capi_blocks.cpp "${here}"/host_encoder.cpp "${here}"/host_emit.cpp "${here}"/host_frame.cpp "${here}"/host_batch.cpp "${here}"/host_multi.cpp)
 
 # build_variant <output .so> <object directory> [extra flags ...]
 build_variant() {
@@ -19,7 +19,9 @@ build_variant() {
   for s in "${srcs[@]}"; do
     o="${bdir}/$(basename "${s}").o"
     if [[ ! -f "${o}" || "${s}" -nt "${o}" || "${BASH_SOURCE[0]}" -nt "${o}" || -n "$(find "${here}" -maxdepth 1 \( -name '*.h' -o -name '*.inc' \) -newer "${o}" -print -quit)" || "${here}/../../include/jpegenc_mi355x.h" -nt "${o}" ]]; then
-      "${HIPCC}" "${FLAGS[@]}" "$@" -x hip -c "${s}" -o "${o}" ${EXTRA_HIPCC_FLAGS:-} &
+      # (the resource usage of every kernel goes to ${o}.resources: tools/check_spills.py reads it below)
+      ( "${HIPCC}" "${FLAGS[@]}" "$@" -Rpass-analysis=kernel-resource-usage -x hip -c "${s}" -o "${o}" ${EXTRA_HIPCC_FLAGS:-} 2> "${o}.resources" \
+          || { grep -v "remark:" "${o}.resources" >&2; rm -f "${o}"; exit 1; } ) &
       pids+=($!)
     fi
     objs+=("${o}")
@@ -27,6 +29,9 @@ build_variant() {
   for pid in "${pids[@]:-}"; do
     if [[ -n "${pid}" ]]; then wait "${pid}"; fi
   done
+  # warnings of the compiles just run, then the spill guard over every translation unit's kernels
+  for o in "${objs[@]}"; do if [[ -f "${o}.resources" ]]; then grep -E "warning:|error:" "${o}.resources" >&2 || true; fi; done
+  python3 "${here}/../../tools/check_spills.py" "${bdir}"/*.resources
   "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${out}" "${objs[@]}" -lpthread
   echo "built ${out}"
 }

@@ -150,7 +150,8 @@ int upload_huffman_luts(const jpegenc_huffman_spec (*tables)[2], void *d_lut, hi
 // The code tables of the Annex K.3 default Huffman tables (tables == NULL in the C ABI) on the current device: 4 KB, built by
 // the first call that needs them (which waits for the build once - later calls may come on any stream) and kept for the
 // life of the process.  A call with default tables otherwise spends a 6 us launch on them every time.
-static const uint32_t *default_luts(hipStream_t st) {
+static const uint32_t *default_luts(hipStream_t st, int *status) {      // *status: why nullptr came back
+    *status = JPEGENC_ERR_HIP;
     static std::mutex mu;
     static uint32_t *per_device[64] = {};
     int dev = -1;
@@ -159,7 +160,7 @@ static const uint32_t *default_luts(hipStream_t st) {
     if (!per_device[dev]) {
         hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
         if (st && hipStreamIsCapturing(st, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
-            (void)fail(JPEGENC_ERR_INVALID_ARGUMENT, "the first call with default Huffman tables on a device cannot be stream-captured");
+            *status = fail(JPEGENC_ERR_INVALID_ARGUMENT, "the first call with default Huffman tables on a device cannot be stream-captured");
             return nullptr;
         }
         uint32_t *lut = nullptr;
@@ -260,8 +261,9 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
     if (d_lut) {
         p.lut = (const uint32_t *)d_lut;
     } else if (!tables) {                                      // Encoder::new's defaults: built once per device, not once per call
-        const uint32_t *lut = default_luts(st);
-        if (!lut) return JPEGENC_ERR_HIP;
+        int why = JPEGENC_ERR_HIP;
+        const uint32_t *lut = default_luts(st, &why);
+        if (!lut) return why;                                  // (the status that goes with jpegenc_last_error())
         p.lut = lut;
     } else {
         int rc = upload_huffman_luts(tables, ws + pl.off_lut, st);

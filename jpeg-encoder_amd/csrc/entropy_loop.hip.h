@@ -135,7 +135,7 @@ __device__ __forceinline__ int coefficient_at(uint32_t image_at, uint32_t k) {
 // One non-zero coefficient: v at position k (of the current half of the mask).  Order inside a trip: this symbol's table
 // entry is requested as soon as its size is known, then the PREVIOUS symbol goes to the sink (its entry was requested a
 // whole trip ago), then the zero-run symbols of this one.
-template <class Sink>
+template <bool ZRL, class Sink>
 __device__ __forceinline__ void walk_trip(uint32_t k, int v, uint32_t &after, u32x2 put_entry, uint32_t put_mag, u32x2 &new_entry, uint32_t &new_mag,
                                           uint32_t rows, u32x2 zrl, Sink &s) {
     typedef const __attribute__((address_space(3))) u32x2 *lut_ptr;
@@ -143,11 +143,27 @@ __device__ __forceinline__ void walk_trip(uint32_t k, int v, uint32_t &after, u3
     after = k + 1u;
     const int t = v + (v >> 31);
     const uint32_t sb = sign_bits(t);                                             // 32 - size category (v != 0: t is neither 0 nor -1)
-    new_entry = *(lut_ptr)(uintptr_t)(rows + ((run & 15u) << 7) + (sb << 3));
+    new_entry = *(lut_ptr)(uintptr_t)(rows + ((ZRL ? run & 15u : run) << 7) + (sb << 3));
     new_mag = __builtin_amdgcn_ubfe((uint32_t)t, 0u, 32u - sb);
     __builtin_amdgcn_sched_barrier(0);       // (left alone the scheduler hoists the first use of put_entry - and the wait for it - to the top of the trip)
     s.put(put_entry.x | put_mag, put_entry.y);
-    while (run >= 16u) { s.put(zrl.x, zrl.y); run -= 16u; }
+    if (ZRL) {
+        while (run >= 16u) { s.put(zrl.x, zrl.y); run -= 16u; }
+    }
+}
+
+// Whether the block has a run of 16 or more zeros in front of a non-zero coefficient of the band that starts at position
+// `first` (a ZRL symbol, writer.rs:371-376): some set bit k of the mask with no set bit among the 16 below it, the position
+// before the band counting as set.  A wave none of whose blocks has one walks without the zero-run test (three instructions
+// of every trip); dense content never has one, and neither have blocks whose non-zeros end below position 17.
+__device__ __forceinline__ bool has_long_zero_run(uint64_t mask, uint32_t first) {
+    const uint64_t m = mask | (1ull << (first - 1u));
+    uint64_t below = m << 1;                        // bit k: some set bit among the 1, 2, 4, 8, 16 positions below k
+    below |= below << 1;
+    below |= below << 2;
+    below |= below << 4;
+    below |= below << 8;
+    return (mask & ~below) != 0;
 }
 
 // AC symbols of the band [first, end) of the lane's block (write_ac_block, writer.rs:356-388): mask = its non-zero
@@ -155,8 +171,8 @@ __device__ __forceinline__ void walk_trip(uint32_t k, int v, uint32_t &after, u3
 // symbol, neither waited for where it is issued: the coefficient of the NEXT non-zero is requested while this one is
 // coded, and the table entry of a symbol is consumed in the next trip.  Two trips per iteration, so that the values in
 // flight alternate between two sets of registers instead of being copied.
-template <class Sink>
-__device__ __forceinline__ void walk_nonzeros(uint64_t mask, uint32_t first, uint32_t end, uint32_t image_at, uint32_t ac_table, Sink &s) {
+template <bool ZRL, class Sink>
+__device__ __forceinline__ void walk_nonzeros_t(uint64_t mask, uint32_t first, uint32_t end, uint32_t image_at, uint32_t ac_table, Sink &s) {
     typedef const __attribute__((address_space(3))) u32x2 *lut_ptr;
     const u32x2 zrl = *(lut_ptr)(uintptr_t)(ac_table + loop_lut_slot(0xF0u) * 8u), eob = *(lut_ptr)(uintptr_t)(ac_table + loop_lut_slot(0u) * 8u);
     const uint32_t rows = ac_table - 16u * 8u;     // entry of (run, size n) = rows + run * 128 + (32 - n) * 8; 32 - n = 22 .. 31 is what v_ffbh_i32 returns
@@ -176,16 +192,23 @@ __device__ __forceinline__ void walk_nonzeros(uint64_t mask, uint32_t first, uin
             m &= m - 1u;
             kb = lowest_bit(m);
             vb = coefficient_at(column, kb);
-            walk_trip(ka, va, after, pend, pend_mag, other, other_mag, rows, zrl, s);
+            walk_trip<ZRL>(ka, va, after, pend, pend_mag, other, other_mag, rows, zrl, s);
             if (!m) { pend = other; pend_mag = other_mag; break; }
             m &= m - 1u;
             ka = lowest_bit(m);
             va = coefficient_at(column, ka);
-            walk_trip(kb, vb, after, other, other_mag, pend, pend_mag, rows, zrl, s);
+            walk_trip<ZRL>(kb, vb, after, other, other_mag, pend, pend_mag, rows, zrl, s);
         }
     }
     s.put(pend.x | pend_mag, pend.y);
     if (after != end - 32u) s.put(eob.x, eob.y);
+}
+
+// zero_runs: whether ANY block of the wave has a run of 16 zeros (wave-uniform: has_long_zero_run over the wave)
+template <class Sink>
+__device__ __forceinline__ void walk_nonzeros(uint64_t mask, uint32_t first, uint32_t end, uint32_t image_at, uint32_t ac_table, Sink &s, bool zero_runs = true) {
+    if (zero_runs) walk_nonzeros_t<true>(mask, first, end, image_at, ac_table, s);
+    else walk_nonzeros_t<false>(mask, first, end, image_at, ac_table, s);
 }
 
 // After the prefix sum: a strip whose block begins at strip bit `from` (its bits [from, from + nbits)) goes to bit offset

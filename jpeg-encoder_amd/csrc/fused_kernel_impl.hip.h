@@ -52,7 +52,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     int16_t *dcs = reinterpret_cast<int16_t *>(lens + bpm * 64u);
     uint32_t *flags = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);              // [0]: a block outgrew its strip, [1]: bits of the run (only summed for a lowered window)
     const uint32_t tid = threadIdx.x, grp = blockIdx.x, f = blockIdx.y;
-    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- (0) the code tables (k_build_lut leaves them in LDS form behind the first one: 544 entries of 8 bytes over 192 ... 384
     // threads), zeroed strips ---------------------------------------------------------------------------------------------
@@ -89,11 +89,14 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         BlockRegs r;
         const bool active = block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, f, w, r.c);
         mine_valid = active && w.inside;
-        stage_block(r.c, image, lane);
+        stage_block(r.c, image, w.lane);
         mask = mine_valid ? nonzero_mask(r.c) : 0ull;
         my_dc = mine_valid ? (int)(int16_t)(r.c[0] & 0xFFFFu) : 0;
     }
     const u32x16 Wv = w.Wv;
+    // (the lane number is taken afresh here - two v_mbcnt - so that nothing of the workgroup's bookkeeping has to stay in a
+    // register across block_compute: the byte-plane instantiations with decimation sat at the 96-register budget and spilled)
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t mcu_local = Wv[1] + (lane >> w.lg);                          // MCU of the group; (w.lg etc. are set for padding waves too)
     const uint32_t pos = Wv[7] + (lane & ((1u << w.lg) - 1u));                  // block position inside the MCU (FastWave::out_base of MCU order)
     const uint32_t s = mcu_local * bpm + pos;                                   // the block's place in the run (scan order)
@@ -131,9 +134,10 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     const uint32_t image_at = (uint32_t)(uintptr_t)(lds_bytes)(smem) + bpm * kGPriv * 256u + kGSpillBytes + wave_id * kGImageWords * 4u + lane * 4u;
     lds_word *strip = (lds_word *)(strips + wave_id * kGPriv * 64u) + lane;
     uint32_t ac_bits = 0;
+    const bool zero_runs = __builtin_amdgcn_ballot_w64(has_long_zero_run(mask, 1u)) != 0;     // wave-uniform
     if (mine_valid) {
         StripOr so = {(uint32_t)(uintptr_t)strip, 32u * 8u};
-        walk_nonzeros(mask, 1u, 64u, image_at, ac_table, so);
+        walk_nonzeros(mask, 1u, 64u, image_at, ac_table, so, zero_runs);
         ac_bits = so.bits() - 32u;
     }
     if (ac_bits > (kGPriv - 1u) * 32u) __hip_atomic_fetch_or((lds_word *)flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -180,12 +184,26 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     __syncthreads();                                                             // (2) lengths posted, window zeroed
 
     // ---- bit offset of every block in the run: each wave adds up the MCUs itself (lane = MCU) ----------------------------
-    uint32_t mcu_bits = 0;
-    for (uint32_t j = 0; j < bpm; j++) mcu_bits += lens[lane * bpm + j];
+    // (fixed trip counts - fused_supported admits at most 6 blocks per MCU - so that the twelve LDS reads are issued together and
+    // waited for once: with `bpm` as the bound each read was its own round trip.  The reads past an MCU's blocks stay inside
+    // the lengths / DC arrays and are discarded.)
+    uint32_t mcu_bits = 0, at = 0;
+    {
+        uint32_t mine_of[6], before[6];
+#pragma unroll
+        for (uint32_t j = 0; j < 6u; j++) {
+            mine_of[j] = lens[lane * bpm + j];
+            before[j] = lens[(mcu_local & 63u) * bpm + j];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 6u; j++) {
+            mcu_bits += j < bpm ? mine_of[j] : 0u;
+            at += j < pos ? before[j] : 0u;
+        }
+    }
     const uint32_t upto = wave_inclusive_dpp(mcu_bits);
     const uint32_t total = (uint32_t)__shfl((int)upto, 63);
-    uint32_t at = (uint32_t)__shfl((int)(upto - mcu_bits), (int)(mcu_local & 63u));
-    for (uint32_t j = 0; j < bpm; j++) { const uint32_t v = lens[(mcu_local & 63u) * bpm + j]; if (j < pos) at += v; }
+    at += (uint32_t)__shfl((int)(upto - mcu_bits), (int)(mcu_local & 63u));
     if (tid == 0) p.wsum[(size_t)f * p.nwaves + grp] = total;
     if (p.nintervals > 1u && mine_valid) p.bits[(size_t)f * p.nblocks + (size_t)group_first * bpm + s] = at;   // (interval offsets need them, k_interval_len)
     const uint32_t nwords = (total + 31u) >> 5;

@@ -1,0 +1,599 @@
+// host_frame.cpp — one frame on the device: FrameRun (plan, launch sequence, hipGraph capture / replay, download, emission) and
+// the upload of host pixels in front of it.  Mirrors encode_image_internal (encoder.rs:517-567) with every pixel -> bits step
+// in the HIP kernels.
+#include "host_internal.h"
+
+namespace jpegenc {
+
+// The staging copy of a frame (the caller's pageable pixels -> a worker's pinned buffer) with streaming stores: the
+// destination is only ever read by the DMA engine, so it should neither be fetched (a cached store first reads the
+// line it overwrites) nor pushed through the worker's cache.  Per frame byte the host memory then moves read + write +
+// DMA read = 3 instead of 4 - what matters when eight ranks stage 50 GB/s each through the two sockets' DRAM
+// (the host side is the limiter of the 8-GPU batch).  JPEGENC_PLAIN_STAGING_COPY=1 = memcpy.
+__attribute__((target("avx2"))) static void stream_copy_avx2(uint8_t *dst, const uint8_t *src, size_t n) {
+    size_t head = (size_t)(-(uintptr_t)dst & 31u);
+    if (head > n) head = n;
+    if (head) { memcpy(dst, src, head); dst += head; src += head; n -= head; }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(src + i)), b = _mm256_loadu_si256((const __m256i *)(src + i + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i *)(src + i + 64)), d = _mm256_loadu_si256((const __m256i *)(src + i + 96));
+        _mm256_stream_si256((__m256i *)(dst + i), a); _mm256_stream_si256((__m256i *)(dst + i + 32), b);
+        _mm256_stream_si256((__m256i *)(dst + i + 64), c); _mm256_stream_si256((__m256i *)(dst + i + 96), d);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+void staging_copy(void *dst, const void *src, size_t n) {
+    static const bool streaming = [] { return !JPEGENC_DIAG_ENV("JPEGENC_PLAIN_STAGING_COPY") && __builtin_cpu_supports("avx2"); }();
+    if (streaming && n >= ((size_t)256 << 10)) stream_copy_avx2((uint8_t *)dst, (const uint8_t *)src, n);
+    else memcpy(dst, src, n);
+}
+
+
+// The whole of encode_image_internal for one frame, as the steps encode_frame walks through: what the frame needs
+// (prepare, plan_scans: tables, geometry, the scans the device coder will produce and their buffers), how its launch
+// sequence runs (choose_replay: launch by launch, captured into a hipGraph, or replayed), the launches themselves
+// (begin_sequence, enqueue_blocks_and_statistics, enqueue_scans, launch_and_wait) and what comes back
+// (emit_device_coded: compressed bytes; collect_host_coded: coefficients for the host coder).
+struct FrameRun {
+    struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap, ws_off, ws; };
+    enum How { DIRECT, CAPTURE, REPLAY };
+    struct CaptureGuard {            // a failure between begin and end must not leave the stream capturing
+        hipStream_t st = nullptr; bool active = false;
+        ~CaptureGuard() { if (active) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); } }
+    };
+    typedef std::chrono::steady_clock::time_point time_point;
+
+    const Config &c;
+    DeviceCtx &ctx;
+    const int jct, width, height, color_type_or_planes;
+    const size_t pixel_bytes;
+    const jpegenc_write_fn sink;
+    void *const user;
+
+    Tables t;
+    Mode mode = MODE_INTERLEAVED;
+    int order = JPEGENC_ORDER_MCU;
+    jpegenc_layout L;
+    size_t coeff_bytes = 0;
+    BlockKernelParams p;
+    bool optimize = false;
+    FusedSource fused_src = {};
+    bool fused = false;                 // interleaved baseline scan of an RGB-family image: ONE kernel from the pixels to the coded runs
+    std::vector<Job> jobs;
+    bool supported = false;
+    void *gather = nullptr;             // where a single scan is coded to / several are gathered: [lengths][bytes] in device memory, or in pinned host memory (small frames)
+    size_t first_piece = 0;             // coded bytes fetched in the same copy as the scan lengths
+    bool together = false;              // the frame's scans share launches (scan_device_multi), each with its own workspace
+    bool host_gather = false;
+    How how = DIRECT;
+    CaptureGuard capture_guard;
+    bool enqueue = true;
+    bool hist_folded = false;           // the tuned block kernel counted the symbols itself
+    size_t nbytes = 0;
+    uint32_t scan_len[DeviceCtx::kMaxScans];                                // (the header may move if the buffer grows)
+    time_point t_begin, t_launched, t_len;
+
+    FrameRun(const Config &c_, DeviceCtx &ctx_, int jct_, int width_, int height_, int color_type_or_planes_, size_t pixel_bytes_,
+             jpegenc_write_fn sink_, void *user_)
+        : c(c_), ctx(ctx_), jct(jct_), width(width_), height(height_), color_type_or_planes(color_type_or_planes_), pixel_bytes(pixel_bytes_),
+          sink(sink_), user(user_) {}
+    static time_point now() { return std::chrono::steady_clock::now(); }
+    static long us(time_point a, time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); }
+
+    // tables, geometry, device buffers, the upload (`upload` copies the source into ctx.d_pixels on ctx.stream), the block
+    // kernel's parameters
+    int prepare(const std::function<int(DeviceCtx &)> &upload) {
+        int rc = jpegenc_qtable_init(&t.q[0], c.qtype[0], c.qcustom[0], c.quality, 1);   // encoder.rs:528-531
+        if (rc) return rc;
+        rc = jpegenc_qtable_init(&t.q[1], c.qtype[1], c.qcustom[1], c.quality, 0);
+        if (rc) return rc;
+        default_huffman(t);
+        int hs, vs;
+        sampling_hv(c.sampling, &hs, &vs);
+        mode = select_mode(c);
+        order = mode == MODE_INTERLEAVED ? JPEGENC_ORDER_MCU : JPEGENC_ORDER_PLANAR;
+        rc = jpegenc_layout_init(&L, width, height, color_type_or_planes, hs, vs, order);
+        if (rc) return rc;
+
+        // ---- device: upload, fused kernel, [histogram], download ---------------------------------
+        coeff_bytes = (size_t)L.total_blocks * 128;
+        rc = ctx.reserve(ctx.external_pixels || ctx.external_planes ? 0 : pixel_bytes, coeff_bytes, color_type_or_planes >= 100 && !ctx.external_planes);
+        if (rc) return rc;
+        rc = upload(ctx);
+        if (rc) return rc;
+        if (color_type_or_planes >= 100) rc = build_block_params_planes(&p, L, width, height, t.q, order);
+        else rc = build_block_params(&p, L, width, height, color_type_or_planes, t.q, order);
+        if (rc) return rc;
+        p.pixels = (const uint8_t *)(ctx.external_pixels ? ctx.external_pixels : ctx.d_pixels);
+        p.coeffs = ctx.d_coeffs;
+        p.pixel_frame_stride = pixel_bytes;
+        p.coeff_frame_stride = L.total_blocks;
+        optimize = c.optimize && mode != MODE_INTERLEAVED;
+        // interleaved baseline scan of an RGB-family image: ONE kernel goes from the pixels to the entropy-coded runs
+        // (fused_kernels.hip); the coefficients never reach HBM
+        fused_src = FusedSource{&p, c.fdct_variant, ctx.external_planes, ctx.external_planes_subsampled};
+        fused = false;
+        t_begin = now();
+        return JPEGENC_OK;
+    }
+
+    int plan_scans() {
+        // ---- the scans the device entropy coder will produce (planned before anything is launched: their
+        // buffers must exist before a launch sequence can be captured) ------------------------------------
+        int rc = JPEGENC_OK;
+        supported = false;
+        gather = nullptr;
+        first_piece = 0;
+        together = false;
+        if (c.device_entropy) {
+            auto add = [&](int comp, int with_dc, int s0, int s1, int first, int n, int ss, int se) {
+                Job j;
+                j.sc = jpegenc_scan{comp, with_dc, s0, s1, c.restart_interval};
+                j.first = first; j.n = n; j.ss = ss; j.se = se; j.off = 0; j.cap = 0; j.ws_off = 0; j.ws = 0;
+                jobs.push_back(j);
+            };
+            if (mode == MODE_INTERLEAVED) {
+                add(-1, 1, 1, 64, 0, L.num_components, 0, 63);
+            } else if (mode == MODE_SEQUENTIAL) {                               // encoder.rs:823-861
+                for (int i = 0; i < L.num_components; i++) add(i, 1, 1, 64, i, 1, 0, 63);
+            } else {                                                            // encoder.rs:885-972
+                for (int i = 0; i < L.num_components; i++) add(i, 1, 1, 1, i, 1, 0, 0);
+                const int scans = c.progressive_scans - 1, per = 64 / scans;
+                for (int sidx = 0; sidx < scans; sidx++) {
+                    const int start = sidx * per < 1 ? 1 : sidx * per;
+                    const int end = sidx == scans - 1 ? 64 : (sidx + 1) * per;
+                    for (int i = 0; i < L.num_components; i++) add(i, 0, start, end, i, 1, start, end - 1);
+                }
+            }
+            supported = (int)jobs.size() <= DeviceCtx::kMaxScans;
+            size_t ws = 0, ws_sum = 0, out_total = 0;
+            for (auto &j : jobs) {
+                if (!j.sc.with_dc && j.sc.ac_end == j.sc.ac_start) continue;       // empty band: nothing to code
+                j.cap = scan_max_bytes(L, j.sc);
+                const size_t w = scan_workspace_size(L, j.sc, 1);
+                if (!j.cap || !w) { supported = false; break; }
+                j.off = out_total;
+                out_total += j.cap;
+                j.ws = w;
+                j.ws_off = ws_sum;
+                ws_sum += (w + 255) & ~(size_t)255;
+                if (w > ws) ws = w;
+            }
+            first_piece = out_total < DeviceCtx::kFirstPiece ? out_total : DeviceCtx::kFirstPiece;
+            fused = supported && mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() &&
+                    (ctx.external_planes ? fused_planes_supported(p, ctx.external_planes, ctx.external_planes_subsampled) : fused_supported(p));
+            if (supported) {
+                // The scans of a sequential / progressive frame are independent: coded in shared launches they cost
+                // ~10 launches per 8 scans instead of ~10 per scan (a 4K progressive frame: 12 scans; such frames were
+                // bound by the host enqueueing ~120 small launches).  Needs one workspace per scan.
+                static const bool together_off = JPEGENC_DIAG_ENV("JPEGENC_SCANS_ONE_BY_ONE") != nullptr;
+                together = jobs.size() > 1 && !together_off && ws_sum <= ((size_t)3 << 30);
+                rc = ctx.reserve_scan(together ? ws_sum : ws, out_total);
+                if (rc) return rc;
+                // A small single-scan frame is coded STRAIGHT into the pinned host buffer the file is assembled from (the kernels'
+                // stores cross PCIe themselves; visible to the host once the stream has drained): the download - one more node
+                // of a sequence whose every node costs 6-10 us - disappears: 256x256 75 -> 68 us, 720p 122 -> 117, nothing beyond
+                // 1080p (tools/diag/zero_copy_ab.sh).  Frames above 1 MB of pixels keep the DMA: bulk copies are what it is good at.
+                static const size_t zero_copy_max = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)1 << 20); }();
+                if (out_total && pixel_bytes <= zero_copy_max) {                  // (several scans: the gather kernel writes there)
+                    rc = ctx.reserve_scan_host(kGatherHeader + out_total);
+                    if (rc) return rc;
+                    gather = ctx.h_scan_out;
+                }
+            }
+        }
+        if (!gather) gather = ctx.d_gather;
+        host_gather = gather != ctx.d_gather;
+        return rc;
+
+    }
+
+    void choose_replay() {
+        // ---- launch sequence of the frame.  With fixed Huffman tables nothing in it depends on the image
+        // content, so the second consecutive frame with identical parameters and buffers captures it into a
+        // hipGraph and later ones replay it.  Measured (profiles/README.md): 3-10 % off the latency of a
+        // baseline image (about 12 launches); nothing for the ~140 launches of a progressive file, whose
+        // small kernels are bound by their own dependent execution on the GPU, not by enqueueing - so only
+        // single-scan frames use it.  (JPEGENC_NO_GRAPH=1 disables it.)
+        static const bool graphs_off = JPEGENC_DIAG_ENV("JPEGENC_NO_GRAPH") != nullptr;
+        how = DIRECT;
+        if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1) {
+            std::string key;
+            auto put = [&](const void *v, size_t n) { key.append((const char *)v, n); };
+            const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, gather, ctx.h_scan_out};
+            const int64_t vals[] = {width, height, color_type_or_planes, (int64_t)pixel_bytes, order, c.fdct_variant, c.sampling,
+                                    c.progressive_scans, c.restart_interval, (int64_t)ctx.d_scan_ws_cap, (int64_t)jobs.size(), (int64_t)fused};
+            put(ptrs, sizeof ptrs); put(vals, sizeof vals); put(t.q, sizeof t.q);
+            if (ctx.external_planes) {                                        // a described planar source: its descriptors are part of what the sequence bakes in
+                for (int i = 0; i < L.num_components; i++) {
+                    const jpegenc_plane &pl = ctx.external_planes[i];
+                    const int64_t d[] = {(int64_t)(uintptr_t)pl.d_data, (int64_t)pl.pitch, pl.pixel_stride, pl.invert, (int64_t)ctx.external_planes_subsampled};
+                    put(d, sizeof d);
+                }
+            }
+            if (ctx.graph_exec && key == ctx.graph_key) how = REPLAY;
+            else if (key == ctx.last_key) how = CAPTURE;
+            ctx.last_key.swap(key);
+        }
+    }
+
+        // The device code tables are rebuilt only when the Huffman tables differ from the ones they were built from
+        // (never, for a caller that keeps encoding with the default tables).  Fixed tables: before any capture, so
+        // that a replayed sequence can rely on them; optimised tables: after the histogram, below.
+        int ensure_lut() {
+            jpegenc_huffman_spec specs[2][2];
+            for (int d = 0; d < 2; d++)
+                for (int k = 0; k < 2; k++) {
+                    memset(&specs[d][k], 0, sizeof specs[d][k]);
+                    memcpy(specs[d][k].bits, t.h[d][k].bits, 16);
+                    memcpy(specs[d][k].values, t.h[d][k].vals, (size_t)t.h[d][k].nvals);
+                    specs[d][k].num_values = t.h[d][k].nvals;
+                }
+            std::string key((const char *)specs, sizeof specs);
+            if (key == ctx.lut_key) return JPEGENC_OK;
+            ctx.lut_key.clear();
+            const int r = upload_huffman_luts(specs, ctx.d_lut, ctx.stream);
+            if (r) return r;
+            ctx.lut_key.swap(key);
+            return JPEGENC_OK;
+        }
+
+    int begin_sequence() {
+        int rc = JPEGENC_OK;
+        if (c.device_entropy && supported && !optimize) { rc = ensure_lut(); if (rc) return rc; }
+        // likewise the parameter block of a single scan: stored outside any capture (and only when it differs from what
+        // the workspace holds), so that a replayed sequence finds it in place
+        if (c.device_entropy && supported && !optimize && jobs.size() == 1 && jobs[0].cap) {
+            rc = scan_store_params(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, ctx.d_lut, (uint8_t *)gather + kGatherHeader, jobs[0].cap,
+                                   (uint32_t *)gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params, fused ? &fused_src : nullptr);
+            if (rc) return rc;
+        }
+        if (how == CAPTURE) JPEGENC_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
+        capture_guard.st = ctx.stream;
+        capture_guard.active = how == CAPTURE;
+        enqueue = how != REPLAY;
+        hist_folded = false;
+        return JPEGENC_OK;
+    }
+
+    int enqueue_blocks_and_statistics() {
+        int rc = JPEGENC_OK;
+        if (optimize) {
+            // optimize_huffman_table's statistics (encoder.rs:1086-1200) are gathered by the block kernel while the
+            // coefficients are in registers; layouts only the generic kernel handles keep the separate pass over HBM
+            static const bool fold_off = JPEGENC_DIAG_ENV("JPEGENC_NO_FOLDED_HISTOGRAM") != nullptr;
+            rc = ctx.reserve_hist((size_t)L.total_blocks);
+            if (rc) return rc;
+            if (!fold_off && L.total_blocks < (1ull << 32)) {
+                p.hist_partials = (uint32_t *)((uint8_t *)ctx.d_hist + DeviceCtx::kHistFreqBytes);
+                p.dc_side = (int16_t *)ctx.d_dc_side;
+                p.hist_total_blocks = (uint32_t)L.total_blocks;
+                p.hist_band_mask = 0;
+                if (c.progressive_scans) {                                   // AC bands of encode_image_progressive (encoder.rs:1123-1134)
+                    const int scans = c.progressive_scans - 1, per = 64 / scans;
+                    for (int sidx = 1; sidx < scans; sidx++)
+                        if (sidx * per > 1 && sidx * per < 64) p.hist_band_mask |= 1ull << (sidx * per);
+                }
+            }
+        }
+        if (enqueue && !fused) {
+            hipError_t err = hipSuccess;
+            if (p.hist_partials) JPEGENC_HIP(hipMemsetAsync(ctx.d_hist, 0, DeviceCtx::kHistBytes, ctx.stream));
+            if (ctx.external_planes) {
+                err = launch_blocks_planes(p, ctx.external_planes, ctx.external_planes_subsampled, c.fdct_variant, ctx.stream);
+                if (err == hipErrorInvalidValue) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane layout not supported on the device (pixel stride 2 with a sampling factor of 4, or a plane of 2 GiB)");
+                hist_folded = p.hist_partials != nullptr;
+            } else if (launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) {
+                hist_folded = p.hist_partials != nullptr;
+            } else {
+                err = launch_blocks_generic(p, 1, c.fdct_variant, ctx.stream);
+            }
+            if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+        }
+        if (optimize) {
+            const void *d_freq = ctx.d_freq;
+            if (hist_folded) {
+                HistFinishParams hf;
+                memset(&hf, 0, sizeof hf);
+                hf.partials = p.hist_partials; hf.dc_side = p.dc_side; hf.freq = (uint32_t *)ctx.d_hist; hf.ncomp = L.num_components;
+                uint64_t off = 0;
+                for (int i = 0; i < L.num_components; i++) {
+                    hf.nblocks[i] = (uint32_t)L.blocks[i]; hf.comp_off[i] = off; off += L.blocks[i]; hf.table[i] = L.table[i];
+                }
+                const hipError_t he = launch_hist_finish(hf, ctx.stream);
+                if (he != hipSuccess) return hip_fail(he, "histogram finish kernel launch");
+                d_freq = ctx.d_hist;
+            } else {
+                rc = jpegenc_histogram_device(ctx.d_coeffs, &L, c.progressive_scans, ctx.d_freq, ctx.stream);
+                if (rc) return rc;
+            }
+            JPEGENC_HIP(hipMemcpyAsync(ctx.h_freq, d_freq, sizeof(uint32_t) * 2 * 2 * 257, hipMemcpyDeviceToHost, ctx.stream));
+        }
+        return rc;
+    }
+
+    int enqueue_scans() {
+        // ---- entropy-code every scan on the device and fetch only the compressed bytes ----------------
+        int rc = JPEGENC_OK;
+        if (optimize) {                                  // optimize_huffman_table, encoder.rs:1086-1200
+            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            const int max_tables = L.num_components < 2 ? L.num_components : 2;
+            for (int d = 0; d < max_tables; d++)
+                for (int k = 0; k < 2; k++)
+                    if (!t.h[d][k].assign_optimized(ctx.h_freq + (d * 2 + k) * 257)) return fail_code_too_long();
+        }
+        if (optimize) { rc = ensure_lut(); if (rc) return rc; }
+        if (enqueue) {
+            bool empty_scans = false;                    // (the coder zeroes the length of every scan it codes)
+            for (const Job &j : jobs) empty_scans = empty_scans || !j.cap;
+            if (empty_scans) JPEGENC_HIP(hipMemsetAsync(ctx.d_scan_len, 0, sizeof(uint32_t) * jobs.size(), ctx.stream));
+            if (together) {
+                std::vector<ScanJob> batch;
+                for (size_t k = 0; k < jobs.size(); k++) {
+                    const Job &j = jobs[k];
+                    if (!j.cap) continue;
+                    batch.push_back(ScanJob{j.sc, (uint8_t *)ctx.d_scan_out + j.off, j.cap, ctx.d_scan_len + k,
+                                            (uint8_t *)ctx.d_scan_ws + j.ws_off, j.ws});
+                }
+                ctx.stored_scan_params.clear();
+                rc = scan_device_multi(ctx.d_coeffs, L.total_blocks, 1, L, batch.data(), (int)batch.size(), ctx.d_lut, ctx.stream);
+                if (rc) return rc;
+            } else if (jobs.size() == 1 && jobs[0].cap) {
+                // a single scan (every baseline frame) is coded straight into the gathered layout: [length][bytes]
+                rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, jobs[0].sc, nullptr, ctx.d_lut, (uint8_t *)gather + kGatherHeader,
+                                 jobs[0].cap, (uint32_t *)gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params,
+                                 fused ? &fused_src : nullptr);
+                if (rc) return rc;
+            } else {
+                ctx.stored_scan_params.clear();
+                for (size_t k = 0; k < jobs.size(); k++) {
+                    Job &j = jobs[k];
+                    if (!j.cap) continue;
+                    rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)ctx.d_scan_out + j.off,
+                                     j.cap, ctx.d_scan_len + k, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream);
+                    if (rc) return rc;
+                }
+            }
+            if (!(jobs.size() == 1 && jobs[0].cap)) {
+                GatherArgs ga;
+                ga.n = (uint32_t)jobs.size(); ga.reserved = 0;
+                for (size_t k = 0; k < jobs.size(); k++) ga.off[k] = jobs[k].off;
+                const hipError_t ge = launch_gather_scans(ga, ctx.d_scan_out, ctx.d_scan_len, gather, ctx.stream);
+                if (ge != hipSuccess) return hip_fail(ge, "gather kernel launch");
+            }
+            if (!host_gather)
+                JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out, ctx.d_gather, kGatherHeader + first_piece, hipMemcpyDeviceToHost, ctx.stream));
+        }
+        return rc;
+    }
+
+    int launch_and_wait() {
+        if (how == CAPTURE) {
+            hipGraph_t g = nullptr;
+            capture_guard.active = false;
+            JPEGENC_HIP(hipStreamEndCapture(ctx.stream, &g));
+            if (ctx.graph_exec) { (void)hipGraphExecDestroy(ctx.graph_exec); ctx.graph_exec = nullptr; }
+            const hipError_t ge = hipGraphInstantiate(&ctx.graph_exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ge != hipSuccess) { ctx.graph_exec = nullptr; return hip_fail(ge, "hipGraphInstantiate"); }
+            ctx.graph_key = ctx.last_key;
+        }
+        if (how != DIRECT) JPEGENC_HIP(hipGraphLaunch(ctx.graph_exec, ctx.stream));
+        t_launched = now();
+        JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+        t_len = now();
+        nbytes = 0;
+        for (size_t k = 0; k < jobs.size(); k++) { scan_len[k] = reinterpret_cast<const uint32_t *>(ctx.h_scan_out)[k]; nbytes += scan_len[k]; }
+        return JPEGENC_OK;
+    }
+
+    int emit_device_coded() {
+        int rc = JPEGENC_OK;
+        static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+        // ---- the rest of a large file (what the first copy did not bring along) comes down in pieces.  Into the caller's own
+        // buffer where the sink is the library's (jpegenc_encoder_encode_to_buffer and the _to_buffers batch calls): the DMA
+        // writes each scan where it belongs in the file - the 14 MB memcpy out of the pinned buffer was a third of a
+        // Criterion-sized call.  For a caller's sink into the pinned buffer, each piece handed over while the next ones are
+        // still in flight.
+        const size_t rest = nbytes > first_piece && !host_gather ? nbytes - first_piece : 0;
+        BufferSink *direct = rest && sink == buffer_sink ? (BufferSink *)user : nullptr;
+        size_t piece = 0;
+        int npieces = 0, pieces_done = 0;
+        if (rest && !direct) {
+            rc = ctx.reserve_scan_host(kGatherHeader + nbytes, kGatherHeader + first_piece);
+            if (rc) return rc;
+            piece = (rest + DeviceCtx::kChunks - 1) / DeviceCtx::kChunks;
+            if (piece < ((size_t)1 << 20)) piece = (size_t)1 << 20;
+            piece = (piece + 65535) & ~(size_t)65535;
+            for (size_t done = 0; done < rest; done += piece, npieces++) {
+                const size_t n = rest - done < piece ? rest - done : piece;
+                JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out + kGatherHeader + first_piece + done, (const uint8_t *)ctx.d_gather + kGatherHeader + first_piece + done,
+                                           n, hipMemcpyDeviceToHost, ctx.stream));
+                JPEGENC_HIP(hipEventRecord(ctx.chunk_done[npieces], ctx.stream));
+            }
+        }
+        size_t at = kGatherHeader;
+        Out o;
+        o.sink = sink; o.user = user;
+        write_prologue(o, c, jct);
+        write_frame_header(o, c, width, height, L, t);          // after the tables are final (:821, :881)
+        const auto t_copied = now();
+        // bytes [from, from + n) of the gathered scans -> the file
+        auto emit_scan_bytes = [&](size_t from, size_t n) -> int {
+            if (direct) {
+                o.drain(true);                                               // the headers written so far are in the caller's buffer now
+                if (!o.failed && direct->len + n <= direct->cap) {
+                    uint8_t *dst = direct->out + direct->len;
+                    const size_t fetched_end = kGatherHeader + first_piece;      // what the first copy brought
+                    const size_t a = from < fetched_end ? (from + n < fetched_end ? n : fetched_end - from) : 0;
+                    if (a) memcpy(dst, ctx.h_scan_out + from, a);
+                    if (n > a) JPEGENC_HIP(hipMemcpyAsync(dst + a, (const uint8_t *)ctx.d_gather + from + a, n - a, hipMemcpyDeviceToHost, ctx.stream));
+                }
+                direct->len += n;                                            // (a buffer that is too small still learns the size it needs)
+                return JPEGENC_OK;
+            }
+            if (n < (64u << 10) || !sink) {                                   // small: through the emitter's own buffer
+                while (npieces > pieces_done && from + n > kGatherHeader + first_piece + (size_t)pieces_done * piece) {
+                    JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[pieces_done]));
+                    pieces_done++;
+                }
+                o.bytes(ctx.h_scan_out + from, n);
+                return JPEGENC_OK;
+            }
+            o.drain(true);                                                   // a large scan goes from the pinned buffer straight to the sink (one copy less)
+            size_t pos = from;
+            const size_t end = from + n;
+            while (pos < end && !o.failed) {
+                // the stretch of [pos, end) that has arrived: up to the end of the last finished piece
+                size_t have = kGatherHeader + first_piece + (size_t)pieces_done * piece;
+                if (pieces_done >= npieces || have > kGatherHeader + nbytes) have = kGatherHeader + nbytes;
+                if (have <= pos) {
+                    JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[pieces_done]));
+                    pieces_done++;
+                    continue;
+                }
+                const size_t m = (have < end ? have : end) - pos;
+                if (sink(user, ctx.h_scan_out + pos, m) != 0) o.failed = true;
+                pos += m;
+            }
+            return JPEGENC_OK;
+        };
+        for (size_t k = 0; k < jobs.size(); k++) {
+            const Job &j = jobs[k];
+            write_scan_header(o, L, j.first, j.n, j.ss, j.se);
+            if (j.cap) {
+                rc = emit_scan_bytes(at, scan_len[k]);
+                if (rc) return rc;
+                at += scan_len[k];
+            } else if (c.restart_interval) {
+                // empty band (progressive with > 33 scans, encoder.rs:927-944): no bits at all, but the
+                // restart bookkeeping still emits its markers (encoder.rs:947-951)
+                const uint64_t n = L.blocks[j.sc.component];
+                for (uint64_t b = (uint64_t)c.restart_interval, r = 0; b < n; b += (uint64_t)c.restart_interval, r++) {
+                    o.u8(0xFF); o.u8(0xD0 + (unsigned)(r & 7));
+                }
+            }
+            o.drain(false);
+        }
+        if (direct) JPEGENC_HIP(hipStreamSynchronize(ctx.stream));           // the scans are in the caller's buffer
+        o.marker(0xD9);
+        o.drain(true);
+        if (trace) fprintf(stderr, "[jpegenc] frame: launch %ld us, wait-len %ld us, d2h %ld us, emit %ld us, bytes %zu, scans %zu\n",
+                           us(t_begin, t_launched), us(t_launched, t_len), us(t_len, t_copied), us(t_copied, now()), nbytes, jobs.size());
+        if (o.failed) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
+        return JPEGENC_OK;
+    }
+
+    int collect_host_coded() {
+        int rc = JPEGENC_OK;
+        // coefficient tiles come back in kChunks pieces so that entropy coding of tile k overlaps the
+        // copy of tile k+1 (interleaved mode consumes them in order; the other modes need them all)
+        rc = ctx.reserve_host_coeffs(coeff_bytes);
+        if (rc) return rc;
+        const uint32_t bpm = (uint32_t)(L.total_blocks / (L.mcus ? L.mcus : 1));
+        uint64_t chunk_end_mcu[DeviceCtx::kChunks];
+        int nchunks = 1;
+        if (mode == MODE_INTERLEAVED) {
+            nchunks = (int)(L.mcus < (uint64_t)DeviceCtx::kChunks ? L.mcus : (uint64_t)DeviceCtx::kChunks);
+            uint64_t prev = 0;
+            for (int k = 0; k < nchunks; k++) {
+                const uint64_t end = L.mcus * (uint64_t)(k + 1) / (uint64_t)nchunks;
+                JPEGENC_HIP(hipMemcpyAsync((uint8_t *)ctx.h_coeffs + prev * bpm * 128, (const uint8_t *)ctx.d_coeffs + prev * bpm * 128,
+                                           (end - prev) * bpm * 128, hipMemcpyDeviceToHost, ctx.stream));
+                JPEGENC_HIP(hipEventRecord(ctx.chunk_done[k], ctx.stream));
+                chunk_end_mcu[k] = end;
+                prev = end;
+            }
+        } else {
+            JPEGENC_HIP(hipMemcpyAsync(ctx.h_coeffs, ctx.d_coeffs, coeff_bytes, hipMemcpyDeviceToHost, ctx.stream));
+            JPEGENC_HIP(hipEventRecord(ctx.chunk_done[0], ctx.stream));
+        }
+
+        auto wait = [&](int k) -> int { JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[k])); return JPEGENC_OK; };
+        return emit_host_coded(c, jct, width, height, L, t, mode, optimize, ctx.h_coeffs, ctx.h_freq, nchunks, chunk_end_mcu, wait, sink, user);
+    }
+};
+
+int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,
+                 const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user) {
+    FrameRun run(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, sink, user);
+    int rc = run.prepare(upload);
+    if (rc) return rc;
+    rc = run.plan_scans();
+    if (rc) return rc;
+    run.choose_replay();
+    rc = run.begin_sequence();
+    if (rc) return rc;
+    rc = run.enqueue_blocks_and_statistics();
+    if (rc) return rc;
+    if (!(c.device_entropy && run.supported)) return run.collect_host_coded();
+    rc = run.enqueue_scans();
+    if (rc) return rc;
+    rc = run.launch_and_wait();
+    if (rc) return rc;
+    return run.emit_device_coded();
+}
+
+int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *data, size_t len, int width,
+                         int height, int color_type, jpegenc_write_fn sink, void *user, bool staged) {
+    int rc = validate_image(len, width, height, color_type);      // before any device work
+    if (rc) return rc;
+    if (!sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null sink");
+    rc = ctx.open(device);
+    if (rc) return rc;
+    const size_t bytes = (size_t)width * (size_t)height * (size_t)jpegenc_bytes_per_pixel(color_type);
+    // A small frame (up to 1 MB of pixels) is copied into this handle's pinned host buffer and the kernel reads it from
+    // there across PCIe: no DMA node in front of the launch sequence, 10-15 us of a 70-100 us call (256x256: 65 -> 54 us,
+    // 640x480: 99 -> 86).  Pinned host memory is not cached in L2 and every pixel is read by the waves of all three
+    // components, so it stops paying between 0.9 and 1.4 MB (800x600: 102 -> 112 us; 720p: 117 -> 148) - tools/diag/zero_copy_in_sizes.sh.
+    static const size_t zero_copy_in = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)1 << 20); }();
+    if (!staged && bytes <= zero_copy_in && !ctx.external_pixels) {
+        if (bytes > ctx.h_pixels_cap) {
+            if (ctx.h_pixels) (void)hipHostFree(ctx.h_pixels);
+            ctx.h_pixels = nullptr; ctx.h_pixels_cap = 0;
+            // (coherent memory: allocated hipHostMallocNonCoherent - cacheable in the GPU's L2 - it measured the same at 256x256 and
+            // 4 us SLOWER at 640x480, profiles/r03_small_frames.txt)
+            JPEGENC_HIP(hipHostMalloc((void **)&ctx.h_pixels, bytes, hipHostMallocDefault));
+            ctx.h_pixels_cap = bytes;
+        }
+        memcpy(ctx.h_pixels, data, bytes);
+        ctx.external_pixels = ctx.h_pixels;
+        auto nothing = [&](DeviceCtx &) -> int { return JPEGENC_OK; };
+        rc = encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, nothing, sink, user);
+        ctx.external_pixels = nullptr;
+        return rc;
+    }
+    auto upload = [&](DeviceCtx &cx) -> int {
+        if (staged && is_pinned_host_range(data, bytes)) {
+            // the caller's frame is page-locked already (jpegenc_host_alloc / jpegenc_host_register, or HIP's own calls):
+            // the DMA engine reads it in place - no staging copy, no host DRAM traffic beside the DMA's own read
+            JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
+        } else if (staged) {       // batch workers: copy into this worker's pinned buffer, then a true async DMA
+            if (bytes > cx.h_pixels_cap) {
+                if (cx.h_pixels) (void)hipHostFree(cx.h_pixels);
+                cx.h_pixels = nullptr; cx.h_pixels_cap = 0;
+                JPEGENC_HIP(hipHostMalloc((void **)&cx.h_pixels, bytes, hipHostMallocDefault));
+                cx.h_pixels_cap = bytes;
+            }
+            staging_copy(cx.h_pixels, data, bytes);
+            JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, cx.h_pixels, bytes, hipMemcpyHostToDevice, cx.stream));
+        } else {
+            JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
+        }
+        return JPEGENC_OK;
+    };
+    return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user);
+}
+
+
+int buffer_sink(void *user, const uint8_t *data, size_t n) {
+    BufferSink *b = (BufferSink *)user;
+    if (b->len + n <= b->cap) memcpy(b->out + b->len, data, n);
+    b->len += n;
+    return 0;
+}
+
+
+}  // namespace jpegenc

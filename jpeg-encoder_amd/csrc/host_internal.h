@@ -1,0 +1,645 @@
+// host_internal.h — what the translation units of the Encoder-shaped host half share (host_encoder.cpp: the C entry points of
+// one image; host_emit.cpp: markers, tables and the host entropy coder; host_frame.cpp: one frame on the device;
+// host_batch.cpp: batches, rounds and the worker pool; host_multi.cpp: several devices, NUMA placement, page-locked memory).
+// Internal: nothing here is part of the C ABI (include/jpegenc_mi355x.h).
+#pragma once
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include <immintrin.h>
+
+#include "diag_env.h"
+#include "host_common.h"
+
+
+namespace jpegenc {
+
+void staging_copy(void *dst, const void *src, size_t n);      // host_frame.cpp: a frame into pinned memory with streaming stores
+int fail_code_too_long();                                     // host_emit.cpp
+
+// T.81 Figure A.6 (writer.rs:64-68)
+static const uint8_t kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ---------------------------------------------------------------------------------------------
+// Huffman tables (huffman.rs)
+struct HuffTable {
+    uint8_t bits[16];
+    uint8_t vals[256];
+    int nvals = 0;
+    uint32_t code[256];   // right-aligned code
+    uint8_t size[256];
+
+    void assign(const uint8_t b[16], const uint8_t *v, int n) {
+        memcpy(bits, b, 16);
+        memcpy(vals, v, (size_t)n);
+        nvals = n;
+        memset(code, 0, sizeof code);
+        memset(size, 0, sizeof size);
+        // Figures C.1-C.3 (huffman.rs:240-288): canonical codes in order of increasing length
+        unsigned next = 0;
+        int k = 0;
+        for (int len = 1; len <= 16; len++) {
+            for (int i = 0; i < bits[len - 1]; i++, k++) {
+                code[vals[k]] = next++;
+                size[vals[k]] = (uint8_t)len;
+            }
+            next <<= 1;
+        }
+    }
+
+    // Annex K.2 as HuffmanTable::new_optimized implements it (huffman.rs:99-221), including its
+    // tie rule (`<=`: among equal least frequencies the LARGEST symbol wins) — that rule decides
+    // the emitted DHT bytes, so it is part of the drop-in contract.
+    // Returns false where the reference panics: Figure K.1 can produce code sizes above 32 (a histogram
+    // that grows like the Fibonacci numbers over more than 33 symbols), which index `bits: [u8; 33]` out of
+    // bounds at huffman.rs:161-165.  Nothing is assigned then.
+    bool assign_optimized(const uint32_t freq_in[257]) {
+        uint32_t freq[257];
+        int others[257], codesize[257];
+        memcpy(freq, freq_in, sizeof freq);
+        for (int i = 0; i < 257; i++) { others[i] = -1; codesize[i] = 0; }
+        for (;;) {
+            int v1 = -1, v2 = -1;
+            uint32_t least = UINT32_MAX;
+            for (int i = 0; i < 257; i++)
+                if (freq[i] && freq[i] <= least) { least = freq[i]; v1 = i; }
+            if (v1 < 0) break;
+            least = UINT32_MAX;
+            for (int i = 0; i < 257; i++)
+                if (freq[i] && freq[i] <= least && i != v1) { least = freq[i]; v2 = i; }
+            if (v2 < 0) break;
+            freq[v1] += freq[v2];
+            freq[v2] = 0;
+            for (codesize[v1]++; others[v1] >= 0;) { v1 = others[v1]; codesize[v1]++; }
+            others[v1] = v2;
+            for (codesize[v2]++; others[v2] >= 0;) { v2 = others[v2]; codesize[v2]++; }
+        }
+        int count[33] = {0};
+        for (int i = 0; i < 257; i++) {
+            if (codesize[i] > 32) return false;
+            if (codesize[i]) count[codesize[i]]++;
+        }
+        int i = 32;
+        for (; i > 16; i--) {                       // Figure K.3: fold lengths > 16 back
+            while (count[i] > 0) {
+                int j = i - 2;
+                while (count[j] == 0) j--;
+                count[i] -= 2; count[i - 1]++; count[j + 1] += 2; count[j]--;
+            }
+        }
+        while (i > 0 && count[i] == 0) i--;
+        if (i == 0) return false;                   // (debug_assert upstream, huffman.rs:186: an all-zero histogram)
+        count[i]--;                                 // the reserved all-ones code point (symbol 256)
+        uint8_t v[256], b[16];
+        int n = 0;
+        for (int s = 1; s <= 32; s++)               // Figure K.4
+            for (int sym = 0; sym < 256; sym++)
+                if (codesize[sym] == s) v[n++] = (uint8_t)sym;
+        for (int s = 0; s < 16; s++) b[s] = (uint8_t)count[s + 1];
+        assign(b, v, n);
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Output: segments + entropy-coded data into one growing buffer, handed to the sink in large pieces
+// (the reference may call write_all with 1-byte slices, writer.rs:129-131; the byte stream is
+// what is contractual).
+struct Out {
+    std::vector<uint8_t> buf;
+    jpegenc_write_fn sink = nullptr;
+    void *user = nullptr;
+    bool failed = false;
+    uint64_t acc = 0;
+    int nbits = 0;
+
+    void u8(unsigned v) { buf.push_back((uint8_t)v); }
+    void u16(unsigned v) { u8(v >> 8); u8(v & 0xFF); }
+    void marker(unsigned m) { u8(0xFF); u8(m); }
+    void bytes(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; buf.insert(buf.end(), b, b + n); }
+    void segment(unsigned m, const uint8_t *d, size_t n) { marker(m); u16((unsigned)((n + 2) & 0xFFFF)); bytes(d, n); }
+    void drain(bool force) {
+        if (!sink || failed) return;
+        if (force || buf.size() >= (1u << 20)) {
+            if (!buf.empty() && sink(user, buf.data(), buf.size()) != 0) failed = true;
+            buf.clear();
+        }
+    }
+
+    // entropy-coded segment writer -----------------------------------------------------------
+    uint8_t *cur = nullptr, *lim = nullptr;
+    void begin_bits() { acc = 0; nbits = 0; }
+    void reserve_bits(size_t n) {
+        const size_t used = buf.size();
+        (void)used;
+        if ((size_t)(lim - cur) < n) {
+            const size_t off = cur ? (size_t)(cur - buf.data()) : buf.size();
+            buf.resize(off + n + (1u << 16));
+            cur = buf.data() + off;
+            lim = buf.data() + buf.size();
+        }
+    }
+    void open_bits() { cur = nullptr; lim = nullptr; reserve_bits(1 << 16); }
+    void close_bits() { buf.resize((size_t)(cur - buf.data())); cur = lim = nullptr; }
+
+    inline void put(uint32_t code, int size) {              // write_bits, writer.rs:186-202
+        acc = (acc << size) | code;
+        nbits += size;
+        if (nbits >= 32) {
+            const uint32_t w = (uint32_t)(acc >> (nbits - 32));
+            nbits -= 32;
+            if ((w & 0x80808080u & ~(w + 0x01010101u)) != 0) {   // some byte is 0xFF: stuff
+                for (int s = 24; s >= 0; s -= 8) {
+                    const uint8_t b = (uint8_t)(w >> s);
+                    *cur++ = b;
+                    if (b == 0xFF) *cur++ = 0;
+                }
+            } else {
+                cur[0] = (uint8_t)(w >> 24); cur[1] = (uint8_t)(w >> 16); cur[2] = (uint8_t)(w >> 8); cur[3] = (uint8_t)w;
+                cur += 4;
+            }
+        }
+    }
+    void finalize_bits() {                                   // finalize_bit_buffer, writer.rs:138-154
+        put(0x7F, 7);
+        while (nbits >= 8) {
+            const uint8_t b = (uint8_t)(acc >> (nbits - 8));
+            *cur++ = b;
+            if (b == 0xFF) *cur++ = 0;
+            nbits -= 8;
+        }
+        acc = 0; nbits = 0;
+    }
+};
+
+// where HuffmanTable::new_optimized panics (index out of bounds, huffman.rs:161-165)
+static inline int bit_length(unsigned a) { return a ? 32 - __builtin_clz(a) : 0; }
+
+static inline void put_dc(Out &o, int16_t value, int16_t prev, const HuffTable &dc) {   // write_dc, writer.rs:342-354
+    const int diff = (int16_t)(value - prev);
+    const int nb = bit_length((unsigned)(diff < 0 ? -diff : diff));                     // get_code :455-470
+    const uint32_t mag = (uint32_t)(diff - (diff < 0)) & ((1u << nb) - 1u);
+    o.put((dc.code[nb] << nb) | mag, dc.size[nb] + nb);
+}
+
+static inline void put_ac(Out &o, const int16_t *b, int start, int end, const HuffTable &ac) {   // write_ac_block :356-388
+    uint64_t nz = 0;
+    for (int k = 0; k < 64; k++) nz |= (uint64_t)(b[k] != 0) << k;
+    nz &= (end == 64 ? ~0ull : ((1ull << end) - 1)) & ~((1ull << start) - 1);
+    int next = start;
+    while (nz) {
+        const int pos = __builtin_ctzll(nz);
+        nz &= nz - 1;
+        int run = pos - next;
+        for (; run > 15; run -= 16) o.put(ac.code[0xF0], ac.size[0xF0]);
+        const int v = b[pos];
+        const int nb = bit_length((unsigned)(v < 0 ? -v : v));
+        const uint32_t mag = (uint32_t)(v - (v < 0)) & ((1u << nb) - 1u);
+        const int sym = (run << 4) | nb;
+        o.put((ac.code[sym] << nb) | mag, ac.size[sym] + nb);
+        next = pos + 1;
+    }
+    if (next < end) o.put(ac.code[0], ac.size[0]);           // trailing zeros -> EOB
+}
+
+// restart bookkeeping of every scan loop (encoder.rs:748-757 + 793-800 and the three copies below)
+struct Restart {
+    int interval, restarts = 0, to_go;
+    explicit Restart(int iv) : interval(iv), to_go(iv) {}
+    bool before(Out &o) {
+        if (interval > 0 && to_go == 0) {
+            o.finalize_bits();
+            *o.cur++ = 0xFF; *o.cur++ = (uint8_t)(0xD0 + restarts % 8);
+            return true;
+        }
+        return false;
+    }
+    void after() {
+        if (interval > 0) {
+            if (to_go == 0) { to_go = interval; restarts = (restarts + 1) & 7; }
+            to_go--;
+        }
+    }
+};
+
+// A side stream whose copies must overlap the work of a handle's main stream: created at the highest priority, because
+// every priority has its own hardware queues - two streams of equal priority may be dealt onto the SAME queue (4 per
+// process, in creation order) and then run one after the other (capi_blocks.cpp: jpegenc_blocks_stream lost half its rate so).
+inline hipError_t create_side_stream(hipStream_t *s) {
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct DeviceCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void *d_pixels = nullptr, *d_coeffs = nullptr, *d_freq = nullptr;
+    // optimised tables: [freq 2x2x257 (padded to 4 KiB)][kHistCopies partial AC histograms] - cleared with one memset - and the DC side array
+    void *d_hist = nullptr, *d_dc_side = nullptr;
+    size_t d_dc_side_cap = 0;
+    static constexpr size_t kHistFreqBytes = 4352, kHistBytes = kHistFreqBytes + (size_t)kHistCopies * 2 * 256 * sizeof(uint32_t);
+    const void *external_pixels = nullptr;   // device-resident input: use the caller's buffer, no upload
+    const jpegenc_plane *external_planes = nullptr;   // device-resident planar input (jpegenc_encoder_encode_planes_device)
+    bool external_planes_subsampled = false;
+    size_t d_pixels_cap = 0, d_coeffs_cap = 0;
+    int16_t *h_coeffs = nullptr;
+    size_t h_coeffs_cap = 0;
+    uint8_t *h_pixels = nullptr;
+    size_t h_pixels_cap = 0;
+    uint32_t *h_freq = nullptr;
+    // device entropy coding (interleaved scans): scratch, coded segment, its length
+    void *d_scan_ws = nullptr, *d_scan_out = nullptr, *d_gather = nullptr;       // d_gather: [lengths][all scans back to back]
+    size_t d_scan_ws_cap = 0, d_scan_out_cap = 0, d_gather_cap = 0;
+    static constexpr size_t kFirstPiece = 256 << 10;      // bytes of coded data fetched together with the lengths
+    uint32_t *d_scan_len = nullptr, *h_scan_len = nullptr;     // kMaxScans entries
+    void *d_lut = nullptr;
+    std::string stored_scan_params;    // the parameter blocks a single-scan frame left in d_scan_ws (launch_entropy_scans)
+    std::string lut_key;               // the Huffman tables d_lut was built from (uploads of unchanged tables are skipped)
+    static constexpr int kMaxScans = 4 * 64;
+    uint8_t *h_scan_out = nullptr;
+    size_t h_scan_out_cap = 0;
+    static constexpr int kChunks = 8;
+    hipEvent_t chunk_done[kChunks] = {};
+    // captured launch sequence of a frame (encode_frame) and what it was captured for
+    hipGraphExec_t graph_exec = nullptr;
+    std::string graph_key, last_key;
+
+    int open(int dev) {
+        if (device == dev && stream) {        // (the calling thread may have used another device in between)
+            JPEGENC_HIP(hipSetDevice(dev));
+            return JPEGENC_OK;
+        }
+        close();
+        int rc = ensure_device_ready(dev);
+        if (rc) return rc;
+        device = dev;
+        rc = allocate_fixed();
+        if (rc) close();                  // never leave a half-open context behind: the next call would find `stream` set
+        return rc;
+    }
+    int allocate_fixed() {
+        JPEGENC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto &e : chunk_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        JPEGENC_HIP(hipMalloc(&d_freq, sizeof(uint32_t) * 2 * 2 * 257));
+        JPEGENC_HIP(hipHostMalloc((void **)&h_freq, sizeof(uint32_t) * 2 * 2 * 257, hipHostMallocDefault));
+        JPEGENC_HIP(hipMalloc((void **)&d_scan_len, sizeof(uint32_t) * kMaxScans));
+        JPEGENC_HIP(hipHostMalloc((void **)&h_scan_len, sizeof(uint32_t) * kMaxScans, hipHostMallocDefault));
+        JPEGENC_HIP(hipMalloc(&d_lut, kLutDeviceBytes));
+        return JPEGENC_OK;
+    }
+    int reserve_hist(size_t total_blocks) {            // optimised tables only
+        if (!d_hist) JPEGENC_HIP(hipMalloc(&d_hist, kHistBytes));
+        if (total_blocks * sizeof(int16_t) > d_dc_side_cap) {
+            if (d_dc_side) (void)hipFree(d_dc_side);
+            d_dc_side = nullptr; d_dc_side_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_dc_side, total_blocks * sizeof(int16_t)));
+            d_dc_side_cap = total_blocks * sizeof(int16_t);
+        }
+        return JPEGENC_OK;
+    }
+    int reserve_host_coeffs(size_t coeff_bytes) {      // only the host entropy path needs the coefficients
+        if (coeff_bytes > h_coeffs_cap) {
+            if (h_coeffs) (void)hipHostFree(h_coeffs);
+            h_coeffs = nullptr; h_coeffs_cap = 0;
+            JPEGENC_HIP(hipHostMalloc((void **)&h_coeffs, coeff_bytes, hipHostMallocDefault));
+            h_coeffs_cap = coeff_bytes;
+        }
+        return JPEGENC_OK;
+    }
+    int reserve_scan(size_t ws_bytes, size_t out_bytes) {
+        if (ws_bytes > d_scan_ws_cap) {
+            if (d_scan_ws) (void)hipFree(d_scan_ws);
+            d_scan_ws = nullptr; d_scan_ws_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_scan_ws, ws_bytes));
+            d_scan_ws_cap = ws_bytes;
+        }
+        if (out_bytes > d_scan_out_cap) {
+            if (d_scan_out) (void)hipFree(d_scan_out);
+            d_scan_out = nullptr; d_scan_out_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_scan_out, out_bytes));
+            d_scan_out_cap = out_bytes;
+        }
+        if (kGatherHeader + out_bytes > d_gather_cap) {
+            if (d_gather) (void)hipFree(d_gather);
+            d_gather = nullptr; d_gather_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_gather, kGatherHeader + out_bytes));
+            d_gather_cap = kGatherHeader + out_bytes;
+        }
+        return reserve_scan_host(kGatherHeader + kFirstPiece);
+    }
+    int reserve_scan_host(size_t bytes, size_t keep = 0) {     // keep: leading bytes that must survive a growth
+        if (bytes > h_scan_out_cap) {
+            const size_t cap = bytes + bytes / 2 + (1u << 20);
+            uint8_t *bigger = nullptr;
+            JPEGENC_HIP(hipHostMalloc((void **)&bigger, cap, hipHostMallocDefault));
+            if (h_scan_out) {
+                if (keep) memcpy(bigger, h_scan_out, keep < h_scan_out_cap ? keep : h_scan_out_cap);
+                (void)hipHostFree(h_scan_out);
+            }
+            h_scan_out = bigger;
+            h_scan_out_cap = cap;
+        }
+        return JPEGENC_OK;
+    }
+    int reserve(size_t pixel_bytes, size_t coeff_bytes, bool pinned_pixels) {
+        JPEGENC_HIP(hipSetDevice(device));
+        if (pixel_bytes > d_pixels_cap) {
+            if (d_pixels) (void)hipFree(d_pixels);
+            d_pixels = nullptr; d_pixels_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_pixels, pixel_bytes));
+            d_pixels_cap = pixel_bytes;
+        }
+        if (coeff_bytes > d_coeffs_cap) {
+            if (d_coeffs) (void)hipFree(d_coeffs);
+            d_coeffs = nullptr; d_coeffs_cap = 0;
+            JPEGENC_HIP(hipMalloc(&d_coeffs, coeff_bytes));
+            d_coeffs_cap = coeff_bytes;
+        }
+        if (pinned_pixels && pixel_bytes > h_pixels_cap) {
+            if (h_pixels) (void)hipHostFree(h_pixels);
+            h_pixels = nullptr; h_pixels_cap = 0;
+            JPEGENC_HIP(hipHostMalloc((void **)&h_pixels, pixel_bytes, hipHostMallocDefault));
+            h_pixels_cap = pixel_bytes;
+        }
+        return JPEGENC_OK;
+    }
+    void close() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        for (auto &e : chunk_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (d_pixels) (void)hipFree(d_pixels);
+        if (d_coeffs) (void)hipFree(d_coeffs);
+        if (d_freq) (void)hipFree(d_freq);
+        if (d_hist) (void)hipFree(d_hist);
+        if (d_dc_side) (void)hipFree(d_dc_side);
+        if (h_coeffs) (void)hipHostFree(h_coeffs);
+        if (h_pixels) (void)hipHostFree(h_pixels);
+        if (h_freq) (void)hipHostFree(h_freq);
+        if (d_scan_ws) (void)hipFree(d_scan_ws);
+        if (d_scan_out) (void)hipFree(d_scan_out);
+        if (d_gather) (void)hipFree(d_gather);
+        if (d_scan_len) (void)hipFree(d_scan_len);
+        if (d_lut) (void)hipFree(d_lut);
+        if (h_scan_len) (void)hipHostFree(h_scan_len);
+        if (h_scan_out) (void)hipHostFree(h_scan_out);
+        *this = DeviceCtx();
+    }
+    ~DeviceCtx() { close(); }
+    DeviceCtx() = default;
+    DeviceCtx(const DeviceCtx &) = delete;
+    DeviceCtx &operator=(DeviceCtx &&o) = default;
+};
+
+struct Config {                      // the fields of struct Encoder, encoder.rs:213-231
+    int quality = 0;
+    int density_unit = JPEGENC_DENSITY_PIXEL_ASPECT_RATIO;   // PixelDensity::default, writer.rs:37-45
+    uint16_t density_x = 1, density_y = 1;
+    int sampling = JPEGENC_F_1_1;
+    int qtype[2] = {JPEGENC_Q_DEFAULT, JPEGENC_Q_DEFAULT};
+    uint16_t qcustom[2][64] = {};
+    int progressive_scans = 0;       // Option<u8>
+    int restart_interval = 0;        // Option<u16>
+    bool optimize = false;
+    int fdct_variant = JPEGENC_FDCT_SCALAR;
+    bool device_entropy = true;      // GPU Huffman coding of interleaved scans (same bytes as the host path)
+    int batch_round_frames = 0;      // jpegenc_encoder_set_batch_round_frames: frames of a device-resident batch in flight together (0 = by footprint)
+    std::vector<std::pair<uint8_t, std::vector<uint8_t>>> app_segments;
+};
+
+// Staging of the small-frame batch path (jpegenc_encoder_encode_batch): two rounds of frames in pinned
+// host memory and on the device, so that copying / uploading one round overlaps encoding the other.
+struct SmallBatchBuffers {
+    uint8_t *h[2] = {nullptr, nullptr};
+    void *d[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    hipStream_t up = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int reserve(size_t bytes) {
+        if (!up) {
+            JPEGENC_HIP(create_side_stream(&up));
+            for (auto &ev : done) JPEGENC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        if (bytes <= cap) return JPEGENC_OK;
+        release_buffers();
+        for (int i = 0; i < 2; i++) {
+            JPEGENC_HIP(hipHostMalloc((void **)&h[i], bytes, hipHostMallocDefault));
+            JPEGENC_HIP(hipMalloc(&d[i], bytes));
+        }
+        cap = bytes;
+        return JPEGENC_OK;
+    }
+    void release_buffers() {
+        for (int i = 0; i < 2; i++) {
+            if (h[i]) (void)hipHostFree(h[i]);
+            if (d[i]) (void)hipFree(d[i]);
+            h[i] = nullptr; d[i] = nullptr;
+        }
+        cap = 0;
+    }
+    ~SmallBatchBuffers() {
+        if (up) (void)hipStreamSynchronize(up);
+        release_buffers();
+        for (auto &ev : done) if (ev) (void)hipEventDestroy(ev);
+        if (up) (void)hipStreamDestroy(up);
+    }
+};
+
+// Buffers of the device-resident batch path (jpegenc_encoder_encode_batch_device), kept in the handle
+// across calls and only ever grown: pinned allocations of a few hundred MB cost tens of milliseconds.
+struct BatchBuffers {
+    void *d_coeffs = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_packed = nullptr;      // d_packed: a round's scans back to back
+    uint64_t *d_pos = nullptr;
+    uint32_t *d_len = nullptr, *h_len = nullptr;
+    uint8_t *h_out[2] = {nullptr, nullptr};      // two: the files of one round are assembled while the next round is coded and fetched
+    size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, packed_cap = 0, pos_cap = 0, h_out_cap[2] = {0, 0};
+    static int grow_device(void **p, size_t *cap, size_t need) {
+        if (need <= *cap) return JPEGENC_OK;
+        if (*p) (void)hipFree(*p);
+        *p = nullptr; *cap = 0;
+        JPEGENC_HIP(hipMalloc(p, need));
+        *cap = need;
+        return JPEGENC_OK;
+    }
+    void *d_plane_table = nullptr;        // batches of described planar surfaces: [frame][8] = 4 plane addresses + 4 pitches
+    uint64_t *h_plane_table = nullptr;    // its page-locked source: uploaded in stream order, no synchronisation (the batch call ends only when its work has)
+    size_t plane_table_cap = 0;
+    int reserve_plane_table(size_t bytes) {
+        if (bytes <= plane_table_cap) return JPEGENC_OK;
+        if (d_plane_table) (void)hipFree(d_plane_table);
+        if (h_plane_table) (void)hipHostFree(h_plane_table);
+        d_plane_table = nullptr; h_plane_table = nullptr; plane_table_cap = 0;
+        JPEGENC_HIP(hipMalloc(&d_plane_table, bytes));
+        JPEGENC_HIP(hipHostMalloc((void **)&h_plane_table, bytes, hipHostMallocDefault));
+        plane_table_cap = bytes;
+        return JPEGENC_OK;
+    }
+    // d_out, d_len and h_len hold TWO rounds (halves): one is downloaded while the next is coded
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t coded[2] = {nullptr, nullptr};
+    int open_streams() {
+        if (copy_stream) return JPEGENC_OK;
+        JPEGENC_HIP(create_side_stream(&copy_stream));
+        for (auto &e : coded) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return JPEGENC_OK;
+    }
+    int reserve(size_t coeffs, size_t out, size_t ws, size_t nlen) {
+        int rc = open_streams();
+        out *= 2; nlen *= 2;
+        if (!rc) rc = grow_device(&d_coeffs, &coeffs_cap, coeffs);
+        if (!rc) rc = grow_device(&d_out, &out_cap, out);
+        if (!rc) rc = grow_device(&d_ws, &ws_cap, ws);
+        if (!rc) rc = grow_device(&d_packed, &packed_cap, out + 32 * nlen);             // (+16 per segment: aligned positions)
+        if (!rc) rc = grow_device((void **)&d_pos, &pos_cap, (nlen + 2) * sizeof(uint64_t));
+        if (rc) return rc;
+        if (nlen > len_cap) {
+            if (d_len) (void)hipFree(d_len);
+            if (h_len) (void)hipHostFree(h_len);
+            d_len = nullptr; h_len = nullptr; len_cap = 0;
+            JPEGENC_HIP(hipMalloc((void **)&d_len, nlen * sizeof(uint32_t)));
+            JPEGENC_HIP(hipHostMalloc((void **)&h_len, nlen * sizeof(uint32_t), hipHostMallocDefault));
+            len_cap = nlen;
+        }
+        return JPEGENC_OK;
+    }
+    int reserve_host(size_t bytes, int which) {
+        if (bytes <= h_out_cap[which]) return JPEGENC_OK;
+        if (h_out[which]) (void)hipHostFree(h_out[which]);
+        h_out[which] = nullptr; h_out_cap[which] = 0;
+        const size_t cap = bytes + (bytes >> 2) + 4096;
+        JPEGENC_HIP(hipHostMalloc((void **)&h_out[which], cap, hipHostMallocDefault));
+        h_out_cap[which] = cap;
+        return JPEGENC_OK;
+    }
+    ~BatchBuffers() {
+        if (d_coeffs) (void)hipFree(d_coeffs);
+        if (d_out) (void)hipFree(d_out);
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_packed) (void)hipFree(d_packed);
+        if (d_plane_table) (void)hipFree(d_plane_table);
+        if (h_plane_table) (void)hipHostFree(h_plane_table);
+        if (d_pos) (void)hipFree(d_pos);
+        if (d_len) (void)hipFree(d_len);
+        if (h_len) (void)hipHostFree(h_len);
+        for (auto *h : h_out) if (h) (void)hipHostFree(h);
+        for (auto &e : coded) if (e) (void)hipEventDestroy(e);
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+    }
+};
+
+// JPEGENC_NUMA_BIND=1: the default of jpegenc_encoder_set_numa_bind (see bind_thread_near_device)
+inline bool numa_bind_default() {
+    static const bool on = getenv("JPEGENC_NUMA_BIND") != nullptr;
+    return on;
+}
+
+
+}  // namespace jpegenc
+
+using namespace jpegenc;
+
+struct jpegenc_encoder {
+    Config cfg;
+    int device = 0;
+    DeviceCtx ctx;
+    std::vector<std::unique_ptr<DeviceCtx>> workers;   // batch API: one per in-flight frame, kept across calls
+    BatchBuffers batch;                                  // device-resident batch API
+    SmallBatchBuffers small;                             // batches of small frames
+    int max_batch_workers = 16;                          // host threads of jpegenc_encoder_encode_batch
+    bool numa_bind = jpegenc::numa_bind_default();      // those threads run on the NUMA node of the device (jpegenc_encoder_set_numa_bind)
+    // jpegenc_encoder_encode_batch_multi: one child encoder per entry of `devices` (its own workers, streams,
+    // pinned staging and device buffers), kept across calls
+    std::vector<std::unique_ptr<jpegenc_encoder>> shards;
+};
+
+
+#define REQUIRE(e) do { if (!(e)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null encoder"); } while (0)
+
+namespace jpegenc {
+
+inline void sampling_hv(int sf, int *h, int *v) { *h = (sf >> 4) & 0x07; *v = sf & 0x0F; }   // encoder.rs:173-176
+
+inline bool known_sampling(int sf) {
+    switch (sf) {
+    case JPEGENC_F_1_1: case JPEGENC_F_2_1: case JPEGENC_F_1_2: case JPEGENC_F_2_2: case JPEGENC_F_4_1:
+    case JPEGENC_F_4_2: case JPEGENC_F_1_4: case JPEGENC_F_2_4: case JPEGENC_R_4_4_4: case JPEGENC_R_4_4_0:
+    case JPEGENC_R_4_4_1: case JPEGENC_R_4_2_2: case JPEGENC_R_4_2_0: case JPEGENC_R_4_2_1: case JPEGENC_R_4_1_1:
+    case JPEGENC_R_4_1_0: return true;
+    }
+    return false;
+}
+
+struct Tables {
+    jpegenc_qtable q[2];
+    HuffTable h[2][2];               // [destination][0 = DC, 1 = AC]
+};
+
+
+enum Mode { MODE_INTERLEAVED, MODE_SEQUENTIAL, MODE_PROGRESSIVE };
+inline Mode select_mode(const Config &c) {                    // encoder.rs:556-562
+    int h, v;
+    sampling_hv(c.sampling, &h, &v);
+    if (c.progressive_scans) return MODE_PROGRESSIVE;
+    const bool interleavable = (h == 1 || h == 2) && (v == 1 || v == 2);   // supports_interleaved :178-187
+    return (c.optimize || !interleavable) ? MODE_SEQUENTIAL : MODE_INTERLEAVED;
+}
+
+// ---- host_emit.cpp: markers, Huffman tables, the host entropy coder --------------------------------------------------------
+void default_huffman(Tables &t);
+void write_prologue(Out &o, const Config &c, int jct);
+void write_frame_header(Out &o, const Config &c, int width, int height, const jpegenc_layout &L, const Tables &t);
+void write_scan_header(Out &o, const jpegenc_layout &L, int first, int n, int ss, int se);
+// headers + entropy coding of coefficients that are (or arrive) in host memory; wait(k) returns once piece k is there
+int emit_host_coded(const Config &c, int jct, int width, int height, const jpegenc_layout &L, Tables &t, Mode mode, bool optimize,
+                    const int16_t *coeffs, const uint32_t *freq, int nchunks, const uint64_t *chunk_end_mcu, const std::function<int(int)> &wait,
+                    jpegenc_write_fn sink, void *user);
+void host_histogram(const jpegenc_layout &L, int progressive_scans, const int16_t *coeffs, uint32_t freq[2 * 2 * 257]);
+int validate_image(size_t len, int width, int height, int color_type);
+
+// ---- host_frame.cpp: one frame on the device ---------------------------------------------------------------------------------
+// the library's own sink (jpegenc_encoder_encode_to_buffer and friends): encode_frame recognises it and lets the DMA write
+// large scans straight into the caller's buffer
+struct BufferSink {
+    uint8_t *out;
+    size_t cap, len;
+};
+int buffer_sink(void *user, const uint8_t *data, size_t n);
+// The whole of encode_image_internal for one frame; `upload` copies the source into ctx.d_pixels on ctx.stream.
+int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,
+                 const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user);
+int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *data, size_t len, int width, int height, int color_type,
+                  jpegenc_write_fn sink, void *user, bool staged = false);
+
+// ---- host_batch.cpp: device-resident batches --------------------------------------------------------------------------------
+// encode_device_batch returns this (before any device work) for frames whose scans the device entropy coder declines
+// (32-bit bit offsets: about 2.45 M blocks and more); the caller then encodes frame by frame, where encode_frame
+// hands such scans to the host coder - same bytes.
+constexpr int kBatchNeedsPerFrame = -1000;
+// A batch of described planar surfaces (jpegenc_encoder_encode_planes_batch_device): every frame's planes share pitch, sample
+// stride and inversion (planes = frame 0's descriptors with each component's largest pitch); every frame's plane addresses and pitches are a device table [frame][8].
+struct PlaneBatch { const jpegenc_plane *planes; bool subsampled; const uint64_t *d_table; int jct; };
+int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b, int device, const void *d_frames, size_t frame_stride, int num_frames,
+                        int width, int height, int color_type, jpegenc_write_fn sink, void *const *users, const PlaneBatch *pb = nullptr);
+
+// ---- host_multi.cpp ------------------------------------------------------------------------------------------------------------
+void bind_thread_near_device(int device, bool on);            // (opt-in) the calling thread onto the NUMA node of the device
+
+}  // namespace jpegenc

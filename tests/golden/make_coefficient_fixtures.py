@@ -8,7 +8,7 @@ transforms, its own Annex-K table construction; no code, structure or table shar
 NOT by the C oracle that the tests use as their checker: so `test_oracle_reproduces_the_committed_coefficient_fixtures`
 (C oracle vs this file) and `test_golden_coefficient_fixtures` (HIP path vs this file) each compare against a SECOND
 reading of the source, not against the checker's own output.  The arrays that have a SHA-256 anchor in SURVEY.md
-Appendix A (five of the twelve) are re-checked against it by the CPU test.  The reference itself (Rust) cannot run in
+Appendix A (seven of the twelve) are re-checked against it by the CPU test.  The reference itself (Rust) cannot run in
 this image.  The file holds numbers only and travels to the GPU box.
 """
 import os

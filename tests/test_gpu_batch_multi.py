@@ -122,7 +122,7 @@ def test_encode_batch_multi_shards(binding, c3, devices):
 
 def test_encode_batch_multi_on_distinct_devices(binding, c3):
     """One process driving SEVERAL GPUs (skipped on the one-GPU boxes): every device of the node gets its own child encoder,
-    worker set, streams, pinned staging and default code tables (jpegenc_encoder_encode_batch_multi, host_encoder.cpp) - the
+    worker set, streams, pinned staging and default code tables (jpegenc_encoder_encode_batch_multi, host_multi.cpp) - the
     125-frame shard size of config 3 per device, the files compared with the oracle's, twice (the second pass replays the
     captured launch sequences of every device), then with the worker threads bound to each device's NUMA node."""
     n_dev = min(binding.device_count(), 8)

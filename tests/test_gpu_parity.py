@@ -408,6 +408,47 @@ def test_encoder_simd_variant_file(binding, oracle, synth):
     assert e.encode(px, 96, 80, binding.RGB) == oracle.encode_jpeg(px, 96, 80, oracle.RGB, 95, variant=oracle.FDCT_SIMD)
 
 
+def test_simd_variant_every_fused_layout(binding, oracle, synth):
+    """Deterministic sweep of the SIMD-variant (VARIANT = 1) instantiations of the pixels -> bits kernel: every ColorType it takes x
+    the sampling factors 1 and 2, and described planes (I420-style and full-resolution).  These are the instantiations that
+    spill SGPRs - the combination with VGPR spills is what hipcc 7.2 mis-compiled (fused_kernel_impl.hip.h; build.sh runs
+    tools/check_spills.py) - so each one gets a byte-for-byte file check of its own, not only the randomised sweeps' samples."""
+    import torch
+    w, h = 200, 136
+    for ct, bpp, name in ((binding.RGB, 3, "RGB"), (binding.RGBA, 4, "RGBA"), (binding.BGR, 3, "BGR"), (binding.BGRA, 4, "BGRA"),
+                          (binding.YCBCR, 3, "YCBCR"), (binding.CMYK, 4, "CMYK"), (binding.CMYK_AS_YCCK, 4, "CMYK_AS_YCCK"), (binding.YCCK, 4, "YCCK")):
+        px = synth.lcg_image(w, h, bpp, 31 + bpp)
+        px = (px.astype(np.int16) // 3 + np.add.outer(np.arange(h), np.arange(w))[..., None] // 2).clip(0, 255).astype(np.uint8)
+        for hs, vs in ((1, 1), (2, 1), (1, 2), (2, 2)):
+            for restart in (0, 5):
+                e = binding.Encoder(88)
+                e.set_sampling_factor(binding.sampling_factor(hs, vs))
+                e.set_fdct_variant(binding.FDCT_SIMD)
+                if restart:
+                    e.set_restart_interval(restart)
+                want = oracle.encode_jpeg(px, w, h, getattr(oracle, name), 88, sampling=(hs, vs), variant=oracle.FDCT_SIMD,
+                                          restart_interval=restart)
+                for _ in range(3):                                   # direct, captured, replayed
+                    assert e.encode(px, w, h, ct) == want, (name, hs, vs, restart)
+    # described planes: 4:2:0 with subsampled chroma planes (I420) and three full-resolution planes (4:4:4)
+    rng = np.random.default_rng(5)
+    smooth = lambda a: (a.astype(np.int16) // 4 + np.add.outer(np.arange(a.shape[0]), np.arange(a.shape[1])) // 3).clip(0, 255).astype(np.uint8)
+    for hs, vs in ((2, 2), (1, 1)):
+        cw, ch = -(-w // hs), -(-h // vs)
+        y = smooth(rng.integers(0, 256, (h, w), dtype=np.uint8))
+        cb = smooth(rng.integers(0, 256, (ch, cw), dtype=np.uint8))
+        cr = smooth(rng.integers(0, 256, (ch, cw), dtype=np.uint8))
+        up = lambda c: np.repeat(np.repeat(c, vs, axis=0), hs, axis=1)[:h, :w]
+        full = np.stack([y, up(cb), up(cr)], axis=-1)
+        d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (y, cb, cr)]
+        e = binding.Encoder(88)
+        e.set_sampling_factor(binding.sampling_factor(hs, vs))
+        e.set_fdct_variant(binding.FDCT_SIMD)
+        got = e.encode_planes_device(binding.J_YCBCR, w, h, [(d[0].data_ptr(), w, 1, 0), (d[1].data_ptr(), cw, 1, 0), (d[2].data_ptr(), cw, 1, 0)],
+                                     planes_subsampled=(hs, vs) != (1, 1))
+        assert got == oracle.encode_jpeg(full, w, h, oracle.YCBCR, 88, sampling=(hs, vs), variant=oracle.FDCT_SIMD), (hs, vs)
+
+
 def test_encoder_reuse_and_size_changes(binding, oracle, synth):
     """One handle, several images of different geometry (device buffers regrow)."""
     e = binding.Encoder(75)
