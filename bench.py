@@ -541,7 +541,7 @@ def main():
                 algo = Fd * (W * H * 3.0 + scan_bytes)
                 ach = algo / (ms_per_call * 1e-3) / 1e9
                 return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                        "algorithmic_bytes_per_call": int(algo), "limited_by": "VALU issue of conversion + FDCT + symbol walk, not bytes"}
+                        "algorithmic_bytes_per_call": int(algo), "limited_by": "instruction issue (all types, ~0.9 per cycle and SIMD: SQ counters, profiles/README.md) of conversion + FDCT + symbol loop, not bytes"}
 
             def leg(px):
                 ms = timed(one_kernel, px)

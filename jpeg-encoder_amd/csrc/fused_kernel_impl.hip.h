@@ -35,7 +35,7 @@ static_assert(kGPriv == 16, "StripOr finds a strip's word with a 4-bit field of 
 __host__ __device__ inline uint32_t group_lds_bytes(uint32_t bpm) {
     // strips (16 words per lane: 4 KiB per wave, 4 KiB-aligned) | one row that takes what the last wave's overflowing strips spill |
     // coefficient images, then the run's window (2 048 words per wave) | code tables | lengths | DCs | flags
-    return bpm * kGPriv * 64u * 4u + kGSpillBytes + bpm * kGImageWords * 4u + kLoopLutBytes + bpm * 64u * 2u + bpm * 64u * 2u + 16u;
+    return bpm * kGPriv * 64u * 4u + kGSpillBytes + bpm * kGImageWords * 4u + kLoopLutBytes + bpm * 64u * 2u + bpm * 64u * 2u + 64u;
 }
 
 template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
@@ -47,36 +47,33 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     uint32_t *strips = reinterpret_cast<uint32_t *>(smem);
     uint32_t *window = strips + bpm * kGPriv * 64u + kGSpillBytes / 4u;          // first: every wave's coefficient image
     uint8_t *lut_bytes = reinterpret_cast<uint8_t *>(window + bpm * kGImageWords);
-    u32x2 *lut = reinterpret_cast<u32x2 *>(lut_bytes);
     uint16_t *lens = reinterpret_cast<uint16_t *>(lut_bytes + kLoopLutBytes);
     int16_t *dcs = reinterpret_cast<int16_t *>(lens + bpm * 64u);
-    uint32_t *flags = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);              // [0]: a block outgrew its strip, [1]: bits of the run (only summed for a lowered window)
+    uint32_t *flags = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);              // per wave: [w] a block outgrew its strip, [8 + w] AC bits of its blocks (only summed for a lowered window); stored, never zeroed
     const uint32_t tid = threadIdx.x, grp = blockIdx.x, f = blockIdx.y;
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- (0) the code tables (k_build_lut leaves them in LDS form behind the first one: 544 entries of 8 bytes over 192 ... 384
-    // threads), zeroed strips ---------------------------------------------------------------------------------------------
+    // ---- (0) the code tables, by LDS DMA and by every wave FOR ITSELF (k_build_lut leaves them in LDS form behind the first
+    // tables: 272 chunks of 16 bytes, five global_load_lds_dwordx4 per wave): no register holds them while block_compute runs,
+    // and no barrier stands between a wave and its pixel loads - a wave waits for its own copies (long there) before its walk,
+    // the other waves write the same bytes.  (Loaded and stored once per workgroup the tables needed a barrier here, and every
+    // wave sat out their round trip before it could ask for a pixel.)  Each wave zeroes its own strips.
     {
-        typedef const __attribute__((address_space(1))) u32x2 *hbm_entries;
-        const hbm_entries compact = (hbm_entries)(p.lut + kLutWords);
-        u32x2 lutv[3];
+        typedef __attribute__((address_space(1))) const uint8_t *gsrc;
+        typedef __attribute__((address_space(3))) void *lds_dst;
+        const gsrc compact = (gsrc)(p.lut + kLutWords);
+        const uint32_t l = tid & 63u;
+        // (the strips first: the compiler orders every LDS store issued AFTER an LDS DMA behind its completion)
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const uint32_t e = (uint32_t)i * nthreads + tid;
-            lutv[i] = compact[min(e, kLoopLutEntries - 1u)];
+        for (uint32_t i = 0; i < kGPriv / 4u; i++) reinterpret_cast<uint4 *>(strips + wave_id * kGPriv * 64u)[i * 64u + l] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t i = 0; i < (kLoopLutBytes + 1023u) / 1024u; i++) {
+            if (i * 64u + l < kLoopLutBytes / 16u)
+                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void *)(compact + (size_t)(i * 64u + l) * 16u), (lds_dst)(lut_bytes + i * 1024u), 16, 0, 0);
         }
         const uint32_t gid = grp * nthreads + tid;
         if (gid < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + gid] = 0;      // k_push adds its 0xFF counts to these
-#pragma unroll
-        for (uint32_t i = 0; i < kGPriv / 4u; i++) reinterpret_cast<uint4 *>(strips)[i * nthreads + tid] = make_uint4(0, 0, 0, 0);
-        if (tid < 2u) flags[tid] = 0;
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const uint32_t e = (uint32_t)i * nthreads + tid;
-            if (e < kLoopLutEntries) lut[e] = lutv[i];
-        }
     }
-    __syncthreads();
 
     // ---- the block kernel's wave: this lane's 64 quantised zig-zag coefficients -> LDS image + non-zero mask -------------
     typedef __attribute__((address_space(3))) uint8_t *lds_bytes;
@@ -134,17 +131,18 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     const uint32_t image_at = (uint32_t)(uintptr_t)(lds_bytes)(smem) + bpm * kGPriv * 256u + kGSpillBytes + wave_id * kGImageWords * 4u + lane * 4u;
     lds_word *strip = (lds_word *)(strips + wave_id * kGPriv * 64u) + lane;
     uint32_t ac_bits = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // this wave's copies of the code tables (issued before its pixel loads) are in LDS
     const bool zero_runs = __builtin_amdgcn_ballot_w64(has_long_zero_run(mask, 1u)) != 0;     // wave-uniform
     if (mine_valid) {
         StripOr so = {(uint32_t)(uintptr_t)strip, 32u * 8u};
         walk_nonzeros(mask, 1u, 64u, image_at, ac_table, so, zero_runs);
         ac_bits = so.bits() - 32u;
     }
-    if (ac_bits > (kGPriv - 1u) * 32u) __hip_atomic_fetch_or((lds_word *)flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const bool lowered_window = p.window_words < kGWin;                          // (the tests' way to the second walk: then the run's length matters too)
-    if (lowered_window) {
-        const uint32_t wave_bits = wave_sum(ac_bits);
-        if (lane == 0) __hip_atomic_fetch_add((lds_word *)(flags + 1), wave_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    {
+        const bool outgrown = __builtin_amdgcn_ballot_w64(ac_bits > (kGPriv - 1u) * 32u) != 0;
+        const uint32_t wave_bits = lowered_window ? wave_sum(ac_bits) : 0u;
+        if (lane == 0) { flags[wave_id] = outgrown ? 1u : 0u; flags[8u + wave_id] = wave_bits; }
     }
     int pred_first = 0;
     if (need_pred) {
@@ -156,7 +154,13 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
 
     // whether the run goes through the window: decided here (workgroup-uniform) because the window takes the images' place
     // (a run whose strips all hold cannot outgrow the full window: at most 15 * 32 + 27 of its 1 024 bits per block)
-    const bool fits = flags[0] == 0u && (!lowered_window || ((flags[1] + 64u * bpm * kGDcBits + 31u) >> 5) + 4u <= p.window_words * bpm);   // (+4: the zero word, 16-byte copies)
+    uint32_t any_outgrown = 0, run_ac_bits = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 6u; j++) {
+        any_outgrown |= j < bpm ? flags[j] : 0u;
+        run_ac_bits += j < bpm ? flags[8u + j] : 0u;
+    }
+    const bool fits = any_outgrown == 0u && (!lowered_window || ((run_ac_bits + 64u * bpm * kGDcBits + 31u) >> 5) + 4u <= p.window_words * bpm);   // (+4: the zero word, 16-byte copies)
     if (fits) {
 #pragma unroll
         for (uint32_t i = 0; i < kGImageWords / 256u; i++) reinterpret_cast<uint4 *>(window)[i * nthreads + tid] = make_uint4(0, 0, 0, 0);

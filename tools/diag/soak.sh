@@ -14,8 +14,14 @@ run small_a JPEGENC_FUZZ_SEED=$((S + 1)) JPEGENC_FUZZ_TRIALS=20000
 run small_b JPEGENC_FUZZ_SEED=$((S + 2)) JPEGENC_FUZZ_TRIALS=20000
 run medium JPEGENC_FUZZ_SEED=$((S + 5)) JPEGENC_FUZZ_TRIALS=6000 JPEGENC_FUZZ_MAX_W=700 JPEGENC_FUZZ_MAX_H=500
 run large JPEGENC_FUZZ_SEED=$((S + 3)) JPEGENC_FUZZ_TRIALS=1500 JPEGENC_FUZZ_MAX_W=2100 JPEGENC_FUZZ_MAX_H=1300
-run two_kernels JPEGENC_FUSED=0 JPEGENC_FUZZ_SEED=$((S + 4)) JPEGENC_FUZZ_TRIALS=6000
-run dma_only JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES=0 JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES=0 JPEGENC_FUZZ_SEED=$((S + 6)) JPEGENC_FUZZ_TRIALS=6000
+# (the switches below exist in the diagnostic build only: diag_env.h)
+DIAG=$PWD/jpeg-encoder_amd/libjpegenc_mi355x_diag.so
+run two_kernels JPEGENC_LIB=$DIAG JPEGENC_FUSED=0 JPEGENC_FUZZ_SEED=$((S + 4)) JPEGENC_FUZZ_TRIALS=6000
+run dma_only JPEGENC_LIB=$DIAG JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES=0 JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES=0 JPEGENC_FUZZ_SEED=$((S + 6)) JPEGENC_FUZZ_TRIALS=6000
+# the pixels -> bits kernel's second walk (runs coded again chunk by chunk out of the LDS images): every workgroup takes it with a
+# window of 8 words per wave, chunks of 8 x bpm words
+run tiny_window JPEGENC_LIB=$DIAG JPEGENC_PACK_WINDOW_WORDS=8 JPEGENC_FUZZ_SEED=$((S + 8)) JPEGENC_FUZZ_TRIALS=6000
+run tiny_window_medium JPEGENC_LIB=$DIAG JPEGENC_PACK_WINDOW_WORDS=20 JPEGENC_FUZZ_SEED=$((S + 9)) JPEGENC_FUZZ_TRIALS=2000 JPEGENC_FUZZ_MAX_W=700 JPEGENC_FUZZ_MAX_H=500
 ( JPEGENC_FUZZ_SEED=$((S + 7)) JPEGENC_FUZZ_TRIALS=4000 timeout 1200 python3 -m pytest tests/test_gpu_batch_multi.py -q -x -k test_randomised_planar_sources 2>&1 | tail -2 ) > $out/${tag}_soak_planar.log 2>&1
 tail -1 $out/${tag}_soak_planar.log
 ( JPEGENC_FUZZ_SEED=9 JPEGENC_GEOMETRY_TRIALS=1500 timeout 1200 python3 -m pytest tests/test_gpu_parity.py -q -x -k test_blocks_random_geometry 2>&1 | tail -2 ) > $out/${tag}_soak_geometry.log 2>&1
