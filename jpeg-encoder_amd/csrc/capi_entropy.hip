@@ -279,6 +279,12 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
         p.slot_words = fused_slot_words(*fused->blocks, pl.slot_words);
         if ((uint64_t)p.nwaves * p.slot_words > (uint64_t)pl.max_waves * pl.slot_words) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "scan workspace too small for the fused kernel's runs");
         if (p.nwaves > pl.max_waves) return fail(JPEGENC_ERR_BUFFER_TOO_SMALL, "scan workspace too small for the fused kernel's runs");
+        // one frame, no restart markers, every workgroup resident at once: the kernel finishes the scan itself
+        if (fused->chain && fused->finish_abort && frames == 1 && p.nintervals == 1 && p.nwaves <= kFinishMaxRuns) {
+            p.chain = fused->chain;
+            p.finish_abort = fused->finish_abort;
+            p.finish_done = fused->finish_done;
+        }
     }
     *d_params_out = (EntropyParams *)(ws + pl.off_params);
     return JPEGENC_OK;

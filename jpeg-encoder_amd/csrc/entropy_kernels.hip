@@ -824,6 +824,7 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
         e = fused->planes ? launch_group_planes(*fused->blocks, fused->planes, fused->planes_subsampled, d_params, frames, fused->variant, st)
                           : launch_fused_code(*fused->blocks, d_params, restart, frames, fused->variant, st);
         if (e != hipSuccess) return e;
+        if (jobs[0].chain) return hipGetLastError();          // the kernel finished the scan itself (finish_run.hip.h)
     } else {
         hipLaunchKernelGGL(k_block_code, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
     }

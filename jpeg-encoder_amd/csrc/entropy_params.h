@@ -9,6 +9,9 @@ namespace jpegenc {
 #endif
 constexpr uint32_t kPackWindowWords = JPEGENC_PACK_WINDOW;      // words of LDS per wave of the bit packer
 constexpr uint32_t kFusedPrefixRuns = 2048, kFusedPrefixTiles = 8192;   // runs / (worst-case) tiles up to which the prefix sums are folded into their consumers
+constexpr uint32_t kFinishMaxRuns = 1024;                        // runs up to which the pixels -> bits kernel finishes the scan itself (finish_run.hip.h): every workgroup resident at once
+constexpr uint32_t kFinishTimingAt = 2u * kFinishMaxRuns + 16u;  // (diagnostic build) 16 time stamps per workgroup, the first 64 workgroups
+constexpr uint32_t kFinishChainWords = kFinishTimingAt + 64u * 16u; // its look-back words: [runs] lengths, [runs] 0xFF counts, the count of finished workgroups
 constexpr uint32_t kMaxScansPerLaunch = 16;                      // scans coded by one launch sequence (blockIdx.z)
 // Device memory of one set of Huffman code tables (k_build_lut): [destination][0 = DC, 1 = AC][256 symbols] = size << 16 | code,
 // followed by the same tables the way the pixels -> bits kernel keeps them in LDS (entropy_loop.hip.h: 2 x (16 + 256) entries
@@ -87,6 +90,10 @@ struct EntropyParams {
     uint8_t *out;                    // [frames][out_stride]   stuffed segment incl. RSTn markers
     uint64_t out_stride;
     uint32_t *out_bytes;             // [frames] its length
+    // the pixels -> bits kernel finishing the scan itself (finish_run.hip.h; one frame, no restart markers, <= kFinishMaxRuns runs)
+    uint32_t *chain;                 // kFinishChainWords of device memory, zero between launches; nullptr = the ordinary sequence
+    uint32_t *finish_abort;          // pinned host word: set when a workgroup gave up waiting (the host then codes the frame again)
+    uint32_t *finish_done;           // pinned host word (or nullptr): set to 1 once every byte of the scan and its length are in host memory
 };
 
 }  // namespace jpegenc

@@ -9,6 +9,7 @@
 #include "diag_env.h"
 #include "entropy_loop.hip.h"
 #include "fast_kernel_impl.hip.h"
+#include "finish_run.hip.h"
 
 namespace jpegenc {
 
@@ -52,6 +53,13 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     uint32_t *flags = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);              // per wave: [w] a block outgrew its strip, [8 + w] AC bits of its blocks (only summed for a lowered window); stored, never zeroed
     const uint32_t tid = threadIdx.x, grp = blockIdx.x, f = blockIdx.y;
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool finish = p.chain != nullptr;                                      // the workgroups put the scan together themselves (finish_run.hip.h)
+#ifdef JPEGENC_DIAG          // tools/diag/small_frame_timeline.sh: where a workgroup's time goes (100 MHz clock), thread 0 of the first 64 workgroups
+#define JPEGENC_STAMP(i) do { if (finish && tid == 0 && grp < 64u) p.chain[kFinishTimingAt + grp * 16u + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define JPEGENC_STAMP(i) do { } while (0)
+#endif
+    JPEGENC_STAMP(0);
 
     // ---- (0) the code tables, by LDS DMA and by every wave FOR ITSELF (k_build_lut leaves them in LDS form behind the first
     // tables: 272 chunks of 16 bytes, five global_load_lds_dwordx4 per wave): no register holds them while block_compute runs,
@@ -72,7 +80,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
                 __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void *)(compact + (size_t)(i * 64u + l) * 16u), (lds_dst)(lut_bytes + i * 1024u), 16, 0, 0);
         }
         const uint32_t gid = grp * nthreads + tid;
-        if (gid < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + gid] = 0;      // k_push adds its 0xFF counts to these
+        if (!finish && gid < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + gid] = 0;      // k_push adds its 0xFF counts to these
     }
 
     // ---- the block kernel's wave: this lane's 64 quantised zig-zag coefficients -> LDS image + non-zero mask -------------
@@ -90,6 +98,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         mask = mine_valid ? nonzero_mask(r.c) : 0ull;
         my_dc = mine_valid ? (int)(int16_t)(r.c[0] & 0xFFFFu) : 0;
     }
+    JPEGENC_STAMP(1);
     const u32x16 Wv = w.Wv;
     // (the lane number is taken afresh here - two v_mbcnt - so that nothing of the workgroup's bookkeeping has to stay in a
     // register across block_compute: the byte-plane instantiations with decimation sat at the 96-register budget and spilled)
@@ -138,6 +147,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         walk_nonzeros(mask, 1u, 64u, image_at, ac_table, so, zero_runs);
         ac_bits = so.bits() - 32u;
     }
+    JPEGENC_STAMP(2);
     const bool lowered_window = p.window_words < kGWin;                          // (the tests' way to the second walk: then the run's length matters too)
     {
         const bool outgrown = __builtin_amdgcn_ballot_w64(ac_bits > (kGPriv - 1u) * 32u) != 0;
@@ -151,6 +161,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         pred_first = __builtin_amdgcn_readfirstlane(dot2((uint32_t)v, qc[0], (int)qc[1]) >> 16);   // natural coefficient 0
     }
     __syncthreads();                                                             // (1) DCs posted, every AC walk done: the images are dead
+    JPEGENC_STAMP(3);
 
     // whether the run goes through the window: decided here (workgroup-uniform) because the window takes the images' place
     // (a run whose strips all hold cannot outgrow the full window: at most 15 * 32 + 27 of its 1 024 bits per block)
@@ -186,6 +197,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     strip[0] = head;                                                             // (stored, not OR-ed: a neighbour's overflowing strip may have spilt into it)
     if (mcu_local < 64u) lens[s] = (uint16_t)mine;
     __syncthreads();                                                             // (2) lengths posted, window zeroed
+    JPEGENC_STAMP(4);
 
     // ---- bit offset of every block in the run: each wave adds up the MCUs itself (lane = MCU) ----------------------------
     // (fixed trip counts - fused_supported admits at most 6 blocks per MCU - so that the twelve LDS reads are issued together and
@@ -208,15 +220,16 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     const uint32_t upto = wave_inclusive_dpp(mcu_bits);
     const uint32_t total = (uint32_t)__shfl((int)upto, 63);
     at += (uint32_t)__shfl((int)(upto - mcu_bits), (int)(mcu_local & 63u));
-    if (tid == 0) p.wsum[(size_t)f * p.nwaves + grp] = total;
+    if (tid == 0 && !finish) p.wsum[(size_t)f * p.nwaves + grp] = total;
     if (p.nintervals > 1u && mine_valid) p.bits[(size_t)f * p.nblocks + (size_t)group_first * bpm + s] = at;   // (interval offsets need them, k_interval_len)
     const uint32_t nwords = (total + 31u) >> 5;
     uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)grp * p.slot_words;
     if (fits) {
         strip_to_window_from(strip, from, mine, at, (lds_word *)window);
         __syncthreads();                                                         // (3) the run is complete
-        for (uint32_t i = tid * 4u; i <= nwords; i += nthreads * 4u)
-            *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(window + i);
+        if (!finish)
+            for (uint32_t i = tid * 4u; i <= nwords; i += nthreads * 4u)
+                *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(window + i);
     } else {
         // A block longer than its strip (quality 95 and up) or a run longer than the window: the images are still there, so
         // the run is coded again chunk by chunk - every lane whose block reaches into the chunk walks its symbols a second
@@ -239,6 +252,10 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
             __syncthreads();
         }
     }
+    // the strips (dead by now) stage the stuffed bytes, the flags the workgroup's few shared words
+    JPEGENC_STAMP(5);
+    if (finish) finish_run(p, grp, tid, nthreads, fits ? window : slot, total, reinterpret_cast<uint8_t *>(strips), flags);
+    JPEGENC_STAMP(9);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------

@@ -56,7 +56,11 @@ hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_pla
 // scan again and again (an Encoder fed frames of one geometry) skips the store launch
 hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, hipStream_t stream, std::string *stored);
 // fused_kernels.hip: the Encoder's interleaved baseline scan coded straight from the pixels (no coefficients in HBM)
-struct FusedSource { const BlockKernelParams *blocks; int variant; const jpegenc_plane *planes; bool planes_subsampled; };   // planes: a described planar source (else null)
+struct FusedSource {
+    const BlockKernelParams *blocks; int variant; const jpegenc_plane *planes; bool planes_subsampled;   // planes: a described planar source (else null)
+    uint32_t *chain = nullptr, *finish_abort = nullptr;      // both set: the kernel may finish the scan itself (finish_run.hip.h) where the scan qualifies
+    uint32_t *finish_done = nullptr;                         // (the scan goes to pinned host memory) the host word the kernel sets when all of it is there
+};
 bool fused_supported(const BlockKernelParams &b);      // the layout has a fused kernel (interleaved order, 3 to 6 blocks per MCU, sampling factors 1 and 2)
 bool fused_enabled();                                    // the Encoder uses it (default; JPEGENC_FUSED=0 keeps block kernel + k_block_code)
 uint32_t fused_run_blocks(const BlockKernelParams &b);

@@ -36,6 +36,8 @@ void staging_copy(void *dst, const void *src, size_t n) {
 // sequence runs (choose_replay: launch by launch, captured into a hipGraph, or replayed), the launches themselves
 // (begin_sequence, enqueue_blocks_and_statistics, enqueue_scans, launch_and_wait) and what comes back
 // (emit_device_coded: compressed bytes; collect_host_coded: coefficients for the host coder).
+constexpr int kFinishGaveUp = -1001;        // (internal) launch_and_wait: code the frame again through the ordinary sequence
+
 struct FrameRun {
     struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap, ws_off, ws; };
     enum How { DIRECT, CAPTURE, REPLAY };
@@ -51,6 +53,7 @@ struct FrameRun {
     const size_t pixel_bytes;
     const jpegenc_write_fn sink;
     void *const user;
+    const bool allow_finish;            // the pixels -> bits kernel may finish the scan itself (off for the second attempt after it gave up)
 
     Tables t;
     Mode mode = MODE_INTERLEAVED;
@@ -60,6 +63,7 @@ struct FrameRun {
     BlockKernelParams p;
     bool optimize = false;
     FusedSource fused_src = {};
+    bool self_finishing = false;        // ... and its workgroups put the scan together themselves: the launch sequence is that one kernel
     bool fused = false;                 // interleaved baseline scan of an RGB-family image: ONE kernel from the pixels to the coded runs
     std::vector<Job> jobs;
     bool supported = false;
@@ -76,9 +80,9 @@ struct FrameRun {
     time_point t_begin, t_launched, t_len;
 
     FrameRun(const Config &c_, DeviceCtx &ctx_, int jct_, int width_, int height_, int color_type_or_planes_, size_t pixel_bytes_,
-             jpegenc_write_fn sink_, void *user_)
+             jpegenc_write_fn sink_, void *user_, bool allow_finish_)
         : c(c_), ctx(ctx_), jct(jct_), width(width_), height(height_), color_type_or_planes(color_type_or_planes_), pixel_bytes(pixel_bytes_),
-          sink(sink_), user(user_) {}
+          sink(sink_), user(user_), allow_finish(allow_finish_) {}
     static time_point now() { return std::chrono::steady_clock::now(); }
     static long us(time_point a, time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); }
 
@@ -114,6 +118,11 @@ struct FrameRun {
         // interleaved baseline scan of an RGB-family image: ONE kernel goes from the pixels to the entropy-coded runs
         // (fused_kernels.hip); the coefficients never reach HBM
         fused_src = FusedSource{&p, c.fdct_variant, ctx.external_planes, ctx.external_planes_subsampled};
+        // (a frame of few runs without restart markers: the kernel's workgroups put the scan together themselves, two launches
+        // less - finish_run.hip.h; JPEGENC_NO_FINISH=1 in the diagnostic build keeps the ordinary sequence)
+        static const bool finish_off = JPEGENC_DIAG_ENV("JPEGENC_NO_FINISH") != nullptr;
+        if (allow_finish && !finish_off) { fused_src.chain = ctx.d_chain; fused_src.finish_abort = (uint32_t *)ctx.h_words; }
+        self_finishing = false;
         fused = false;
         t_begin = now();
         return JPEGENC_OK;
@@ -186,6 +195,10 @@ struct FrameRun {
         }
         if (!gather) gather = ctx.d_gather;
         host_gather = gather != ctx.d_gather;
+        // (fill_scan's condition for the kernel finishing the scan itself)
+        self_finishing = fused && fused_src.chain && !c.restart_interval && fused_runs(p) <= kFinishMaxRuns;
+        static const bool poll_off = JPEGENC_DIAG_ENV("JPEGENC_NO_DONE_FLAG") != nullptr;
+        if (self_finishing && host_gather && !poll_off) fused_src.finish_done = (uint32_t *)(ctx.h_words + 2);
         return rc;
 
     }
@@ -199,10 +212,12 @@ struct FrameRun {
         // single-scan frames use it.  (JPEGENC_NO_GRAPH=1 disables it.)
         static const bool graphs_off = JPEGENC_DIAG_ENV("JPEGENC_NO_GRAPH") != nullptr;
         how = DIRECT;
-        if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1) {
+        // (a frame whose one kernel finishes the scan itself is launched directly: replaying a one-kernel graph costs 6 us on the
+        // host where the launch costs 3, and more on the GPU's side - 256x256: 51 -> 42 us per call, 1080p: 182 -> 175)
+        if (c.device_entropy && supported && !optimize && !graphs_off && jobs.size() == 1 && !self_finishing) {
             std::string key;
             auto put = [&](const void *v, size_t n) { key.append((const char *)v, n); };
-            const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, gather, ctx.h_scan_out};
+            const void *ptrs[] = {p.pixels, ctx.d_coeffs, ctx.d_scan_out, ctx.d_scan_ws, ctx.d_scan_len, ctx.d_lut, gather, ctx.h_scan_out, fused_src.chain};
             const int64_t vals[] = {width, height, color_type_or_planes, (int64_t)pixel_bytes, order, c.fdct_variant, c.sampling,
                                     c.progressive_scans, c.restart_interval, (int64_t)ctx.d_scan_ws_cap, (int64_t)jobs.size(), (int64_t)fused};
             put(ptrs, sizeof ptrs); put(vals, sizeof vals); put(t.q, sizeof t.q);
@@ -250,6 +265,8 @@ struct FrameRun {
                                    (uint32_t *)gather, ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.stream, &ctx.stored_scan_params, fused ? &fused_src : nullptr);
             if (rc) return rc;
         }
+        ctx.h_words[0] = 0;                                          // nothing has given up
+        ctx.h_words[2] = 0;                                          // the scan is not in host memory
         if (how == CAPTURE) JPEGENC_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal));
         capture_guard.st = ctx.stream;
         capture_guard.active = how == CAPTURE;
@@ -382,8 +399,42 @@ struct FrameRun {
         }
         if (how != DIRECT) JPEGENC_HIP(hipGraphLaunch(ctx.graph_exec, ctx.stream));
         t_launched = now();
-        JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+        bool announced = false;
+        if (fused_src.finish_done) {                                 // the kernel says when the scan is in host memory (finish_run.hip.h)
+            const time_point give_up = t_launched + std::chrono::milliseconds(2);
+            for (uint32_t spins = 0; !(announced = ctx.h_words[2] != 0); spins++) {
+                _mm_pause();
+                if ((spins & 1023u) == 1023u && now() > give_up) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            // (the stream itself is then not waited for: what follows on it is ordered behind the kernel anyway.  Every 256th
+            // frame it is, so that the runtime's bookkeeping of launches it was never asked about stays short.)
+            if (announced && ++ctx.unsynchronised >= 256u) announced = false;
+        }
+        if (!announced) {
+            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            ctx.unsynchronised = 0;
+        }
         t_len = now();
+#ifdef JPEGENC_DIAG
+        if (fused && fused_src.chain && getenv("JPEGENC_GROUP_TIMELINE")) {             // tools/diag/small_frame_timeline.sh
+            uint32_t tm[64 * 16];
+            JPEGENC_HIP(hipMemcpy(tm, ctx.d_chain + kFinishTimingAt, sizeof tm, hipMemcpyDeviceToHost));
+            uint32_t first = ~0u;
+            for (int g = 0; g < 64; g++) if (tm[g * 16] && tm[g * 16] < first) first = tm[g * 16];
+            for (int g = 0; g < 64 && (g == 0 || tm[g * 16]); g++) {
+                fprintf(stderr, "[jpegenc] group %2d (x10 ns from the first start):", g);
+                for (int i = 0; i < 10; i++) fprintf(stderr, " %5u", tm[g * 16 + i] - first);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
+        if (ctx.h_words[0]) {            // a workgroup of the self-finishing kernel gave up waiting for its predecessors: nothing of the scan is valid
+            ctx.h_words[0] = 0;
+            JPEGENC_HIP(hipMemsetAsync(ctx.d_chain, 0, sizeof(uint32_t) * kFinishChainWords, ctx.stream));
+            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            return kFinishGaveUp;
+        }
         nbytes = 0;
         for (size_t k = 0; k < jobs.size(); k++) { scan_len[k] = reinterpret_cast<const uint32_t *>(ctx.h_scan_out)[k]; nbytes += scan_len[k]; }
         return JPEGENC_OK;
@@ -522,9 +573,9 @@ struct FrameRun {
     }
 };
 
-int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,
-                 const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user) {
-    FrameRun run(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, sink, user);
+static int encode_frame_once(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,
+                             const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user, bool allow_finish) {
+    FrameRun run(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, sink, user, allow_finish);
     int rc = run.prepare(upload);
     if (rc) return rc;
     rc = run.plan_scans();
@@ -540,6 +591,17 @@ int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height
     rc = run.launch_and_wait();
     if (rc) return rc;
     return run.emit_device_coded();
+}
+
+int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,
+                 const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user) {
+    int rc = encode_frame_once(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, upload, sink, user, true);
+    // (nothing has reached the sink at that point; the pixels are where the first attempt put them)
+    if (rc == kFinishGaveUp) {
+        auto nothing = [](DeviceCtx &) -> int { return JPEGENC_OK; };
+        rc = encode_frame_once(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, nothing, sink, user, false);
+    }
+    return rc;
 }
 
 int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *data, size_t len, int width,

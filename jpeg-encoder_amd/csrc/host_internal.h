@@ -268,7 +268,13 @@ struct DeviceCtx {
     void *d_scan_ws = nullptr, *d_scan_out = nullptr, *d_gather = nullptr;       // d_gather: [lengths][all scans back to back]
     size_t d_scan_ws_cap = 0, d_scan_out_cap = 0, d_gather_cap = 0;
     static constexpr size_t kFirstPiece = 256 << 10;      // bytes of coded data fetched together with the lengths
-    uint32_t *d_scan_len = nullptr, *h_scan_len = nullptr;     // kMaxScans entries
+    uint32_t *d_scan_len = nullptr;                            // kMaxScans entries
+    // the pixels -> bits kernel finishing a scan itself (finish_run.hip.h): its look-back words in device memory (zero between
+    // launches) and the words the kernel and the host share in pinned memory: [0] a workgroup gave up waiting
+    uint32_t *d_chain = nullptr;
+    uint32_t unsynchronised = 0;       // frames in a row whose kernel announced its result through h_words[2] while the stream was not waited for
+    volatile uint32_t *h_words = nullptr;
+    static constexpr int kHostWords = 16;
     void *d_lut = nullptr;
     std::string stored_scan_params;    // the parameter blocks a single-scan frame left in d_scan_ws (launch_entropy_scans)
     std::string lut_key;               // the Huffman tables d_lut was built from (uploads of unchanged tables are skipped)
@@ -300,7 +306,10 @@ struct DeviceCtx {
         JPEGENC_HIP(hipMalloc(&d_freq, sizeof(uint32_t) * 2 * 2 * 257));
         JPEGENC_HIP(hipHostMalloc((void **)&h_freq, sizeof(uint32_t) * 2 * 2 * 257, hipHostMallocDefault));
         JPEGENC_HIP(hipMalloc((void **)&d_scan_len, sizeof(uint32_t) * kMaxScans));
-        JPEGENC_HIP(hipHostMalloc((void **)&h_scan_len, sizeof(uint32_t) * kMaxScans, hipHostMallocDefault));
+        JPEGENC_HIP(hipMalloc((void **)&d_chain, sizeof(uint32_t) * kFinishChainWords));
+        JPEGENC_HIP(hipMemsetAsync(d_chain, 0, sizeof(uint32_t) * kFinishChainWords, stream));
+        JPEGENC_HIP(hipHostMalloc((void **)&h_words, sizeof(uint32_t) * kHostWords, hipHostMallocDefault));
+        for (int i = 0; i < kHostWords; i++) h_words[i] = 0;
         JPEGENC_HIP(hipMalloc(&d_lut, kLutDeviceBytes));
         return JPEGENC_OK;
     }
@@ -399,7 +408,8 @@ struct DeviceCtx {
         if (d_gather) (void)hipFree(d_gather);
         if (d_scan_len) (void)hipFree(d_scan_len);
         if (d_lut) (void)hipFree(d_lut);
-        if (h_scan_len) (void)hipHostFree(h_scan_len);
+        if (d_chain) (void)hipFree(d_chain);
+        if (h_words) (void)hipHostFree((void *)h_words);
         if (h_scan_out) (void)hipHostFree(h_scan_out);
         *this = DeviceCtx();
     }
