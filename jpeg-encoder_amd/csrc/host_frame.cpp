@@ -424,9 +424,16 @@ struct FrameRun {
             for (int g = 0; g < 64; g++) if (tm[g * 16] && tm[g * 16] < first) first = tm[g * 16];
             for (int g = 0; g < 64 && (g == 0 || tm[g * 16]); g++) {
                 fprintf(stderr, "[jpegenc] group %2d (x10 ns from the first start):", g);
-                for (int i = 0; i < 10; i++) fprintf(stderr, " %5u", tm[g * 16 + i] - first);
+                for (int i = 0; i < 11; i++) fprintf(stderr, " %5u", tm[g * 16 + i] ? tm[g * 16 + i] - first : 0u);
                 fprintf(stderr, "\n");
             }
+        }
+#endif
+#ifdef JPEGENC_DIAG
+        {   // tests: every second self-finished frame is treated as if a workgroup had given up (the kernel never does on its own)
+            static const bool force = getenv("JPEGENC_FORCE_FINISH_GAVE_UP") != nullptr;
+            static std::atomic<unsigned> nth(0);
+            if (force && self_finishing && (nth.fetch_add(1) & 1u)) ctx.h_words[0] = 1;
         }
 #endif
         if (ctx.h_words[0]) {            // a workgroup of the self-finishing kernel gave up waiting for its predecessors: nothing of the scan is valid

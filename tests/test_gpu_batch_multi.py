@@ -258,8 +258,11 @@ def test_pixels_scan_device_matches_the_two_kernel_path_and_the_oracle(binding, 
 
 @pytest.mark.parametrize("env", [{"JPEGENC_FUSED": "1"}, {"JPEGENC_FUSED": "0"}, {"JPEGENC_FUSED": "1", "JPEGENC_PACK_WINDOW_WORDS": "8"},
                                  {"JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES": "0", "JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES": "0"},
-                                 {"JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES": "100000000", "JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES": "100000000"}],
-                         ids=["fused", "two-kernels", "fused-tiny-window", "dma-both-ways", "zero-copy-both-ways-any-size"])
+                                 {"JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES": "100000000", "JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES": "100000000"},
+                                 {"JPEGENC_NO_FINISH": "1"}, {"JPEGENC_NO_DONE_FLAG": "1"}, {"JPEGENC_FORCE_FINISH_GAVE_UP": "1"},
+                                 {"JPEGENC_FORCE_FINISH_GAVE_UP": "1", "JPEGENC_PACK_WINDOW_WORDS": "8"}],
+                         ids=["fused", "two-kernels", "fused-tiny-window", "dma-both-ways", "zero-copy-both-ways-any-size",
+                              "separate-push-and-stuff", "stream-wait", "finish-gave-up", "finish-gave-up-tiny-window"])
 def test_encoder_with_and_without_the_fused_kernel(binding, tmp_path, env):
     """The Encoder codes its interleaved baseline scan of an RGB-family image straight from the pixels (one workgroup =
     one run of 64 MCUs; JPEGENC_FUSED=0 keeps block kernel + coder; the switches are read once per process, hence the
@@ -267,7 +270,11 @@ def test_encoder_with_and_without_the_fused_kernel(binding, tmp_path, env):
     blocks longer than a lane's strip (noise at quality 100) and runs longer than the window (forced by
     JPEGENC_PACK_WINDOW_WORDS: the second-walk path), the worker-pool batch and the device-resident batch -
     byte-identical to the oracle's files every way.  Small frames are read from and coded into pinned host memory by
-    the kernels themselves (no DMA nodes); the last two runs force the DMA path and the zero-copy path for every size."""
+    the kernels themselves (no DMA nodes); two runs force the DMA path and the zero-copy path for every size.  A single frame of
+    up to 1 024 runs without restart markers is finished by the kernel's own workgroups (finish_run.hip.h - the default in every
+    run above): the last four runs keep k_push / k_stuff as separate launches, make the host wait for the stream instead of the
+    kernel's flag, and pretend that a workgroup gave up waiting on every second frame (the frame is then coded again through
+    the ordinary sequence)."""
     import os
     import subprocess
     import sys

@@ -1011,6 +1011,38 @@ def test_device_entropy_pack_window_overflow_path(binding, oracle, synth):
         assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_self_finishing_kernel_edges(binding, oracle, synth):
+    """A single baseline frame of up to 1 024 runs without restart markers is put together by the workgroups of the pixels ->
+    bits kernel themselves (finish_run.hip.h: look-back over the runs, 0xFF stuffing in LDS).  Its edges: one run; a last run
+    of a single MCU (a dozen bits); exactly 1 024 runs and the first size beyond (the ordinary sequence); every workgroup
+    size (3, 4 and 6 blocks per MCU); runs whose first byte is shared with the run before at every bit offset; content
+    full of 0xFF bytes (binary noise, quality 100: stuffing doubles stretches of the scan) and blocks that outgrow their
+    strip (second walk, the run read back from its slot); a frame large enough that its scan goes through device memory
+    and a download (above 1 MB of pixels) and small ones that the kernel writes to pinned host memory."""
+    cases = [((8, 8), dict(quality=90)), ((16, 16), dict(quality=75)), ((520, 8), dict(quality=92)), ((1032, 24), dict(quality=80, sampling=(2, 1))),
+             ((2048, 2048), dict(quality=91)), ((2048, 2056), dict(quality=91)), ((1024, 520), dict(quality=60, sampling=(2, 2))),
+             ((777, 333), dict(quality=85, sampling=(1, 2))), ((640, 480), dict(quality=100)), ((1000, 700), dict(quality=100, sampling=(2, 2)))]
+    for i, ((w, h), kw) in enumerate(cases):
+        for content in ("photo", "binary"):
+            if content == "photo":
+                px = synth.test_img_rgb(w, h)
+                px = np.clip(px.astype(np.int16) + np.random.default_rng(i).integers(-9, 10, px.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+            else:
+                if w * h > 1 << 21:
+                    continue
+                px = (synth.noise_image(w, h, 3, 40 + i) >> 7) * np.uint8(255)
+            e = _encoder(binding, kw)
+            want = oracle.encode_jpeg(px, w, h, oracle.RGB, **kw)
+            for _ in range(3):
+                assert e.encode(px, w, h, binding.RGB) == want, ((w, h), kw, content)
+    # many frames in a row on one handle, sizes changing: the look-back words are left clean by every launch
+    e = _encoder(binding, dict(quality=83))
+    for k in range(40):
+        w, h = 64 + 37 * (k % 9), 48 + 29 * (k % 7)
+        px = synth.lcg_image(w, h, 3, k)
+        assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, quality=83), (w, h)
+
+
 def test_large_progressive_frame_takes_the_launched_prefix_sums(binding, oracle, synth):
     """Beyond 2 048 runs per scan the prefix sums are separate launches again (below, k_push / k_stuff fold them in):
     a 15-Mpixel 4:4:4 frame has 3 663 runs per component scan; progressive + optimised, its 9 scans share their
