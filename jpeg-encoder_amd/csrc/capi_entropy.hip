@@ -284,6 +284,7 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
             p.chain = fused->chain;
             p.finish_abort = fused->finish_abort;
             p.finish_done = fused->finish_done;
+            p.stripe_ends = fused->stripe_ends;
         }
     }
     *d_params_out = (EntropyParams *)(ws + pl.off_params);

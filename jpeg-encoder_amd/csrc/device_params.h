@@ -91,6 +91,9 @@ struct BlockKernelParams {
                                       // component (they cover the same pixels, read from HBM once); 0 -> 4 tasks in
                                       // component-major sequence (more than 10 waves per round)
     uint32_t groups;                  // groups per frame
+    // the pixels -> bits kernel launched stripe by stripe while the frame is still being uploaded (host_frame.cpp,
+    // run_striped): this launch's workgroups are groups [group_base, group_base + group_count) of the frame (0 = all of them)
+    uint32_t group_base, group_count, stripe_index;
     uint32_t persistent_frames;       // -DJPEGENC_PERSISTENT experiment: frames of the launch (the grid is the resident workgroups)
     // Symbol statistics for optimised Huffman tables folded into the block kernel (planar order, tuned kernels): every wave
     // counts the AC symbols of its 64 blocks while their coefficients are in registers (encoder.rs:1123-1161) and writes

@@ -94,6 +94,7 @@ struct EntropyParams {
     uint32_t *chain;                 // kFinishChainWords of device memory, zero between launches; nullptr = the ordinary sequence
     uint32_t *finish_abort;          // pinned host word: set when a workgroup gave up waiting (the host then codes the frame again)
     uint32_t *finish_done;           // pinned host word (or nullptr): set to 1 once every byte of the scan and its length are in host memory
+    uint32_t *stripe_ends;           // pinned host words (or nullptr): [stripe] bytes of the scan up to the end of that launch's last run
 };
 
 }  // namespace jpegenc

@@ -46,14 +46,15 @@ __device__ __forceinline__ uint32_t finish_ff4(uint32_t w) {                  //
 
 // run: the workgroup's run from bit 0 of word 0 (memory = byte-stream order), followed by a zero word - in LDS or in its slot
 // (a generic pointer).  stage: nthreads * 64 bytes of LDS; sh: 16 words of LDS.  All threads of the workgroup call this after a
-// barrier that completed the run.
+// barrier that completed the run.  The runs of a frame may come in several launches (stripes of the frame, in order): the
+// chain carries over, a run looks back into the earlier launches like into its own.
 #ifdef JPEGENC_DIAG
 #define FINISH_STAMP(i) do { if (tid == 0 && g < 64u) p.chain[kFinishTimingAt + g * 16u + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FINISH_STAMP(i) do { } while (0)
 #endif
 __device__ __forceinline__ void finish_run(Params p, uint32_t g, uint32_t tid, uint32_t nthreads, const uint32_t *run, uint32_t total,
-                                           uint8_t *stage, uint32_t *sh) {
+                                           uint8_t *stage, uint32_t *sh, bool last_of_launch, uint32_t stripe_index) {
     uint32_t *chain = p.chain, *chain2 = chain + kFinishMaxRuns, *ctl = chain + 2u * kFinishMaxRuns;
     const uint32_t G = p.nwaves, lane = tid & 63u, wave = tid >> 6, nwaves_wg = nthreads >> 6;
     const bool last = g + 1u == G;
@@ -175,6 +176,8 @@ __device__ __forceinline__ void finish_run(Params p, uint32_t g, uint32_t tid, u
         }
         FINISH_STAMP(8);
         if (last && tid == 0) p.out_bytes[0] = base;
+        // (a frame coded stripe by stripe: where this launch's part of the scan ends - final once the launch has completed)
+        if (last_of_launch && tid == 0 && p.stripe_ends) p.stripe_ends[stripe_index] = base;
     } else if (tid == 0) {
         *p.finish_abort = 1u;
     }

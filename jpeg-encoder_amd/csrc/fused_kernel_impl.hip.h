@@ -51,7 +51,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     uint16_t *lens = reinterpret_cast<uint16_t *>(lut_bytes + kLoopLutBytes);
     int16_t *dcs = reinterpret_cast<int16_t *>(lens + bpm * 64u);
     uint32_t *flags = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);              // per wave: [w] a block outgrew its strip, [8 + w] AC bits of its blocks (only summed for a lowered window); stored, never zeroed
-    const uint32_t tid = threadIdx.x, grp = blockIdx.x, f = blockIdx.y;
+    const uint32_t tid = threadIdx.x, grp = blockIdx.x + bp.group_base, f = blockIdx.y;
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool finish = p.chain != nullptr;                                      // the workgroups put the scan together themselves (finish_run.hip.h)
 #ifdef JPEGENC_DIAG          // tools/diag/small_frame_timeline.sh: where a workgroup's time goes (100 MHz clock), thread 0 of the first 64 workgroups
@@ -254,7 +254,8 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     }
     // the strips (dead by now) stage the stuffed bytes, the flags the workgroup's few shared words
     JPEGENC_STAMP(5);
-    if (finish) finish_run(p, grp, tid, nthreads, fits ? window : slot, total, reinterpret_cast<uint8_t *>(strips), flags);
+    if (finish) finish_run(p, grp, tid, nthreads, fits ? window : slot, total, reinterpret_cast<uint8_t *>(strips), flags,
+                           blockIdx.x + 1u == gridDim.x, bp.stripe_index);
     JPEGENC_STAMP(9);
 }
 
@@ -265,7 +266,8 @@ static hipError_t launch_group_t(const BlockKernelParams &b, const ColourConsts 
                                  hipStream_t st, const jpegenc_plane *planes = nullptr, bool planes_subsampled = false) {
     BlockKernelParams q = b;
     if (!fill_fast_params(q, k, BPP, SX, SY, CONV, planes, planes_subsampled) || q.fast_hdr.group_mcus != 64u || q.per_group != q.bpm) return hipErrorInvalidValue;
-    const dim3 grid(q.groups, (unsigned)frames), block(q.per_group * 64u);
+    if (q.group_base + q.group_count > q.groups || (q.group_count && frames != 1)) return hipErrorInvalidValue;
+    const dim3 grid(q.group_count ? q.group_count : q.groups, (unsigned)frames), block(q.per_group * 64u);
     size_t lds = group_lds_bytes(q.bpm);
     static const char *pad_env = JPEGENC_DIAG_ENV("JPEGENC_GROUP_LDS_PAD_KB");               // diagnostic: fewer resident workgroups per CU
     if (pad_env) lds += (size_t)atoi(pad_env) * 1024u;

@@ -60,6 +60,7 @@ struct FusedSource {
     const BlockKernelParams *blocks; int variant; const jpegenc_plane *planes; bool planes_subsampled;   // planes: a described planar source (else null)
     uint32_t *chain = nullptr, *finish_abort = nullptr;      // both set: the kernel may finish the scan itself (finish_run.hip.h) where the scan qualifies
     uint32_t *finish_done = nullptr;                         // (the scan goes to pinned host memory) the host word the kernel sets when all of it is there
+    uint32_t *stripe_ends = nullptr;                         // (the frame is coded in several launches: blocks->group_base / group_count / stripe_index) where each launch's bytes end
 };
 bool fused_supported(const BlockKernelParams &b);      // the layout has a fused kernel (interleaved order, 3 to 6 blocks per MCU, sampling factors 1 and 2)
 bool fused_enabled();                                    // the Encoder uses it (default; JPEGENC_FUSED=0 keeps block kernel + k_block_code)

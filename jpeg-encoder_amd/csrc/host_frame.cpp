@@ -54,6 +54,7 @@ struct FrameRun {
     const jpegenc_write_fn sink;
     void *const user;
     const bool allow_finish;            // the pixels -> bits kernel may finish the scan itself (off for the second attempt after it gave up)
+    const uint8_t *const host_pixels;   // the frame in the caller's host memory where the upload is this run's to do (run_striped), else nullptr
 
     Tables t;
     Mode mode = MODE_INTERLEAVED;
@@ -63,6 +64,7 @@ struct FrameRun {
     BlockKernelParams p;
     bool optimize = false;
     FusedSource fused_src = {};
+    int stripes = 0;                    // > 0: a large frame between page-locked buffers, through run_striped in that many stripes
     bool self_finishing = false;        // ... and its workgroups put the scan together themselves: the launch sequence is that one kernel
     bool fused = false;                 // interleaved baseline scan of an RGB-family image: ONE kernel from the pixels to the coded runs
     std::vector<Job> jobs;
@@ -80,15 +82,14 @@ struct FrameRun {
     time_point t_begin, t_launched, t_len;
 
     FrameRun(const Config &c_, DeviceCtx &ctx_, int jct_, int width_, int height_, int color_type_or_planes_, size_t pixel_bytes_,
-             jpegenc_write_fn sink_, void *user_, bool allow_finish_)
+             jpegenc_write_fn sink_, void *user_, bool allow_finish_, const uint8_t *host_pixels_)
         : c(c_), ctx(ctx_), jct(jct_), width(width_), height(height_), color_type_or_planes(color_type_or_planes_), pixel_bytes(pixel_bytes_),
-          sink(sink_), user(user_), allow_finish(allow_finish_) {}
+          sink(sink_), user(user_), allow_finish(allow_finish_), host_pixels(host_pixels_) {}
     static time_point now() { return std::chrono::steady_clock::now(); }
     static long us(time_point a, time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); }
 
-    // tables, geometry, device buffers, the upload (`upload` copies the source into ctx.d_pixels on ctx.stream), the block
-    // kernel's parameters
-    int prepare(const std::function<int(DeviceCtx &)> &upload) {
+    // tables, geometry, device buffers, the block kernel's parameters (the upload follows plan_scans: encode_frame_once)
+    int prepare() {
         int rc = jpegenc_qtable_init(&t.q[0], c.qtype[0], c.qcustom[0], c.quality, 1);   // encoder.rs:528-531
         if (rc) return rc;
         rc = jpegenc_qtable_init(&t.q[1], c.qtype[1], c.qcustom[1], c.quality, 0);
@@ -104,8 +105,6 @@ struct FrameRun {
         // ---- device: upload, fused kernel, [histogram], download ---------------------------------
         coeff_bytes = (size_t)L.total_blocks * 128;
         rc = ctx.reserve(ctx.external_pixels || ctx.external_planes ? 0 : pixel_bytes, coeff_bytes, color_type_or_planes >= 100 && !ctx.external_planes);
-        if (rc) return rc;
-        rc = upload(ctx);
         if (rc) return rc;
         if (color_type_or_planes >= 100) rc = build_block_params_planes(&p, L, width, height, t.q, order);
         else rc = build_block_params(&p, L, width, height, color_type_or_planes, t.q, order);
@@ -199,6 +198,21 @@ struct FrameRun {
         self_finishing = fused && fused_src.chain && !c.restart_interval && fused_runs(p) <= kFinishMaxRuns;
         static const bool poll_off = JPEGENC_DIAG_ENV("JPEGENC_NO_DONE_FLAG") != nullptr;
         if (self_finishing && host_gather && !poll_off) fused_src.finish_done = (uint32_t *)(ctx.h_words + 2);
+        // A large frame between page-locked host buffers: uploaded, coded and downloaded stripe by stripe (run_striped) - from 4 MB
+        // of pixels, where a stripe's copies are worth their fixed costs.
+        static const size_t striped_from = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_STRIPED_FROM_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)4 << 20); }();
+        stripes = 0;
+        if (self_finishing && !host_gather && host_pixels && sink == buffer_sink && pixel_bytes >= striped_from && pixel_bytes < (1ull << 31)) {
+            const BufferSink *bs = (const BufferSink *)user;
+            const uint32_t mcu_rows = (uint32_t)((L.mcus + p.mcus_x - 1) / p.mcus_x);
+            stripes = pixel_bytes >= ((size_t)8 << 20) ? 4 : 2;                 // (tools/diag/stripes_ab.sh: 3-4 stripes of 2.7-6 MB are the best of 1 ... 8)
+            static const int forced = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_STRIPES"); return e ? atoi(e) : 0; }();
+            if (forced) stripes = forced;
+            if (stripes > DeviceCtx::kChunks) stripes = DeviceCtx::kChunks;
+            if ((uint32_t)stripes > mcu_rows) stripes = (int)mcu_rows;
+            if (stripes < 2 || !is_pinned_host_range(host_pixels, pixel_bytes) || !bs->out || !is_pinned_host_range(bs->out, bs->cap)) stripes = 0;
+        }
+        if (stripes) fused_src.stripe_ends = (uint32_t *)(ctx.h_words + 4);
         return rc;
 
     }
@@ -386,6 +400,24 @@ struct FrameRun {
         return rc;
     }
 
+    // A workgroup of the self-finishing kernel gave up waiting for its predecessors (finish_run.hip.h): nothing of the scan is
+    // valid, the frame is coded again through the ordinary sequence (encode_frame).
+    bool gave_up() {
+#ifdef JPEGENC_DIAG
+        // tests: every second self-finished frame is treated as if a workgroup had given up (the kernel never does on its own)
+        static const bool force = getenv("JPEGENC_FORCE_FINISH_GAVE_UP") != nullptr;
+        static std::atomic<unsigned> nth(0);
+        if (force && self_finishing && (nth.fetch_add(1) & 1u)) ctx.h_words[0] = 1;
+#endif
+        return ctx.h_words[0] != 0;
+    }
+    int reset_chain() {
+        ctx.h_words[0] = 0;
+        JPEGENC_HIP(hipMemsetAsync(ctx.d_chain, 0, sizeof(uint32_t) * kFinishChainWords, ctx.stream));
+        JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+        return kFinishGaveUp;
+    }
+
     int launch_and_wait() {
         if (how == CAPTURE) {
             hipGraph_t g = nullptr;
@@ -429,21 +461,89 @@ struct FrameRun {
             }
         }
 #endif
-#ifdef JPEGENC_DIAG
-        {   // tests: every second self-finished frame is treated as if a workgroup had given up (the kernel never does on its own)
-            static const bool force = getenv("JPEGENC_FORCE_FINISH_GAVE_UP") != nullptr;
-            static std::atomic<unsigned> nth(0);
-            if (force && self_finishing && (nth.fetch_add(1) & 1u)) ctx.h_words[0] = 1;
-        }
-#endif
-        if (ctx.h_words[0]) {            // a workgroup of the self-finishing kernel gave up waiting for its predecessors: nothing of the scan is valid
-            ctx.h_words[0] = 0;
-            JPEGENC_HIP(hipMemsetAsync(ctx.d_chain, 0, sizeof(uint32_t) * kFinishChainWords, ctx.stream));
-            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
-            return kFinishGaveUp;
-        }
+        if (gave_up()) return reset_chain();
         nbytes = 0;
         for (size_t k = 0; k < jobs.size(); k++) { scan_len[k] = reinterpret_cast<const uint32_t *>(ctx.h_scan_out)[k]; nbytes += scan_len[k]; }
+        return JPEGENC_OK;
+    }
+
+    // A large baseline frame between PAGE-LOCKED host buffers (jpegenc_host_alloc / jpegenc_host_register, or HIP's own calls),
+    // in stripes of whole MCU rows: every copy is then truly asynchronous, and one thread keeps three streams busy - the
+    // uploads, the pixels -> bits kernel of each stripe as soon as its rows are there (its workgroups look back over ALL
+    // earlier runs of the frame, whichever launch they came in, and write their bytes where they belong in the scan -
+    // finish_run.hip.h), and the download of the finished part of the scan straight to its place in the caller's buffer.
+    // One after the other - upload, kernel, download - Criterion's 2000x1800 frame at quality 100 (10.8 MB up, 14.4 MB
+    // down) takes 0.62 ms of which the two copies alone are 0.47; in four stripes 0.45.
+    // (Pageable buffers stay with the one-piece sequence: a copy on pageable memory does not return before it is done and
+    // costs ~35 us per call on top of its bytes - csrc/tools/pageable_async.cpp; with a second host thread for the downloads
+    // two stripes gained 5 % on that frame and lost on every other.  The kernel storing the scan into the caller's page-locked
+    // buffer itself - no download at all - is slower than the DMA for megabytes: 0.54-0.58 ms.  profiles/README.md.)
+    int run_striped() {
+        static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+        BufferSink *bs = (BufferSink *)user;
+        const size_t len0 = bs->len;
+        if (!ctx.kernel_stream) {
+            JPEGENC_HIP(hipStreamCreateWithFlags(&ctx.kernel_stream, hipStreamNonBlocking));
+            JPEGENC_HIP(hipStreamCreateWithFlags(&ctx.download_stream, hipStreamNonBlocking));
+            for (auto &e : ctx.uploaded) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        Out o;
+        o.sink = sink; o.user = user;
+        write_prologue(o, c, jct);
+        write_frame_header(o, c, width, height, L, t);
+        const Job &j = jobs[0];
+        write_scan_header(o, L, j.first, j.n, j.ss, j.se);
+        o.drain(true);                                                   // the headers are in the caller's buffer
+        const size_t at = bs->len;
+        volatile uint32_t *ends = ctx.h_words + 4;
+        for (int k = 0; k < stripes; k++) ends[k] = 0;
+
+        const uint32_t mcu_h = 8u * (uint32_t)p.vmax, mcu_rows = (uint32_t)((L.mcus + p.mcus_x - 1) / p.mcus_x), total_groups = fused_runs(p);
+        const size_t pitch = pixel_bytes / (size_t)height;
+        uint32_t rows_done = 0, groups_done = 0;
+        int rc = JPEGENC_OK;
+        hipError_t he = hipSuccess;
+        int launched = 0;
+        for (int k = 0; k < stripes && rc == JPEGENC_OK && he == hipSuccess; k++, launched++) {
+            const uint32_t rows_end = k + 1 == stripes ? mcu_rows : (uint32_t)((uint64_t)mcu_rows * (uint32_t)(k + 1) / (uint32_t)stripes);
+            const size_t y0 = std::min<size_t>((size_t)rows_done * mcu_h, (size_t)height), y1 = std::min<size_t>((size_t)rows_end * mcu_h, (size_t)height);
+            if (y1 > y0) he = hipMemcpyAsync((uint8_t *)ctx.d_pixels + y0 * pitch, host_pixels + y0 * pitch, (y1 - y0) * pitch, hipMemcpyHostToDevice, ctx.stream);
+            if (he == hipSuccess) he = hipEventRecord(ctx.uploaded[k], ctx.stream);      // (also behind the scan's parameter block and the code tables)
+            if (he == hipSuccess) he = hipStreamWaitEvent(ctx.kernel_stream, ctx.uploaded[k], 0);
+            const uint32_t groups_end = k + 1 == stripes ? total_groups : (uint32_t)(((uint64_t)rows_end * p.mcus_x) / 64u);   // groups whose every MCU is uploaded
+            if (he == hipSuccess && groups_end > groups_done) {
+                p.group_base = groups_done; p.group_count = groups_end - groups_done; p.stripe_index = (uint32_t)k;
+                rc = scan_device(ctx.d_coeffs, L.total_blocks, 1, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)gather + kGatherHeader, j.cap, (uint32_t *)gather,
+                                 ctx.d_scan_ws, ctx.d_scan_ws_cap, ctx.kernel_stream, &ctx.stored_scan_params, &fused_src);
+                groups_done = groups_end;
+            }
+            if (he == hipSuccess && rc == JPEGENC_OK) he = hipEventRecord(ctx.chunk_done[k], ctx.kernel_stream);
+            rows_done = rows_end;
+        }
+        p.group_base = 0; p.group_count = 0; p.stripe_index = 0;
+        // the finished part of the scan, stripe by stripe, to its place behind the headers
+        const size_t room = bs->cap > at ? bs->cap - at : 0;
+        size_t prev = 0;
+        for (int k = 0; k < launched && rc == JPEGENC_OK && he == hipSuccess; k++) {
+            he = hipEventSynchronize(ctx.chunk_done[k]);
+            const size_t end = ends[k];
+            if (he == hipSuccess && end > prev && end <= room)               // (a buffer that is too small is left alone; the caller learns the size)
+                he = hipMemcpyAsync(bs->out + at + prev, (const uint8_t *)ctx.d_gather + kGatherHeader + prev, end - prev, hipMemcpyDeviceToHost, ctx.download_stream);
+            if (end > prev) prev = end;
+        }
+        (void)hipStreamSynchronize(ctx.kernel_stream);
+        (void)hipStreamSynchronize(ctx.stream);
+        const hipError_t de = hipStreamSynchronize(ctx.download_stream);
+        ctx.unsynchronised = 0;
+        if (rc != JPEGENC_OK) { bs->len = len0; return rc; }
+        if (he != hipSuccess || de != hipSuccess) { bs->len = len0; return hip_fail(he != hipSuccess ? he : de, "striped frame"); }
+        if (gave_up()) { bs->len = len0; return reset_chain(); }
+        nbytes = prev;
+        bs->len = at + nbytes;                                           // (a buffer that is too small still learns the size it needs)
+        o.marker(0xD9);
+        o.drain(true);
+        if (trace) fprintf(stderr, "[jpegenc] frame: %d stripes, %ld us, bytes %zu\n", stripes, us(t_begin, now()), nbytes);
+        if (o.failed) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
         return JPEGENC_OK;
     }
 
@@ -581,15 +681,21 @@ struct FrameRun {
 };
 
 static int encode_frame_once(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,
-                             const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user, bool allow_finish) {
-    FrameRun run(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, sink, user, allow_finish);
-    int rc = run.prepare(upload);
+                             const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user, bool allow_finish,
+                             const uint8_t *host_pixels) {
+    FrameRun run(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, sink, user, allow_finish, host_pixels);
+    int rc = run.prepare();
     if (rc) return rc;
     rc = run.plan_scans();
     if (rc) return rc;
+    if (!run.stripes) {                      // (a striped frame uploads its own stripes)
+        rc = upload(ctx);
+        if (rc) return rc;
+    }
     run.choose_replay();
     rc = run.begin_sequence();
     if (rc) return rc;
+    if (run.stripes) return run.run_striped();
     rc = run.enqueue_blocks_and_statistics();
     if (rc) return rc;
     if (!(c.device_entropy && run.supported)) return run.collect_host_coded();
@@ -601,12 +707,12 @@ static int encode_frame_once(const Config &c, DeviceCtx &ctx, int jct, int width
 }
 
 int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,
-                 const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user) {
-    int rc = encode_frame_once(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, upload, sink, user, true);
+                 const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user, const uint8_t *host_pixels) {
+    int rc = encode_frame_once(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, upload, sink, user, true, host_pixels);
     // (nothing has reached the sink at that point; the pixels are where the first attempt put them)
     if (rc == kFinishGaveUp) {
         auto nothing = [](DeviceCtx &) -> int { return JPEGENC_OK; };
-        rc = encode_frame_once(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, nothing, sink, user, false);
+        rc = encode_frame_once(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, nothing, sink, user, false, nullptr);
     }
     return rc;
 }
@@ -659,7 +765,7 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
         }
         return JPEGENC_OK;
     };
-    return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user);
+    return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user, staged ? nullptr : data);
 }
 
 

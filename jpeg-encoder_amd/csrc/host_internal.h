@@ -272,6 +272,10 @@ struct DeviceCtx {
     // the pixels -> bits kernel finishing a scan itself (finish_run.hip.h): its look-back words in device memory (zero between
     // launches) and the words the kernel and the host share in pinned memory: [0] a workgroup gave up waiting
     uint32_t *d_chain = nullptr;
+    // a large frame between page-locked host buffers, coded stripe by stripe (FrameRun::run_striped): kernels and downloads on
+    // their own streams, one event per uploaded stripe
+    hipStream_t kernel_stream = nullptr, download_stream = nullptr;
+    hipEvent_t uploaded[8] = {};
     uint32_t unsynchronised = 0;       // frames in a row whose kernel announced its result through h_words[2] while the stream was not waited for
     volatile uint32_t *h_words = nullptr;
     static constexpr int kHostWords = 16;
@@ -394,6 +398,9 @@ struct DeviceCtx {
         (void)hipSetDevice(device);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
         for (auto &e : chunk_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (auto &e : uploaded) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (kernel_stream) (void)hipStreamDestroy(kernel_stream);
+        if (download_stream) (void)hipStreamDestroy(download_stream);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (d_pixels) (void)hipFree(d_pixels);
         if (d_coeffs) (void)hipFree(d_coeffs);
@@ -634,7 +641,7 @@ struct BufferSink {
 int buffer_sink(void *user, const uint8_t *data, size_t n);
 // The whole of encode_image_internal for one frame; `upload` copies the source into ctx.d_pixels on ctx.stream.
 int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,
-                 const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user);
+                 const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user, const uint8_t *host_pixels = nullptr);
 int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *data, size_t len, int width, int height, int color_type,
                   jpegenc_write_fn sink, void *user, bool staged = false);
 

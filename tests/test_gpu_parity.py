@@ -1043,6 +1043,54 @@ def test_self_finishing_kernel_edges(binding, oracle, synth):
         assert e.encode(px, w, h, binding.RGB) == oracle.encode_jpeg(px, w, h, oracle.RGB, quality=83), (w, h)
 
 
+def test_large_frame_between_registered_buffers_is_coded_in_stripes(binding, oracle, synth):
+    """A baseline frame of 4 MB of pixels and more, from a page-locked host buffer into a page-locked buffer of the caller's
+    (jpegenc_host_register; encode_to_buffer), is uploaded, coded and downloaded stripe by stripe on three streams
+    (host_frame.cpp, run_striped): the kernel's workgroups look back over the runs of the earlier launches.  Same file as the
+    oracle's: pageable buffers (one piece), only the output registered (one piece), both registered (stripes); sizes whose
+    stripes end inside a group, a frame with few MCU rows, smaller frames below the stripe limit, a buffer that is too small
+    (nothing is written past its end - a guard band stays intact - and the size it needs comes back), calls with other
+    sizes in between."""
+    cases = [((2000, 1800), dict(quality=100)), ((3840, 2160), dict(quality=90)), ((1920, 1080), dict(quality=75, sampling=(2, 1))),
+             ((4100, 345), dict(quality=85, sampling=(1, 2))), ((16384, 96), dict(quality=88)), ((2500, 1300), dict(quality=93, sampling=(1, 1))),
+             ((801, 603), dict(quality=96)), ((640, 360), dict(quality=50, sampling=(2, 2)))]
+    for i, ((w, h), kw) in enumerate(cases):
+        px = synth.test_img_rgb(w, h)
+        px = np.ascontiguousarray(np.clip(px.astype(np.int16) + np.random.default_rng(i).integers(-9, 10, px.shape, dtype=np.int16), 0, 255).astype(np.uint8).reshape(-1))
+        want = oracle.encode_jpeg(px.reshape(h, w, 3), w, h, oracle.RGB, **kw)
+        e = _encoder(binding, kw)
+        out = np.empty(len(want) + 4096, dtype=np.uint8)
+        guarded = np.full(len(want) // 2 + 256, 0xA5, dtype=np.uint8)
+        n = e.encode_to_buffer(px, w, h, binding.RGB, out)                 # everything pageable: the ordinary sequence
+        assert n == len(want) and out[:n].tobytes() == want, ((w, h), kw)
+        registered = []
+        try:
+            for a in (out, guarded, px):                                    # first the buffers alone (pageable pixels), then the pixels too
+                binding.host_register(a)
+                registered.append(a)
+                if a is guarded:
+                    continue
+                for _ in range(3):
+                    out[:] = 0
+                    n = e.encode_to_buffer(px, w, h, binding.RGB, out)
+                    assert n == len(want) and out[:n].tobytes() == want, ((w, h), kw, len(registered))
+                small = synth.lcg_image(200, 120, 3, i)
+                assert e.encode(small, 200, 120, binding.RGB) == oracle.encode_jpeg(small, 200, 120, oracle.RGB, **kw)
+                out[:] = 0
+                n = e.encode_to_buffer(px, w, h, binding.RGB, out)
+                assert n == len(want) and out[:n].tobytes() == want, ((w, h), kw, len(registered))
+                if len(registered) >= 2:
+                    tight = guarded[:len(want) // 2]
+                    with pytest.raises(binding.JpegEncError) as err:
+                        e.encode_to_buffer(px, w, h, binding.RGB, tight)
+                    assert err.value.status == binding.ERR_BUFFER_TOO_SMALL and f"needs {len(want)} bytes" in str(err.value)
+                    assert (guarded[len(tight):] == 0xA5).all(), "stores past the end of the caller's buffer"
+                    guarded[:] = 0xA5
+        finally:
+            for a in registered:
+                binding.host_unregister(a)
+
+
 def test_large_progressive_frame_takes_the_launched_prefix_sums(binding, oracle, synth):
     """Beyond 2 048 runs per scan the prefix sums are separate launches again (below, k_push / k_stuff fold them in):
     a 15-Mpixel 4:4:4 frame has 3 663 runs per component scan; progressive + optimised, its 9 scans share their
