@@ -279,13 +279,32 @@ def criterion_workloads(binding, synth, device):
         gpu_ms = sorted(times)[len(times) // 2] * 1e3
         res[name] = {"gpu_ms": round(gpu_ms, 3), "gpu_Mpixels_per_s": round(w * h / gpu_ms / 1e3, 1), "jpeg_bytes": int(n)}
         files[name] = out[:n].tobytes()
+    # the same calls between page-locked buffers (jpegenc_host_register - INTEGRATION.md): copies on such memory are asynchronous,
+    # and a large baseline frame then goes through upload, kernel and download stripe by stripe (host_frame.cpp, run_striped)
+    flat = px.reshape(-1)
+    binding.host_register(flat)
+    binding.host_register(out)
+    try:
+        for name, enc in encs.items():
+            n = enc.encode_to_buffer(flat, w, h, binding.RGB, out)
+            times = []
+            for _ in range(9):
+                t = time.perf_counter()
+                enc.encode_to_buffer(flat, w, h, binding.RGB, out)
+                times.append(time.perf_counter() - t)
+            res[name]["gpu_ms_registered_buffers"] = round(sorted(times)[len(times) // 2] * 1e3, 3)
+            res[name]["registered_identical"] = bool(out[:n].tobytes() == files[name])
+    finally:
+        binding.host_unregister(flat)
+        binding.host_unregister(out)
     t = time.perf_counter()
     for _ in range(5):
         for name in CRITERION_MIXED:
             encs[name].encode_to_buffer(px, w, h, binding.RGB, out)
     res["encode rgb mixed"] = {"gpu_ms": round((time.perf_counter() - t) / 5 * 1e3, 3)}
     res["what"] = ("criterion/benches/encode.rs:57-188: 2000x1800 RGB pattern, one Encoder::encode per call from one host thread, pageable "
-                   "host pixels -> JPEG bytes in a host buffer, median of 9; cpu_port_ms = the oracle's C port on one core, one call")
+                   "host pixels -> JPEG bytes in a host buffer, median of 9; gpu_ms_registered_buffers = the same with both buffers page-locked "
+                   "(jpegenc_host_register); cpu_port_ms = the oracle's C port on one core, one call")
     return res, files
 
 

@@ -59,7 +59,8 @@ def main():
                  "C3": ("C3 1920x1080 RGB q80 4:2:0 mcu", 1920, 1080, b.RGB, 2, 2, 80, 0, 125),
                  "C4": ("C4 7680x4320 CMYK q95 4:4:4 mcu", 7680, 4320, b.CMYK, 1, 1, 95, 0, 4),
                  "C5": ("C5 3840x2160 RGB q90 4:4:4 planar", 3840, 2160, b.RGB, 1, 1, 90, 1, 16),
-                 "P420": ("RGB 3840x2160 q90 4:2:0 planar", 3840, 2160, b.RGB, 2, 2, 90, 1, 32)}
+                 "P420": ("RGB 3840x2160 q90 4:2:0 planar", 3840, 2160, b.RGB, 2, 2, 90, 1, 32),
+                 "M444": ("RGB 3840x2160 q90 4:4:4 mcu", 3840, 2160, b.RGB, 1, 1, 90, 0, 16)}
         time_blocks(*table[only], reps=20)
         return
     time_blocks("C1 256x256 RGB q90 4:4:4 mcu", 256, 256, b.RGB, 1, 1, 90, 0, 1024)

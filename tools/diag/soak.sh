@@ -22,6 +22,12 @@ run dma_only JPEGENC_LIB=$DIAG JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES=0 JPEGENC_ZERO_
 # window of 8 words per wave, chunks of 8 x bpm words
 run tiny_window JPEGENC_LIB=$DIAG JPEGENC_PACK_WINDOW_WORDS=8 JPEGENC_FUZZ_SEED=$((S + 8)) JPEGENC_FUZZ_TRIALS=6000
 run tiny_window_medium JPEGENC_LIB=$DIAG JPEGENC_PACK_WINDOW_WORDS=20 JPEGENC_FUZZ_SEED=$((S + 9)) JPEGENC_FUZZ_TRIALS=2000 JPEGENC_FUZZ_MAX_W=700 JPEGENC_FUZZ_MAX_H=500
+# single frames are finished by the pixels -> bits kernel itself (finish_run.hip.h) in every run above; here: the ordinary launch
+# sequence, the stream wait, and the give-up path forced on every second frame (with and without the second walk)
+run separate_push_and_stuff JPEGENC_LIB=$DIAG JPEGENC_NO_FINISH=1 JPEGENC_FUZZ_SEED=$((S + 10)) JPEGENC_FUZZ_TRIALS=6000
+run stream_wait JPEGENC_LIB=$DIAG JPEGENC_NO_DONE_FLAG=1 JPEGENC_FUZZ_SEED=$((S + 11)) JPEGENC_FUZZ_TRIALS=6000
+run finish_gave_up JPEGENC_LIB=$DIAG JPEGENC_FORCE_FINISH_GAVE_UP=1 JPEGENC_FUZZ_SEED=$((S + 12)) JPEGENC_FUZZ_TRIALS=6000
+run finish_gave_up_tiny_window JPEGENC_LIB=$DIAG JPEGENC_FORCE_FINISH_GAVE_UP=1 JPEGENC_PACK_WINDOW_WORDS=8 JPEGENC_FUZZ_SEED=$((S + 13)) JPEGENC_FUZZ_TRIALS=4000
 ( JPEGENC_FUZZ_SEED=$((S + 7)) JPEGENC_FUZZ_TRIALS=4000 timeout 1200 python3 -m pytest tests/test_gpu_batch_multi.py -q -x -k test_randomised_planar_sources 2>&1 | tail -2 ) > $out/${tag}_soak_planar.log 2>&1
 tail -1 $out/${tag}_soak_planar.log
 ( JPEGENC_FUZZ_SEED=9 JPEGENC_GEOMETRY_TRIALS=1500 timeout 1200 python3 -m pytest tests/test_gpu_parity.py -q -x -k test_blocks_random_geometry 2>&1 | tail -2 ) > $out/${tag}_soak_geometry.log 2>&1
