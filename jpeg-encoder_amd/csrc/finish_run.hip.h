@@ -39,6 +39,22 @@ __device__ __forceinline__ uint32_t finish_wait(const uint32_t *word, bool &ok) 
     }
 }
 
+// The words of the runs before g, lane i taking runs i, i + 64, ...: every load is issued before the first is looked at (one
+// round trip for a frame of 1 000 runs instead of sixteen in a row), then the lane waits for the ones that were not ready.
+// Words of runs from g on come back as 0 (READY is stripped by the callers' masks).
+__device__ __forceinline__ void finish_look_back(const uint32_t *words, uint32_t g, uint32_t lane, uint32_t (&v)[kFinishMaxRuns / 64u], bool &ok) {
+#pragma unroll
+    for (uint32_t k = 0; k < kFinishMaxRuns / 64u; k++) {
+        const uint32_t i = lane + 64u * k;
+        v[k] = i < g ? __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFinishReady;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kFinishMaxRuns / 64u; k++) {
+        if (!(v[k] & kFinishReady)) v[k] = finish_wait(words + lane + 64u * k, ok);
+        if (lane + 64u * k >= g) v[k] = 0;
+    }
+}
+
 __device__ __forceinline__ uint32_t finish_ff4(uint32_t w) {                  // number of 0xFF bytes in a dword
     const uint32_t t = w & (w >> 4), u = t & (t >> 2), m = u & (u >> 1) & 0x01010101u;
     return (m * 0x01010101u) >> 24;
@@ -74,10 +90,12 @@ __device__ __forceinline__ void finish_run(Params p, uint32_t g, uint32_t tid, u
         }
         bool ok = true;
         uint32_t sum = 0, t8 = 0;
-        for (uint32_t i = lane; i < g; i += 64u) {
-            const uint32_t v = finish_wait(chain + i, ok);
-            sum += v & kFinishLenMask;
-            if (i + 1u == g) t8 = (v >> 23) & 0xFFu;
+        uint32_t v[kFinishMaxRuns / 64u];
+        finish_look_back(chain, g, lane, v, ok);
+#pragma unroll
+        for (uint32_t k = 0; k < kFinishMaxRuns / 64u; k++) {
+            sum += v[k] & kFinishLenMask;
+            if (lane + 64u * k + 1u == g) t8 = (v[k] >> 23) & 0xFFu;
         }
         sum = wave_sum(sum); t8 = wave_sum(t8);
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
@@ -120,7 +138,10 @@ __device__ __forceinline__ void finish_run(Params p, uint32_t g, uint32_t tid, u
         if (lane == 0) __hip_atomic_store(chain2 + g, kFinishReady | run_ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool ok = true;
         uint32_t sum = 0;
-        for (uint32_t i = lane; i < g; i += 64u) sum += finish_wait(chain2 + i, ok) & ~kFinishReady;
+        uint32_t v[kFinishMaxRuns / 64u];
+        finish_look_back(chain2, g, lane, v, ok);
+#pragma unroll
+        for (uint32_t k = 0; k < kFinishMaxRuns / 64u; k++) sum += v[k] & ~kFinishReady;
         sum = wave_sum(sum);
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
         if (lane == 0) { sh[0] = sum; if (!all_ok) sh[2] = 1u; }
