@@ -194,26 +194,27 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
     uint8_t *ws = (uint8_t *)d_ws;
     memset(&p, 0, sizeof p);
     uint64_t first_block = 0;
+    uint8_t pos_table[12] = {}, pos_prev_delta[12] = {}, pos_last_of_comp[12] = {};      // per block position of the MCU (<= 10 positions)
     if (sc.component < 0) {
         p.bpm = (uint32_t)(L.total_blocks / L.mcus);
         uint32_t pos = 0;
         for (int c = 0; c < L.num_components; c++) {
             const uint32_t hv = (uint32_t)(L.h[c] * L.v[c]);
             for (uint32_t k = 0; k < hv; k++, pos++) {
-                p.pos_table[pos] = (uint8_t)L.table[c];
-                p.pos_prev_delta[pos] = k > 0 ? 1 : 0;
-                p.pos_last_of_comp[pos] = (uint8_t)(pos - k + hv - 1);
+                pos_table[pos] = (uint8_t)L.table[c];
+                pos_prev_delta[pos] = k > 0 ? 1 : 0;
+                pos_last_of_comp[pos] = (uint8_t)(pos - k + hv - 1);
             }
         }
     } else {
         p.bpm = 1;
-        p.pos_table[0] = (uint8_t)L.table[sc.component];
+        pos_table[0] = (uint8_t)L.table[sc.component];
         for (int c = 0; c < sc.component; c++) first_block += L.blocks[c];
     }
     for (uint32_t pos = 0; pos < 12; pos++) {
-        p.pos_table_bits |= (uint32_t)(p.pos_table[pos] & 1u) << pos;
-        p.pos_delta_bits |= (uint32_t)(p.pos_prev_delta[pos] & 1u) << pos;
-        p.pos_last_nibbles |= (uint64_t)(p.pos_last_of_comp[pos] & 15u) << (4 * pos);
+        p.pos_table_bits |= (uint32_t)(pos_table[pos] & 1u) << pos;
+        p.pos_delta_bits |= (uint32_t)(pos_prev_delta[pos] & 1u) << pos;
+        p.pos_last_nibbles |= (uint64_t)(pos_last_of_comp[pos] & 15u) << (4 * pos);
     }
     p.coeffs = (const int16_t *)d_coeffs + first_block * 64;
     p.coeff_frame_stride = coeff_frame_stride;

@@ -53,7 +53,7 @@ struct ParamPack {
     uint32_t n;
     EntropyParams p[kScansPerStore];
 };
-static_assert(sizeof(ParamPack) <= 4096 && kScansPerStore >= 8, "parameter blocks per store launch");
+static_assert(sizeof(ParamPack) <= 4096 && kScansPerStore >= 12, "the twelve scans of a progressive(4) frame go in one store launch");
 
 __global__ void __launch_bounds__(256) k_store_params(const ParamPack pack, EntropyParams *dst) {
     const uint32_t words = pack.n * (uint32_t)(sizeof(EntropyParams) / 4);

@@ -48,10 +48,10 @@ struct EntropyParams {
     uint32_t ac_start, ac_end;       // zig-zag band [ac_start, ac_end), ac_start >= 1; empty = no AC
     uint32_t interval_blocks;        // restart interval in blocks (R * bpm), = nblocks when there is none
     uint32_t nintervals;
-    uint8_t pos_table[12];           // Huffman table destination of each block position in the MCU (<= 10 positions)
-    uint8_t pos_prev_delta[12];      // 1 when the previous block of the MCU has the same component
-    uint8_t pos_last_of_comp[12];    // position of the component's last block inside an MCU
-    // the same three, packed for register arithmetic (bit / nibble `pos`): no memory access on the way to the first load
+    // per block position `pos` of the MCU (<= 10 positions), packed for register arithmetic - no memory access on the way to the
+    // first load: bit pos = the Huffman table destination / the previous block of the MCU has the same component; nibble pos =
+    // the position of the component's last block inside an MCU.  (The block is sized so that the twelve scans of a
+    // progressive frame fit one k_store_params launch: kScansPerStore, entropy_kernels.hip.)
     uint32_t pos_table_bits, pos_delta_bits;
     uint64_t pos_last_nibbles;
     // Huffman code tables: [destination][0 = DC, 1 = AC][symbol] = size << 16 | code

@@ -568,16 +568,27 @@ struct FrameRun {
         if (rest && !direct) {
             rc = ctx.reserve_scan_host(kGatherHeader + nbytes, kGatherHeader + first_piece);
             if (rc) return rc;
+            // (pieces only where handing them over one by one can hide something: up to 4 MB the rest comes down in one copy - the
+            // two copies, two events and two waits of a 1.7 MB progressive 4K file cost a batch of such frames, sixteen workers
+            // calling into the runtime at once, a fifth of its rate: tools/diag/c5_batch_ab.sh)
             piece = (rest + DeviceCtx::kChunks - 1) / DeviceCtx::kChunks;
             if (piece < ((size_t)1 << 20)) piece = (size_t)1 << 20;
+            if (rest <= ((size_t)4 << 20)) piece = rest;
             piece = (piece + 65535) & ~(size_t)65535;
             for (size_t done = 0; done < rest; done += piece, npieces++) {
                 const size_t n = rest - done < piece ? rest - done : piece;
                 JPEGENC_HIP(hipMemcpyAsync(ctx.h_scan_out + kGatherHeader + first_piece + done, (const uint8_t *)ctx.d_gather + kGatherHeader + first_piece + done,
                                            n, hipMemcpyDeviceToHost, ctx.stream));
-                JPEGENC_HIP(hipEventRecord(ctx.chunk_done[npieces], ctx.stream));
+                if (piece < rest) JPEGENC_HIP(hipEventRecord(ctx.chunk_done[npieces], ctx.stream));      // (one piece: the stream itself is waited for)
             }
         }
+        // the piece with index pieces_done has arrived
+        auto wait_for_piece = [&]() -> int {
+            if (npieces == 1) JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            else JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[pieces_done]));
+            pieces_done++;
+            return JPEGENC_OK;
+        };
         size_t at = kGatherHeader;
         Out o;
         o.sink = sink; o.user = user;
@@ -600,8 +611,8 @@ struct FrameRun {
             }
             if (n < (64u << 10) || !sink) {                                   // small: through the emitter's own buffer
                 while (npieces > pieces_done && from + n > kGatherHeader + first_piece + (size_t)pieces_done * piece) {
-                    JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[pieces_done]));
-                    pieces_done++;
+                    const int wr = wait_for_piece();
+                    if (wr) return wr;
                 }
                 o.bytes(ctx.h_scan_out + from, n);
                 return JPEGENC_OK;
@@ -614,8 +625,8 @@ struct FrameRun {
                 size_t have = kGatherHeader + first_piece + (size_t)pieces_done * piece;
                 if (pieces_done >= npieces || have > kGatherHeader + nbytes) have = kGatherHeader + nbytes;
                 if (have <= pos) {
-                    JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[pieces_done]));
-                    pieces_done++;
+                    const int wr = wait_for_piece();
+                    if (wr) return wr;
                     continue;
                 }
                 const size_t m = (have < end ? have : end) - pos;
@@ -686,9 +697,15 @@ static int encode_frame_once(const Config &c, DeviceCtx &ctx, int jct, int width
     FrameRun run(c, ctx, jct, width, height, color_type_or_planes, pixel_bytes, sink, user, allow_finish, host_pixels);
     int rc = run.prepare();
     if (rc) return rc;
+    // (the upload first where it cannot become a striped one: its copy then runs under the planning below)
+    const bool may_stripe = host_pixels != nullptr && sink == buffer_sink;
+    if (!may_stripe) {
+        rc = upload(ctx);
+        if (rc) return rc;
+    }
     rc = run.plan_scans();
     if (rc) return rc;
-    if (!run.stripes) {                      // (a striped frame uploads its own stripes)
+    if (may_stripe && !run.stripes) {        // (a striped frame uploads its own stripes)
         rc = upload(ctx);
         if (rc) return rc;
     }
