@@ -3,9 +3,8 @@
 // stuffing, writer.rs:157-167; the 1-padding of finalize_bit_buffer, writer.rs:138-154) do in two more launches of a
 // sequence whose every launch costs 4-5 us of dependent start-up - a third of the GPU time of a 256x256 call.
 //
-// Every workgroup of such a launch is resident at once (<= 256 workgroups on 256 CUs) and workgroups start in blockIdx
-// order, so a run learns where it goes from the runs BEFORE it only (a decoupled look-back; nothing waits for a later
-// workgroup):
+// Workgroups start in blockIdx order, so a run learns where it goes from the runs BEFORE it only - workgroups that are
+// running or done, whatever the GPU's other load (a decoupled look-back; nothing ever waits for a later workgroup):
 //   1. publish  chain[g]  = READY | last 8 bits of the run | its length in bits         (one relaxed agent-scope store)
 //   2. look back: lo = sum of the lengths before g, carry = the last lo % 8 bits of run g - 1 (they open this run's first byte).
 //      A byte of the stream belongs to the run that holds its LAST bit; the last run also owns the 1-padded final byte.
@@ -16,6 +15,9 @@
 // GPU: 2-6 us).  The workgroup that finishes last zeroes the chain for the next launch.  A workgroup that waits longer than
 // kFinishSpinTicks (a predecessor that never started: dispatch out of order under contention - not observed) raises
 // *finish_abort in pinned host memory and the host codes the frame again through the ordinary sequence.
+// This is a LATENCY path: a run's place depends on every run before it, so the workgroups of a frame wait - on their CU slots -
+// for the slowest among them.  With one frame on an otherwise idle GPU that costs nothing; with 16 frames per launch it costs
+// a third of the throughput (profiles/README.md), which is why batches keep k_push / k_stuff as launches of their own.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
