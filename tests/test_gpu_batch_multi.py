@@ -271,7 +271,7 @@ def test_encoder_with_and_without_the_fused_kernel(binding, tmp_path, env):
     JPEGENC_PACK_WINDOW_WORDS: the second-walk path), the worker-pool batch and the device-resident batch -
     byte-identical to the oracle's files every way.  Small frames are read from and coded into pinned host memory by
     the kernels themselves (no DMA nodes); two runs force the DMA path and the zero-copy path for every size.  A single frame of
-    up to 1 024 runs without restart markers is finished by the kernel's own workgroups (finish_run.hip.h - the default in every
+    up to 512 runs without restart markers is finished by the kernel's own workgroups (finish_run.hip.h - the default in every
     run above): the last four runs keep k_push / k_stuff as separate launches, make the host wait for the stream instead of the
     kernel's flag, and pretend that a workgroup gave up waiting on every second frame (the frame is then coded again through
     the ordinary sequence)."""

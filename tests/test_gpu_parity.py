@@ -1012,15 +1012,16 @@ def test_device_entropy_pack_window_overflow_path(binding, oracle, synth):
 
 
 def test_self_finishing_kernel_edges(binding, oracle, synth):
-    """A single baseline frame of up to 1 024 runs without restart markers is put together by the workgroups of the pixels ->
+    """A single baseline frame of up to 512 runs without restart markers is put together by the workgroups of the pixels ->
     bits kernel themselves (finish_run.hip.h: look-back over the runs, 0xFF stuffing in LDS).  Its edges: one run; a last run
-    of a single MCU (a dozen bits); exactly 1 024 runs and the first size beyond (the ordinary sequence); every workgroup
+    of a single MCU (a dozen bits); exactly 512 runs (the most one launch finishes itself) and the first size beyond, 1 024 runs and
+    beyond (the ordinary sequence); every workgroup
     size (3, 4 and 6 blocks per MCU); runs whose first byte is shared with the run before at every bit offset; content
     full of 0xFF bytes (binary noise, quality 100: stuffing doubles stretches of the scan) and blocks that outgrow their
     strip (second walk, the run read back from its slot); a frame large enough that its scan goes through device memory
     and a download (above 1 MB of pixels) and small ones that the kernel writes to pinned host memory."""
     cases = [((8, 8), dict(quality=90)), ((16, 16), dict(quality=75)), ((520, 8), dict(quality=92)), ((1032, 24), dict(quality=80, sampling=(2, 1))),
-             ((2048, 2048), dict(quality=91)), ((2048, 2056), dict(quality=91)), ((1024, 520), dict(quality=60, sampling=(2, 2))),
+             ((2048, 1024), dict(quality=91)), ((2048, 1032), dict(quality=91)), ((2048, 2048), dict(quality=91)), ((2048, 2056), dict(quality=91)), ((1024, 520), dict(quality=60, sampling=(2, 2))),
              ((777, 333), dict(quality=85, sampling=(1, 2))), ((640, 480), dict(quality=100)), ((1000, 700), dict(quality=100, sampling=(2, 2)))]
     for i, ((w, h), kw) in enumerate(cases):
         for content in ("photo", "binary"):
