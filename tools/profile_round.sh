@@ -13,6 +13,8 @@ export TMPDIR=/tmp
 BENCH="bench.py --steps 1000 --warmup 20 --cpu-seconds 0.2 --headline-only"
 PMC_BENCH="bench.py --steps 20 --warmup 5 --settle-ms 0 --cpu-seconds 0.2 --headline-only"
 
+# (nothing of an earlier round of the same tag: reduce_pmc.py takes one counter file per pass)
+rm -rf "$out/${tag}_stats" "$out/${tag}_fetch" "$out/${tag}_write" "$out/${tag}_sq" "$out/${tag}_sq2"
 # which sources the library under test was built from (bench.py compares it with the tree it runs in)
 python3 jpeg-encoder_amd/srchash.py > "$out/${tag}_srchash.txt"
 python3 tools/step_series.py 400 > "$out/${tag}_step_series.txt" 2>/dev/null

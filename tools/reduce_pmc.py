@@ -24,7 +24,13 @@ import os
 def reduce_dir(path, kernel_substr):
     per_counter = collections.defaultdict(lambda: collections.defaultdict(float))
     name = None
-    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True)
+    if len(files) > 1:
+        # one pass = one process = one file: a directory that holds the files of two runs (gpurun merges what a second run of the
+        # same tag writes) would add their counters up per dispatch id - the traffic came out at 2.0 x algorithmic once
+        raise SystemExit(f"{path}: {len(files)} counter files ({', '.join(sorted(os.path.basename(f) for f in files))}) - "
+                         "keep the one of the pass that is meant and remove the others")
+    for f in files:
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 if kernel_substr not in row["Kernel_Name"]:
