@@ -694,7 +694,7 @@ __global__ void __launch_bounds__(256) k_gather_scans(const GatherArgs a, const 
     const uint32_t job = blockIdx.x;
     __shared__ uint32_t part[4];
     uint32_t before = 0;
-    for (uint32_t i = threadIdx.x; i < job; i += 256u) before += len[i];
+    for (uint32_t i = threadIdx.x; i < job; i += 256u) before += len[i] + (a.with_prefixes ? a.pre_len[i + 1u] : 0u);   // (scan i, then the header of scan i + 1)
     before = wave_sum(before);
     if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = before;
     __syncthreads();
@@ -705,6 +705,7 @@ __global__ void __launch_bounds__(256) k_gather_scans(const GatherArgs a, const 
     const uint32_t lo = min(n, blockIdx.y * per), hi = min(n, lo + per);
     const uint8_t *s = src + a.off[job];
     uint8_t *d = dst + kGatherHeader + start;
+    if (a.with_prefixes && job && blockIdx.y == 0 && threadIdx.x < a.pre_len[job]) d[(int)threadIdx.x - (int)a.pre_len[job]] = a.pre[job][threadIdx.x];
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u) d[i] = s[i];
 }
 

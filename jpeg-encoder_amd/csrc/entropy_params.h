@@ -23,9 +23,14 @@ constexpr uint32_t kLutDeviceBytes = kLutWords * 4u + kLutCompactBytes;
 // k_gather_scans: the coded scans of one frame, collected behind a header of their lengths
 constexpr uint32_t kGatherMaxScans = 256;
 constexpr uint32_t kGatherHeader = kGatherMaxScans * 4;
+constexpr uint32_t kGatherPrefixScans = 32, kGatherPrefixBytes = 16;
 struct GatherArgs {
-    uint32_t n, reserved;
+    uint32_t n;
+    uint32_t with_prefixes;             // != 0: scan k > 0 is preceded by pre[k][0 .. pre_len[k]) - its SOS header - so that the frame's scans and
+                                        // the headers between them come down as ONE piece (n <= kGatherPrefixScans)
     uint64_t off[kGatherMaxScans];      // byte offset of each scan's output inside the source buffer
+    uint8_t pre_len[kGatherPrefixScans];
+    uint8_t pre[kGatherPrefixScans][kGatherPrefixBytes];
 };
 
 // k_batch_prefix / k_batch_gather: the coded scans of a ROUND of frames packed back to back (frame-major, scans in
