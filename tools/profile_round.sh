@@ -4,7 +4,7 @@
 # Writes under gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards (see profiles/README.md).
 # --pmc passes are separate runs and never combined with a trace option.
 set -u
-tag=${1:-rXX}
+tag=${1:-rXX}    # (a tag used before: remove its gpurun_out/<tag>_{stats,fetch,write,sq,sq2} locally first - gpurun merges new files beside old ones)
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p "$out"
