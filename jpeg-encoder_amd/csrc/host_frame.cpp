@@ -370,14 +370,19 @@ struct FrameRun {
     int enqueue_scans() {
         // ---- entropy-code every scan on the device and fetch only the compressed bytes ----------------
         int rc = JPEGENC_OK;
+        static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+        time_point t_stats = t_begin, t_tables = t_begin;
         if (optimize) {                                  // optimize_huffman_table, encoder.rs:1086-1200
             JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            t_stats = now();
             const int max_tables = L.num_components < 2 ? L.num_components : 2;
             for (int d = 0; d < max_tables; d++)
                 for (int k = 0; k < 2; k++)
                     if (!t.h[d][k].assign_optimized(ctx.h_freq + (d * 2 + k) * 257)) return fail_code_too_long();
+            t_tables = now();
         }
         if (optimize) { rc = ensure_lut(); if (rc) return rc; }
+        if (optimize && trace) fprintf(stderr, "[jpegenc]   optimised tables: statistics on the host after %ld us, tables built in %ld us\n", us(t_begin, t_stats), us(t_stats, t_tables));
         if (enqueue) {
             bool empty_scans = false;                    // (the coder zeroes the length of every scan it codes)
             for (const Job &j : jobs) empty_scans = empty_scans || !j.cap;

@@ -8,7 +8,8 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 
 
 def kernel_sources_sha256(csrc=CSRC):
-    files = sorted(p for pat in ("*.hip", "*.h", "*.inc", "build.sh") for p in glob.glob(os.path.join(csrc, pat)))
+    files = sorted(p for pat in ("*.hip", "*.h", "*.inc", "build.sh") for p in glob.glob(os.path.join(csrc, pat))
+                   if os.path.basename(p) != "host_internal.h")       # (included by the host-only *.cpp alone)
     h = hashlib.sha256()
     for p in files:
         h.update(os.path.basename(p).encode() + b"\0")
