@@ -83,6 +83,7 @@ struct FrameRun {
     uint8_t scan_header_bytes[kGatherPrefixScans] = {};                    // (merged) length of the SOS header in front of scan k > 0
     uint32_t scan_len[DeviceCtx::kMaxScans];                                // (the header may move if the buffer grows)
     time_point t_begin, t_launched, t_len;
+    const time_point t_created = now();
 
     FrameRun(const Config &c_, DeviceCtx &ctx_, int jct_, int width_, int height_, int color_type_or_planes_, size_t pixel_bytes_,
              jpegenc_write_fn sink_, void *user_, bool allow_finish_, const uint8_t *host_pixels_)
@@ -198,7 +199,11 @@ struct FrameRun {
                 // of a sequence whose every node costs 6-10 us - disappears: 256x256 75 -> 68 us, 720p 122 -> 117, nothing beyond
                 // 1080p (tools/diag/zero_copy_ab.sh).  Frames above 1 MB of pixels keep the DMA: bulk copies are what it is good at.
                 static const size_t zero_copy_max = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)1 << 20); }();
-                if (out_total && pixel_bytes <= zero_copy_max) {                  // (several scans: the gather kernel writes there)
+                // (Larger frames whose files are small - the handle's last file of this geometry fitted the first copy - take the same
+                // way while that lasts: 720p 113 -> 108 us, 1080p 178 -> 175; at 1440p and beyond the copy engine wins again.)
+                const bool small_file_again = ctx.last_file_geometry == ((uint64_t)width << 32 | (uint32_t)height) && ctx.last_scan_bytes &&
+                                              ctx.last_scan_bytes <= DeviceCtx::kFirstPiece && pixel_bytes <= ((size_t)13 << 19) && jobs.size() == 1;
+                if (out_total && (pixel_bytes <= zero_copy_max || (small_file_again && zero_copy_max))) {   // (several scans: the gather kernel writes there)
                     rc = ctx.reserve_scan_host(kGatherHeader + out_total);
                     if (rc) return rc;
                     gather = ctx.h_scan_out;
@@ -501,6 +506,8 @@ struct FrameRun {
         nbytes = 0;
         for (size_t k = 0; k < jobs.size(); k++) { scan_len[k] = reinterpret_cast<const uint32_t *>(ctx.h_scan_out)[k]; nbytes += scan_len[k]; }
         for (size_t k = 1; merged && k < jobs.size(); k++) nbytes += scan_header_bytes[k];
+        ctx.last_scan_bytes = nbytes;
+        ctx.last_file_geometry = (uint64_t)width << 32 | (uint32_t)height;
         return JPEGENC_OK;
     }
 
@@ -698,8 +705,8 @@ struct FrameRun {
         if (direct) JPEGENC_HIP(hipStreamSynchronize(ctx.stream));           // the scans are in the caller's buffer
         o.marker(0xD9);
         o.drain(true);
-        if (trace) fprintf(stderr, "[jpegenc] frame: launch %ld us, wait-len %ld us, d2h %ld us, emit %ld us, bytes %zu, scans %zu\n",
-                           us(t_begin, t_launched), us(t_launched, t_len), us(t_len, t_copied), us(t_copied, now()), nbytes, jobs.size());
+        if (trace) fprintf(stderr, "[jpegenc] frame: prepare %.1f us, launch %ld us, wait-len %ld us, d2h %ld us, emit %ld us, bytes %zu, scans %zu\n",
+                           (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t_begin - t_created).count() / 1e3, us(t_begin, t_launched), us(t_launched, t_len), us(t_len, t_copied), us(t_copied, now()), nbytes, jobs.size());
         if (o.failed) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
         return JPEGENC_OK;
     }

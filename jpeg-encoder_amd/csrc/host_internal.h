@@ -281,6 +281,8 @@ struct DeviceCtx {
     // their own streams, one event per uploaded stripe
     hipStream_t kernel_stream = nullptr, download_stream = nullptr;
     hipEvent_t uploaded[8] = {};
+    size_t last_scan_bytes = 0;        // coded bytes of the handle's last device-coded frame and its size: a mid-size frame whose file was
+    uint64_t last_file_geometry = 0;   // small is coded straight into pinned host memory the next time (host_frame.cpp, plan_scans)
     uint32_t unsynchronised = 0;       // frames in a row whose kernel announced its result through h_words[2] while the stream was not waited for
     volatile uint32_t *h_words = nullptr;
     static constexpr int kHostWords = 16;
