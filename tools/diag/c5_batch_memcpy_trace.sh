@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 for v in ${VARIANTS:-ab_libs/wt_a .}; do
   out=$GRAFT_REPO_ROOT/gpurun_out/c5mc_$(basename $v | tr . h); rm -rf $out; mkdir -p $out
-  (cd $GRAFT_REPO_ROOT/$v && timeout -s KILL 300 rocprofv3 --hip-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/diag/c5_batch_only.py > $out/stdout.txt 2> $out/err.txt)
+  (cd $GRAFT_REPO_ROOT/$v && timeout -s KILL 300 rocprofv3 --hip-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/${TRACE_SCRIPT:-tools/diag/c5_batch_only.py} > $out/stdout.txt 2> $out/err.txt)
   echo "== $v"; cat $out/stdout.txt
   f=$(find $out -name '*hip_api_trace.csv' | head -1)
   [ -n "$f" ] && python3 - "$f" <<'PY'
