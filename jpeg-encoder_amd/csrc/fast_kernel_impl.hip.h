@@ -218,9 +218,9 @@ struct ByteConv {          // the sample is a byte of the pixel word itself
 #ifndef JPEGENC_MIN_WAVES
 #define JPEGENC_MIN_WAVES 5
 #endif
-// The SIMD-variant instantiations of the byte-plane kernels spill ~19 SGPRs (the variant's extra constants), and at the
-// 5-wave budget some of them also spill VGPRs - the combination hipcc 7.2 got wrong in the pixels -> bits kernel
-// (fused_kernel_impl.hip.h).  These pass every test as compiled, but they get the 4-wave budget (no VGPR spills) anyway.
+// The simd-variant instantiations of the byte-plane kernels with decimated 3- / 4-byte pixels would spill a few VGPRs at the
+// 5-wave budget next to two SGPRs parked in VGPR lanes - the combination hipcc 7.2 got wrong in the pixels -> bits kernel
+// (fused_kernel_impl.hip.h): the byte-plane simd variants get the 4-wave budget (no VGPR spills).
 #define JPEGENC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(VARIANT == 1 && !CONV ? 4 : JPEGENC_MIN_WAVES)))
 // CONV = the kernel carries the RGB -> YCbCr roles (RGB family, CmykAsYcck); otherwise byte planes only.
 // 3-byte RGB with sampling factors 1 and 2 has at most 6 waves per 64-MCU group; 4:1:0-style factors (4x2), CmykAsYcck
@@ -300,6 +300,33 @@ struct WaveCtx {
 #endif
 };
 
+// The wave-uniform half of a wave's context: the launch's FastHeader and the wave's FastWave record (two s_load_dwordx16
+// from the kernel argument block) and what follows from them.  `again` = after the block math: the same loads from
+// laundered offsets, so that neither the records nor anything derived from them stays in scalar registers across the
+// FDCT - the transform wants up to four columns of quantiser constants (64 SGPRs) in flight, and what the epilogue needs
+// costs two scalar loads and a dozen scalar instructions to have again.  (Kept live they pushed the simd-variant
+// instantiations past the SGPR file: 19-38 spilled SGPRs and a scratch allocation per wave in every one of them.)
+__device__ __forceinline__ void wave_uniforms(WaveCtx &w, const uint32_t grp, const bool again, const uint32_t after = 0u) {
+    uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t oh = (uint32_t)__builtin_offsetof(BlockKernelParams, fast_hdr);
+    uint32_t ow = (uint32_t)__builtin_offsetof(BlockKernelParams, fast_wave) + wave * (uint32_t)sizeof(FastWave);
+    if (again) asm volatile("" : "+s"(oh), "+s"(ow) : "v"(after));
+    const u32x16 H = kernarg16(oh), Wv = kernarg16(ow);
+    const uint32_t bits = Wv[0];
+    w.H = H; w.Wv = Wv; w.wave = wave; w.bits = bits; w.order = H[11];
+    w.c = (int)((bits >> FW_COMP_SHIFT) & 3u);
+    w.role = (int)((bits >> FW_ROLE_SHIFT) & 3u);
+    w.qsel = (int)((bits >> FW_QSEL_SHIFT) & 1u);
+    w.lg = (bits >> FW_LG_SHIFT) & 3u; w.vrow = (bits >> FW_VROW_SHIFT) & 7u; w.lgv = (bits >> FW_LGV_SHIFT) & 3u;
+    w.units_x = Wv[3]; w.limit = Wv[4]; w.magic = Wv[5]; w.shift = Wv[6];
+    // Both block orders walk the image MCU by MCU - that is what makes the waves of a workgroup read the
+    // same pixels; the order only decides where a block is stored (stage_and_store).
+    w.first_unit = grp * H[15] + Wv[1];
+    w.wave_mcus = (bits >> FW_COUNT_SHIFT) & 127u;               // MCUs this wave covers
+    w.row0 = (uint32_t)(((uint64_t)w.first_unit * w.magic) >> w.shift);
+    w.col0 = w.first_unit - w.row0 * w.units_x;
+}
+
 // Prologue + fetch + conversion + FDCT + quantiser of one wave over one group of 64 MCUs of frame `frm` (see the notes
 // at the top of the file): packed[j] = zig-zag coefficients (2j, 2j + 1) of the lane's block.  false: a padding wave
 // of the last group (nothing computed).
@@ -330,26 +357,17 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     w.tm0 = __builtin_readcyclecounter();
 #endif
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Two wide scalar loads bring everything the prologue needs (device_params.h: FastHeader, FastWave);
     // the workgroup holds exactly the waves of one group, so group = blockIdx.x and the wave's number
     // selects its FastWave record.
-    const u32x16 H = kernarg16(__builtin_offsetof(BlockKernelParams, fast_hdr));
-    const u32x16 Wv = kernarg16(__builtin_offsetof(BlockKernelParams, fast_wave) + (size_t)wave * sizeof(FastWave));
-    const uint32_t bits = Wv[0];
-    const int c = (int)((bits >> FW_COMP_SHIFT) & 3u);
-    const int role = (int)((bits >> FW_ROLE_SHIFT) & 3u);
-    const int qsel = (int)((bits >> FW_QSEL_SHIFT) & 1u);
+    wave_uniforms(w, grp, false);
+    const u32x16 H = w.H, Wv = w.Wv;
+    const uint32_t bits = w.bits, lg = w.lg, vrow = w.vrow, lgv = w.lgv;
+    const int c = w.c, role = w.role, qsel = w.qsel;
     const bool sub = (bits >> FW_SUB_SHIFT) & 1u;                   // this component is decimated by (SX, SY)
-    const uint32_t lg = (bits >> FW_LG_SHIFT) & 3u, vrow = (bits >> FW_VROW_SHIFT) & 7u, lgv = (bits >> FW_LGV_SHIFT) & 3u;
-    const uint32_t order = H[11], units_x = Wv[3], limit = Wv[4], magic = Wv[5], shift = Wv[6];
-    // Both block orders walk the image MCU by MCU - that is what makes the waves of a workgroup read the
-    // same pixels; the order only decides where a block is stored (stage_and_store).
-    const uint32_t first_unit = grp * H[15] + Wv[1];
-    const uint32_t wave_mcus = (bits >> FW_COUNT_SHIFT) & 127u;   // MCUs this wave covers
-    w.H = H; w.Wv = Wv; w.lane = lane; w.wave = wave; w.bits = bits; w.order = order; w.lg = lg; w.lgv = lgv; w.vrow = vrow;
-    w.first_unit = first_unit; w.wave_mcus = wave_mcus; w.limit = limit; w.units_x = units_x; w.magic = magic; w.shift = shift;
-    w.c = c; w.role = role; w.qsel = qsel;
+    const uint32_t order = w.order, units_x = w.units_x, limit = w.limit, magic = w.magic, shift = w.shift;
+    const uint32_t first_unit = w.first_unit, wave_mcus = w.wave_mcus;
+    w.lane = lane;
     if (first_unit >= limit) return false;                          // padding wave of the last group: nothing to do
     uint32_t pitch = PLANES ? Wv[9] : H[10];                        // frame bytes < 2^31 (checked by the launcher)
     const gbytes frame = frame_base<PLANES>(H, Wv, frm, (uint32_t)c, pitch);
@@ -360,7 +378,7 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     const int sxc = sub ? SX : 1, syc = sub ? SY : 1;
 
     // this lane's block: MCU (ux, uy), then block sub_k of the wave's block row inside it
-    const uint32_t row0 = (uint32_t)(((uint64_t)first_unit * magic) >> shift), col0 = first_unit - row0 * units_x;   // wave-uniform
+    const uint32_t row0 = w.row0, col0 = w.col0;                                                                       // wave-uniform
     const uint32_t dm = lane >> lg, sub_k = lane & ((1u << lg) - 1u);
     uint32_t ux = col0 + dm, uy = row0;
     if (units_x >= 64u) {                      // at most one wrap: dm < 64 <= units_x
@@ -372,7 +390,7 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     bool inside = first_unit + dm < limit && dm < wave_mcus;
     if (order != 0) inside = inside && (ux << lg) + sub_k < Wv[2] && (uy << lgv) + vrow < Wv[13];   // planar: the plane may end inside the last MCUs
     if (!inside) { ux = 0; uy = 0; }                                // such slots read block 0 and store nothing
-    w.col0 = col0; w.row0 = row0; w.dm = dm; w.sub_k = sub_k; w.ux = ux; w.uy = uy; w.inside = inside;
+    w.dm = dm; w.sub_k = sub_k; w.ux = ux; w.uy = uy; w.inside = inside;
     w.frame = frame; w.pitch = pitch; w.width = width; w.hlim = hlim;
     BlockRef me;
     me.x0 = (int)(ux * mcu_w + sub_k * 8u * (uint32_t)sxc);
@@ -462,6 +480,7 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
     WaveCtx w;
     uint32_t packed[32];
     if (!block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, frm, w, packed)) return;
+    wave_uniforms(w, grp, true, packed[0]);
     const u32x16 H = w.H, Wv = w.Wv;
     const uint32_t lane = w.lane, wave = w.wave, order = w.order, lg = w.lg, lgv = w.lgv, vrow = w.vrow, sub_k = w.sub_k, ux = w.ux, uy = w.uy;
     const uint32_t first_unit = w.first_unit, wave_mcus = w.wave_mcus, limit = w.limit, units_x = w.units_x, magic = w.magic, shift = w.shift;

@@ -81,6 +81,15 @@ __device__ __forceinline__ int dot2_first(uint32_t a, uint32_t k_vgpr, int round
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(k_vgpr), "s"(round_sgpr));
     return d;
 }
+// The same with an accumulator that is an inline constant of the instruction (-16 .. 64: pass 2's rounding terms 2 and 0):
+// no scalar register per value.
+template <int ROUND>
+__device__ __forceinline__ int dot2_first_imm(uint32_t a, uint32_t k_vgpr) {
+    static_assert(ROUND >= -16 && ROUND <= 64, "inline constants only");
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(k_vgpr), "n"(ROUND));
+    return d;
+}
 // pair constants that start a chain; kept in VGPRs for the whole block
 struct ChainConsts {
     uint32_t k2, k6, o1, o3, o5, o7, p1_0, p1_4, p2_0, p2_4;
@@ -128,7 +137,7 @@ __device__ __forceinline__ void islow_pass(uint32_t a, uint32_t b, uint32_t c, u
     if (PASS == 1) {
         constexpr int n = CONST_BITS - PASS1_BITS, r = 1 << (n - 1);
         out[0] = dot2_first(ta, K.p1_0, -4096);   // fdct.rs:137: (tmp10 + tmp11) << 2, minus 8*128*4
-        out[4] = dot2_first(ta, K.p1_4, 0);       // fdct.rs:138
+        out[4] = dot2_first_imm<0>(ta, K.p1_4);   // fdct.rs:138
         out[2] = dot2_first(ts, K.k2, r) >> n;
         out[6] = dot2_first(ts, K.k6, r) >> n;
         out[1] = odd(d01, d32, ODD1, K.o1, r) >> n;
@@ -138,8 +147,8 @@ __device__ __forceinline__ void islow_pass(uint32_t a, uint32_t b, uint32_t c, u
     } else {
         constexpr int n = CONST_BITS + PASS1_BITS, r = 1 << (n - 1);
         constexpr int r2 = SIMD_ODD_LANE ? 0 : (1 << (PASS1_BITS - 1));   // avx2/fdct.rs:196-209,:291
-        out[0] = dot2_first(ta, K.p2_0, r2) >> PASS1_BITS;                 // fdct.rs:197
-        out[4] = dot2_first(ta, K.p2_4, r2) >> PASS1_BITS;                 // fdct.rs:198
+        out[0] = dot2_first_imm<r2>(ta, K.p2_0) >> PASS1_BITS;             // fdct.rs:197
+        out[4] = dot2_first_imm<r2>(ta, K.p2_4) >> PASS1_BITS;             // fdct.rs:198
         out[2] = dot2_first(ts, K.k2, r) >> n;
         out[6] = dot2_first(ts, K.k6, r) >> n;
         out[1] = odd(d01, d32, ODD1, K.o1, r) >> n;

@@ -15,11 +15,12 @@ namespace jpegenc {
 
 // Register budget: 5 waves per SIMD (<= 96 VGPRs) although two workgroups per CU are all that run: left at 4 the compiler
 // keeps every row load of a block in flight (104 VGPRs) and the kernel is 12 % slower - the block kernel's own finding.
-// The SIMD-variant instantiations stay at 4: their extra scalar constants push the kernel past the SGPR file, and at the
-// 5-wave budget the VGPRs that hold the spilled SGPRs are themselves spilled to scratch - code that hipcc 7.2 gets wrong
-// (scan bytes differ, memory faults; caught by test_encoder_simd_variant_file).  SGPR spills alone (4 waves) are fine; the
-// byte-plane SIMD-variant instantiations need 3 waves (168 VGPRs) to keep their 40 spilled SGPRs in VGPRs that are not
-// spilled themselves.  build.sh checks the combination after every build (tools/check_spills.py).
+// The simd-variant instantiations used to sit at 4 and 3 waves with 35-40 spilled SGPRs and a scratch allocation; since the
+// wave's records are loaded AGAIN after the block math instead of being kept in scalar registers across it (wave_uniforms,
+// fast_kernel_impl.hip.h) the RGB family has the scalar variant's budget and no scratch.  The byte-plane simd-variant
+// instantiations with decimated 3- / 4-byte pixels keep 4 waves: at 5 they spill a few VGPRs next to the 11 SGPRs that
+// live in VGPR lanes - the combination hipcc 7.2 gets wrong (scan bytes differ, memory faults; caught by
+// test_encoder_simd_variant_file).  build.sh checks both after every build (tools/check_spills.py).
 #ifndef JPEGENC_GROUP_WAVES
 #define JPEGENC_GROUP_WAVES 5
 #endif
@@ -40,7 +41,7 @@ __host__ __device__ inline uint32_t group_lds_bytes(uint32_t bpm) {
 }
 
 template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
-__global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 ? (CONV ? 4 : 3) : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
+__global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 && !CONV ? 4 : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
 k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
     extern __shared__ __attribute__((aligned(4096))) uint8_t smem[];              // (the kernel has no static LDS: the dynamic part starts at 0)
@@ -93,6 +94,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     {
         BlockRegs r;
         const bool active = block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, f, w, r.c);
+        wave_uniforms(w, grp, true, r.c[0]);          // (the wave's records again: nothing of them is kept in scalar registers across the FDCT)
         mine_valid = active && w.inside;
         stage_block(r.c, image, w.lane);
         mask = mine_valid ? nonzero_mask(r.c) : 0ull;

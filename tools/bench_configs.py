@@ -15,6 +15,9 @@ ge.load_package()
 b = importlib.import_module("jpeg_encoder_amd.binding")
 
 
+VARIANT = b.FDCT_SIMD if "--fdct" in sys.argv and sys.argv[sys.argv.index("--fdct") + 1] == "simd" else b.FDCT_SCALAR      # --fdct {scalar,simd}
+
+
 def time_blocks(name, w, h, ct, hs, vs, q, order, frames, reps=100):
     dev = torch.device("cuda:0")
     bpp = b.BPP[ct]
@@ -29,7 +32,7 @@ def time_blocks(name, w, h, ct, hs, vs, q, order, frames, reps=100):
     st = torch.cuda.current_stream()
 
     def run():
-        b.blocks_device(d_px.data_ptr(), fb, frames, w, h, ct, hs, vs, qt, order, 0, d_co.data_ptr(), nblk, st.cuda_stream)
+        b.blocks_device(d_px.data_ptr(), fb, frames, w, h, ct, hs, vs, qt, order, VARIANT, d_co.data_ptr(), nblk, st.cuda_stream)
     import time
     t0 = time.perf_counter()                      # run-in: see profiles/r01_k_step_series.txt
     while time.perf_counter() - t0 < 0.15:
@@ -44,7 +47,7 @@ def time_blocks(name, w, h, ct, hs, vs, q, order, frames, reps=100):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     algo = frames * (fb + nblk * 128)
-    res = {"config": name, "frames_per_launch": frames, "kernel_ms": round(ms, 4),
+    res = {"config": name, "fdct": "simd" if VARIANT == b.FDCT_SIMD else "scalar", "frames_per_launch": frames, "kernel_ms": round(ms, 4),
            "Mpixels_per_s": round(frames * w * h / ms / 1e3, 1), "algorithmic_GBps": round(algo / ms / 1e6, 1),
            "frac_of_8TBps": round(algo / ms / 1e6 / 8000, 4)}
     print(json.dumps(res))

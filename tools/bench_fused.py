@@ -17,6 +17,9 @@ b = importlib.import_module("jpeg_encoder_amd.binding")
 synth = importlib.import_module("jpeg_encoder_amd.synth")
 
 
+VARIANT = b.FDCT_SIMD if "--fdct" in sys.argv and sys.argv[sys.argv.index("--fdct") + 1] == "simd" else b.FDCT_SCALAR      # --fdct {scalar,simd}
+
+
 def frames_of(kind, n, w, h, dev):
     if kind == "noise":
         g = torch.Generator(device=dev)
@@ -47,15 +50,15 @@ def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
             continue
         d_px = frames_of(kind, n, w, h, dev)
         outs, lens = {}, {}
-        res = {"content": kind, "frames": n, "size": f"{w}x{h}", "sampling": f"{hs}x{vs}", "quality": quality}
+        res = {"content": kind, "fdct": "simd" if VARIANT == b.FDCT_SIMD else "scalar", "frames": n, "size": f"{w}x{h}", "sampling": f"{hs}x{vs}", "quality": quality}
 
         def two_kernel(d_out, d_len):
-            b.blocks_device(d_px.data_ptr(), w * h * 3, n, w, h, b.RGB, hs, vs, q, b.ORDER_MCU, b.FDCT_SCALAR, d_co.data_ptr(), nblk, stream.cuda_stream)
+            b.blocks_device(d_px.data_ptr(), w * h * 3, n, w, h, b.RGB, hs, vs, q, b.ORDER_MCU, VARIANT, d_co.data_ptr(), nblk, stream.cuda_stream)
             b.scan_device(d_co.data_ptr(), nblk, n, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(), d_ws.data_ptr(), wsz, stream.cuda_stream)
 
         def fused(d_out, d_len):
             b.pixels_scan_device(d_px.data_ptr(), w * h * 3, n, w, h, b.RGB, hs, vs, q, d_out.data_ptr(), cap, d_len.data_ptr(),
-                                 d_ws.data_ptr(), wsz, stream.cuda_stream)
+                                 d_ws.data_ptr(), wsz, stream.cuda_stream, variant=VARIANT)
         for name, fn in (("two_kernel", two_kernel), ("fused", fused)):
             if only and only.split(":")[1] != name:
                 continue
@@ -86,6 +89,9 @@ def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
 
 
 if __name__ == "__main__":
+    if "--fdct" in sys.argv:
+        i = sys.argv.index("--fdct")
+        del sys.argv[i:i + 2]
     if len(sys.argv) > 1 and sys.argv[1] == "1080p":
         main(n=32, w=1920, h=1080, quality=80)
     elif len(sys.argv) > 1 and sys.argv[1].startswith("q"):      # e.g. q98: 4K frames at another quality (long blocks: the second-walk paths)

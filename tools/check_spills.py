@@ -4,7 +4,9 @@ spills SGPRs AND ALSO spills VGPRs (SGPR spills alone - also those that end up i
 that are themselves spilled: wrong scan bytes and memory faults in the SIMD-variant instantiations at a 5-wave register
 budget, fused_kernel_impl.hip.h) - the waves_per_eu budgets that avoid it were picked by hand, so a compiler bump, an
 EXTRA_HIPCC_FLAGS variant or a new instantiation must not bring it back unnoticed.  Also reports scratch in any scalar-variant
-instantiation of the pixels -> bits kernel (round 3's kernel has none).
+instantiation of the pixels -> bits kernel, and FAILS on scratch in any RGB-family instantiation (CONV = true: Rgb / Rgba / Bgr /
+Bgra / CmykAsYcck, either FDCT variant) of either kernel: round 4 removed the simd variant's 68 bytes per lane there, and a
+scratch allocation per wave is what a register-allocation accident looks like from outside.
 
 usage: check_spills.py FILE...   (the stderr of hipcc -Rpass-analysis=kernel-resource-usage, one file per translation unit)"""
 import re
@@ -34,14 +36,17 @@ def main(paths):
                 cur[m.group(1)] = int(m.group(2))
     names = sorted(kernels)
     pretty = dict(zip(names, demangle(names)))
-    bad, noted = [], []
+    bad, noted, scratchy = [], [], []
     for n in names:
         k, name = kernels[n], pretty[n]
         if "k_group_code" not in name and "k_blocks_fast" not in name:
             continue
         sg, vg, sc = k.get("SGPRs Spill", 0), k.get("VGPRs Spill", 0), k.get("ScratchSize [bytes/lane]", 0)
+        rgb_family = re.search(r"<\d+, \d+, \d+, \d+, true", name) is not None
         if sg and vg:
             bad.append(f"{name}: {sg} SGPRs spilled AND {vg} VGPRs spilled ({sc} B scratch per lane)")
+        elif rgb_family and sc:
+            scratchy.append(f"{name}: {sc} B scratch per lane ({sg} SGPRs, {vg} VGPRs spilled)")
         elif "k_group_code" in name and sc:
             noted.append(f"{name}: {sc} B scratch per lane")
     checked = sum(1 for n in names if "k_group_code" in pretty[n] or "k_blocks_fast" in pretty[n])
@@ -52,7 +57,12 @@ def main(paths):
         for line in bad:
             print("  " + line, file=sys.stderr)
         return 1
-    print(f"check_spills: {checked} k_group_code / k_blocks_fast instantiations, none spills SGPRs together with VGPRs")
+    if scratchy:
+        print("check_spills: scratch in an RGB-family instantiation:", file=sys.stderr)
+        for line in scratchy:
+            print("  " + line, file=sys.stderr)
+        return 1
+    print(f"check_spills: {checked} k_group_code / k_blocks_fast instantiations, none spills SGPRs together with VGPRs, no scratch in the RGB family")
     return 0
 
 
