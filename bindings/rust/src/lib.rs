@@ -706,8 +706,17 @@ impl PinnedFrame {
     /// A page-locked copy of `pixels`.
     pub fn from_slice(pixels: &[u8]) -> Result<PinnedFrame, EncodingError> {
         let mut f = PinnedFrame::new(pixels.len())?;
-        f.copy_from_slice(pixels);
+        f.fill_from(pixels);
         Ok(f)
+    }
+
+    /// Overwrites the frame with `pixels` (same length) through the library's staging copy (`jpegenc_host_copy`: streaming
+    /// stores - the destination is about to be read by the DMA engine, not by this core).
+    pub fn fill_from(&mut self, pixels: &[u8]) {
+        assert_eq!(pixels.len(), self.len);
+        if self.len != 0 {
+            unsafe { sys::jpegenc_host_copy(self.ptr as *mut core::ffi::c_void, pixels.as_ptr() as *const core::ffi::c_void, self.len) };
+        }
     }
 }
 

@@ -388,6 +388,10 @@ int  jpegenc_host_alloc(size_t bytes, void **out);
 int  jpegenc_host_free(void *p);
 int  jpegenc_host_register(void *p, size_t bytes);
 int  jpegenc_host_unregister(void *p);
+/* The copy the batch workers stage a pageable frame with (streaming stores: the destination - page-locked memory the DMA
+ * engine is about to read - is neither fetched nor pushed through the copying core's cache), for callers that fill their
+ * own page-locked pool.  Plain memory on both sides; no device involved (works without a GPU). */
+int  jpegenc_host_copy(void *dst, const void *src, size_t bytes);
 
 /* Same batch, each frame into its own caller buffer (no callbacks): outs[i] has capacities[i]
  * bytes, lengths[i] receives the size frame i needs; a frame that does not fit makes the call

@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_encode_image", "jpegenc_encoder_block_order", "jpegenc_encoder_encode_coefficients",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
     "jpegenc_encoder_encode_planes_device", "jpegenc_encoder_encode_planes_batch_device",
-    "jpegenc_host_alloc", "jpegenc_host_free", "jpegenc_host_register", "jpegenc_host_unregister",
+    "jpegenc_host_alloc", "jpegenc_host_free", "jpegenc_host_register", "jpegenc_host_unregister", "jpegenc_host_copy",
     "jpegenc_shard_frames", "jpegenc_encoder_encode_batch_multi", "jpegenc_encoder_encode_batch_multi_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
 ]
@@ -174,6 +174,7 @@ def lib():
         l.jpegenc_host_free.argtypes = [C.c_void_p]
         l.jpegenc_host_register.argtypes = [C.c_void_p, C.c_size_t]
         l.jpegenc_host_unregister.argtypes = [C.c_void_p]
+        l.jpegenc_host_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         l.jpegenc_encoder_encode_batch_multi_to_buffers.argtypes = [
             C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]

@@ -3,8 +3,10 @@
 // walk_once (entropy_walk.hip.h) visits the 63 AC positions of a block as a chain of exec-masked regions, so a wave pays
 // for every zig-zag position at which ANY of its 64 blocks is non-zero: 30 positions on photo-like 4K frames whose blocks
 // hold 8.7 non-zeros on average and 17 at most (tools/diag/nonzero_stats.py).  Here the lane
-//   1. leaves its 64 quantised coefficients in a lane-private column of LDS (coefficient pair j of lane L = word
-//      j * 64 + L of the wave's 8 KiB image: stores and per-lane indexed loads are both bank-conflict free),
+//   1. leaves its quantised coefficients in a lane-private column of LDS (coefficient pair j of lane L = word
+//      j * 64 + L of the wave's image: stores and per-lane indexed loads are both bank-conflict free) - HALF a block at a
+//      time (round 4): positions 0 .. 31, walked, then positions 32 .. 63 into the same 4 KiB, so that a wave's image is
+//      4 KiB instead of 8 and a third workgroup of the pixels -> bits kernel fits a CU (fused_kernel_impl.hip.h),
 //   2. builds the 64-bit mask of its non-zero coefficients in zig-zag order from the 32 packed registers - per register
 //      one v_pk_min_u16 (0 / 1 flags) and ONE v_dot2_u32_u16 whose constant pair (1 << 2i, 2 << 2i) shifts both flags
 //      into place and whose accumulator is the mask so far,
@@ -24,29 +26,41 @@ namespace jpegenc {
 
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
-// ---- the code tables in LDS, compact: per destination 16 DC entries + 256 AC entries of (code << n, size + n) ----------
-// A symbol (run, n) sits at slot run * 16 + ((16 - n) & 15): the walk gets 32 - n from v_ffbh_i32 and indexes with it as it
-// is (no subtraction on the way to the table read).
-constexpr uint32_t kLoopLutPerTable = 16u + 256u;
+// ---- the code tables in LDS, compact: per destination 16 DC entries + 16 x 11 AC entries of (code << n, -(size + n)) ----
+// DC category n sits at slot (16 - n) & 15.  An AC symbol (run, n) sits at slot run * 11 + (n ? 11 - n : 0) of its table:
+// only the sizes 0 .. 10 exist for 8-bit samples (|AC| <= 8 * 128 * 0.9 / 8 after the smallest divisor, 8: below 1 024), so
+// a row of sixteen had five slots nobody reads - 1 280 of the 4 352 bytes a workgroup keeps, and 3 072 is what lets three
+// workgroups of six waves share a CU's LDS.  The walk gets 32 - n from v_ffbh_i32 and indexes with it as it is:
+// entry = (ac_table - 21 * 8) + run * 88 + (32 - n) * 8, one v_mad_u32_u24 + one v_lshl_add_u32.
+constexpr uint32_t kLoopAcSlots = 11u;
+constexpr uint32_t kLoopLutPerTable = 16u + 16u * kLoopAcSlots;
 constexpr uint32_t kLoopLutEntries = 2u * kLoopLutPerTable;
 constexpr uint32_t kLoopLutBytes = kLoopLutEntries * 8u;
-__host__ __device__ constexpr uint32_t loop_lut_slot(uint32_t symbol) { return (symbol & 0xF0u) | ((16u - (symbol & 15u)) & 15u); }   // (its own inverse)
-// compact entry e (destination-major: 16 DC slots, 256 AC slots) <- word of EntropyParams::lut ([destination][0 = DC, 1 = AC][256] = size << 16 | code)
+__host__ __device__ constexpr uint32_t loop_dc_slot(uint32_t n) { return (16u - n) & 15u; }                      // (its own inverse)
+__host__ __device__ constexpr uint32_t loop_ac_slot(uint32_t run, uint32_t n) { return run * kLoopAcSlots + (n ? kLoopAcSlots - n : 0u); }
+// size category of the symbol in compact entry e (destination-major: 16 DC slots, 176 AC slots)
+__device__ __forceinline__ uint32_t loop_lut_size(uint32_t e) {
+    const uint32_t r = e % kLoopLutPerTable;
+    if (r < 16u) return loop_dc_slot(r);
+    const uint32_t slot = (r - 16u) % kLoopAcSlots;
+    return slot ? kLoopAcSlots - slot : 0u;
+}
+// compact entry e <- word of EntropyParams::lut ([destination][0 = DC, 1 = AC][256] = size << 16 | code)
 __device__ __forceinline__ uint32_t loop_lut_source(uint32_t e) {
-    const uint32_t t = e >= kLoopLutPerTable ? 1u : 0u, r = e - t * kLoopLutPerTable;
-    return t * 512u + (r < 16u ? loop_lut_slot(r) : 256u + loop_lut_slot(r - 16u));
+    const uint32_t t = e / kLoopLutPerTable, r = e % kLoopLutPerTable, n = loop_lut_size(e);
+    return t * 512u + (r < 16u ? n : 256u + ((((r - 16u) / kLoopAcSlots) << 4) | n));
 }
 __device__ __forceinline__ u32x2 loop_lut_entry(uint32_t e, uint32_t word) {
-    const uint32_t n = (16u - (e & 15u)) & 15u;     // size category of the slot's symbol (DC: the symbol itself; kLoopLutPerTable is a multiple of 16)
+    const uint32_t n = loop_lut_size(e);
     // (code << n, -(size + n)): the length is kept NEGATED - the sinks subtract it from shift amounts and cursors
     return u32x2{(word & 0xFFFFu) << n, 0u - ((word >> 16) + n)};   // (a symbol without a code still carries its magnitude bits: writer.rs:342-354 with size 0)
 }
 
 // ---- a lane's block in LDS + its non-zero mask -------------------------------------------------------------------------
-// image = the wave's 8 KiB area; pair j of lane L at word j * 64 + L
-__device__ __forceinline__ void stage_block(const uint32_t (&c)[32], uint32_t *image, uint32_t lane) {
+// image = the wave's 4 KiB area; pair j of the staged half (positions 32 * half ...) of lane L at word j * 64 + L
+__device__ __forceinline__ void stage_half(const uint32_t (&c)[32], uint32_t half, uint32_t *image, uint32_t lane) {
 #pragma unroll
-    for (int j = 0; j < 32; j++) image[j * 64 + (int)lane] = c[j];
+    for (int j = 0; j < 16; j++) image[j * 64 + (int)lane] = half ? c[16 + j] : c[j];
 }
 
 // bit k = coefficient k of the block is non-zero (k = 1 .. 63; bit 0 - the DC - is left clear)
@@ -112,7 +126,7 @@ __device__ __forceinline__ u32x2 dc_code(uint32_t dc_table /* LDS byte address *
     const int diff = (int16_t)(dc - prev_dc);
     const int t = diff + (diff >> 31);
     const uint32_t n = category_of(t);
-    const u32x2 e = *(lut_ptr)(uintptr_t)(dc_table + (loop_lut_slot(n) << 3));
+    const u32x2 e = *(lut_ptr)(uintptr_t)(dc_table + (loop_dc_slot(n) << 3));
     return u32x2{e.x | __builtin_amdgcn_ubfe((uint32_t)t, 0u, n), 0u - e.y};
 }
 
@@ -122,8 +136,8 @@ __device__ __forceinline__ uint32_t lowest_bit(uint32_t m) {
     asm("v_ffbl_b32 %0, %1" : "=v"(k) : "v"(m));
     return k;
 }
-// coefficient k of the lane whose column of the wave's image starts at LDS byte address image_at: halfword (k & 1) of
-// word (k >> 1) * 64 + lane, i.e. byte (k << 7) - 126 * (k & 1) of the column.  (k = 0xFFFFFFFF - "no further non-zero" -
+// coefficient k (0 .. 31: its position inside the staged half) of the lane whose column of the wave's image starts at LDS
+// byte address image_at: halfword (k & 1) of word (k >> 1) * 64 + lane, i.e. byte (k << 7) - 126 * (k & 1) of the column.  (k = 0xFFFFFFFF - "no further non-zero" -
 // reads 254 bytes below the column: some other word of the workgroup's LDS, never used.)
 __device__ __forceinline__ int coefficient_at(uint32_t image_at, uint32_t k) {
     typedef const __attribute__((address_space(3))) int16_t *coef_ptr;
@@ -143,7 +157,9 @@ __device__ __forceinline__ void walk_trip(uint32_t k, int v, uint32_t &after, u3
     after = k + 1u;
     const int t = v + (v >> 31);
     const uint32_t sb = sign_bits(t);                                             // 32 - size category (v != 0: t is neither 0 nor -1)
-    new_entry = *(lut_ptr)(uintptr_t)(rows + ((ZRL ? run & 15u : run) << 7) + (sb << 3));
+    uint32_t row;                                                                  // rows + run * 88 (run < 16; with ZRL the run modulo 16)
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(ZRL ? run & 15u : run), "v"(kLoopAcSlots * 8u), "v"(rows));
+    new_entry = *(lut_ptr)(uintptr_t)(row + (sb << 3));
     new_mag = __builtin_amdgcn_ubfe((uint32_t)t, 0u, 32u - sb);
     __builtin_amdgcn_sched_barrier(0);       // (left alone the scheduler hoists the first use of put_entry - and the wait for it - to the top of the trip)
     s.put(put_entry.x | put_mag, put_entry.y);
@@ -166,37 +182,40 @@ __device__ __forceinline__ bool has_long_zero_run(uint64_t mask, uint32_t first)
     return (mask & ~below) != 0;
 }
 
-// AC symbols of the band [first, end) of the lane's block (write_ac_block, writer.rs:356-388): mask = its non-zero
-// positions inside the band; ac_table = LDS byte address of the AC table (loop_lut_slot order).  Two LDS reads per
-// symbol, neither waited for where it is issued: the coefficient of the NEXT non-zero is requested while this one is
-// coded, and the table entry of a symbol is consumed in the next trip.  Two trips per iteration, so that the values in
-// flight alternate between two sets of registers instead of being copied.
+// AC symbols of the band [first, end) of the lane's block (write_ac_block, writer.rs:356-388): c = its 32 coefficient pairs
+// (registers), mask = its non-zero positions inside the band; image = the wave's 4 KiB staging area, image_at = LDS byte
+// address of the lane's column in it; ac_table = LDS byte address of the AC table (loop_ac_slot order).  Each half of the
+// block is staged and walked in turn (a wave's LDS operations execute in order: the second half's stores cannot overtake the
+// first half's last reads).  Two LDS reads per symbol, neither waited for where it is issued: the coefficient of the NEXT
+// non-zero is requested while this one is coded, and the table entry of a symbol is consumed in the next trip.  Two trips
+// per iteration, so that the values in flight alternate between two sets of registers instead of being copied.
 template <bool ZRL, class Sink>
-__device__ __forceinline__ void walk_nonzeros_t(uint64_t mask, uint32_t first, uint32_t end, uint32_t image_at, uint32_t ac_table, Sink &s) {
+__device__ __forceinline__ void walk_nonzeros_t(const uint32_t (&c)[32], uint64_t mask, uint32_t first, uint32_t end, uint32_t *image, uint32_t lane,
+                                                uint32_t image_at, uint32_t ac_table, Sink &s) {
     typedef const __attribute__((address_space(3))) u32x2 *lut_ptr;
-    const u32x2 zrl = *(lut_ptr)(uintptr_t)(ac_table + loop_lut_slot(0xF0u) * 8u), eob = *(lut_ptr)(uintptr_t)(ac_table + loop_lut_slot(0u) * 8u);
-    const uint32_t rows = ac_table - 16u * 8u;     // entry of (run, size n) = rows + run * 128 + (32 - n) * 8; 32 - n = 22 .. 31 is what v_ffbh_i32 returns
+    const u32x2 zrl = *(lut_ptr)(uintptr_t)(ac_table + loop_ac_slot(15u, 0u) * 8u), eob = *(lut_ptr)(uintptr_t)(ac_table + loop_ac_slot(0u, 0u) * 8u);
+    const uint32_t rows = ac_table - 21u * 8u;     // entry of (run, size n) = rows + run * 88 + (32 - n) * 8; 32 - n = 22 .. 31 is what v_ffbh_i32 returns
     u32x2 pend = {0u, 0u};                          // (put(0, 0) is a no-op)
     uint32_t pend_mag = 0;
     uint32_t after = first;                         // position after the last non-zero coded so far (relative to the current half)
 #pragma unroll
     for (uint32_t half = 0; half < 2u; half++) {
         uint32_t m = half ? (uint32_t)(mask >> 32) : (uint32_t)mask;
-        const uint32_t column = image_at + half * (32u << 7);                    // positions 32 .. 63 as 0 .. 31
+        stage_half(c, half, image, lane);                                        // positions 32 * half .. as 0 .. 31
         if (half) after -= 32u;
         uint32_t ka = lowest_bit(m), kb;
-        int va = coefficient_at(column, ka), vb;
+        int va = coefficient_at(image_at, ka), vb;
         u32x2 other;
         uint32_t other_mag;
         while (m) {
             m &= m - 1u;
             kb = lowest_bit(m);
-            vb = coefficient_at(column, kb);
+            vb = coefficient_at(image_at, kb);
             walk_trip<ZRL>(ka, va, after, pend, pend_mag, other, other_mag, rows, zrl, s);
             if (!m) { pend = other; pend_mag = other_mag; break; }
             m &= m - 1u;
             ka = lowest_bit(m);
-            va = coefficient_at(column, ka);
+            va = coefficient_at(image_at, ka);
             walk_trip<ZRL>(kb, vb, after, other, other_mag, pend, pend_mag, rows, zrl, s);
         }
     }
@@ -206,9 +225,10 @@ __device__ __forceinline__ void walk_nonzeros_t(uint64_t mask, uint32_t first, u
 
 // zero_runs: whether ANY block of the wave has a run of 16 zeros (wave-uniform: has_long_zero_run over the wave)
 template <class Sink>
-__device__ __forceinline__ void walk_nonzeros(uint64_t mask, uint32_t first, uint32_t end, uint32_t image_at, uint32_t ac_table, Sink &s, bool zero_runs = true) {
-    if (zero_runs) walk_nonzeros_t<true>(mask, first, end, image_at, ac_table, s);
-    else walk_nonzeros_t<false>(mask, first, end, image_at, ac_table, s);
+__device__ __forceinline__ void walk_nonzeros(const uint32_t (&c)[32], uint64_t mask, uint32_t first, uint32_t end, uint32_t *image, uint32_t lane,
+                                              uint32_t image_at, uint32_t ac_table, Sink &s, bool zero_runs = true) {
+    if (zero_runs) walk_nonzeros_t<true>(c, mask, first, end, image, lane, image_at, ac_table, s);
+    else walk_nonzeros_t<false>(c, mask, first, end, image, lane, image_at, ac_table, s);
 }
 
 // After the prefix sum: a strip whose block begins at strip bit `from` (its bits [from, from + nbits)) goes to bit offset

@@ -14,10 +14,10 @@ constexpr uint32_t kFinishTimingAt = 2u * kFinishMaxRuns + 16u;  // (diagnostic 
 constexpr uint32_t kFinishChainWords = kFinishTimingAt + 64u * 16u; // its look-back words: [runs] lengths, [runs] 0xFF counts, the count of finished workgroups
 constexpr uint32_t kMaxScansPerLaunch = 16;                      // scans coded by one launch sequence (blockIdx.z)
 // Device memory of one set of Huffman code tables (k_build_lut): [destination][0 = DC, 1 = AC][256 symbols] = size << 16 | code,
-// followed by the same tables the way the pixels -> bits kernel keeps them in LDS (entropy_loop.hip.h: 2 x (16 + 256) entries
+// followed by the same tables the way the pixels -> bits kernel keeps them in LDS (entropy_loop.hip.h: 2 x (16 + 16 x 11) entries
 // of (code << n, -(size + n)), slots ordered for the walk) so that its workgroups copy instead of deriving them.
 constexpr uint32_t kLutWords = 4u * 256u;
-constexpr uint32_t kLutCompactBytes = 2u * (16u + 256u) * 8u;
+constexpr uint32_t kLutCompactBytes = 2u * (16u + 16u * 11u) * 8u;
 constexpr uint32_t kLutDeviceBytes = kLutWords * 4u + kLutCompactBytes;
 
 // k_gather_scans: the coded scans of one frame, collected behind a header of their lengths

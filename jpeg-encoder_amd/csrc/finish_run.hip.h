@@ -218,6 +218,10 @@ __device__ __forceinline__ void finish_run(Params p, uint32_t g, uint32_t tid, u
         if (lane == 0) old = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
         if (old + 1u == G) {
+            // (the other workgroups' release fences pair with THIS acquire through the counter's read-modify-write chain: their
+            // bytes, the scan's length and a raised finish_abort happen-before the host's read of finish_done == 1.  Only the
+            // last workgroup pays for it.)
+            if (p.finish_done) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
             if (p.finish_done && lane == 0) __hip_atomic_store(p.finish_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             for (uint32_t i = lane; i < G; i += 64u) {
                 __hip_atomic_store(chain + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

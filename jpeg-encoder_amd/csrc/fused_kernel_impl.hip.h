@@ -28,17 +28,21 @@ namespace jpegenc {
 #define JPEGENC_GROUP_PRIV_WORDS 16
 #endif
 constexpr uint32_t kGPriv = JPEGENC_GROUP_PRIV_WORDS;     // words of a lane's strip: word 0 = the DC code (right-aligned), AC bits from bit 32
-constexpr uint32_t kGImageWords = 2048;                  // a wave's coefficient image (64 lanes x 32 pairs) = its share of the window later
+constexpr uint32_t kGImageWords = 1024;                  // a wave's coefficient image - HALF of its 64 blocks' coefficients at a time (64 lanes x 16 pairs,
+                                                         // entropy_loop.hip.h) - and its share of the run's window later
 constexpr uint32_t kGWin = kGImageWords;
 constexpr uint32_t kGDcBits = 27;                        // longest DC code + magnitude bits (16 + 11)
 
 constexpr uint32_t kGSpillBytes = 256;
 static_assert(kGPriv == 16, "StripOr finds a strip's word with a 4-bit field of the cursor");
-__host__ __device__ inline uint32_t group_lds_bytes(uint32_t bpm) {
+static_assert(64u * ((kGPriv - 1u) * 32u + kGDcBits) + 128u <= kGWin * 32u, "a run whose strips all hold fits the window (+ the zero word, 16-byte copies)");
+__host__ __device__ constexpr uint32_t group_lds_bytes(uint32_t bpm) {
     // strips (16 words per lane: 4 KiB per wave, 4 KiB-aligned) | one row that takes what the last wave's overflowing strips spill |
-    // coefficient images, then the run's window (2 048 words per wave) | code tables | lengths | DCs | flags
+    // half-block coefficient images, then the run's window (1 024 words per wave) | code tables | lengths | DCs | flags
+    // = 54 080 bytes for the six waves of 4:2:0: THREE workgroups per CU (163 840 / 3 = 54 613; round 3: 79.9 KB, two)
     return bpm * kGPriv * 64u * 4u + kGSpillBytes + bpm * kGImageWords * 4u + kLoopLutBytes + bpm * 64u * 2u + bpm * 64u * 2u + 64u;
 }
+static_assert(group_lds_bytes(6u) * 3u <= 160u * 1024u, "three six-wave workgroups per CU");
 
 template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 && !CONV ? 4 : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
@@ -91,12 +95,12 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     bool mine_valid;
     int my_dc;
     uint32_t *image = window + wave_id * kGImageWords;
+    // (the block's 32 registers stay alive until the workgroup knows that every strip held: a second walk stages them again)
+    BlockRegs r;
     {
-        BlockRegs r;
         const bool active = block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, f, w, r.c);
         wave_uniforms(w, grp, true, r.c[0]);          // (the wave's records again: nothing of them is kept in scalar registers across the FDCT)
         mine_valid = active && w.inside;
-        stage_block(r.c, image, w.lane);
         mask = mine_valid ? nonzero_mask(r.c) : 0ull;
         my_dc = mine_valid ? (int)(int16_t)(r.c[0] & 0xFFFFu) : 0;
     }
@@ -146,7 +150,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     const bool zero_runs = __builtin_amdgcn_ballot_w64(has_long_zero_run(mask, 1u)) != 0;     // wave-uniform
     if (mine_valid) {
         StripOr so = {(uint32_t)(uintptr_t)strip, 32u * 8u};
-        walk_nonzeros(mask, 1u, 64u, image_at, ac_table, so, zero_runs);
+        walk_nonzeros(r.c, mask, 1u, 64u, image, lane, image_at, ac_table, so, zero_runs);
         ac_bits = so.bits() - 32u;
     }
     JPEGENC_STAMP(2);
@@ -233,9 +237,10 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
             for (uint32_t i = tid * 4u; i <= nwords; i += nthreads * 4u)
                 *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(window + i);
     } else {
-        // A block longer than its strip (quality 95 and up) or a run longer than the window: the images are still there, so
-        // the run is coded again chunk by chunk - every lane whose block reaches into the chunk walks its symbols a second
-        // time and ORs them at their final place into the zeroed chunk (the strips' area), which then goes to the slot.
+        // A block longer than its strip (quality 95 and up) or a run longer than the window: the blocks are still in their
+        // lanes' registers, so the run is coded again chunk by chunk - every lane whose block reaches into the chunk stages
+        // and walks its symbols a second time and ORs them at their final place into the zeroed chunk (the strips' area),
+        // which then goes to the slot.
         const uint32_t chunk_words = (max(min(p.window_words, kGPriv * 64u), 4u) & ~3u) * bpm, chunk_bits = chunk_words * 32u;   // (a multiple of 16 bytes)
         for (uint32_t w0 = 0; w0 <= nwords; w0 += chunk_words) {                 // (word nwords = the zero word after the run)
             for (uint32_t i = tid; i < chunk_words; i += nthreads) strips[i] = 0;
@@ -245,7 +250,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
                 ChunkOr co = {(lds_word *)strips, (int32_t)(at - c0), chunk_words};
                 const u32x2 dc = dc_code(dc_table, my_dc, prev_dc);
                 co.put(dc.x, 0u - dc.y);
-                walk_nonzeros(mask, 1u, 64u, image_at, ac_table, co);
+                walk_nonzeros(r.c, mask, 1u, 64u, image, lane, image_at, ac_table, co);
             }
             __syncthreads();
             const uint32_t n = min(chunk_words, nwords + 1u - w0);

@@ -114,7 +114,7 @@ struct BatchRun {
         // 42.4 Gpixel/s in four rounds, 44.1 in eight)
         if (coeff_bytes >= ((size_t)4 << 20) && num_frames >= 8) {
             const int eighth = (num_frames + 7) / 8;
-            if (eighth < per_round) per_round = eighth < 4 ? 4 : eighth;
+            if (eighth < per_round) per_round = std::min(per_round, eighth < 4 ? 4 : eighth);   // (never above the footprint / the caller's bound)
         }
         if (per_round > num_frames) per_round = num_frames;
         ws = 0;
@@ -327,6 +327,7 @@ static int encode_device_frames_pooled(jpegenc_encoder *e, const void *d_frames,
     auto body = [&](int w) {
         if (w > 0) bind_thread_near_device(e->device, e->numa_bind);
         DeviceCtx &ctx = *e->workers[(size_t)w];
+        ctx.batch_worker = true;
         int r = ctx.open(e->device);
         while (r == JPEGENC_OK) {
             const int i = next.fetch_add(1);
@@ -518,6 +519,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     auto body = [&](int w) {
         if (w > 0) bind_thread_near_device(e->device, e->numa_bind);   // (opt-in) spawned workers; the caller's own affinity is left alone
         DeviceCtx &ctx = *e->workers[(size_t)w];
+        ctx.batch_worker = true;
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= num_frames || status.load() != JPEGENC_OK) break;

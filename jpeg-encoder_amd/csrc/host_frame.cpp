@@ -215,7 +215,8 @@ struct FrameRun {
         // (fill_scan's condition for the kernel finishing the scan itself)
         self_finishing = fused && fused_src.chain && !c.restart_interval && fused_runs(p) <= kFinishMaxRuns;
         static const bool poll_off = JPEGENC_DIAG_ENV("JPEGENC_NO_DONE_FLAG") != nullptr;
-        if (self_finishing && host_gather && !poll_off) fused_src.finish_done = (uint32_t *)(ctx.h_words + 2);
+        // (the single-image latency path only: a batch's sixteen workers would each burn a core spinning while the GPU is shared)
+        if (self_finishing && host_gather && !poll_off && !ctx.batch_worker) fused_src.finish_done = (uint32_t *)(ctx.h_words + 2);
         // A large frame between page-locked host buffers: uploaded, coded and downloaded stripe by stripe (run_striped) - from 4 MB
         // of pixels, where a stripe's copies are worth their fixed costs.
         static const size_t striped_from = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_STRIPED_FROM_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)4 << 20); }();
@@ -579,6 +580,9 @@ struct FrameRun {
         (void)hipStreamSynchronize(ctx.stream);
         const hipError_t de = hipStreamSynchronize(ctx.download_stream);
         ctx.unsynchronised = 0;
+        // (a failure after some stripes were launched leaves READY words and a part-way counter in the look-back chain: the last
+        // workgroup's zeroing never ran, and the next self-finishing frame of this handle would read them)
+        if ((rc != JPEGENC_OK || he != hipSuccess || de != hipSuccess) && launched > 0) (void)reset_chain();
         if (rc != JPEGENC_OK) { bs->len = len0; return rc; }
         if (he != hipSuccess || de != hipSuccess) { bs->len = len0; return hip_fail(he != hipSuccess ? he : de, "striped frame"); }
         if (gave_up()) { bs->len = len0; return reset_chain(); }
@@ -607,7 +611,8 @@ struct FrameRun {
         for (const Job &j : jobs) coded_scans += j.cap ? 1 : 0;
         if (merged) coded_scans = 1;
         const bool large_scans = coded_scans && rest / coded_scans >= ((size_t)512 << 10);
-        BufferSink *direct = rest && large_scans && sink == buffer_sink ? (BufferSink *)user : nullptr;
+        static const bool no_direct = JPEGENC_DIAG_ENV("JPEGENC_NO_DIRECT_D2H") != nullptr;     // diagnosis: every scan through the pinned buffer
+        BufferSink *direct = rest && large_scans && sink == buffer_sink && !no_direct ? (BufferSink *)user : nullptr;
         size_t piece = 0;
         int npieces = 0, pieces_done = 0;
         if (rest && !direct) {
@@ -835,6 +840,14 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
     return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user, staged ? nullptr : data);
 }
 
+
+// the batch workers' staging copy for callers that fill their own page-locked pools (tools/host_load_proxy.py also loads a
+// host with it the way more ranks would)
+extern "C" int jpegenc_host_copy(void *dst, const void *src, size_t bytes) {
+    if ((!dst || !src) && bytes) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null buffer");
+    if (bytes) staging_copy(dst, src, bytes);
+    return JPEGENC_OK;
+}
 
 int buffer_sink(void *user, const uint8_t *data, size_t n) {
     BufferSink *b = (BufferSink *)user;

@@ -503,3 +503,18 @@ def test_shipping_library_reads_no_diagnostic_switches(pkg):
     syms = lambda path: set(l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", path], text=True).splitlines()
                             if " T " in l and "jpegenc_" in l)
     assert syms(default) == syms(b.DIAG_LIB_PATH)
+
+
+def test_host_copy_is_a_plain_copy_that_needs_no_device(binding):
+    """jpegenc_host_copy: the batch workers' staging copy (streaming stores above 256 KB), exported for callers that fill their own
+    page-locked pools - every length and alignment copies exactly, nothing beyond the range is touched."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 31, 4096, (256 << 10) - 1, (256 << 10) + 77, 3 * 1920 * 1080):
+        for so, do in ((0, 0), (1, 3), (13, 32)):
+            src = rng.integers(0, 256, n + 64, dtype=np.uint8)
+            dst = np.full(n + 128, 0xA5, dtype=np.uint8)
+            assert binding.lib().jpegenc_host_copy(dst.ctypes.data + do + 32, src.ctypes.data + so, n) == binding.OK
+            assert np.array_equal(dst[do + 32:do + 32 + n], src[so:so + n])
+            assert (dst[:do + 32] == 0xA5).all() and (dst[do + 32 + n:] == 0xA5).all()
+    assert binding.lib().jpegenc_host_copy(None, None, 16) == binding.ERR_INVALID_ARGUMENT
