@@ -174,7 +174,8 @@ def lib():
         l.jpegenc_host_free.argtypes = [C.c_void_p]
         l.jpegenc_host_register.argtypes = [C.c_void_p, C.c_size_t]
         l.jpegenc_host_unregister.argtypes = [C.c_void_p]
-        l.jpegenc_host_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        if hasattr(l, "jpegenc_host_copy"):          # (A/B runs load older builds through JPEGENC_LIB)
+            l.jpegenc_host_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         l.jpegenc_encoder_encode_batch_multi_to_buffers.argtypes = [
             C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]

@@ -27,7 +27,8 @@ namespace jpegenc {
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
 // ---- the code tables in LDS, compact: per destination 16 DC entries + 16 x 11 AC entries of (code << n, -(size + n)) ----
-// DC category n sits at slot (16 - n) & 15.  An AC symbol (run, n) sits at slot run * 11 + (n ? 11 - n : 0) of its table:
+// DC category n sits at slot n (12 .. 15 never occur: the pixels -> bits kernel keeps a workgroup's flags in those 32 bytes of
+// each table).  An AC symbol (run, n) sits at slot run * 11 + (n ? 11 - n : 0) of its table:
 // only the sizes 0 .. 10 exist for 8-bit samples (|AC| <= 8 * 128 * 0.9 / 8 after the smallest divisor, 8: below 1 024), so
 // a row of sixteen had five slots nobody reads - 1 280 of the 4 352 bytes a workgroup keeps, and 3 072 is what lets three
 // workgroups of six waves share a CU's LDS.  The walk gets 32 - n from v_ffbh_i32 and indexes with it as it is:
@@ -36,12 +37,12 @@ constexpr uint32_t kLoopAcSlots = 11u;
 constexpr uint32_t kLoopLutPerTable = 16u + 16u * kLoopAcSlots;
 constexpr uint32_t kLoopLutEntries = 2u * kLoopLutPerTable;
 constexpr uint32_t kLoopLutBytes = kLoopLutEntries * 8u;
-__host__ __device__ constexpr uint32_t loop_dc_slot(uint32_t n) { return (16u - n) & 15u; }                      // (its own inverse)
+constexpr uint32_t kLoopDcHoleAt = 12u * 8u, kLoopDcHoleBytes = 4u * 8u;      // bytes of a table nothing reads: DC slots 12 .. 15
 __host__ __device__ constexpr uint32_t loop_ac_slot(uint32_t run, uint32_t n) { return run * kLoopAcSlots + (n ? kLoopAcSlots - n : 0u); }
 // size category of the symbol in compact entry e (destination-major: 16 DC slots, 176 AC slots)
 __device__ __forceinline__ uint32_t loop_lut_size(uint32_t e) {
     const uint32_t r = e % kLoopLutPerTable;
-    if (r < 16u) return loop_dc_slot(r);
+    if (r < 16u) return r;
     const uint32_t slot = (r - 16u) % kLoopAcSlots;
     return slot ? kLoopAcSlots - slot : 0u;
 }
@@ -126,7 +127,7 @@ __device__ __forceinline__ u32x2 dc_code(uint32_t dc_table /* LDS byte address *
     const int diff = (int16_t)(dc - prev_dc);
     const int t = diff + (diff >> 31);
     const uint32_t n = category_of(t);
-    const u32x2 e = *(lut_ptr)(uintptr_t)(dc_table + (loop_dc_slot(n) << 3));
+    const u32x2 e = *(lut_ptr)(uintptr_t)(dc_table + (n << 3));
     return u32x2{e.x | __builtin_amdgcn_ubfe((uint32_t)t, 0u, n), 0u - e.y};
 }
 

@@ -33,16 +33,17 @@ constexpr uint32_t kGImageWords = 1024;                  // a wave's coefficient
 constexpr uint32_t kGWin = kGImageWords;
 constexpr uint32_t kGDcBits = 27;                        // longest DC code + magnitude bits (16 + 11)
 
-constexpr uint32_t kGSpillBytes = 256;
 static_assert(kGPriv == 16, "StripOr finds a strip's word with a 4-bit field of the cursor");
 static_assert(64u * ((kGPriv - 1u) * 32u + kGDcBits) + 128u <= kGWin * 32u, "a run whose strips all hold fits the window (+ the zero word, 16-byte copies)");
 __host__ __device__ constexpr uint32_t group_lds_bytes(uint32_t bpm) {
-    // strips (16 words per lane: 4 KiB per wave, 4 KiB-aligned) | one row that takes what the last wave's overflowing strips spill |
-    // half-block coefficient images, then the run's window (1 024 words per wave) | code tables | lengths | DCs | flags
-    // = 54 080 bytes for the six waves of 4:2:0: THREE workgroups per CU (163 840 / 3 = 54 613; round 3: 79.9 KB, two)
-    return bpm * kGPriv * 64u * 4u + kGSpillBytes + bpm * kGImageWords * 4u + kLoopLutBytes + bpm * 64u * 2u + bpm * 64u * 2u + 64u;
+    // strips (16 words per lane: 4 KiB per wave, 4 KiB-aligned) | lengths (2 bytes per block; until barrier 1 their first row takes
+    // what the last wave's overflowing strips spill) | DCs | half-block coefficient images, then the run's window (1 024 words per
+    // wave) | code tables (the workgroup's flags in the DC slots nothing reads)
+    // = 53 760 bytes for the six waves of 4:2:0 = 42 of gfx950's 1 280-byte LDS granules: THREE workgroups per CU (128 granules;
+    // round 3: 79.9 KB, two workgroups - and 54 080 bytes, 43 granules, were still two)
+    return bpm * kGPriv * 64u * 4u + bpm * 64u * 2u + bpm * 64u * 2u + bpm * kGImageWords * 4u + kLoopLutBytes;
 }
-static_assert(group_lds_bytes(6u) * 3u <= 160u * 1024u, "three six-wave workgroups per CU");
+static_assert((group_lds_bytes(6u) + 1279u) / 1280u * 3u <= 128u, "three six-wave workgroups per CU");
 
 template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 && !CONV ? 4 : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
@@ -51,11 +52,14 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     extern __shared__ __attribute__((aligned(4096))) uint8_t smem[];              // (the kernel has no static LDS: the dynamic part starts at 0)
     const uint32_t nthreads = blockDim.x, bpm = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);   // one wave per block position of the MCU
     uint32_t *strips = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *window = strips + bpm * kGPriv * 64u + kGSpillBytes / 4u;          // first: every wave's coefficient image
-    uint8_t *lut_bytes = reinterpret_cast<uint8_t *>(window + bpm * kGImageWords);
-    uint16_t *lens = reinterpret_cast<uint16_t *>(lut_bytes + kLoopLutBytes);
+    uint16_t *lens = reinterpret_cast<uint16_t *>(strips + bpm * kGPriv * 64u);
     int16_t *dcs = reinterpret_cast<int16_t *>(lens + bpm * 64u);
-    uint32_t *flags = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);              // per wave: [w] a block outgrew its strip, [8 + w] AC bits of its blocks (only summed for a lowered window); stored, never zeroed
+    uint32_t *window = reinterpret_cast<uint32_t *>(dcs + bpm * 64u);             // first: every wave's coefficient image (half a block at a time)
+    uint8_t *lut_bytes = reinterpret_cast<uint8_t *>(window + bpm * kGImageWords);
+    // per wave: [w] a block outgrew its strip | [w] AC bits of its blocks (only summed for a lowered window); stored, never zeroed.
+    // They live in the DC slots 12 .. 15 of the two code tables (no such category exists; the table copies below leave them out).
+    uint32_t *flags = reinterpret_cast<uint32_t *>(lut_bytes + kLoopDcHoleAt), *flags_bits = reinterpret_cast<uint32_t *>(lut_bytes + kLoopLutPerTable * 8u + kLoopDcHoleAt);
+    static_assert(kLoopDcHoleBytes >= 6u * 4u && kLoopDcHoleAt % 16u == 0u && (kLoopLutPerTable * 8u) % 16u == 0u, "one word per wave, whole 16-byte chunks");
     const uint32_t tid = threadIdx.x, grp = blockIdx.x + bp.group_base, f = blockIdx.y;
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool finish = p.chain != nullptr;                                      // the workgroups put the scan together themselves (finish_run.hip.h)
@@ -81,7 +85,8 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         for (uint32_t i = 0; i < kGPriv / 4u; i++) reinterpret_cast<uint4 *>(strips + wave_id * kGPriv * 64u)[i * 64u + l] = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (uint32_t i = 0; i < (kLoopLutBytes + 1023u) / 1024u; i++) {
-            if (i * 64u + l < kLoopLutBytes / 16u)
+            const uint32_t chunk = i * 64u + l, in_table = chunk % (kLoopLutPerTable * 8u / 16u);
+            if (chunk < kLoopLutBytes / 16u && (in_table < kLoopDcHoleAt / 16u || in_table >= (kLoopDcHoleAt + kLoopDcHoleBytes) / 16u))     // (not the flags: another wave may have set its own already)
                 __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void *)(compact + (size_t)(i * 64u + l) * 16u), (lds_dst)(lut_bytes + i * 1024u), 16, 0, 0);
         }
         const uint32_t gid = grp * nthreads + tid;
@@ -143,7 +148,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     // ---- the AC symbols of the block, into the lane's strip from bit 32 (before the barrier: the other waves still fetch) ----
     const uint32_t table = (uint32_t)w.qsel;                                    // quantisation = DC = AC table destination (encoder.rs:569-619)
     const uint32_t dc_table = (uint32_t)(uintptr_t)(lds_bytes)lut_bytes + table * kLoopLutPerTable * 8u, ac_table = dc_table + 16u * 8u;
-    const uint32_t image_at = (uint32_t)(uintptr_t)(lds_bytes)(smem) + bpm * kGPriv * 256u + kGSpillBytes + wave_id * kGImageWords * 4u + lane * 4u;
+    const uint32_t image_at = (uint32_t)(uintptr_t)(lds_bytes)(smem) + bpm * kGPriv * 256u + bpm * 256u + wave_id * kGImageWords * 4u + lane * 4u;
     lds_word *strip = (lds_word *)(strips + wave_id * kGPriv * 64u) + lane;
     uint32_t ac_bits = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // this wave's copies of the code tables (issued before its pixel loads) are in LDS
@@ -158,7 +163,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     {
         const bool outgrown = __builtin_amdgcn_ballot_w64(ac_bits > (kGPriv - 1u) * 32u) != 0;
         const uint32_t wave_bits = lowered_window ? wave_sum(ac_bits) : 0u;
-        if (lane == 0) { flags[wave_id] = outgrown ? 1u : 0u; flags[8u + wave_id] = wave_bits; }
+        if (lane == 0) { flags[wave_id] = outgrown ? 1u : 0u; flags_bits[wave_id] = wave_bits; }
     }
     int pred_first = 0;
     if (need_pred) {
@@ -175,7 +180,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
 #pragma unroll
     for (uint32_t j = 0; j < 6u; j++) {
         any_outgrown |= j < bpm ? flags[j] : 0u;
-        run_ac_bits += j < bpm ? flags[8u + j] : 0u;
+        run_ac_bits += j < bpm ? flags_bits[j] : 0u;
     }
     const bool fits = any_outgrown == 0u && (!lowered_window || ((run_ac_bits + 64u * bpm * kGDcBits + 31u) >> 5) + 4u <= p.window_words * bpm);   // (+4: the zero word, 16-byte copies)
     if (fits) {
@@ -259,9 +264,10 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
             __syncthreads();
         }
     }
-    // the strips (dead by now) stage the stuffed bytes, the flags the workgroup's few shared words
+    // the strips (dead by now) stage the stuffed bytes
     JPEGENC_STAMP(5);
-    if (finish) finish_run(p, grp, tid, nthreads, fits ? window : slot, total, reinterpret_cast<uint8_t *>(strips), flags,
+    // (the code tables are dead by now: their first 16 words are the workgroup's few shared words)
+    if (finish) finish_run(p, grp, tid, nthreads, fits ? window : slot, total, reinterpret_cast<uint8_t *>(strips), reinterpret_cast<uint32_t *>(lut_bytes),
                            blockIdx.x + 1u == gridDim.x, bp.stripe_index);
     JPEGENC_STAMP(9);
 }
