@@ -352,7 +352,8 @@ __device__ __forceinline__ gbytes frame_base(const u32x16 &H, const u32x16 &Wv, 
 // launch - every wave takes its plane's address, pitch, size, MCU size and sample stride (1 or 2 bytes; BPP = 2 is then
 // the largest stride the kernel is built for) from its FastWave record instead of the frame-wide header.
 template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
-__device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint32_t grp, const uint32_t frm, WaveCtx &w, uint32_t (&packed)[32]) {
+__device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint32_t grp, const uint32_t frm, WaveCtx &w, uint32_t (&packed)[32],
+                                              uint8_t *edge_lds /* 4 KiB of LDS of the wave's own, free until the block math is done */) {
 #ifdef JPEGENC_WAVE_TIMING
     w.tm0 = __builtin_readcyclecounter();
 #endif
@@ -447,16 +448,31 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
             }
         }
     } else {
-        // right-edge blocks: per-sample clamped reads = the reference's replicated last column
-        // (encoder.rs:738-744); one shared copy for all roles, taken by a handful of lanes
-#pragma unroll
-        for (int y = 0; y < 8; y++) {
+        // right-edge blocks: per-sample clamped reads = the reference's replicated last column (encoder.rs:738-744); one
+        // shared copy for all roles, taken by a handful of lanes.  A ROLLED loop that leaves the 64 samples as bytes in the
+        // lane's 64 bytes of the wave's LDS area and reads them back as the packed rows: unrolled over registers it was a
+        // third of the kernel's code and the one place that spilled at a six-wave register budget.
+        typedef __attribute__((address_space(3))) uint8_t *lds_u8;
+        typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(3))) u32x4e *lds_u128;
+        const lds_u8 mine = (lds_u8)edge_lds + lane * 64u;
+#pragma nounroll
+        for (int i = 0; i < 64; i++) {
+            const int y = i >> 3, x = i & 7;
             const gbytes row = frame + (size_t)min(me.y0 + y * syc, hlim) * pitch;
-            uint32_t v[8];
+            mine[i] = (uint8_t)edge_sample(row + (size_t)min(me.x0 + x * sxc, width - 1) * (size_t)bpp, role, c, k);
+        }
 #pragma unroll
-            for (int x = 0; x < 8; x++) v[x] = edge_sample(row + (size_t)min(me.x0 + x * sxc, width - 1) * (size_t)bpp, role, c, k);
-            rows[y][0] = v[0] | (v[1] << 16); rows[y][1] = v[3] | (v[2] << 16);
-            rows[y][2] = v[7] | (v[6] << 16); rows[y][3] = v[4] | (v[5] << 16);
+        for (int q = 0; q < 4; q++) {
+            const u32x4e d = ((lds_u128)mine)[q];
+            const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                rows[2 * q + h][0] = __builtin_amdgcn_perm(0u, w[2 * h], 0x0C010C00u);         // (x0, x1)
+                rows[2 * q + h][1] = __builtin_amdgcn_perm(0u, w[2 * h], 0x0C020C03u);         // (x3, x2)
+                rows[2 * q + h][2] = __builtin_amdgcn_perm(0u, w[2 * h + 1], 0x0C020C03u);     // (x7, x6)
+                rows[2 * q + h][3] = __builtin_amdgcn_perm(0u, w[2 * h + 1], 0x0C010C00u);     // (x4, x5)
+            }
         }
     }
 #ifdef JPEGENC_WAVE_TIMING
@@ -479,7 +495,7 @@ template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
 __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const ColourConsts &k, uint8_t *smem, const uint32_t grp, const uint32_t frm) {
     WaveCtx w;
     uint32_t packed[32];
-    if (!block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, frm, w, packed)) return;
+    if (!block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, frm, w, packed, smem + (threadIdx.x >> 6) * kStageBytes)) return;
     wave_uniforms(w, grp, true, packed[0]);
     const u32x16 H = w.H, Wv = w.Wv;
     const uint32_t lane = w.lane, wave = w.wave, order = w.order, lg = w.lg, lgv = w.lgv, vrow = w.vrow, sub_k = w.sub_k, ux = w.ux, uy = w.uy;

@@ -13,16 +13,21 @@
 
 namespace jpegenc {
 
-// Register budget: 5 waves per SIMD (<= 96 VGPRs) although two workgroups per CU are all that run: left at 4 the compiler
-// keeps every row load of a block in flight (104 VGPRs) and the kernel is 12 % slower - the block kernel's own finding.
-// The simd-variant instantiations used to sit at 4 and 3 waves with 35-40 spilled SGPRs and a scratch allocation; since the
-// wave's records are loaded AGAIN after the block math instead of being kept in scalar registers across it (wave_uniforms,
-// fast_kernel_impl.hip.h) the RGB family has the scalar variant's budget and no scratch.  The byte-plane simd-variant
-// instantiations with decimated 3- / 4-byte pixels keep 4 waves: at 5 they spill a few VGPRs next to the 11 SGPRs that
-// live in VGPR lanes - the combination hipcc 7.2 gets wrong (scan bytes differ, memory faults; caught by
-// test_encoder_simd_variant_file).  build.sh checks both after every build (tools/check_spills.py).
+// Register budget.  What decides how many of these workgroups a CU keeps is the SHAPE of the workgroup as much as its LDS
+// (csrc/tools/occupancy_probe2.hip, profiles/r04_occupancy_probe.txt): six-wave workgroups at 88-96 VGPRs are resident two
+// at a time whatever their LDS (12 waves per CU), at 80 VGPRs two and a half (15 waves), at 72 three; three- and four-wave
+// workgroups reach 16-19 waves at 96 VGPRs and are bounded by their LDS instead.  So the six-wave layouts (4:2:0: sampling
+// 2x2) take a 6-wave budget (80 VGPRs) - +6 % photo-like, +10 % smooth, +5 % noise on 4K frames against the 5-wave build
+// with the same 53.8 KB of LDS (profiles/r04_fused_wave_budgets.txt) - and the others 5 waves (left at 4 the compiler keeps
+// every row load of a block in flight, 104 VGPRs: -12 %).  The byte-plane simd-variant instantiations with decimated
+// 3- / 4-byte pixels keep 4 waves: above that they spill VGPRs next to SGPRs that live in VGPR lanes - the combination
+// hipcc 7.2 gets wrong (scan bytes differ, memory faults; caught by test_encoder_simd_variant_file).  build.sh checks the
+// spills of every instantiation after every build (tools/check_spills.py).
 #ifndef JPEGENC_GROUP_WAVES
 #define JPEGENC_GROUP_WAVES 5
+#endif
+#ifndef JPEGENC_GROUP_WAVES_6
+#define JPEGENC_GROUP_WAVES_6 6           // the six-wave workgroups (SX * SY == 4)
 #endif
 #ifndef JPEGENC_GROUP_PRIV_WORDS
 #define JPEGENC_GROUP_PRIV_WORDS 16
@@ -46,7 +51,7 @@ __host__ __device__ constexpr uint32_t group_lds_bytes(uint32_t bpm) {
 static_assert((group_lds_bytes(6u) + 1279u) / 1280u * 3u <= 128u, "three six-wave workgroups per CU");
 
 template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
-__global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 && !CONV ? 4 : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
+__global__ void __attribute__((amdgpu_waves_per_eu(VARIANT == 1 && !CONV ? 4 : SX * SY == 4 ? JPEGENC_GROUP_WAVES_6 : JPEGENC_GROUP_WAVES))) __launch_bounds__(384)
 k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
     extern __shared__ __attribute__((aligned(4096))) uint8_t smem[];              // (the kernel has no static LDS: the dynamic part starts at 0)
@@ -103,7 +108,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     // (the block's 32 registers stay alive until the workgroup knows that every strip held: a second walk stages them again)
     BlockRegs r;
     {
-        const bool active = block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, f, w, r.c);
+        const bool active = block_compute<BPP, SX, SY, VARIANT, CONV, PLANES>(k, grp, f, w, r.c, reinterpret_cast<uint8_t *>(image));
         wave_uniforms(w, grp, true, r.c[0]);          // (the wave's records again: nothing of them is kept in scalar registers across the FDCT)
         mine_valid = active && w.inside;
         mask = mine_valid ? nonzero_mask(r.c) : 0ull;

@@ -17,26 +17,34 @@ b = importlib.import_module("jpeg_encoder_amd.binding")
 synth = importlib.import_module("jpeg_encoder_amd.synth")
 
 
+CT = {"rgb": b.RGB, "bgr": b.BGR, "rgba": b.RGBA, "bgra": b.BGRA}[sys.argv[sys.argv.index("--ct") + 1]] if "--ct" in sys.argv else b.RGB      # --ct {rgb,bgr,rgba,bgra}
+BPP = b.BPP[CT]
 VARIANT = b.FDCT_SIMD if "--fdct" in sys.argv and sys.argv[sys.argv.index("--fdct") + 1] == "simd" else b.FDCT_SCALAR      # --fdct {scalar,simd}
 
 
 def frames_of(kind, n, w, h, dev):
-    if kind == "noise":
-        g = torch.Generator(device=dev)
-        g.manual_seed(7)
-        return torch.randint(0, 256, (n, w * h * 3), dtype=torch.uint8, device=dev, generator=g)
-    base = torch.from_numpy(synth.test_img_rgb(w, h).reshape(-1)).to(dev)
+    """n frames of the colour type CT: noise, the reference's gradient with a little noise, or the gradient alone (4-byte pixels: the
+    fourth byte is noise - alpha is ignored by the encoder)."""
     g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    if kind == "noise":
+        return torch.randint(0, 256, (n, w * h * BPP), dtype=torch.uint8, device=dev, generator=g)
+    base = torch.from_numpy(synth.test_img_rgb(w, h)).to(dev)
     g.manual_seed(11)
     if kind == "smooth":
-        return base[None, :].repeat(n, 1).contiguous()
-    return torch.clamp(base.to(torch.int16)[None, :] + torch.randint(-6, 7, (n, base.numel()), dtype=torch.int16, device=dev, generator=g),
-                       0, 255).to(torch.uint8)
+        rgb = base[None].repeat(n, 1, 1, 1)
+    else:
+        rgb = torch.clamp(base.to(torch.int16)[None] + torch.randint(-6, 7, (n,) + tuple(base.shape), dtype=torch.int16, device=dev, generator=g), 0, 255).to(torch.uint8)
+    if CT in (b.BGR, b.BGRA):
+        rgb = rgb.flip(-1)
+    if BPP == 4:
+        rgb = torch.cat([rgb, torch.randint(0, 256, (n, h, w, 1), dtype=torch.uint8, device=dev, generator=g)], dim=-1)
+    return rgb.reshape(n, -1).contiguous()
 
 
 def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
     dev = torch.device("cuda", 0)
-    L = b.layout(w, h, b.RGB, hs, vs, b.ORDER_MCU)
+    L = b.layout(w, h, CT, hs, vs, b.ORDER_MCU)
     nblk = int(L.total_blocks)
     q = b.qtables(quality)
     scan = b.baseline_scan()
@@ -50,14 +58,14 @@ def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
             continue
         d_px = frames_of(kind, n, w, h, dev)
         outs, lens = {}, {}
-        res = {"content": kind, "fdct": "simd" if VARIANT == b.FDCT_SIMD else "scalar", "frames": n, "size": f"{w}x{h}", "sampling": f"{hs}x{vs}", "quality": quality}
+        res = {"content": kind, "colour_type": {b.RGB: "rgb", b.BGR: "bgr", b.RGBA: "rgba", b.BGRA: "bgra"}[CT], "fdct": "simd" if VARIANT == b.FDCT_SIMD else "scalar", "frames": n, "size": f"{w}x{h}", "sampling": f"{hs}x{vs}", "quality": quality}
 
         def two_kernel(d_out, d_len):
-            b.blocks_device(d_px.data_ptr(), w * h * 3, n, w, h, b.RGB, hs, vs, q, b.ORDER_MCU, VARIANT, d_co.data_ptr(), nblk, stream.cuda_stream)
+            b.blocks_device(d_px.data_ptr(), w * h * BPP, n, w, h, CT, hs, vs, q, b.ORDER_MCU, VARIANT, d_co.data_ptr(), nblk, stream.cuda_stream)
             b.scan_device(d_co.data_ptr(), nblk, n, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(), d_ws.data_ptr(), wsz, stream.cuda_stream)
 
         def fused(d_out, d_len):
-            b.pixels_scan_device(d_px.data_ptr(), w * h * 3, n, w, h, b.RGB, hs, vs, q, d_out.data_ptr(), cap, d_len.data_ptr(),
+            b.pixels_scan_device(d_px.data_ptr(), w * h * BPP, n, w, h, CT, hs, vs, q, d_out.data_ptr(), cap, d_len.data_ptr(),
                                  d_ws.data_ptr(), wsz, stream.cuda_stream, variant=VARIANT)
         for name, fn in (("two_kernel", two_kernel), ("fused", fused)):
             if only and only.split(":")[1] != name:
@@ -89,9 +97,10 @@ def main(n=16, w=3840, h=2160, quality=90, hs=2, vs=2, reps=10):
 
 
 if __name__ == "__main__":
-    if "--fdct" in sys.argv:
-        i = sys.argv.index("--fdct")
-        del sys.argv[i:i + 2]
+    for opt in ("--fdct", "--ct"):
+        if opt in sys.argv:
+            i = sys.argv.index(opt)
+            del sys.argv[i:i + 2]
     if len(sys.argv) > 1 and sys.argv[1] == "1080p":
         main(n=32, w=1920, h=1080, quality=80)
     elif len(sys.argv) > 1 and sys.argv[1].startswith("q"):      # e.g. q98: 4K frames at another quality (long blocks: the second-walk paths)

@@ -6,7 +6,9 @@ budget, fused_kernel_impl.hip.h) - the waves_per_eu budgets that avoid it were p
 EXTRA_HIPCC_FLAGS variant or a new instantiation must not bring it back unnoticed.  Also reports scratch in any scalar-variant
 instantiation of the pixels -> bits kernel, and FAILS on scratch in any RGB-family instantiation (CONV = true: Rgb / Rgba / Bgr /
 Bgra / CmykAsYcck, either FDCT variant) of either kernel: round 4 removed the simd variant's 68 bytes per lane there, and a
-scratch allocation per wave is what a register-allocation accident looks like from outside.
+scratch allocation per wave is what a register-allocation accident looks like from outside.  One exception, listed as a note:
+the six-wave layouts (2x2 sampling) of the pixels -> bits kernel at their 6-wave register budget may keep up to 32 bytes
+(a few values parked once per block, outside every loop) - the budget is worth more than they cost (fused_kernel_impl.hip.h).
 
 usage: check_spills.py FILE...   (the stderr of hipcc -Rpass-analysis=kernel-resource-usage, one file per translation unit)"""
 import re
@@ -15,11 +17,14 @@ import sys
 
 
 def demangle(names):
-    try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout
-        return out.splitlines()
-    except Exception:
-        return names
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True, check=True).stdout.splitlines()
+            if len(out) == len(names):
+                return out
+        except Exception:
+            pass
+    return names
 
 
 def main(paths):
@@ -42,11 +47,16 @@ def main(paths):
         if "k_group_code" not in name and "k_blocks_fast" not in name:
             continue
         sg, vg, sc = k.get("SGPRs Spill", 0), k.get("VGPRs Spill", 0), k.get("ScratchSize [bytes/lane]", 0)
-        rgb_family = re.search(r"<\d+, \d+, \d+, \d+, true", name) is not None
+        # CONV = true (5th template argument), in the demangled or - without a demangler - the mangled name
+        rgb_family = re.search(r"<\d+, \d+, \d+, \d+, true", name) is not None or re.search(r"ILi\d+ELi\d+ELi\d+ELi\d+ELb1ELb[01]EE", n) is not None
+        m = re.search(r"<\d+, (\d+), (\d+), \d+, (?:true|false)", name) or re.search(r"ILi\d+ELi(\d+)ELi(\d+)ELi\d+ELb[01]ELb[01]EE", n)
+        six_wave_layout = bool(m) and int(m.group(1)) * int(m.group(2)) == 4
         if sg and vg:
             bad.append(f"{name}: {sg} SGPRs spilled AND {vg} VGPRs spilled ({sc} B scratch per lane)")
-        elif rgb_family and sc:
+        elif rgb_family and sc and not (six_wave_layout and "k_group_code" in name and sc <= 32):
             scratchy.append(f"{name}: {sc} B scratch per lane ({sg} SGPRs, {vg} VGPRs spilled)")
+        elif rgb_family and sc:
+            noted.append(f"{name}: {sc} B scratch per lane at the 6-wave budget of the six-wave layouts ({vg} VGPRs spilled outside the loops; measured faster than 5 waves without)")
         elif "k_group_code" in name and sc:
             noted.append(f"{name}: {sc} B scratch per lane")
     checked = sum(1 for n in names if "k_group_code" in pretty[n] or "k_blocks_fast" in pretty[n])
