@@ -63,6 +63,8 @@ pub struct jpegenc_plane {
     pub pitch: usize,
     pub pixel_stride: i32,
     pub invert: i32,
+    pub shift: i32,
+    pub reserved: i32,
 }
 
 pub enum jpegenc_encoder {}
@@ -157,6 +159,7 @@ extern "C" {
     pub fn jpegenc_encoder_encode_planes_batch_device(e: *mut jpegenc_encoder, jpeg_color_type: c_int, width: c_int, height: c_int,
                                                       planes: *const jpegenc_plane, num_frames: c_int, planes_subsampled: c_int,
                                                       sink: jpegenc_write_fn, users: *const *mut c_void) -> c_int;
+    pub fn jpegenc_packed_planes(surface_format: c_int, d_planes: *const *const c_void, pitches: *const usize, planes: *mut jpegenc_plane) -> c_int;
     pub fn jpegenc_encoder_encode_batch(e: *mut jpegenc_encoder, frames: *const *const u8, frame_len: usize, num_frames: c_int,
                                         width: c_int, height: c_int, color_type: c_int, sink: jpegenc_write_fn,
                                         users: *const *mut c_void) -> c_int;

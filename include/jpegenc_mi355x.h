@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define JPEGENC_ABI_VERSION 1
+#define JPEGENC_ABI_VERSION 2      /* 2: jpegenc_plane gained `shift` / `reserved` (round 4) */
 
 /* EncodingError (src/error.rs:5-28) + device errors. */
 typedef enum jpegenc_status {
@@ -52,7 +52,14 @@ typedef enum jpegenc_status {
 /* enum ColorType (src/encoder.rs:72-99), same order. */
 typedef enum jpegenc_color_type {
     JPEGENC_LUMA = 0, JPEGENC_RGB = 1, JPEGENC_RGBA = 2, JPEGENC_BGR = 3, JPEGENC_BGRA = 4,
-    JPEGENC_YCBCR = 5, JPEGENC_CMYK = 6, JPEGENC_CMYK_AS_YCCK = 7, JPEGENC_YCCK = 8
+    JPEGENC_YCBCR = 5, JPEGENC_CMYK = 6, JPEGENC_CMYK_AS_YCCK = 7, JPEGENC_YCCK = 8,
+    /* Extensions (no counterpart in the reference's ColorType): 16-bit packed RGB as cameras, displays and GPUs' own render
+     * targets hold it, little-endian words r5 g6 b5 (RGB565: red in bits 15..11) / b5 g6 r5 (BGR565).  Every 5- / 6-bit channel
+     * is widened by bit replication (r8 = r5 << 3 | r5 >> 2, g8 = g6 << 2 | g6 >> 4) and then converted like Rgb: the device
+     * form of a user ImageBuffer whose fill_buffers unpacks the words (image_buffer.rs:40-98) - same bytes as that host
+     * callback gives (tests/test_gpu_packed_formats.py), no host code, half the upload.  Accepted wherever a colour type is
+     * (host and device-resident entry points, batches); sampling factors 1 and 2, frames below 2 GiB. */
+    JPEGENC_RGB565 = 9, JPEGENC_BGR565 = 10
 } jpegenc_color_type;
 
 /* enum JpegColorType (src/encoder.rs:23-35). */
@@ -332,8 +339,15 @@ int  jpegenc_encoder_encode_image(jpegenc_encoder *e, int jpeg_color_type, int w
  * image_buffer.rs:86-98; no host code runs per row and nothing is uploaded).
  *   planes[c]: sample (x, y) of component c is the byte at d_data + y * pitch + x * pixel_stride, optionally `255 - byte`
  *     (CmykImage, image_buffer.rs:247-256); pixel_stride 1 = planar, 2 = one byte of an interleaved pair (NV12: Cb =
- *     {uv, pitch, 2}, Cr = {uv + 1, pitch, 2}).  Components: 1 (J_LUMA), 3 (J_YCBCR) or 4 (J_CMYK, J_YCCK) as in
- *     init_components (encoder.rs:569-619).
+ *     {uv, pitch, 2}, Cr = {uv + 1, pitch, 2}), 4 = one byte of four (packed 4:2:2: YUYV is Y = {p, pitch, 2}, Cb =
+ *     {p + 1, pitch, 4}, Cr = {p + 3, pitch, 4} with planes_subsampled = 1 at the sampling factor F_2_1; UYVY likewise from
+ *     p + 1 / p / p + 2).  `shift` makes the sample eight bits of a little-endian 16-bit word instead (P010: Y = {y, pitch, 2,
+ *     0, 8}, Cb = {uv, pitch, 4, 0, 8}, Cr = {uv + 2, pitch, 4, 0, 8}; planar 10-bit 4:2:0 with the value in the low bits:
+ *     pixel_stride 2, shift 2): the packed and deep formats a camera or a decoder hands over need no host unpacking and no
+ *     upload - the device counterpart of an ImageBuffer::fill_buffers that does that unpacking (image_buffer.rs:40-98), with
+ *     the same bytes out (tests/test_gpu_packed_formats.py).  16-bit samples are 2-byte aligned; a shift of 1 .. 7 needs
+ *     pixel_stride 2.  jpegenc_packed_planes() fills the descriptors of the common layouts.
+ *     Components: 1 (J_LUMA), 3 (J_YCBCR) or 4 (J_CMYK, J_YCCK) as in init_components (encoder.rs:569-619).
  *   planes_subsampled = 0: every plane has width x height samples, like the rows fill_buffers delivers; the encoder
  *     decimates by its sampling factor as get_block does (encoder.rs:1222-1242).
  *   planes_subsampled = 1: a component the sampling factor decimates by (sx, sy) is given as ceil(width / sx) x
@@ -343,21 +357,36 @@ int  jpegenc_encoder_encode_image(jpegenc_encoder *e, int jpeg_color_type, int w
  * wave's record) - and an interleaved baseline scan goes from the samples to the coded runs in ONE kernel, like the
  * interleaved pixel formats; sampling factors of 4 take one block-kernel launch per plane.
  * The planes must stay valid and unmodified until the call returns.  Every Encoder mode applies (progressive,
- * optimised tables, restart intervals ...).  Sampling factors of 4 are not taken for two-byte pixel strides. */
+ * optimised tables, restart intervals ...).  Sampling factors of 4 are not taken for pixel strides above 1 unless the
+ * planes arrive subsampled, nor with a shift of 1 .. 7. */
 typedef struct jpegenc_plane {
     const void *d_data;
     size_t pitch;
-    int32_t pixel_stride;
-    int32_t invert;
+    int32_t pixel_stride;    /* 1, 2 or 4 bytes from one sample of this component to the next */
+    int32_t invert;          /* sample = 255 - value */
+    int32_t shift;           /* 0: the sample is the byte at d_data + ...; 1 .. 8: it is bits shift .. shift + 7 of the little-endian
+                              * 16-bit word there (8 = the high byte: P010 / P016 and other MSB-aligned 10- / 12- / 16-bit surfaces;
+                              * 2 / 4 = 10- / 12-bit samples kept in the low bits) */
+    int32_t reserved;        /* 0 */
 } jpegenc_plane;
 int  jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
                                           const jpegenc_plane planes[4], int planes_subsampled,
                                           jpegenc_write_fn sink, void *user);
+/* The descriptors of the layouts decoders and cameras hand over, from their base addresses: d_planes / pitches = the
+ * surface's own planes in their usual order (I420, YV12: 3; NV12, NV21, P010, P016: 2 - luma, interleaved chroma; YUYV, UYVY:
+ * 1; I010 = planar 10-bit 4:2:0 with the value in the low bits: 3).  Fills planes[0 .. 2] (Y, Cb, Cr; planes[3] zeroed) and
+ * returns the sampling factor the layout is subsampled for (JPEGENC_F_2_2 or JPEGENC_F_2_1; pass planes_subsampled = 1 and set
+ * that sampling factor on the encoder), or -JPEGENC_ERR_INVALID_ARGUMENT.  Pure arithmetic: no device work. */
+typedef enum jpegenc_surface_format {
+    JPEGENC_SURFACE_I420 = 0, JPEGENC_SURFACE_YV12 = 1, JPEGENC_SURFACE_NV12 = 2, JPEGENC_SURFACE_NV21 = 3,
+    JPEGENC_SURFACE_YUYV = 4, JPEGENC_SURFACE_UYVY = 5, JPEGENC_SURFACE_P010 = 6, JPEGENC_SURFACE_P016 = 7, JPEGENC_SURFACE_I010 = 8
+} jpegenc_surface_format;
+int  jpegenc_packed_planes(int surface_format, const void *const *d_planes, const size_t *pitches, jpegenc_plane planes[4]);
 /* A batch of such surfaces of one geometry (a decoder's or camera pipeline's frame pool): planes = num_frames x 4
  * descriptors, frame-major (frame f, component c at planes[4 * f + c]), the surfaces anywhere in device memory.  Frame
  * f -> sink(users[f], ...), one complete file each (sink threading: see jpegenc_encoder_encode_batch).  The device
  * work of the whole batch shares its launches as in jpegenc_encoder_encode_batch_device when the descriptors of each
- * component agree in pixel_stride and invert over the frames (address and pitch are per frame); otherwise - and with optimised Huffman tables, the
+ * component agree in pixel_stride, invert, shift and the byte they start at inside an interleaved group over the frames (address and pitch are per frame); otherwise - and with optimised Huffman tables, the
  * host entropy coder or sampling factors of 4 - the frames are encoded ONE AT A TIME on the handle's own stream, strictly in
  * sequence (no worker pool as for pixel frames: expect ~280 us per 4K frame instead of ~30; a sink error returns with the
  * earlier frames already delivered).  Same bytes either way. */

@@ -17,6 +17,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libjpegenc_mi355x_diag.so")
 
 # enum jpegenc_color_type == reference `enum ColorType` order (src/encoder.rs:72-99)
 LUMA, RGB, RGBA, BGR, BGRA, YCBCR, CMYK, CMYK_AS_YCCK, YCCK = range(9)
+RGB565, BGR565 = 9, 10          # extensions: 16-bit packed RGB, unpacked on the device (include/jpegenc_mi355x.h)
 J_LUMA, J_YCBCR, J_CMYK, J_YCCK = range(4)
 ORDER_MCU, ORDER_PLANAR = 0, 1
 FDCT_SCALAR, FDCT_SIMD = 0, 1
@@ -26,7 +27,7 @@ DENSITY_PIXEL_ASPECT_RATIO, DENSITY_INCHES, DENSITY_CENTIMETERS = range(3)
 (OK, ERR_INVALID_APP_SEGMENT, ERR_APP_SEGMENT_TOO_LARGE, ERR_ICC_TOO_LARGE, ERR_BAD_IMAGE_DATA,
  ERR_ZERO_IMAGE_DIMENSIONS, ERR_WRITE, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE,
  ERR_BUFFER_TOO_SMALL) = range(11)
-BPP = {LUMA: 1, RGB: 3, RGBA: 4, BGR: 3, BGRA: 4, YCBCR: 3, CMYK: 4, CMYK_AS_YCCK: 4, YCCK: 4}
+BPP = {LUMA: 1, RGB: 3, RGBA: 4, BGR: 3, BGRA: 4, YCBCR: 3, CMYK: 4, CMYK_AS_YCCK: 4, YCCK: 4, RGB565: 2, BGR565: 2}
 
 
 def sampling_factor(h, v):
@@ -57,7 +58,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_encode", "jpegenc_encoder_encode_device", "jpegenc_encoder_encode_batch_device", "jpegenc_encoder_encode_batch_device_to_buffers", "jpegenc_encoder_encode_to_buffer", "jpegenc_encoder_encode_to_file",
     "jpegenc_encoder_encode_image", "jpegenc_encoder_block_order", "jpegenc_encoder_encode_coefficients",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
-    "jpegenc_encoder_encode_planes_device", "jpegenc_encoder_encode_planes_batch_device",
+    "jpegenc_encoder_encode_planes_device", "jpegenc_encoder_encode_planes_batch_device", "jpegenc_packed_planes",
     "jpegenc_host_alloc", "jpegenc_host_free", "jpegenc_host_register", "jpegenc_host_unregister", "jpegenc_host_copy",
     "jpegenc_shard_frames", "jpegenc_encoder_encode_batch_multi", "jpegenc_encoder_encode_batch_multi_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
@@ -75,7 +76,32 @@ class Layout(C.Structure):
 
 
 class Plane(C.Structure):
-    _fields_ = [("d_data", C.c_void_p), ("pitch", C.c_size_t), ("pixel_stride", C.c_int32), ("invert", C.c_int32)]
+    _fields_ = [("d_data", C.c_void_p), ("pitch", C.c_size_t), ("pixel_stride", C.c_int32), ("invert", C.c_int32),
+                ("shift", C.c_int32), ("reserved", C.c_int32)]
+
+
+def _plane(t):
+    """(device_ptr, pitch, pixel_stride, invert[, shift]) -> Plane"""
+    ptr, pitch, stride, inv = t[:4]
+    return Plane(ptr, pitch, stride, 1 if inv else 0, t[4] if len(t) > 4 else 0, 0)
+
+
+(SURFACE_I420, SURFACE_YV12, SURFACE_NV12, SURFACE_NV21, SURFACE_YUYV, SURFACE_UYVY, SURFACE_P010, SURFACE_P016,
+ SURFACE_I010) = range(9)
+
+
+def packed_planes(surface_format, ptrs, pitches):
+    """jpegenc_packed_planes -> ([(ptr, pitch, pixel_stride, invert, shift)] * 3, sampling factor the layout is subsampled for)."""
+    n = len(ptrs)
+    p = (C.c_void_p * max(n, 3))(*ptrs)
+    s = (C.c_size_t * max(n, 3))(*pitches)
+    arr = (Plane * 4)()
+    f = lib().jpegenc_packed_planes
+    f.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Plane)]
+    rc = f(surface_format, p, s, arr)
+    if rc < 0:
+        check(-rc)
+    return [(arr[i].d_data, arr[i].pitch, arr[i].pixel_stride, arr[i].invert, arr[i].shift) for i in range(3)], rc
 
 
 class Scan(C.Structure):
@@ -508,8 +534,8 @@ class Encoder:
     def encode_planes_device(self, jpeg_color_type, width, height, planes, planes_subsampled=False):
         """jpegenc_encoder_encode_planes_device: planes = [(device_ptr, pitch, pixel_stride, invert), ...] per component."""
         arr = (Plane * 4)()
-        for i, (ptr, pitch, stride, inv) in enumerate(planes):
-            arr[i] = Plane(ptr, pitch, stride, 1 if inv else 0)
+        for i, t in enumerate(planes):
+            arr[i] = _plane(t)
         chunks = []
 
         def sink(_user, ptr, n):
@@ -526,8 +552,8 @@ class Encoder:
         n = len(frames)
         arr = (Plane * (4 * max(n, 1)))()
         for f, planes in enumerate(frames):
-            for i, (ptr, pitch, stride, inv) in enumerate(planes):
-                arr[4 * f + i] = Plane(ptr, pitch, stride, 1 if inv else 0)
+            for i, t in enumerate(planes):
+                arr[4 * f + i] = _plane(t)
         outs = [[] for _ in range(n)]
 
         def sink(user, ptr, nbytes):

@@ -214,6 +214,7 @@ hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream) {
 
 // ---- launchers (called from the C ABI) --------------------------------------------------------
 hipError_t launch_blocks_generic(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream) {
+    if (p.packed565) return hipErrorInvalidValue;          // (16-bit packed pixels: tuned kernels only - build_block_params rejects what they do not take)
     dim3 grid, block;
     size_t lds;
     {

@@ -34,6 +34,7 @@ int jpeg_color_type_of(int ct) {
     switch (ct) {
     case JPEGENC_LUMA: return JPEGENC_J_LUMA;
     case JPEGENC_RGB: case JPEGENC_RGBA: case JPEGENC_BGR: case JPEGENC_BGRA: case JPEGENC_YCBCR:
+    case JPEGENC_RGB565: case JPEGENC_BGR565:
         return JPEGENC_J_YCBCR;
     case JPEGENC_CMYK: return JPEGENC_J_CMYK;
     case JPEGENC_CMYK_AS_YCCK: case JPEGENC_YCCK: return JPEGENC_J_YCCK;
@@ -137,6 +138,13 @@ int build_block_params(BlockKernelParams *p, const jpegenc_layout &L, int width,
     case JPEGENC_YCBCR: case JPEGENC_YCCK: p->xform = XF_PASS; break;
     case JPEGENC_CMYK: p->xform = XF_CMYK_INVERT; break;
     case JPEGENC_CMYK_AS_YCCK: p->xform = XF_CMYK2YCCK; break;
+    case JPEGENC_RGB565: case JPEGENC_BGR565:
+        // 16-bit packed pixels: unpacked to an RGB-order word on the device, then the Rgb conversion (tuned kernels only)
+        p->xform = XF_RGB2YCC;
+        p->packed565 = 0x10000u | (color_type == JPEGENC_RGB565 ? 11u : 0u) | ((color_type == JPEGENC_RGB565 ? 0u : 11u) << 8);
+        if (L.max_h > 2 || L.max_v > 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "RGB565 / BGR565 frames take sampling factors 1 and 2");
+        if ((uint64_t)width * (uint64_t)height * 2u >= (1ull << 31)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "RGB565 / BGR565 frames must be smaller than 2 GiB");
+        break;
     default: return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");
     }
     return JPEGENC_OK;
@@ -200,6 +208,7 @@ const char *jpegenc_status_string(int s) {
 int jpegenc_bytes_per_pixel(int ct) {   // encoder.rs:101-111
     switch (ct) {
     case JPEGENC_LUMA: return 1;
+    case JPEGENC_RGB565: case JPEGENC_BGR565: return 2;
     case JPEGENC_RGB: case JPEGENC_BGR: case JPEGENC_YCBCR: return 3;
     case JPEGENC_RGBA: case JPEGENC_BGRA: case JPEGENC_CMYK: case JPEGENC_CMYK_AS_YCCK: case JPEGENC_YCCK: return 4;
     }

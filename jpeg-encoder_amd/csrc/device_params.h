@@ -63,7 +63,9 @@ enum : uint32_t {                     // FastWave::bits
     FW_INVERT_SHIFT = 11,             // 1 bit: ROLE_BYTE sample = 255 - byte
     FW_LGV_SHIFT = 12,                // 2 bits: log2 of the component's block rows per MCU (= log2 v)
     FW_COUNT_SHIFT = 14,              // 7 bits: MCUs this wave covers (64 >> lg, fewer when the group is smaller than that)
-    FW_BPP2_SHIFT = 21,               // 1 bit: described planes (PLANES kernels) - the samples of this component are two bytes apart
+    FW_BPP2_SHIFT = 21,               // 2 bits: described planes (PLANES kernels) - log2 of the byte distance of this component's samples (1, 2 or 4)
+    FW_BITOFF_SHIFT = 23,             // 5 bits: described planes - bit offset of the 8-bit sample inside its aligned pixel word where that is not a
+                                      // whole byte (16-bit samples with a right shift of 1 .. 7: 10- / 12-bit planes kept in the low bits); 0 = byte_pack picks a byte
 };
 
 struct BlockKernelParams {
@@ -109,6 +111,7 @@ struct BlockKernelParams {
     uint32_t pitch_bytes;             // 0 = width * bpp
     uint32_t plane_mcu_w, plane_mcu_h;   // 0 = 8 * hmax / 8 * vmax
     uint32_t plane_byte_index, plane_invert;
+    uint32_t packed565;               // != 0: the pixels are 16-bit r5 g6 b5 words (bpp 2): bit 16 set, bits 0..7 / 8..15 = bit position of the red / blue field
     QuantDev q[2];
     FastHeader fast_hdr;
     FastWave fast_wave[10];

@@ -65,9 +65,11 @@ struct ColourConsts {
     uint32_t cb_lo, cb_hi, cb_xor;
     uint32_t cr_lo, cr_hi, cr_xor;
     int32_t o_r, o_g, o_b;      // byte offsets (edge path)
+    uint32_t packed565;         // != 0: 16-bit r5 g6 b5 pixels (BlockKernelParams::packed565)
     int32_t role[4];            // what each component is made of
     int32_t byte_index[4];      // ROLE_BYTE: which byte of the pixel
     int32_t invert[4];          // ROLE_BYTE: sample = 255 - byte (CmykImage, image_buffer.rs:251-254)
+    int32_t shift[4];           // ROLE_BYTE of described planes: the sample is bits shift .. shift + 7 of the little-endian 16-bit word at byte_index
     uint64_t plane_offset[4];   // XF_PLANES: start of the component's plane inside the frame
 };
 
@@ -131,13 +133,32 @@ __device__ __forceinline__ uint32_t chroma16(uint32_t w, uint32_t lo, uint32_t h
     return __builtin_amdgcn_udot4(u, hi, t, false);              // Cb/Cr in bits 8..15
 }
 
+// A 16-bit r5 g6 b5 word -> the RGB-order pixel word [r8 g8 b8 0], every channel widened by bit replication (r8 = r5 << 3 | r5 >> 2
+// = (33 r5) >> 2, g8 = g6 << 2 | g6 >> 4 = (65 g6) >> 4); rs / bs = bit position of the red / blue field (RGB565: 11 / 0).
+__device__ __forceinline__ uint32_t unpack565(uint32_t w, uint32_t rs, uint32_t bs) {
+    const uint32_t r5 = __builtin_amdgcn_ubfe(w, rs, 5u), g6 = __builtin_amdgcn_ubfe(w, 5u, 6u), b5 = __builtin_amdgcn_ubfe(w, bs, 5u);
+    const uint32_t r8 = (r5 * 33u) >> 2, g8 = (g6 * 65u) >> 4, b8 = (b5 * 33u) >> 2;
+    return r8 | (g8 << 8) | (b8 << 16);
+}
+template <class Conv>
+struct Unpack565 {         // Conv on the unpacked word
+    Conv conv;
+    uint32_t rs, bs;
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return conv(unpack565(w, rs, bs)); }
+};
+
 // scalar arithmetic for the clamped edge path (identical results by construction)
 __device__ __forceinline__ uint32_t edge_sample(gbytes px, int role, int c, const ColourConsts &k) {
     if (role == ROLE_BYTE) {
-        const uint32_t v = px[k.byte_index[c]];
+        uint32_t v = px[k.byte_index[c]];
+        if (k.shift[c]) v = ((v | ((uint32_t)px[k.byte_index[c] + 1] << 8)) >> k.shift[c]) & 0xFFu;
         return k.invert[c] ? 255u - v : v;
     }
-    const int r = px[k.o_r], g = px[k.o_g], b = px[k.o_b];
+    int r = px[k.o_r], g = px[k.o_g], b = px[k.o_b];
+    if (k.packed565) {
+        const uint32_t w = unpack565((uint32_t)px[0] | ((uint32_t)px[1] << 8), k.packed565 & 0xFFu, (k.packed565 >> 8) & 0xFFu);
+        r = (int)(w & 0xFFu); g = (int)((w >> 8) & 0xFFu); b = (int)((w >> 16) & 0xFFu);
+    }
     if (role == ROLE_Y) return (uint32_t)((19595 * r + 38470 * g + 7471 * b + 0x7FFF) >> 16);
     if (role == ROLE_CB) return (uint32_t)((-11059 * r - 21709 * g + 32768 * b + kBias) >> 16);
     return (uint32_t)((32768 * r - 27439 * g - 5329 * b + kBias) >> 16);
@@ -210,6 +231,10 @@ __device__ __forceinline__ void fetch_rows(gbytes frame, bool aligned4, uint32_t
 }
 struct ByteConv {          // the sample is a byte of the pixel word itself
     __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w; }
+};
+struct ShiftConv {         // the sample is eight bits of the pixel word that do not start at a byte (10- / 12-bit samples in the low bits of 16)
+    uint32_t off;
+    __device__ __forceinline__ uint32_t operator()(uint32_t w) const { return w >> off; }
 };
 
 // Register budget: at least 5 waves per SIMD (<= 102 VGPRs).  Left to itself the compiler keeps every
@@ -374,8 +399,8 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     const gbytes frame = frame_base<PLANES>(H, Wv, frm, (uint32_t)c, pitch);
     const int width = PLANES ? (int)(Wv[10] & 0xFFFFu) : (int)H[8], hlim = (PLANES ? (int)(Wv[10] >> 16) : (int)H[9]) - 1;
     const uint32_t mcu_w = PLANES ? Wv[11] & 0xFFFFu : H[13], mcu_h = PLANES ? Wv[11] >> 16 : H[14];
-    const bool two_bytes = PLANES && ((bits >> FW_BPP2_SHIFT) & 1u);  // wave-uniform
-    const int bpp = PLANES ? (two_bytes ? 2 : 1) : BPP;
+    const uint32_t lg_stride = PLANES ? (bits >> FW_BPP2_SHIFT) & 3u : 0u;   // wave-uniform: the plane's samples are 1, 2 or 4 bytes apart
+    const int bpp = PLANES ? 1 << lg_stride : BPP;
     const int sxc = sub ? SX : 1, syc = sub ? SY : 1;
 
     // this lane's block: MCU (ux, uy), then block sub_k of the wave's block row inside it
@@ -416,7 +441,16 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     if (false)
 #endif
     if (me.x0 + 8 * sxc <= width) {
-        if (CONV && role == ROLE_Y) {
+        if (CONV && BPP == 2) {                                     // 16-bit r5 g6 b5 pixels: unpacked, then converted like Rgb
+            const uint32_t rs = Wv[12] & 0xFFu, bs = (Wv[12] >> 8) & 0xFFu;
+            if (role == ROLE_Y) {
+                fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, LumaConv::kPack, Unpack565<LumaConv>{LumaConv{Wv[9], Wv[10]}, rs, bs}, rows);
+            } else if (SX * SY <= JPEGENC_DOT4_MAX_DECIMATION) {
+                fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, ChromaConv::kPack, Unpack565<ChromaConv>{ChromaConv{Wv[9], Wv[10], Wv[11]}, rs, bs}, rows);
+            } else {
+                fetch_rows<BPP, SX, SY>(frame, aligned4, first, last, pitch, ChromaConvDot2::kPack, Unpack565<ChromaConvDot2>{ChromaConvDot2{Wv[9], Wv[10], Wv[11]}, rs, bs}, rows);
+            }
+        } else if (CONV && role == ROLE_Y) {
             fetch_rows<BPP, 1, 1>(frame, aligned4, first, last, pitch, LumaConv::kPack, LumaConv{Wv[9], Wv[10]}, rows);
         } else if (CONV && role != ROLE_BYTE) {
             if (SX * SY <= JPEGENC_DOT4_MAX_DECIMATION) {
@@ -431,7 +465,15 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
             // In the conversion kernels only CmykAsYcck's K plane (4-byte pixels, never decimated) gets here.
             const uint32_t pack = Wv[12];
             if (PLANES) {                                           // the sample stride is the plane's (wave-uniform)
-                if (two_bytes) {
+                const uint32_t bitoff = (bits >> FW_BITOFF_SHIFT) & 31u;
+                if (bitoff) {                                       // 16-bit samples shifted right by 1 .. 7 (two bytes apart)
+                    const ShiftConv sc = {bitoff};
+                    if (sub && (SX > 1 || SY > 1)) fetch_rows<2, SX, SY>(frame, aligned4, first, last, pitch, 0x0C040C00u, sc, rows);
+                    else fetch_rows<2, 1, 1>(frame, aligned4, first, last, pitch, 0x0C040C00u, sc, rows);
+                } else if (lg_stride == 2u) {
+                    if (sub && (SX > 1 || SY > 1)) fetch_rows<4, SX, SY>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
+                    else fetch_rows<4, 1, 1>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
+                } else if (lg_stride == 1u) {
                     if (sub && (SX > 1 || SY > 1)) fetch_rows<2, SX, SY>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
                     else fetch_rows<2, 1, 1>(frame, aligned4, first, last, pitch, pack, ByteConv{}, rows);
                 } else {
@@ -650,8 +692,10 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
             if (sx * sy <= JPEGENC_DOT4_MAX_DECIMATION) { f.conv[0] = cb ? k.cb_lo : k.cr_lo; f.conv[1] = cb ? k.cb_hi : k.cr_hi; f.conv[2] = cb ? k.cb_xor : k.cr_xor; }
             else { f.conv[0] = cb ? k.sel_cb : k.sel_cr; f.conv[1] = cb ? k.k_cb : k.k_cr; f.conv[2] = cb ? k.sh_b : k.sh_r; }
         }
-        const uint32_t b = (uint32_t)k.byte_index[c];
+        // (a shift of 8 on a 16-bit sample is its high byte: still a byte pick)
+        const uint32_t b = (uint32_t)k.byte_index[c] + (k.shift[c] == 8 ? 1u : 0u);
         f.byte_pack = 0x0C040C00u | b | (b << 16);     // byte b of each pixel word -> zero-extended 16-bit pair
+        if (conv && k.packed565) f.byte_pack = k.packed565 & 0xFFFFu;            // (no byte role in these kernels: the slot carries the field positions)
         f.plane_lo = (uint32_t)k.plane_offset[c]; f.plane_hi = (uint32_t)(k.plane_offset[c] >> 32);
         if (planes) {
             const bool own_size = planes_subsampled && decimated;
@@ -659,6 +703,8 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
             const uint32_t ph = own_size ? (uint32_t)((q.height + q.sy[c] - 1) / q.sy[c]) : (uint32_t)q.height;
             const uint32_t mw = own_size ? 8u * hc : 8u * (uint32_t)q.hmax, mh = own_size ? 8u * (uint32_t)q.v[c] : 8u * (uint32_t)q.vmax;
             if (planes[c].pixel_stride == 2) f.bits |= 1u << FW_BPP2_SHIFT;
+            if (planes[c].pixel_stride == 4) f.bits |= 2u << FW_BPP2_SHIFT;
+            if (k.shift[c] > 0 && k.shift[c] < 8) f.bits |= ((uint32_t)k.byte_index[c] * 8u + (uint32_t)k.shift[c]) << FW_BITOFF_SHIFT;
             f.conv[0] = (uint32_t)planes[c].pitch; f.conv[1] = pw | (ph << 16); f.conv[2] = mw | (mh << 16);
         }
     }
@@ -697,6 +743,8 @@ bool launch_conv_s4(const BlockKernelParams &p, const ColourConsts &k, int sx, i
                     hipStream_t stream, hipError_t *err);
 bool launch_bytes_s4(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant,
                      hipStream_t stream, hipError_t *err);
+// fast_kernels_565.hip: 16-bit packed RGB (BPP = 2 with the conversion roles)
+bool launch_conv_565(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant, hipStream_t stream, hipError_t *err);
 // fast_kernels_bytes.hip
 bool launch_bytes_family(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant,
                          hipStream_t stream, hipError_t *err);

@@ -29,6 +29,7 @@ bool colour_consts(const BlockKernelParams &p, ColourConsts *out, int *sx_out, i
     k.cr_hi = bytes3(32768 >> 8, 27439 >> 8, 5329 >> 8);
     k.cr_xor = bytes3(0, 255, 255);
     k.o_r = o_r; k.o_g = o_g; k.o_b = o_b;
+    k.packed565 = p.packed565;
     for (int c = 0; c < p.ncomp; c++) {
         k.role[c] = ROLE_BYTE; k.byte_index[c] = c; k.invert[c] = 0; k.plane_offset[c] = 0;
         switch (p.xform) {
@@ -76,6 +77,7 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
     if (!colour_consts(p, &k, &sx, &sy)) return false;
     const bool conv = p.xform == XF_RGB2YCC || p.xform == XF_CMYK2YCCK;
     if (!conv) return launch_bytes_family(p, k, sx, sy, num_frames, variant, stream, err);
+    if (p.packed565) return p.bpp == 2 && launch_conv_565(p, k, sx, sy, num_frames, variant, stream, err);
 #define JPEGENC_CASE(B, X, Y) if (p.bpp == B && sx == X && sy == Y) { *err = launch_fast<B, X, Y, true>(p, k, num_frames, variant, stream); return true; }
     JPEGENC_CASE(3, 1, 1) JPEGENC_CASE(3, 2, 1) JPEGENC_CASE(3, 1, 2) JPEGENC_CASE(3, 2, 2)
     JPEGENC_CASE(4, 1, 1) JPEGENC_CASE(4, 2, 1) JPEGENC_CASE(4, 1, 2) JPEGENC_CASE(4, 2, 2)
@@ -101,8 +103,11 @@ hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_pla
         q.plane_stride = 0;
         uintptr_t ptr = (uintptr_t)planes[c].d_data;
         q.bpp = planes[c].pixel_stride;
-        q.plane_byte_index = 0;
-        if (q.bpp == 2 && (ptr & 1u)) { ptr -= 1; q.plane_byte_index = 1; }       // second byte of an interleaved pair (NV12: Cr)
+        if (q.bpp != 1 && q.bpp != 2 && q.bpp != 4) return hipErrorInvalidValue;
+        if (planes[c].shift != 0 && (planes[c].shift != 8 || q.bpp < 2 || (ptr & 1u))) return hipErrorInvalidValue;   // (whole-byte picks only on this path)
+        q.plane_byte_index = (uint32_t)(ptr & (uintptr_t)(q.bpp - 1));            // byte of an interleaved group (NV12: Cr = 1)
+        ptr -= q.plane_byte_index;
+        if (planes[c].shift == 8) q.plane_byte_index += 1;                        // the high byte of a 16-bit sample
         q.pixels = (const uint8_t *)ptr;
         q.pitch_bytes = (uint32_t)planes[c].pitch;
         q.plane_invert = planes[c].invert ? 1u : 0u;

@@ -14,9 +14,13 @@ static bool planes_consts(const BlockKernelParams &p, const jpegenc_plane planes
     int sx = 1, sy = 1;
     for (int c = 0; c < p.ncomp; c++) {
         const uintptr_t ptr = (uintptr_t)planes[c].d_data;
-        if (planes[c].pixel_stride != 1 && planes[c].pixel_stride != 2) return false;
-        const uintptr_t odd = planes[c].pixel_stride == 2 ? (ptr & 1u) : 0u;      // second byte of an interleaved pair (NV12: Cr)
-        k.role[c] = ROLE_BYTE; k.byte_index[c] = (int32_t)odd; k.invert[c] = planes[c].invert ? 1 : 0;
+        const int stride = planes[c].pixel_stride, shift = planes[c].shift;
+        if (stride != 1 && stride != 2 && stride != 4) return false;
+        // the byte of an interleaved group the plane starts at (NV12: Cr = byte 1 of a pair; YUYV: Cb = byte 1, Cr = byte 3 of four)
+        const uintptr_t odd = ptr & (uintptr_t)(stride - 1);
+        if (shift < 0 || shift > 8 || (shift && (stride < 2 || (odd & 1u)))) return false;      // 16-bit samples are 2-byte aligned
+        if (shift > 0 && shift < 8 && stride != 2) return false;                                 // (a shift inside a byte: planes of 16-bit samples only)
+        k.role[c] = ROLE_BYTE; k.byte_index[c] = (int32_t)odd; k.invert[c] = planes[c].invert ? 1 : 0; k.shift[c] = shift;
         k.plane_offset[c] = (uint64_t)(ptr - odd);
         const bool decimated = p.sx[c] > 1 || p.sy[c] > 1;
         if (p.sx[c] > 2 || p.sy[c] > 2) return false;
@@ -37,8 +41,8 @@ bool launch_blocks_planes_once(const BlockKernelParams &p, const jpegenc_plane p
     int sx, sy;
     if (!planes_consts(p, planes, planes_subsampled, &k, &sx, &sy)) return false;
     BlockKernelParams probe = p;
-    if (!fill_fast_params(probe, k, 2, sx, sy, false, planes, planes_subsampled)) return false;
-#define JPEGENC_CASE(X, Y) if (sx == X && sy == Y) { *err = launch_fast<2, X, Y, false, true>(p, k, num_frames, variant, stream, planes, planes_subsampled); return true; }
+    if (!fill_fast_params(probe, k, 4, sx, sy, false, planes, planes_subsampled)) return false;
+#define JPEGENC_CASE(X, Y) if (sx == X && sy == Y) { *err = launch_fast<4, X, Y, false, true>(p, k, num_frames, variant, stream, planes, planes_subsampled); return true; }
     JPEGENC_CASE(1, 1) JPEGENC_CASE(2, 1) JPEGENC_CASE(1, 2) JPEGENC_CASE(2, 2)
 #undef JPEGENC_CASE
     return false;
@@ -60,7 +64,7 @@ hipError_t launch_group_planes(const BlockKernelParams &p, const jpegenc_plane p
     ColourConsts k;
     int sx, sy;
     if (!planes_consts(p, planes, planes_subsampled, &k, &sx, &sy)) return hipErrorInvalidValue;
-#define JPEGENC_CASE(X, Y) if (sx == X && sy == Y) return launch_group_t<2, X, Y, false, true>(p, k, d_params, frames, variant, st, planes, planes_subsampled);
+#define JPEGENC_CASE(X, Y) if (sx == X && sy == Y) return launch_group_t<4, X, Y, false, true>(p, k, d_params, frames, variant, st, planes, planes_subsampled);
     JPEGENC_CASE(1, 1) JPEGENC_CASE(2, 1) JPEGENC_CASE(1, 2) JPEGENC_CASE(2, 2)
 #undef JPEGENC_CASE
     return hipErrorInvalidValue;

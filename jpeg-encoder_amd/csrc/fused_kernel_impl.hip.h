@@ -142,7 +142,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         const uint32_t mcu_w = PLANES ? Wv[11] & 0xFFFFu : H[13], mcu_h = PLANES ? Wv[11] >> 16 : H[14];
         const int pw = PLANES ? (int)(Wv[10] & 0xFFFFu) : (int)H[8], ph = PLANES ? (int)(Wv[10] >> 16) : (int)H[9];
         uint32_t ppitch = PLANES ? Wv[9] : H[10];
-        const size_t pbpp = PLANES ? (((wbits >> FW_BPP2_SHIFT) & 1u) ? 2u : 1u) : (size_t)BPP;
+        const size_t pbpp = PLANES ? (size_t)1 << ((wbits >> FW_BPP2_SHIFT) & 3u) : (size_t)BPP;
         const int bx = (int)(pmx * mcu_w + ((1u << lg) - 1u) * 8u * (uint32_t)csx) + (int)(lane & 7u) * csx;
         const int by = (int)(pmy * mcu_h + ((1u << lgv) - 1u) * 8u * (uint32_t)csy) + (int)(lane >> 3) * csy;
         const int c = (int)((wbits >> FW_COMP_SHIFT) & 3u), role = (int)((wbits >> FW_ROLE_SHIFT) & 3u);
@@ -305,6 +305,9 @@ static hipError_t launch_group_t(const BlockKernelParams &b, const ColourConsts 
     return hipGetLastError();
 }
 
+// fast_kernels_565.hip: 16-bit packed RGB
+hipError_t launch_group_565(const BlockKernelParams &b, const ColourConsts &k, int sx, int sy, const EntropyParams *d_params, int frames,
+                            int variant, hipStream_t st);
 // fused_kernels_bytes.hip: the byte-plane instantiations (Ycbcr, Cmyk, Ycck)
 hipError_t launch_group_bytes(const BlockKernelParams &b, const ColourConsts &k, int sx, int sy, const EntropyParams *d_params, int frames,
                               int variant, hipStream_t st);

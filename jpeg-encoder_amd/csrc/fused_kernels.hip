@@ -62,6 +62,7 @@ static hipError_t launch_group_code(const BlockKernelParams &b, const EntropyPar
     int sx, sy;
     if (!colour_consts(b, &k, &sx, &sy)) return hipErrorInvalidValue;
     if (b.xform != XF_RGB2YCC && b.xform != XF_CMYK2YCCK) return launch_group_bytes(b, k, sx, sy, d_params, frames, variant, st);
+    if (b.packed565) return launch_group_565(b, k, sx, sy, d_params, frames, variant, st);
 #define JPEGENC_CASE(B, X, Y) if (b.bpp == B && sx == X && sy == Y) return launch_group_t<B, X, Y, true>(b, k, d_params, frames, variant, st);
 #ifdef JPEGENC_FUSED_ONLY_C2      // experiments: compile one instantiation
     JPEGENC_CASE(3, 2, 2)

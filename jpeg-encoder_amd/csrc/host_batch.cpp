@@ -156,7 +156,11 @@ struct BatchRun {
         p.pixel_frame_stride = pb ? kPlaneTableStrideHost : frame_stride;
         p.coeff_frame_stride = L.total_blocks;
         const FusedSource fused_src = {&p, c.fdct_variant, pb ? pb->planes : nullptr, pb ? pb->subsampled : false};
-        const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() &&
+        // (dense content - the last collected round of frames of this size coded to more than kDenseBitsPerBlock - takes the two
+        // kernels: host_internal.h)
+        static const bool route_off = JPEGENC_DIAG_ENV("JPEGENC_NO_DENSE_ROUTING") != nullptr;
+        const bool dense = !route_off && b.dense_geometry == ((uint64_t)width << 32 | (uint32_t)height) && b.dense_bits_per_block > DeviceCtx::kDenseBitsPerBlock;
+        const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() && !dense &&
                            (pb ? fused_planes_supported(p, pb->planes, pb->subsampled) : fused_supported(p));
         if (!fused) {
             hipError_t err = hipSuccess;
@@ -246,6 +250,12 @@ struct BatchRun {
                 (*lens)[(size_t)f * jobs.size() + k] = len;
                 need += ((size_t)len + 15) & ~(size_t)15;
             }
+        if (jobs.size() == 1 && n > 0 && L.total_blocks) {                     // what the next rounds (and calls) of this size can expect
+            uint64_t bytes = 0;
+            for (int f = 0; f < n; f++) bytes += (*lens)[(size_t)f];
+            b.dense_geometry = (uint64_t)width << 32 | (uint32_t)height;
+            b.dense_bits_per_block = bytes * 8u / ((uint64_t)n * L.total_blocks);
+        }
         int rc = b.reserve_host(need, slot);
         if (rc) return rc;
         uint8_t *h_out = b.h_out[slot];
@@ -390,11 +400,10 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
     for (int f = 0; f < num_frames; f++)
         for (int i = 0; i < ncomp; i++) {
             const jpegenc_plane &pl = planes[(size_t)f * 4 + i], &p0 = planes[i];
-            if (!pl.d_data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null plane");
-            if (pl.pixel_stride != 1 && pl.pixel_stride != 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "pixel_stride must be 1 or 2");
-            if (pl.pitch > 0x7FFFFFFFu) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane pitch too large");
-            if (pl.pixel_stride != p0.pixel_stride || (pl.invert != 0) != (p0.invert != 0) ||
-                (pl.pixel_stride == 2 && (((uintptr_t)pl.d_data ^ (uintptr_t)p0.d_data) & 1u)))
+            const int rc_plane = validate_plane(pl, hs, vs, planes_subsampled != 0);
+            if (rc_plane) return rc_plane;
+            if (pl.pixel_stride != p0.pixel_stride || (pl.invert != 0) != (p0.invert != 0) || pl.shift != p0.shift ||
+                (((uintptr_t)pl.d_data ^ (uintptr_t)p0.d_data) & (uintptr_t)(pl.pixel_stride - 1)))
                 uniform = false;
         }
     auto one_by_one = [&]() -> int {
@@ -424,7 +433,7 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
             if (i >= ncomp) { table[(size_t)f * 8 + i] = table[(size_t)f * 8 + 4 + i] = 0; continue; }
             const jpegenc_plane &pl = planes[(size_t)f * 4 + i];
             const uintptr_t ptr = (uintptr_t)pl.d_data;
-            table[(size_t)f * 8 + i] = (uint64_t)(ptr - (pl.pixel_stride == 2 ? (ptr & 1u) : 0u));
+            table[(size_t)f * 8 + i] = (uint64_t)(ptr - (ptr & (uintptr_t)(pl.pixel_stride - 1)));
             table[(size_t)f * 8 + 4 + i] = (uint64_t)pl.pitch;
             if (pl.pitch > rep[i].pitch) rep[i].pitch = pl.pitch;
         }

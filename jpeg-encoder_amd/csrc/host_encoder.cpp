@@ -298,10 +298,8 @@ int jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jct, int width,
     sampling_hv(e->cfg.sampling, &hs, &vs);
     for (int i = 0; i < ncomp; i++) {
         if (!planes[i].d_data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null plane");
-        if (planes[i].pixel_stride != 1 && planes[i].pixel_stride != 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "pixel_stride must be 1 or 2");
-        if (planes[i].pixel_stride == 2 && (hs == 4 || vs == 4) && !planes_subsampled)
-            return fail(JPEGENC_ERR_INVALID_ARGUMENT, "two-byte pixel strides are not decimated by 4 on the device");
-        if (planes[i].pitch > 0x7FFFFFFFu) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane pitch too large");
+        const int rc_plane = validate_plane(planes[i], hs, vs, planes_subsampled != 0);
+        if (rc_plane) return rc_plane;
     }
     int rc = e->ctx.open(e->device);
     if (rc) return rc;
@@ -313,5 +311,36 @@ int jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jct, int width,
     return rc;
 }
 
+
+// The plane descriptors of the surface layouts decoders and cameras produce (see the header).
+int jpegenc_packed_planes(int surface_format, const void *const *d_planes, const size_t *pitches, jpegenc_plane planes[4]) {
+    if (!d_planes || !pitches || !planes) return -fail(JPEGENC_ERR_INVALID_ARGUMENT, "null argument");
+    memset(planes, 0, 4 * sizeof(jpegenc_plane));
+    auto set = [&](int c, int src, size_t byte, int stride, int shift) {
+        planes[c].d_data = (const uint8_t *)d_planes[src] + byte; planes[c].pitch = pitches[src]; planes[c].pixel_stride = stride; planes[c].shift = shift;
+    };
+    int need = 0, sampling = JPEGENC_F_2_2;
+    switch (surface_format) {
+    case JPEGENC_SURFACE_I420: need = 3; break;
+    case JPEGENC_SURFACE_YV12: need = 3; break;
+    case JPEGENC_SURFACE_I010: need = 3; break;
+    case JPEGENC_SURFACE_NV12: case JPEGENC_SURFACE_NV21: case JPEGENC_SURFACE_P010: case JPEGENC_SURFACE_P016: need = 2; break;
+    case JPEGENC_SURFACE_YUYV: case JPEGENC_SURFACE_UYVY: need = 1; sampling = JPEGENC_F_2_1; break;
+    default: return -fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown surface format");
+    }
+    for (int i = 0; i < need; i++) if (!d_planes[i]) return -fail(JPEGENC_ERR_INVALID_ARGUMENT, "null plane");
+    switch (surface_format) {
+    case JPEGENC_SURFACE_I420: set(0, 0, 0, 1, 0); set(1, 1, 0, 1, 0); set(2, 2, 0, 1, 0); break;
+    case JPEGENC_SURFACE_YV12: set(0, 0, 0, 1, 0); set(1, 2, 0, 1, 0); set(2, 1, 0, 1, 0); break;            // Y, V, U in memory
+    case JPEGENC_SURFACE_I010: set(0, 0, 0, 2, 2); set(1, 1, 0, 2, 2); set(2, 2, 0, 2, 2); break;            // 10 bits in the low bits of 16
+    case JPEGENC_SURFACE_NV12: set(0, 0, 0, 1, 0); set(1, 1, 0, 2, 0); set(2, 1, 1, 2, 0); break;
+    case JPEGENC_SURFACE_NV21: set(0, 0, 0, 1, 0); set(1, 1, 1, 2, 0); set(2, 1, 0, 2, 0); break;
+    case JPEGENC_SURFACE_P010: case JPEGENC_SURFACE_P016:                                                     // MSB-aligned 16-bit words
+        set(0, 0, 0, 2, 8); set(1, 1, 0, 4, 8); set(2, 1, 2, 4, 8); break;
+    case JPEGENC_SURFACE_YUYV: set(0, 0, 0, 2, 0); set(1, 0, 1, 4, 0); set(2, 0, 3, 4, 0); break;
+    case JPEGENC_SURFACE_UYVY: set(0, 0, 1, 2, 0); set(1, 0, 0, 4, 0); set(2, 0, 2, 4, 0); break;
+    }
+    return sampling;
+}
 
 }  // extern "C"

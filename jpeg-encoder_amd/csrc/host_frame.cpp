@@ -186,6 +186,10 @@ struct FrameRun {
             first_piece = out_total < DeviceCtx::kFirstPiece ? out_total : DeviceCtx::kFirstPiece;
             fused = supported && mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() &&
                     (ctx.external_planes ? fused_planes_supported(p, ctx.external_planes, ctx.external_planes_subsampled) : fused_supported(p));
+            // (dense content takes the two kernels - DeviceCtx::dense_last_time; frames of up to 1 MB of pixels keep the one kernel
+            // that finishes the scan itself: their time is launches, not walks)
+            static const bool route_off = JPEGENC_DIAG_ENV("JPEGENC_NO_DENSE_ROUTING") != nullptr;
+            if (fused && !route_off && pixel_bytes > ((size_t)1 << 20) && ctx.dense_last_time((uint64_t)width << 32 | (uint32_t)height, L.total_blocks)) fused = false;
             if (supported) {
                 // The scans of a sequential / progressive frame are independent: coded in shared launches they cost
                 // ~10 launches per 8 scans instead of ~10 per scan (a 4K progressive frame: 12 scans; such frames were
@@ -266,7 +270,7 @@ struct FrameRun {
             if (ctx.external_planes) {                                        // a described planar source: its descriptors are part of what the sequence bakes in
                 for (int i = 0; i < L.num_components; i++) {
                     const jpegenc_plane &pl = ctx.external_planes[i];
-                    const int64_t d[] = {(int64_t)(uintptr_t)pl.d_data, (int64_t)pl.pitch, pl.pixel_stride, pl.invert, (int64_t)ctx.external_planes_subsampled};
+                    const int64_t d[] = {(int64_t)(uintptr_t)pl.d_data, (int64_t)pl.pitch, pl.pixel_stride, pl.invert, pl.shift, (int64_t)ctx.external_planes_subsampled};
                     put(d, sizeof d);
                 }
             }

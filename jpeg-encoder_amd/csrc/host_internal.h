@@ -281,6 +281,15 @@ struct DeviceCtx {
     // their own streams, one event per uploaded stripe
     hipStream_t kernel_stream = nullptr, download_stream = nullptr;
     hipEvent_t uploaded[8] = {};
+    // Dense content (noise-like frames, quality 95 and up on detailed ones): blocks longer than a lane's 480-bit strip send their
+    // whole 64-MCU group through the pixels -> bits kernel's second walk, and from ~400 bits per block on average that is every
+    // group - the block kernel + k_block_code are then the faster pair (4K 4:2:0 noise at quality 95: 35.5 against 45 us; at
+    // quality 90, 333 bits per block, the one kernel still leads: profiles/r04_fused_dense.txt).  Both paths produce the same
+    // bytes, so the size of the last scan of this geometry is a path-independent predictor.
+    static constexpr uint64_t kDenseBitsPerBlock = 390;
+    bool dense_last_time(uint64_t geometry, uint64_t total_blocks) const {
+        return last_file_geometry == geometry && total_blocks && (uint64_t)last_scan_bytes * 8u > kDenseBitsPerBlock * total_blocks;
+    }
     size_t last_scan_bytes = 0;        // coded bytes of the handle's last device-coded frame and its size: a mid-size frame whose file was
     uint64_t last_file_geometry = 0;   // small is coded straight into pinned host memory the next time (host_frame.cpp, plan_scans)
     bool batch_worker = false;         // one of a batch's pool of host threads: waits for its stream instead of busy-polling the kernel's done word (the pool's cores belong to the caller)
@@ -494,6 +503,7 @@ struct BatchBuffers {
     void *d_coeffs = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_packed = nullptr;      // d_packed: a round's scans back to back
     uint64_t *d_pos = nullptr;
     uint32_t *d_len = nullptr, *h_len = nullptr;
+    uint64_t dense_geometry = 0, dense_bits_per_block = 0;     // coded bits per block of the last collected round of frames of that size (DeviceCtx::kDenseBitsPerBlock)
     uint8_t *h_out[2] = {nullptr, nullptr};      // two: the files of one round are assembled while the next round is coded and fetched
     size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, packed_cap = 0, pos_cap = 0, h_out_cap[2] = {0, 0};
     static int grow_device(void **p, size_t *cap, size_t need) {
@@ -663,6 +673,20 @@ constexpr int kBatchNeedsPerFrame = -1000;
 struct PlaneBatch { const jpegenc_plane *planes; bool subsampled; const uint64_t *d_table; int jct; };
 int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b, int device, const void *d_frames, size_t frame_stride, int num_frames,
                         int width, int height, int color_type, jpegenc_write_fn sink, void *const *users, const PlaneBatch *pb = nullptr);
+
+// one descriptor of a device-resident planar source (jpegenc_encoder_encode_planes_device and its batch form)
+inline int validate_plane(const jpegenc_plane &pl, int hs, int vs, bool planes_subsampled) {
+    if (!pl.d_data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null plane");
+    if (pl.pixel_stride != 1 && pl.pixel_stride != 2 && pl.pixel_stride != 4) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "pixel_stride must be 1, 2 or 4");
+    if (pl.shift < 0 || pl.shift > 8 || pl.reserved != 0) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane shift must be 0 .. 8 (and reserved 0)");
+    if (pl.shift && (pl.pixel_stride < 2 || ((uintptr_t)pl.d_data & 1u))) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "a shifted plane holds 2-byte aligned 16-bit samples");
+    if (pl.shift > 0 && pl.shift < 8 && pl.pixel_stride != 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "a shift of 1 .. 7 needs pixel_stride 2");
+    if ((hs == 4 || vs == 4) && !planes_subsampled && pl.pixel_stride != 1)
+        return fail(JPEGENC_ERR_INVALID_ARGUMENT, "pixel strides above 1 are not decimated by 4 on the device");
+    if ((hs == 4 || vs == 4) && pl.shift > 0 && pl.shift < 8) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "a shift of 1 .. 7 is not taken with sampling factors of 4");
+    if (pl.pitch > 0x7FFFFFFFu) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane pitch too large");
+    return JPEGENC_OK;
+}
 
 // ---- host_multi.cpp ------------------------------------------------------------------------------------------------------------
 void bind_thread_near_device(int device, bool on);            // (opt-in) the calling thread onto the NUMA node of the device

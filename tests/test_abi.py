@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(binding):
     lib = binding.lib()
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.jpegenc_abi_version() == 1
+    assert lib.jpegenc_abi_version() == 2
 
 
 def test_qtable_matches_oracle(binding, oracle):

@@ -633,3 +633,34 @@ def test_planar_source_launch_sequence_is_replayed_correctly(binding, oracle, sy
     for _ in range(4):
         assert e.encode_planes_device(binding.J_YCBCR, w, h, nv12, planes_subsampled=True) == want
     assert e.encode_planes_device(binding.J_YCBCR, w, h, planes, planes_subsampled=True) == want2
+
+
+def test_dense_frames_are_routed_to_the_two_kernels_and_back(binding, oracle, synth):
+    """A handle whose last scan of a frame size coded to more than ~390 bits per block (noise-like frames, very high qualities)
+    takes block kernel + k_block_code for the next frame of that size instead of the pixels -> bits kernel, whose long-block
+    second walk loses there, and returns to the one kernel when the content thins out (host_internal.h: DeviceCtx::dense_last_time,
+    BatchBuffers::dense_bits_per_block).  Either way the bytes are the oracle's: dense and sparse frames alternate through one
+    handle - single calls, the worker-pool batch, the device-resident batch in rounds of two."""
+    import torch
+    w, h = 1280, 720                                                   # above 1 MB of pixels (smaller frames always keep the one kernel)
+    rng = np.random.default_rng(17)
+    dense = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    sparse = synth.test_img_rgb(w, h)
+    mixed = dense.copy()
+    mixed[:, : w // 2] = sparse[:, : w // 2]
+    for quality, sampling in ((96, (2, 2)), (98, (1, 1))):
+        want = {id(a): oracle.encode_jpeg(a, w, h, oracle.RGB, quality, sampling=sampling) for a in (dense, sparse, mixed)}
+        assert len(want[id(dense)]) * 8 > 390 * (w * h // 64) and len(want[id(sparse)]) * 8 < 200 * (w * h // 64)
+        with binding.Encoder(quality) as e:
+            e.set_sampling_factor(binding.sampling_factor(*sampling))
+            seq = [dense, dense, dense, sparse, sparse, dense, mixed, sparse, dense, dense]
+            for a in seq:
+                assert e.encode(a, w, h, binding.RGB) == want[id(a)]
+            assert e.encode_batch(seq * 2, w, h, binding.RGB) == [want[id(a)] for a in seq * 2]
+            e.set_batch_round_frames(2)                                # rounds of two: the third round is routed by what the first brought back
+            order = [dense, dense, dense, dense, dense, dense, sparse, sparse, sparse, sparse, sparse, sparse, dense, dense]
+            d = torch.from_numpy(np.stack(order)).cuda()
+            files = e.encode_batch_device(d.data_ptr(), w * h * 3, len(order), w, h, binding.RGB)
+            assert files == [want[id(a)] for a in order]
+            files = e.encode_batch_device(d.data_ptr(), w * h * 3, len(order), w, h, binding.RGB)      # (this call starts with what the last one learnt)
+            assert files == [want[id(a)] for a in order]
