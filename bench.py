@@ -18,6 +18,11 @@ roofline the fused kernel reaches.
               memory to complete JPEG files in host buffers; MAX over ranks of the wall time
               (jpeg_encoder_amd/batch.py - the function the CPU gloo test drives with an injected encoder).
 
+Output: ONE compact JSON line on stdout - the contract's keys first, then `roofline`, `cpu_baseline` and one-number summaries of the side
+legs (`to_bytes`, `simd_variant`) - and the full record of every side leg (figures, sample sizes, NUMA placement, what each number
+means) as a second JSON document on stderr and in the file named by --details (default: bench_details.json in the system's
+temporary directory): a truncated capture of stdout still parses.
+
 Multi-GPU: frames are independent, so ranks shard the batch (one process per GPU, no data-path
 collective).  `value` (the device-resident hot path) scales weakly (per-GPU work fixed); `c3_batch` is the
 fixed 1000-frame job of the north star (strong: 1000/N frames per rank).  Launch: python -m
@@ -330,6 +335,36 @@ def cpu_baseline_extras(synth, criterion, criterion_files, c3_samples):
     return out
 
 
+def spread(times, units_per_run, scale=1.0):
+    """min / median / max rate over the timed runs (every run kept: a median alone hides a slow batch and its cause)."""
+    ts = sorted(times)
+    return {"min": round(units_per_run / ts[-1] * scale, 2), "median": round(units_per_run / ts[len(ts) // 2] * scale, 2),
+            "max": round(units_per_run / ts[0] * scale, 2), "runs": len(ts),
+            "spread": round((ts[-1] - ts[0]) / ts[len(ts) // 2], 3)}
+
+
+def placement(hostinfo, enc, sources, outputs, gpu_node):
+    """NUMA node of the source pages, the output pages, the batch workers' page-locked staging and the CPUs the workers last ran
+    on (jpegenc_encoder_batch_worker_info) - what a slow host-fed run is attributed with."""
+    nodes = hostinfo.numa_nodes()
+    info = {"gpu_numa_node": gpu_node,
+            "source_pages": hostinfo.merge_counts([hostinfo.array_nodes(a, 8) for a in sources[:64]]),
+            "output_pages": hostinfo.merge_counts([hostinfo.array_nodes(a, 4) for a in outputs[:64]]),
+            "caller_affinity": hostinfo.affinity_summary(nodes)}
+    try:
+        workers = enc.batch_worker_info()
+        info["workers"] = len(workers)
+        info["staging_pages"] = hostinfo.merge_counts([hostinfo.pages_nodes(p, n, 8) for p, n, _ in workers if p and n])
+        cpus = {}
+        for _, _, cpu in workers:
+            node = hostinfo.node_of_cpu(cpu, nodes) if cpu >= 0 else None
+            cpus[str(node)] = cpus.get(str(node), 0) + 1
+        info["worker_threads_last_ran_on_node"] = cpus
+    except Exception as exc:                                       # introspection only
+        info["workers_error"] = repr(exc)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,8 +378,10 @@ def main():
                          "(profiles/r01_k_step_series.txt); sustained encoding is what the metric describes")
     ap.add_argument("--frames", type=int, default=32, help="4K frames per launch and per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--e2e-frames", type=int, default=32, help="frames for the end-to-end (JPEG bytes) side figure; 0 disables")
+    ap.add_argument("--e2e-frames", type=int, default=32, help="distinct frames of the end-to-end (JPEG bytes) side figure, each used four times per batch; 0 disables")
+    ap.add_argument("--e2e-batches", type=int, default=11, help="timed batches of the end-to-end side figure (min / median / max are reported)")
     ap.add_argument("--c3-frames", type=int, default=1000, help="frames of the config-3 batch (whole job, all ranks); 0 disables")
+    ap.add_argument("--c3-passes", type=int, default=7, help="timed passes of the config-3 batch (min / median / max are reported)")
     ap.add_argument("--numa-bind", type=int, default=0, choices=(0, 1),
                     help="headline variant of the config-3 leg: batch worker threads bound to the NUMA node of the rank's GPU "
                          "(jpegenc_encoder_set_numa_bind); the other setting is timed beside it (c3_batch.variants)")
@@ -354,6 +391,8 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the side figures, so that every launch of the fused kernel in the process is the "
                          "headline launch (what tools/profile_round.sh runs under rocprofv3)")
+    ap.add_argument("--details", default=os.path.join(tempfile.gettempdir(), "bench_details.json"),
+                    help="where the full record of the side legs is written (also printed to stderr)")
     args = ap.parse_args()
 
     import numpy as np
@@ -362,6 +401,7 @@ def main():
     ge.load_package()
     binding = importlib.import_module("jpeg_encoder_amd.binding")
     synth = importlib.import_module("jpeg_encoder_amd.synth")
+    hostinfo = importlib.import_module("jpeg_encoder_amd.hostinfo")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -391,6 +431,7 @@ def main():
             os.close(saved_fd)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    gpu_node = hostinfo.gpu_numa_node(hostinfo.torch_gpu_bus_id(torch, local_rank))
 
     # synthetic frames, full-entropy bytes (data-independent kernel; random keeps DVFS honest),
     # generated on the device so start-up stays short; every rank gets different frames
@@ -405,9 +446,9 @@ def main():
     q = binding.qtables(QUALITY)
     stream = torch.cuda.current_stream()
 
-    def step():
+    def step(variant=binding.FDCT_SCALAR):
         binding.blocks_device(d_px.data_ptr(), frame_bytes, F, W, H, binding.RGB, HS, VS, q,
-                              binding.ORDER_MCU, binding.FDCT_SCALAR, d_co.data_ptr(), nblk, stream.cuda_stream)
+                              binding.ORDER_MCU, variant, d_co.data_ptr(), nblk, stream.cuda_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -440,8 +481,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    parity = None      # filled by the cpu_baseline leg (rank 0, N=1): GPU frame 0 vs the oracle
-
     pixels = world * F * args.steps * W * H
     value = pixels / elapsed / 1e6
     algo_bytes = F * W * H * ALGO_BYTES_PER_PIXEL
@@ -465,36 +504,59 @@ def main():
         except Exception:
             traffic = None
 
+    # the contract's keys first, in the contract's order
     result = {
         "metric": "Mpixels/s encode (4K RGB q=90 4:2:0)", "value": round(value, 1), "unit": "Mpixels/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_ms": args.settle_ms,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8->i16 (i32 intermediates)", "data": "synthetic",
-        "scope": "block-encode kernel only (colour convert + subsample + FDCT + quantise + zig-zag), pixels and coefficients "
-                 "resident in HBM: no entropy coding, no PCIe; the full-encode figures are device_resident_full_encode, "
-                 "device_resident_to_host_jpeg, end_to_end and c3_batch",
-        "config": {"workload": "C2: 3840x2160 RGB q=90 4:2:0 baseline, MCU-order coefficients; "
-                               f"pixels and coefficients resident in HBM; {F} frames per launch per GPU",
-                   "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective"},
+        "config": {"workload": f"C2: 3840x2160 RGB q=90 4:2:0 baseline, MCU-order coefficients, {F} frames per launch per GPU, "
+                               "pixels and coefficients resident in HBM", "frames_per_step_per_gpu": F,
+                   "parallelism": f"frame-sharded x{world}, no collective"},
+        "scope": "block-encode kernel only (colour convert + subsample + FDCT + quantise + zig-zag): no entropy coding, no PCIe; "
+                 "to bytes: see to_bytes",
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
-                     "traffic_source": traffic_source,
-                     "kernel": "fused colour+subsample+FDCT+quant+zigzag", "kernel_ms": round(kernel_ms, 4),
-                     "algorithmic_bytes_per_launch": int(algo_bytes),
-                     "read_only_frac": round(achieved / 2 / HBM_PEAK_GBPS, 4)},
-        "parity_vs_oracle": parity,
+                     "kernel": "k_blocks_fast<3,2,2,0,true,false>", "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_launch": int(algo_bytes), "read_only_frac": round(achieved / 2 / HBM_PEAK_GBPS, 4)},
+        "parity_vs_oracle": None,
     }
+    details = {"settle_ms": args.settle_ms, "roofline_traffic_source": traffic_source,
+               "host": hostinfo.host_summary(torch, local_rank) if rank == 0 else None}
     if rank == 0 and world == 1:
-        result["cpu_baseline"], result["parity_vs_oracle"] = cpu_baseline(
-            args.cpu_seconds, synth, d_px[0].cpu().numpy(), d_co[0].cpu().numpy())
+        cpu, result["parity_vs_oracle"] = cpu_baseline(args.cpu_seconds, synth, d_px[0].cpu().numpy(), d_co[0].cpu().numpy())
+        details["cpu_baseline"] = cpu
+        result["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                  "sample": cpu["sample"][:200], "scalar_port": (cpu.get("scalar") or {}).get("value"),
+                                  "all_cores": {k: (cpu.get("all_cores") or {}).get(k) for k in ("value", "cores")},
+                                  "full_encode_1_core": (cpu.get("full_encode") or {}).get("value")}
+    to_bytes = {}
     link, criterion_files, c3_samples = None, {}, []
     if rank == 0 and world == 1 and not args.headline_only:
         try:
             link = link_rates(torch, dev)
-            result["link_rates"] = link
+            details["link_rates"] = link
         except Exception as exc:                                   # side figure only
             link = {}
-            result["link_rates"] = {"error": str(exc)}
+            details["link_rates"] = {"error": str(exc)}
+        # ---- the simd FDCT variant (what a `--features simd` build of the crate computes on an AVX2 host, avx2/fdct.rs): the
+        # block kernel's fraction of the roofline and pixels -> scan on the same frames
+        try:
+            for _ in range(20):
+                step(binding.FDCT_SIMD)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nsimd = max(50, min(300, args.steps))
+            e0.record(stream)
+            for _ in range(nsimd):
+                step(binding.FDCT_SIMD)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms_simd = e0.elapsed_time(e1) / nsimd
+            result["simd_variant"] = {"block_kernel_frac": round(algo_bytes / (ms_simd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                      "block_kernel_ms": round(ms_simd, 4), "vs_scalar": round(kernel_ms / ms_simd, 4)}
+        except Exception as exc:
+            result["simd_variant"] = {"error": str(exc)}
         # side figure (never `value`): the north-star stream pipeline, jpegenc_blocks_stream — pinned host
         # frames -> H2D -> fused kernel -> D2H of the coefficient tiles into pinned memory -> callback
         # (no entropy coding here), one stream per direction + one for the kernel
@@ -512,15 +574,16 @@ def main():
             binding.blocks_stream(ptrs, frame_bytes, W, H, binding.RGB, HS, VS, q, on_tile)
             dt = time.perf_counter() - t1
             assert tiles == list(range(nfr))
-            result["pcie_pipeline"] = {"value": round(nfr * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
-                                       "what": f"jpegenc_blocks_stream, {nfr} frames: pinned host RGB -> H2D -> fused kernel -> D2H of "
-                                               "coefficient tiles into pinned memory -> callback; one stream per direction + one "
-                                               "for the kernel, buffers allocated inside the timed call; 24.9 MB up + 24.9 MB "
-                                               "down per frame",
-                                       "roofline": pcie_roofline("pcie_both", nfr * frame_bytes, dt, link)}
+            details["pcie_pipeline"] = {"value": round(nfr * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
+                                        "what": f"jpegenc_blocks_stream, {nfr} frames: pinned host RGB -> H2D -> fused kernel -> D2H of "
+                                                "coefficient tiles into pinned memory -> callback; one stream per direction + one "
+                                                "for the kernel, buffers allocated inside the timed call; 24.9 MB up + 24.9 MB "
+                                                "down per frame",
+                                        "roofline": pcie_roofline("pcie_both", nfr * frame_bytes, dt, link)}
+            to_bytes["coefficient_tile_stream_Gpx_s"] = round(nfr * W * H / dt / 1e9, 2)
             del pinned
         except Exception as exc:                                   # side figure only
-            result["pcie_pipeline"] = {"error": str(exc)}
+            details["pcie_pipeline"] = {"error": str(exc)}
         # side figure (never `value`): pixels in HBM -> complete entropy-coded scan bytes in HBM
         # (fused block kernel + device Huffman coding), same frames, HIP-event timed
         try:
@@ -532,24 +595,24 @@ def main():
             d_len = torch.zeros(Fd, dtype=torch.int32, device=dev)
             d_ws = torch.empty(wsz, dtype=torch.uint8, device=dev)
 
-            def two_kernels(px):           # the public coefficient interchange in between: jpegenc_blocks_device + jpegenc_scan_device
+            def two_kernels(px, variant):  # the public coefficient interchange in between: jpegenc_blocks_device + jpegenc_scan_device
                 binding.blocks_device(px.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, HS, VS, q, binding.ORDER_MCU,
-                                      binding.FDCT_SCALAR, d_co.data_ptr(), nblk, stream.cuda_stream)
+                                      variant, d_co.data_ptr(), nblk, stream.cuda_stream)
                 binding.scan_device(d_co.data_ptr(), nblk, Fd, L, scan, d_out.data_ptr(), cap, d_len.data_ptr(),
                                     d_ws.data_ptr(), wsz, stream.cuda_stream)
 
-            def one_kernel(px):            # jpegenc_pixels_scan_device: pixels -> coded runs in ONE kernel (what the Encoder launches)
+            def one_kernel(px, variant):   # jpegenc_pixels_scan_device: pixels -> coded runs in ONE kernel (what the Encoder launches)
                 binding.pixels_scan_device(px.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, HS, VS, q, d_out.data_ptr(), cap,
-                                           d_len.data_ptr(), d_ws.data_ptr(), wsz, stream.cuda_stream)
+                                           d_len.data_ptr(), d_ws.data_ptr(), wsz, stream.cuda_stream, variant=variant)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-            def timed(fn, px, reps=10):
+            def timed(fn, px, variant, reps=10):
                 for _ in range(3):
-                    fn(px)
+                    fn(px, variant)
                 torch.cuda.synchronize()
                 e0.record(stream)
                 for _ in range(reps):
-                    fn(px)
+                    fn(px, variant)
                 e1.record(stream)
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1) / reps
@@ -560,29 +623,37 @@ def main():
                 algo = Fd * (W * H * 3.0 + scan_bytes)
                 ach = algo / (ms_per_call * 1e-3) / 1e9
                 return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                        "algorithmic_bytes_per_call": int(algo), "limited_by": "instruction issue (all types, ~0.9 per cycle and SIMD: SQ counters, profiles/README.md) of conversion + FDCT + symbol loop, not bytes"}
+                        "algorithmic_bytes_per_call": int(algo), "limited_by": "instruction issue of conversion + FDCT + symbol loop at 15 waves per CU, not bytes"}
 
             def leg(px):
-                ms = timed(one_kernel, px)
+                ms = timed(one_kernel, px, binding.FDCT_SCALAR)
                 nbytes = int(d_len.float().mean().item())
-                ms2 = timed(two_kernels, px)
+                ms2 = timed(two_kernels, px, binding.FDCT_SCALAR)
+                ms_simd = timed(one_kernel, px, binding.FDCT_SIMD)
                 return {"value": round(Fd * W * H / ms / 1e3, 1), "unit": "Mpixels/s", "scan_bytes_per_frame": nbytes,
                         "us_per_frame": round(ms * 1e3 / Fd, 2), "roofline_full_encode": full_roofline(ms, nbytes),
+                        "simd_variant_Mpixels_per_s": round(Fd * W * H / ms_simd / 1e3, 1),
                         "two_kernels": {"value": round(Fd * W * H / ms2 / 1e3, 1), "unit": "Mpixels/s", "us_per_frame": round(ms2 * 1e3 / Fd, 2),
                                         "what": "jpegenc_blocks_device + jpegenc_scan_device (coefficients through HBM); same bytes"}}
-            result["device_resident_full_encode"] = dict(
-                leg(d_px), what=f"{Fd} 4K frames in HBM -> entropy-coded scan bytes in HBM, jpegenc_pixels_scan_device: ONE kernel from pixels to "
-                                "coded runs (one workgroup = 64 MCUs) + placement + 0xFF stuffing; noise frames = worst case for entropy coding")
+            dr = dict(leg(d_px), what=f"{Fd} 4K frames in HBM -> entropy-coded scan bytes in HBM, jpegenc_pixels_scan_device: ONE kernel from pixels to "
+                                      "coded runs (one workgroup = 64 MCUs) + placement + 0xFF stuffing; noise frames = worst case for entropy coding")
             # the same on photo-like frames (gradient + a little noise): what entropy coding costs on realistic content
             base = torch.from_numpy(synth.test_img_rgb(W, H).reshape(-1)).to(dev)
             gen = torch.Generator(device=dev)
             gen.manual_seed(11)
             d_photo = torch.clamp(base.to(torch.int16)[None, :] + torch.randint(-6, 7, (Fd, base.numel()), dtype=torch.int16, device=dev, generator=gen),
                                   0, 255).to(torch.uint8)
-            result["device_resident_full_encode"]["photo_like"] = leg(d_photo)
+            dr["photo_like"] = leg(d_photo)
+            details["device_resident_full_encode"] = dr
+            to_bytes["device_resident_Gpx_s"] = {"noise": round(dr["value"] / 1e3, 1), "photo_like": round(dr["photo_like"]["value"] / 1e3, 1),
+                                                 "two_kernels_noise": round(dr["two_kernels"]["value"] / 1e3, 1),
+                                                 "two_kernels_photo_like": round(dr["photo_like"]["two_kernels"]["value"] / 1e3, 1)}
+            if "simd_variant" in result and "error" not in result["simd_variant"]:
+                result["simd_variant"]["pixels_to_scan_Gpx_s"] = {"noise": round(dr["simd_variant_Mpixels_per_s"] / 1e3, 1),
+                                                                  "photo_like": round(dr["photo_like"]["simd_variant_Mpixels_per_s"] / 1e3, 1)}
             del d_out, d_ws, d_photo
         except Exception as exc:                                   # side figure only
-            result["device_resident_full_encode"] = {"error": str(exc)}
+            details["device_resident_full_encode"] = {"error": str(exc)}
         # side figure (never `value`): frames in HBM -> complete JPEG files in host buffers through the Encoder
         # (jpegenc_encoder_encode_batch_device_to_buffers: batched launches, only compressed bytes cross PCIe)
         try:
@@ -605,114 +676,141 @@ def main():
                 binding.check(fn(enc_d._h, d_crit.data_ptr(), frame_bytes, Fd, W, H, binding.RGB, optrs_d, caps_d, lens_d))
             run_d()
             times = []
-            for _ in range(5):
+            for _ in range(7):
                 t1 = time.perf_counter()
                 run_d()
                 times.append(time.perf_counter() - t1)
-            dt = sorted(times)[2]
-            result["device_resident_to_host_jpeg"] = {
-                "value": round(Fd * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
-                "what": f"{Fd} 4K frames (Criterion pattern) in HBM -> JPEG files in host buffers, one Encoder call, batched "
-                        "launches, median of 5", "jpeg_bytes_per_frame": int(sum(lens_d) / Fd),
-                "roofline": pcie_roofline("pcie_d2h", int(sum(lens_d)), dt, link)}
+            dt = sorted(times)[len(times) // 2]
+            details["device_resident_to_host_jpeg"] = {
+                "Gpixel_per_s": spread(times, Fd * W * H, 1e-9), "unit": "Gpixel/s",
+                "what": f"{Fd} 4K frames (Criterion pattern) in HBM -> JPEG files in host buffers, one Encoder call, batched launches",
+                "jpeg_bytes_per_frame": int(sum(lens_d) / Fd), "roofline": pcie_roofline("pcie_d2h", int(sum(lens_d)), dt, link)}
+            to_bytes["device_resident_to_host_files_Gpx_s"] = details["device_resident_to_host_jpeg"]["Gpixel_per_s"]["median"]
             del d_crit, outs_d
         except Exception as exc:                                   # side figure only
-            result["device_resident_to_host_jpeg"] = {"error": str(exc)}
+            details["device_resident_to_host_jpeg"] = {"error": str(exc)}
         if args.e2e_frames > 0:
             # side figure (never `value`): host frames -> JPEG bytes through the Encoder batch API
             # (H2D + kernel + D2H + host Huffman, one host thread per in-flight frame)
-            base = synth.criterion_pattern(W, H)     # the reference's own bench image, scaled to 4K
-            distinct = [np.ascontiguousarray(np.roll(base, 16 * i, axis=1)) for i in range(args.e2e_frames)]
-            frames = distinct * 4                    # a batch long enough for the steady state (16 workers): every frame is uploaded again
-            enc = binding.Encoder(QUALITY, device=local_rank)
-            enc.set_sampling_factor(binding.F_2_2)
-            cap = 10 << 20
-            arrs = [f.reshape(-1) for f in frames]
-            outs = [np.zeros(cap, dtype=np.uint8) for _ in frames]
-            import ctypes as C
-            n = len(frames)
-            ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
-            optrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
-            caps = (C.c_size_t * n)(*([cap] * n))
-            lens = (C.c_size_t * n)()
+            try:
+                base = synth.criterion_pattern(W, H)     # the reference's own bench image, scaled to 4K
+                distinct = [np.ascontiguousarray(np.roll(base, 16 * i, axis=1)) for i in range(args.e2e_frames)]
+                frames = distinct * 4                    # a batch long enough for the steady state (16 workers): every frame is uploaded again
+                enc = binding.Encoder(QUALITY, device=local_rank)
+                enc.set_sampling_factor(binding.F_2_2)
+                cap = 10 << 20
+                arrs = [f.reshape(-1) for f in frames]
+                outs = [np.zeros(cap, dtype=np.uint8) for _ in frames]
+                for o in outs:
+                    o[::4096] = 1                        # (np.zeros alone leaves the pages unplaced until the first file lands in them)
+                import ctypes as C
+                n = len(frames)
+                ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+                optrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+                caps = (C.c_size_t * n)(*([cap] * n))
+                lens = (C.c_size_t * n)()
 
-            def run():
-                binding.check(binding.lib().jpegenc_encoder_encode_batch_to_buffers(
-                    enc._h, ptrs, arrs[0].size, n, W, H, binding.RGB, optrs, caps, lens))
-            run()                                                    # warm-up: buffers, page faults
-            times = []
-            for _ in range(5):
-                t1 = time.perf_counter()
+                def run():
+                    binding.check(binding.lib().jpegenc_encoder_encode_batch_to_buffers(
+                        enc._h, ptrs, arrs[0].size, n, W, H, binding.RGB, optrs, caps, lens))
+                run()                                                    # warm-up: buffers, page faults
                 run()
-                times.append(time.perf_counter() - t1)
-            dt = sorted(times)[len(times) // 2]                      # median of 5 batches
-            result["end_to_end"] = {"value": round(n * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
-                                    "what": "pageable host RGB (Criterion pattern) -> JPEG bytes in host buffers: "
-                                            "H2D + fused kernel + device entropy coding + D2H of compressed bytes, "
-                                            f"{n} frames per batch (median of 5 batches), one GPU, up to 16 host threads of {os.cpu_count()}",
-                                    "jpeg_bytes_per_frame": int(sum(lens) / n),
-                                    "roofline": pcie_roofline("pcie_h2d", n * frame_bytes, dt, link)}
+                times = []
+                for _ in range(max(args.e2e_batches, 3)):
+                    t1 = time.perf_counter()
+                    run()
+                    times.append(time.perf_counter() - t1)
+                dt = sorted(times)[len(times) // 2]
+                sp = spread(times, n * W * H, 1e-9)
+                details["end_to_end"] = {"Gpixel_per_s": sp, "unit": "Gpixel/s",
+                                         "upload_GBps_per_batch": [round(n * frame_bytes / t / 1e9, 1) for t in times],
+                                         "what": "pageable host RGB (Criterion pattern) -> JPEG bytes in host buffers: "
+                                                 "H2D + fused kernel + device entropy coding + D2H of compressed bytes, "
+                                                 f"{n} frames per batch, {len(times)} timed batches after two warm-up batches, one GPU, up to 16 host threads of {os.cpu_count()}",
+                                         "jpeg_bytes_per_frame": int(sum(lens) / n),
+                                         "placement": placement(hostinfo, enc, arrs[:args.e2e_frames], outs, gpu_node),
+                                         "roofline": pcie_roofline("pcie_h2d", n * frame_bytes, dt, link),
+                                         "roofline_min_max_frac": [round(n * frame_bytes / max(times) / 1e9 / link["h2d"], 3), round(n * frame_bytes / min(times) / 1e9 / link["h2d"], 3)] if link.get("h2d") else None}
+                to_bytes["host_fed_4k_Gpx_s"] = dict({k: sp[k] for k in ("min", "median", "max")}, frac_of_h2d_median=details["end_to_end"]["roofline"]["frac"])
+            except Exception as exc:                               # side figure only
+                details["end_to_end"] = {"error": repr(exc)}
         try:
-            result["criterion_workloads"], criterion_files = criterion_workloads(binding, synth, local_rank)
+            details["criterion_workloads"], criterion_files = criterion_workloads(binding, synth, local_rank)
             # each call moves 10.8 MB of pixels up and the file down, one after the other (a scan can only come back once the
             # whole frame is coded): the floor is the SUM of the two copies at this box's link rates
             if link and link.get("h2d") and link.get("d2h"):
-                for name, rec in result["criterion_workloads"].items():
+                for name, rec in details["criterion_workloads"].items():
                     if isinstance(rec, dict) and "jpeg_bytes" in rec:
                         up, down = 2000 * 1800 * 3, rec["jpeg_bytes"]
                         floor_ms = (up / link["h2d"] + down / link["d2h"]) / 1e6
                         rec["roofline"] = {"bound": "pcie_serial", "achieved": round((up + down) / rec["gpu_ms"] / 1e6, 1), "unit": "GB/s",
                                            "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / rec["gpu_ms"], 4),
                                            "peak_source": "h2d + d2h of this run's link_rates, one after the other"}
+            to_bytes["criterion_rgb_100_ms"] = details["criterion_workloads"]["encode rgb 100"]["gpu_ms"]
         except Exception as exc:                                   # side figure only
-            result["criterion_workloads"] = {"error": str(exc)}
+            details["criterion_workloads"] = {"error": str(exc)}
     # ---- BASELINE config 3 on every rank: the frame-sharded 1000-frame batch, pageable host pixels -> JPEG files in
     # host buffers (jpeg_encoder_amd/batch.py; no data-path collective, MAX over ranks of the wall time).  Every frame of
     # the batch is distinct (seeded 42 + k) and a rank only materialises its own shard.  Besides the headline variant
     # (pageable frames, threads unbound) the leg times the two host-side levers an 8-rank host is expected to need - frames
     # in page-locked memory (no staging copy) and worker threads bound to the GPU's NUMA node - and every rank reports its
     # own upload rate against the link rate it measured itself, all ranks copying at once.
+    # Every collective of the leg is reached by every rank whatever happens on it: a rank that fails a phase carries the
+    # failure through the bookkeeping all-reduces (batch.run_sharded_batch, per_rank_table) instead of leaving the others waiting.
     if args.c3_frames > 0 and not args.headline_only:
-        try:
-            batch = importlib.import_module("jpeg_encoder_amd.batch")
+        batch = importlib.import_module("jpeg_encoder_amd.batch")
+        force = os.environ.get("JPEGENC_BENCH_FORCE_DIST") == "1"
+        ddist = dist if distributed else None
+        fb = batch.C3_W * batch.C3_H * 3
+        c3, setup_error = None, None
+        enc3 = pool = pinned_buf = pinned = None
+        idx, pageable, outs3, my_link = [], [], [], {}
+        try:                                                        # ---- phase 1 (local): this rank's shard and buffers
             enc3 = binding.Encoder(batch.C3_QUALITY, device=local_rank)         # q=80 -> default F_2_2 (encoder.rs:256-260)
             enc3.set_numa_bind(bool(args.numa_bind))
             cap3 = 1 << 20
-            fb = batch.C3_W * batch.C3_H * 3
             idx = binding.shard_frames(args.c3_frames, world, rank)
-            n_mine = len(idx)
-            outs3 = [np.zeros(cap3, dtype=np.uint8) for _ in range(n_mine)]      # caller-owned output buffers, reused (and touched: no page faults in the timed pass)
-
-            def encode_frames(frames):                                          # -> views of the files, no copies
-                lens3 = enc3.encode_batch_into(frames, batch.C3_W, batch.C3_H, binding.RGB, outs3)
-                return [outs3[i][:lens3[i]] for i in range(len(frames))]
+            outs3 = [np.zeros(cap3, dtype=np.uint8) for _ in range(len(idx))]  # caller-owned output buffers, reused (and touched: no page faults in the timed pass)
             pool = batch.ShardFrames(synth, torch=torch, device=dev)
             pool.materialise(idx)
-            force = os.environ.get("JPEGENC_BENCH_FORCE_DIST") == "1"
-            ddist = dist if distributed else None
-            # what this rank's link delivers while every rank copies (the peak of its own upload figure)
-            if ddist is not None:
-                ddist.barrier()
-            try:
-                my_link = link if (link and "h2d" in link) else link_rates(torch, dev, reps=12)
-            except Exception:
-                my_link = {}
-            pinned_first = bool(args.pinned_frames)
             pageable = [pool(k) for k in idx]
-            pinned_buf, pinned = None, None
             try:
-                pinned_buf = binding.HostBuffer(max(n_mine, 1) * fb)
+                pinned_buf = binding.HostBuffer(max(len(idx), 1) * fb)
                 for i, k in enumerate(idx):
                     pinned_buf.array[i * fb:(i + 1) * fb] = pool(k).reshape(-1)
-                pinned = [pinned_buf.array[i * fb:(i + 1) * fb] for i in range(n_mine)]
-            except Exception as exc:
-                pinned_err = repr(exc)
-            primary_frames = pinned if (pinned_first and pinned is not None) else pageable
-            lookup = {id(f): f for f in primary_frames}
+                pinned = [pinned_buf.array[i * fb:(i + 1) * fb] for i in range(len(idx))]
+            except Exception:
+                pinned = None
+        except Exception as exc:
+            setup_error = exc
+        n_mine = len(idx)
+        # ---- phase 2: what this rank's link delivers while every rank copies (the peak of its own upload figure)
+        if ddist is not None:
+            ddist.barrier()
+        try:
+            my_link = link if (link and "h2d" in link) else link_rates(torch, dev, reps=12)
+        except Exception:
+            my_link = {}
+        primary_frames = pinned if (args.pinned_frames and pinned is not None) else pageable
 
-            c3, mine = batch.run_sharded_batch(binding, encode_frames, lambda k: primary_frames[idx.index(k)], args.c3_frames, batch.C3_W, batch.C3_H,
+        def encode_frames(frames):                                          # -> views of the files, no copies
+            if setup_error is not None:
+                raise setup_error
+            lens3 = enc3.encode_batch_into(frames, batch.C3_W, batch.C3_H, binding.RGB, outs3)
+            return [outs3[i][:lens3[i]] for i in range(len(frames))]
+
+        def make_frame(k):
+            if setup_error is not None:
+                raise setup_error
+            return primary_frames[idx.index(k)]
+        try:                                                        # ---- phase 3: the sharded batch (collectives inside, failure-safe)
+            c3, mine = batch.run_sharded_batch(binding, encode_frames, make_frame, args.c3_frames, batch.C3_W, batch.C3_H,
                                                world, rank, ddist, warmup_frames=args.c3_frames, device=dev,     # one untimed pass over the rank's frames first
                                                force_collectives=force)
+        except Exception as exc:
+            import traceback
+            details["c3_batch"] = {"error": repr(exc), "trace": traceback.format_exc()[-600:]}
+        if c3 is not None:
             c3["what"] = (f"C3: {args.c3_frames} DISTINCT frames of 1920x1080 RGB q=80 4:2:0 (gradient shifted by 16 k columns + noise seeded 42 + k) "
                           f"sharded frame k -> rank k % {world} (jpegenc_shard_frames), each rank materialises and encodes only its own shard: "
                           f"{'page-locked' if primary_frames is pinned else 'pageable'} host pixels -> complete JPEG files in host buffers through "
@@ -721,7 +819,7 @@ def main():
             c3["scaling"] = "strong"
             c3["numa_bind"] = bool(args.numa_bind)
             c3["frames_in"] = "page-locked memory" if primary_frames is pinned else "pageable memory"
-            first = [bytes(mine[k]) for k in idx[:64]]                         # (outs3 is reused by the variants below)
+            first = [bytes(mine[k]) for k in idx[:64]]                         # (outs3 is reused by the passes below)
 
             def per_rank_report(seconds_mine):
                 """every rank's frames / s and upload GB/s against the h2d rate it measured with all ranks copying at once"""
@@ -741,18 +839,38 @@ def main():
             c3["per_rank"], c3["per_rank_min_max"] = per_rank_report(c3["per_rank_seconds"][rank])
             if world == 1 and my_link:
                 c3["roofline"] = pcie_roofline("pcie_h2d", args.c3_frames * fb, c3["seconds"], my_link)
+            # ---- further timed passes of the headline variant: min / median / max of the whole job (MAX over ranks per pass)
+            pass_seconds = [c3["seconds"]]
+            for _ in range(max(args.c3_passes - 1, 0)):
+                dtp = -1.0
+                if ddist is not None:
+                    ddist.barrier()
+                try:
+                    t1 = time.perf_counter()
+                    enc3.encode_batch_into(primary_frames, batch.C3_W, batch.C3_H, binding.RGB, outs3)
+                    dtp = time.perf_counter() - t1
+                except Exception:
+                    dtp = -1.0
+                tt = batch.per_rank_table(ddist, [dtp], world, rank, dev, force)
+                if (tt[:, 0] > 0).all():
+                    pass_seconds.append(float(tt[:, 0].max()))
+            c3["frames_per_s_passes"] = spread(pass_seconds, args.c3_frames)
+            c3["placement"] = placement(hostinfo, enc3, primary_frames, outs3, gpu_node) if rank == 0 else None
             if rank == 0 and world == 1:
                 # the same frames through the library's own multi-device entry point (one process driving the listed GPUs;
                 # here only this rank's GPU, so it measures the API's overhead, not scaling) - same files
-                some = pageable[:64]
-                enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])     # warm-up: the shard's buffers
-                t1 = time.perf_counter()
-                lens_m = enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])
-                dtm = time.perf_counter() - t1
-                c3["multi_api_one_device"] = {"frames": len(some), "frames_per_s": round(len(some) / dtm, 1),
-                                              "identical_files": all(outs3[k][:lens_m[k]].tobytes() == first[k] for k in range(len(some)))}
-                ks = [0, len(some) // 2]                                      # checked against the oracle by the cpu_baseline leg
-                c3_samples = [(pageable[k], batch.C3_W, batch.C3_H, batch.C3_QUALITY, first[k]) for k in ks]
+                try:
+                    some = pageable[:64]
+                    enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])     # warm-up: the shard's buffers
+                    t1 = time.perf_counter()
+                    lens_m = enc3.encode_batch_into(some, batch.C3_W, batch.C3_H, binding.RGB, outs3, devices=[local_rank])
+                    dtm = time.perf_counter() - t1
+                    c3["multi_api_one_device"] = {"frames": len(some), "frames_per_s": round(len(some) / dtm, 1),
+                                                  "identical_files": all(outs3[k][:lens_m[k]].tobytes() == first[k] for k in range(len(some)))}
+                    ks = [0, len(some) // 2]                                      # checked against the oracle by the cpu_baseline leg
+                    c3_samples = [(pageable[k], batch.C3_W, batch.C3_H, batch.C3_QUALITY, first[k]) for k in ks]
+                except Exception as exc:
+                    c3["multi_api_one_device"] = {"error": repr(exc)}
             # ---- the other three corners of {pageable, page-locked} x {unbound, NUMA-bound}: every rank runs every variant
             # on its shard; the bookkeeping all-reduce inside per_rank_report is unconditional (a rank whose variant failed
             # contributes a negative time), so ranks cannot part ways
@@ -791,7 +909,10 @@ def main():
                     variants[name] = ({"frames_per_s": round(args.c3_frames / slowest, 1), "seconds": round(slowest, 6),
                                        "identical_files": bool(t_same.sum() == 0), "per_rank": rows, **mm, "is_headline_variant": is_primary}
                                       if ok and slowest > 0 else {"error": err_v or "failed on another rank"})
-            enc3.set_numa_bind(bool(args.numa_bind))
+            try:
+                enc3.set_numa_bind(bool(args.numa_bind))
+            except Exception:
+                pass
             c3["variants"] = variants
             c3["variants_what"] = ("the same sharded batch with the frames in pageable / page-locked host memory (jpegenc_host_alloc: DMA reads them in place, "
                                    "no staging copy by the workers) and the batch worker threads unbound / bound to the NUMA node of the rank's GPU "
@@ -801,21 +922,38 @@ def main():
                 c3["pinned_frames"] = {k: variants["pinned"][k] for k in ("frames_per_s", "seconds", "identical_files")}
                 if world == 1 and my_link:
                     c3["pinned_frames"]["roofline"] = pcie_roofline("pcie_h2d", args.c3_frames * fb, variants["pinned"]["seconds"], my_link)
-            if pinned_buf is not None:
-                del pinned, primary_frames
+            details["c3_batch"] = c3
+            to_bytes["c3_frames_per_s"] = dict({k: c3["frames_per_s_passes"][k] for k in ("min", "median", "max")},
+                                               frac_of_h2d=(c3.get("roofline") or {}).get("frac"), per_rank_frac_min_max=[c3["per_rank_min_max"]["frac_min"], c3["per_rank_min_max"]["frac_max"]],
+                                               pinned_frames_per_s=(c3.get("pinned_frames") or {}).get("frames_per_s"), digest=c3.get("digest"))
+        if pinned_buf is not None:
+            pinned = primary_frames = None
+            try:
                 pinned_buf.close()
-            result["c3_batch"] = c3
-        except Exception as exc:                                   # never lose the headline line to a side leg
-            import traceback
-            result["c3_batch"] = {"error": repr(exc), "trace": traceback.format_exc()[-600:]}
+            except Exception:
+                pass
     if rank == 0 and world == 1 and not args.headline_only and args.cpu_seconds >= 2.0:
         try:
-            extras = cpu_baseline_extras(synth, result.get("criterion_workloads"), criterion_files, c3_samples)
-            if "c3_parity_vs_oracle" in extras and isinstance(result.get("c3_batch"), dict):
-                result["c3_batch"]["parity_vs_oracle"] = extras["c3_parity_vs_oracle"]
+            extras = cpu_baseline_extras(synth, details.get("criterion_workloads"), criterion_files, c3_samples)
+            if "c3_parity_vs_oracle" in extras and isinstance(details.get("c3_batch"), dict):
+                details["c3_batch"]["parity_vs_oracle"] = extras["c3_parity_vs_oracle"]
+                to_bytes["c3_parity_vs_oracle"] = extras["c3_parity_vs_oracle"]
+            cw = details.get("criterion_workloads") or {}
+            if "encode rgb 100" in cw and "identical_bytes" in cw["encode rgb 100"]:
+                to_bytes["criterion_files_identical_to_cpu_port"] = all(v.get("identical_bytes", True) for v in cw.values() if isinstance(v, dict) and "gpu_ms" in v and "jpeg_bytes" in v)
         except Exception as exc:                                   # side figures only
-            result.setdefault("cpu_baseline", {})["extras_error"] = repr(exc)
+            details.setdefault("cpu_baseline", {})["extras_error"] = repr(exc)
+    if to_bytes:
+        result["to_bytes"] = to_bytes
     if rank == 0:
+        full = dict(result, details=details)
+        try:
+            with open(args.details, "w") as f:
+                json.dump(full, f)
+            result["details_file"] = args.details
+        except OSError:
+            pass
+        print(json.dumps(full), file=sys.stderr)                   # the full record (second document; stdout carries ONE line)
         print(json.dumps(result))
     if distributed:
         dist.destroy_process_group()

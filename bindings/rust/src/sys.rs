@@ -175,6 +175,8 @@ extern "C" {
     pub fn jpegenc_host_register(p: *mut c_void, bytes: usize) -> c_int;
     pub fn jpegenc_host_unregister(p: *mut c_void) -> c_int;
     pub fn jpegenc_host_copy(dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    pub fn jpegenc_encoder_batch_worker_info(e: *mut jpegenc_encoder, worker: c_int, staging: *mut *const c_void, staging_bytes: *mut usize,
+                                             last_cpu: *mut c_int) -> c_int;
     pub fn jpegenc_shard_frames(num_frames: c_int, num_shards: c_int, shard: c_int, indices: *mut c_int, capacity: c_int) -> c_int;
     pub fn jpegenc_encoder_encode_batch_multi(e: *mut jpegenc_encoder, devices: *const c_int, num_devices: c_int,
                                               frames: *const *const u8, frame_len: usize, num_frames: c_int, width: c_int,

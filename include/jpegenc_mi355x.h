@@ -422,6 +422,12 @@ int  jpegenc_host_unregister(void *p);
  * own page-locked pool.  Plain memory on both sides; no device involved (works without a GPU). */
 int  jpegenc_host_copy(void *dst, const void *src, size_t bytes);
 
+/* Where worker `worker` (0 ...) of the handle's batch pool lives: its page-locked staging buffer (NULL before its first staged
+ * frame) and the CPU it last ran on; returns the number of workers the pool has had so far (negative status on a null handle).
+ * Introspection for placement reports (NUMA node of staging pages and threads: bench.py prints it beside every host-fed
+ * figure); nothing an encode needs. */
+int  jpegenc_encoder_batch_worker_info(jpegenc_encoder *e, int worker, const void **staging, size_t *staging_bytes, int *last_cpu);
+
 /* Same batch, each frame into its own caller buffer (no callbacks): outs[i] has capacities[i]
  * bytes, lengths[i] receives the size frame i needs; a frame that does not fit makes the call
  * return JPEGENC_ERR_BUFFER_TOO_SMALL after all frames have been attempted. */

@@ -105,20 +105,31 @@ def run_sharded_batch(binding, encode_frames, make_frame, num_frames, width, hei
     with digests - a checksum of the per-frame checksums in frame order (independent of world size).
     The exchange is two small tensor all-reduces (no pixels, no coefficients, no files)."""
     mine = binding.shard_frames(num_frames, world, rank)
-    frames = [make_frame(k) for k in mine]
-    if warmup_frames and frames:
-        encode_frames(frames[:warmup_frames])                      # buffers, page faults, clocks
+    # A rank that fails - materialising its shard, in the warm-up, in the timed pass - must still take part in the barrier and
+    # the all-reduces below, or the other ranks wait for it until the collective times out: the failure travels in the table
+    # and every rank raises together afterwards.
+    failure, frames, files, seconds = None, [], [], -1.0
+    try:
+        frames = [make_frame(k) for k in mine]
+        if warmup_frames and frames:
+            encode_frames(frames[:warmup_frames])                  # buffers, page faults, clocks
+    except Exception as exc:                                       # noqa: BLE001 - reported after the collectives
+        failure = exc
     if _dist_ready(dist, force_collectives):
         dist.barrier()
-    t0 = time.perf_counter()
-    files = encode_frames(frames) if frames else []
-    seconds = time.perf_counter() - t0
-    if len(files) != len(mine):
-        raise RuntimeError(f"rank {rank}: {len(files)} files for {len(mine)} frames")
-    # per-rank slots (frames, seconds, bytes) and per-frame (owner count, 60 bits of SHA-256): every entry is written by
+    if failure is None:
+        try:
+            t0 = time.perf_counter()
+            files = encode_frames(frames) if frames else []
+            seconds = time.perf_counter() - t0
+            if len(files) != len(mine):
+                raise RuntimeError(f"rank {rank}: {len(files)} files for {len(mine)} frames")
+        except Exception as exc:                                   # noqa: BLE001
+            failure, files = exc, []
+    # per-rank slots (frames, seconds, bytes, failed) and per-frame (owner count, 60 bits of SHA-256): every entry is written by
     # exactly one rank, so a SUM all-reduce assembles the table on every rank
-    stats = np.zeros((world, 3), dtype=np.float64)
-    stats[rank] = (len(mine), seconds, sum(len(f) for f in files))
+    stats = np.zeros((world, 4), dtype=np.float64)
+    stats[rank] = (len(mine), seconds, sum(len(f) for f in files), 0.0 if failure is None else 1.0)
     table = np.zeros((num_frames, 2), dtype=np.int64)
     for k, f in zip(mine, files):
         table[k, 0] = 1
@@ -131,6 +142,10 @@ def run_sharded_batch(binding, encode_frames, make_frame, num_frames, width, hei
         dist.all_reduce(t_stats)
         dist.all_reduce(t_table)
         stats, table = t_stats.cpu().numpy(), t_table.cpu().numpy()
+    if failure is not None:
+        raise failure
+    if stats[:, 3].any():
+        raise RuntimeError(f"rank(s) {[int(r) for r in np.flatnonzero(stats[:, 3])]} failed their shard of the batch")
     if not np.array_equal(table[:, 0], np.ones(num_frames, dtype=np.int64)):
         bad = np.flatnonzero(table[:, 0] != 1)
         raise RuntimeError(f"sharding lost or duplicated frames, e.g. frame {int(bad[0])} encoded {int(table[bad[0], 0])} times")

@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "jpegenc_encoder_encode_image", "jpegenc_encoder_block_order", "jpegenc_encoder_encode_coefficients",
     "jpegenc_encoder_encode_batch", "jpegenc_encoder_encode_batch_to_buffers",
     "jpegenc_encoder_encode_planes_device", "jpegenc_encoder_encode_planes_batch_device", "jpegenc_packed_planes",
-    "jpegenc_host_alloc", "jpegenc_host_free", "jpegenc_host_register", "jpegenc_host_unregister", "jpegenc_host_copy",
+    "jpegenc_host_alloc", "jpegenc_host_free", "jpegenc_host_register", "jpegenc_host_unregister", "jpegenc_host_copy", "jpegenc_encoder_batch_worker_info",
     "jpegenc_shard_frames", "jpegenc_encoder_encode_batch_multi", "jpegenc_encoder_encode_batch_multi_to_buffers",
     "jpegenc_rgb_to_ycbcr", "jpegenc_cmyk_to_ycck",
 ]
@@ -451,6 +451,20 @@ class Encoder:
 
     def set_device_entropy(self, enable):
         check(lib().jpegenc_encoder_set_device_entropy(self._h, 1 if enable else 0))
+
+    def batch_worker_info(self):
+        """[(staging address, staging bytes, last cpu)] of the handle's batch workers (jpegenc_encoder_batch_worker_info)."""
+        f = lib().jpegenc_encoder_batch_worker_info
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        out, n, i = [], 1, 0
+        while i < n:
+            p, nb, cpu = C.c_void_p(), C.c_size_t(), C.c_int()
+            n = f(self._h, i, C.byref(p), C.byref(nb), C.byref(cpu))
+            if n <= 0:
+                break
+            out.append((p.value or 0, nb.value, cpu.value))
+            i += 1
+        return out
 
     def set_batch_round_frames(self, frames):
         check(lib().jpegenc_encoder_set_batch_round_frames(self._h, int(frames)))

@@ -534,6 +534,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
             if (i >= num_frames || status.load() != JPEGENC_OK) break;
             int r = frames[i] ? encode_pixels(e->cfg, ctx, e->device, frames[i], frame_len, width, height, color_type, sink, users[i], staged)
                               : fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
+            ctx.last_cpu = sched_getcpu();
             if (r != JPEGENC_OK) {
                 int expected = JPEGENC_OK;
                 if (status.compare_exchange_strong(expected, r)) messages[(size_t)w] = jpegenc_last_error();
@@ -550,6 +551,24 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
         return status.load();
     }
     return JPEGENC_OK;
+}
+
+// Where worker `worker` of the handle's batch pool lives: its page-locked staging buffer (NULL / 0 before its first staged frame)
+// and the CPU it last ran on.  Returns the number of workers the pool has had so far.  For placement reports (bench.py: NUMA node
+// of the staging pages and of the threads beside every host-fed figure); not needed to encode.
+int jpegenc_encoder_batch_worker_info(jpegenc_encoder *e, int worker, const void **staging, size_t *staging_bytes, int *last_cpu) {
+    if (!e) return -fail(JPEGENC_ERR_INVALID_ARGUMENT, "null encoder");
+    const int n = (int)e->workers.size();
+    if (staging) *staging = nullptr;
+    if (staging_bytes) *staging_bytes = 0;
+    if (last_cpu) *last_cpu = -1;
+    if (worker >= 0 && worker < n) {
+        const DeviceCtx &c = *e->workers[(size_t)worker];
+        if (staging) *staging = c.h_pixels;
+        if (staging_bytes) *staging_bytes = c.h_pixels_cap;
+        if (last_cpu) *last_cpu = c.last_cpu;
+    }
+    return n;
 }
 
 int jpegenc_encoder_encode_batch_to_buffers(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len,

@@ -292,6 +292,7 @@ struct DeviceCtx {
     }
     size_t last_scan_bytes = 0;        // coded bytes of the handle's last device-coded frame and its size: a mid-size frame whose file was
     uint64_t last_file_geometry = 0;   // small is coded straight into pinned host memory the next time (host_frame.cpp, plan_scans)
+    int last_cpu = -1;                 // the CPU the worker that owns this context ran on when it last finished a frame (jpegenc_encoder_batch_worker_info)
     bool batch_worker = false;         // one of a batch's pool of host threads: waits for its stream instead of busy-polling the kernel's done word (the pool's cores belong to the caller)
     uint32_t unsynchronised = 0;       // frames in a row whose kernel announced its result through h_words[2] while the stream was not waited for
     volatile uint32_t *h_words = nullptr;

@@ -100,3 +100,19 @@ def test_world_size_2_gloo(tmp_path, oracle, synth):
     assert r["seconds"] == max(r["per_rank_seconds"])                 # MAX over ranks
     # checksum of checksums == a single-process encode of every frame, whatever the world size
     assert r["digest"] == _digest_of([oracle.encode_jpeg(synth.lcg_image(W, H, 3, 42 + k), W, H, oracle.RGB, Q) for k in range(N)])
+
+
+def test_a_failing_rank_does_not_leave_the_others_in_a_collective(tmp_path):
+    """One rank's encoder raises in the timed pass: the failure travels through the bookkeeping all-reduce and BOTH ranks raise
+    promptly - no rank is left waiting in a barrier or an all-reduce until the collective times out."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, n=N, w=W, h=H, q=Q).replace(
+        "enc = lambda frames:", "enc = (lambda frames: (_ for _ in ()).throw(RuntimeError('rank 1 breaks'))) if rank == 1 else lambda frames:"))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]               # (a hang would run into the 30-minute gloo timeout: caught here)
+    assert procs[0].returncode != 0 and procs[1].returncode != 0
+    assert "failed their shard" in outs[0][1] and "rank 1 breaks" in outs[1][1]

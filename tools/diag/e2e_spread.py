@@ -58,6 +58,23 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if args.what == "link":            # is the link itself steady?  60 samples of 16 pinned 25 MB uploads each (and downloads), ~7 ms apart
+        nbytes = 24_883_200
+        h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        up, down = [], []
+        for _ in range(60):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(16):
+                d.copy_(h, non_blocking=True)
+            torch.cuda.synchronize(); up.append(round(16 * nbytes / (time.perf_counter() - t) / 1e9, 1))
+            t = time.perf_counter()
+            for _ in range(16):
+                h.copy_(d, non_blocking=True)
+            torch.cuda.synchronize(); down.append(round(16 * nbytes / (time.perf_counter() - t) / 1e9, 1))
+        print(json.dumps({"scenario": "link steadiness: 60 x 16 pinned 25 MB copies", "h2d_GBps": up, "d2h_GBps": down,
+                          "h2d_min_median_max": [min(up), sorted(up)[30], max(up)], "d2h_min_median_max": [min(down), sorted(down)[30], max(down)]}), flush=True)
+        return
     nodes = hostinfo.numa_nodes()
     gpu_node = hostinfo.gpu_numa_node(hostinfo.torch_gpu_bus_id(torch, 0))
     before = os.sched_getaffinity(0)
