@@ -274,9 +274,9 @@ struct BatchRun {
         // frame's sink calls stay in order, different frames' calls may interleave - as in encode_batch)
         auto next = std::make_shared<std::atomic<int>>(0);
         auto assemble = [this, lens, frame_at, next, h_out, n, f0]() { assemble_frames(*lens, *frame_at, *next, h_out, n, f0); };
-        unsigned hw = std::thread::hardware_concurrency();
-        int nthreads = (int)(hw ? hw : 4);
+        int nthreads = usable_cpus() - 2;
         if (nthreads > 8) nthreads = 8;
+        if (nthreads < 1) nthreads = 1;
         if (nthreads > n) nthreads = n;
         if (at < ((size_t)4 << 20)) nthreads = 1;                                // little to copy: not worth the threads
         if (more || nthreads > 1) {
@@ -326,10 +326,7 @@ extern "C" {
 // points of one frame are covered by the others (a batch of 8 optimised 4K frames: 283 us per frame one by one).
 static int encode_device_frames_pooled(jpegenc_encoder *e, const void *d_frames, size_t frame_stride, int num_frames, int width, int height,
                                        int color_type, jpegenc_write_fn sink, void *const *users) {
-    unsigned hw = std::thread::hardware_concurrency();
-    int workers = e->max_batch_workers < (int)(hw ? hw : 4) ? e->max_batch_workers : (int)(hw ? hw : 4);
-    if (workers > num_frames) workers = num_frames;
-    if (workers < 1) workers = 1;
+    const int workers = batch_pool_size(e->max_batch_workers, num_frames);
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
     const size_t bytes = (size_t)width * (size_t)height * (size_t)jpegenc_bytes_per_pixel(color_type);
     std::atomic<int> next(0), status(JPEGENC_OK);
@@ -474,9 +471,9 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
         std::atomic<int> up_status(JPEGENC_OK);
         auto stage_and_upload = [&](int first, int slot) {
             const int n = num_frames - first < per_round ? num_frames - first : per_round;
-            unsigned hwt = std::thread::hardware_concurrency();
-            int nt = (int)(hwt ? hwt : 4);
+            int nt = usable_cpus() - 2;
             if (nt > 8) nt = 8;
+            if (nt < 1) nt = 1;
             if (nt > n) nt = n;
             // in four pieces: the upload of one piece runs while the threads stage the next
             if (hipSetDevice(e->device) != hipSuccess) { up_status.store(JPEGENC_ERR_HIP); return; }
@@ -515,12 +512,14 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     }
     // one host worker per in-flight frame; each owns a stream + buffers, so H2D / kernel / D2H of
     // one frame overlap the entropy coding of the others
-    unsigned hw = std::thread::hardware_concurrency();
-    int workers = (int)(hw ? hw : 4);
     static const int env_workers = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_BATCH_WORKERS"); return v ? atoi(v) : 0; }();   // diagnosis: worker sweep
-    const int cap = env_workers > 0 && e->max_batch_workers == 16 ? env_workers : e->max_batch_workers;
-    if (workers > cap || env_workers > 0) workers = cap < (int)(hw ? hw : 4) ? cap : (int)(hw ? hw : 4);
-    if (workers > num_frames) workers = num_frames;
+    // With the scans coded on the device a worker's time is the link's: from four workers on the link is busy (1000 1080p frames:
+    // 9 180 frames/s with 4 workers, 9 230 with 16; 128 4K frames: 17.2 / 17.1 Gpixel/s) and every further worker is a CPU kept
+    // spinning in the runtime - eight is within 1 % of the best at half the CPUs (tools/diag/r04_quota.sh,
+    // profiles/r04_host_upload_paths.txt).  Host entropy coding is CPU work per frame: the full pool.
+    const int pool_cap = e->cfg.device_entropy && e->max_batch_workers > 8 ? 8 : e->max_batch_workers;
+    int workers = batch_pool_size(pool_cap, num_frames);
+    if (env_workers > 0 && e->max_batch_workers == 16) workers = env_workers < num_frames ? env_workers : num_frames;
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());

@@ -383,7 +383,7 @@ struct FrameRun {
         static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
         time_point t_stats = t_begin, t_tables = t_begin;
         if (optimize) {                                  // optimize_huffman_table, encoder.rs:1086-1200
-            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            JPEGENC_HIP(ctx.wait_stream());
             t_stats = now();
             const int max_tables = L.num_components < 2 ? L.num_components : 2;
             for (int d = 0; d < max_tables; d++)
@@ -490,7 +490,7 @@ struct FrameRun {
             if (announced && ++ctx.unsynchronised >= 256u) announced = false;
         }
         if (!announced) {
-            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            JPEGENC_HIP(ctx.wait_stream());
             ctx.unsynchronised = 0;
         }
         t_len = now();
@@ -638,7 +638,7 @@ struct FrameRun {
         }
         // the piece with index pieces_done has arrived
         auto wait_for_piece = [&]() -> int {
-            if (npieces == 1) JPEGENC_HIP(hipStreamSynchronize(ctx.stream));
+            if (npieces == 1) JPEGENC_HIP(ctx.wait_stream());
             else JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[pieces_done]));
             pieces_done++;
             return JPEGENC_OK;
@@ -711,7 +711,7 @@ struct FrameRun {
             }
             o.drain(false);
         }
-        if (direct) JPEGENC_HIP(hipStreamSynchronize(ctx.stream));           // the scans are in the caller's buffer
+        if (direct) JPEGENC_HIP(ctx.wait_stream());                          // the scans are in the caller's buffer
         o.marker(0xD9);
         o.drain(true);
         if (trace) fprintf(stderr, "[jpegenc] frame: prepare %.1f us, launch %ld us, wait-len %ld us, d2h %ld us, emit %ld us, bytes %zu, scans %zu\n",
@@ -822,12 +822,26 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
         ctx.external_pixels = nullptr;
         return rc;
     }
+    // Batch workers and PAGEABLE frames: a plain hipMemcpyAsync from the caller's memory - the runtime page-locks the range in
+    // place, piece by piece, and the DMA engine reads the caller's pages - instead of a copy into the worker's own page-locked
+    // buffer first (rounds 2-3).  Measured in the pool (tools/diag/r04_quota.sh, profiles/r04_host_upload_paths.txt): 128 4K frames
+    // 17.4 Gpixel/s = 0.93 of the link against 15.2-15.7 staged, 1000 1080p frames 9 230 frames/s against 8 770-9 080; and the
+    // host's DRAM moves every frame byte ONCE (the DMA's read) instead of three times (read, streaming write, DMA read) - the
+    // resource eight ranks on one host run out of first.  The call blocks its worker while the frame crosses the
+    // link; the other workers' kernels and downloads overlap it, which is all the staging copy bought.
+    // (Tried as well: hipHostRegister of the frame + async DMA + hipHostUnregister by the worker - one thread reaches 52 GB/s at
+    // 119 us of CPU per 6.2 MB frame, csrc/tools/host_register_rates.cpp, but in the pool it is 3-5 % slower than the staging copy,
+    // and it cannot tell a range the CALLER has partly registered from its own registration: not kept.)
+    // JPEGENC_STAGING_COPY=1 (diagnostic build): the staging copy.
+    static const bool always_stage = JPEGENC_DIAG_ENV("JPEGENC_STAGING_COPY") != nullptr;
+    // (a frame the caller has page-locked only in part - a registration that ends inside it - is staged: the runtime's own
+    // pinning of the range would replace the caller's registration of the same base address, and the caller's unregister fail)
+    const bool partly_locked = staged && bytes && is_pinned_host((const uint8_t *)data) != is_pinned_host((const uint8_t *)data + bytes - 1);
     auto upload = [&](DeviceCtx &cx) -> int {
-        if (staged && is_pinned_host_range(data, bytes)) {
-            // the caller's frame is page-locked already (jpegenc_host_alloc / jpegenc_host_register, or HIP's own calls):
-            // the DMA engine reads it in place - no staging copy, no host DRAM traffic beside the DMA's own read
+        if (staged && !always_stage && !partly_locked) {
+            // (page-locked by the caller or pageable: either way the DMA engine reads the frame where it lies)
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
-        } else if (staged) {       // batch workers: copy into this worker's pinned buffer, then a true async DMA
+        } else if (staged) {       // a copy into this worker's pinned buffer, then a true async DMA
             if (bytes > cx.h_pixels_cap) {
                 if (cx.h_pixels) (void)hipHostFree(cx.h_pixels);
                 cx.h_pixels = nullptr; cx.h_pixels_cap = 0;

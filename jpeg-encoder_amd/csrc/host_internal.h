@@ -241,6 +241,45 @@ struct Restart {
     }
 };
 
+// The CPUs this process may actually use at once: the smallest of the hardware threads, the calling thread's affinity mask and the
+// container's CPU-time quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  hardware_concurrency() alone says 256
+// inside a container that is throttled to 16 CPUs' worth - sixteen busy-waiting batch workers plus the caller then run into the
+// quota, the kernel freezes the whole process until the next 100 ms period, and a batch takes half as long again
+// (profiles/r04_cpu_quota.txt: the 9-16 Gpixel/s spread of the host -> JPEG leg).
+inline int usable_cpus() {
+    static const int n = [] {
+        long cpus = (long)std::thread::hardware_concurrency();
+        if (cpus <= 0) cpus = 4;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < cpus) cpus = CPU_COUNT(&set);
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // "max 100000" or "1600000 100000"
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+        }
+        if (quota > 0 && period > 0) {
+            const long q = (long)((quota + period - 1) / period);
+            if (q >= 1 && q < cpus) cpus = q;
+        }
+        return (int)(cpus < 1 ? 1 : cpus);
+    }();
+    return n;
+}
+// Host threads of a batch's worker pool: at most `cap` (16 per device: what saturates the link, csrc/tools/h2d_staging.cpp), and
+// two fewer than the CPUs the process may use - the caller's thread and the runtime's own need theirs.
+inline int batch_pool_size(int cap, int num_frames) {
+    int w = usable_cpus() - 2;
+    if (w > cap) w = cap;
+    if (w < 2) w = 2;
+    if (w > num_frames) w = num_frames;
+    return w < 1 ? 1 : w;
+}
+
 // A side stream whose copies must overlap the work of a handle's main stream: created at the highest priority, because
 // every priority has its own hardware queues - two streams of equal priority may be dealt onto the SAME queue (4 per
 // process, in creation order) and then run one after the other (capi_blocks.cpp: jpegenc_blocks_stream lost half its rate so).
@@ -309,6 +348,23 @@ struct DeviceCtx {
     hipGraphExec_t graph_exec = nullptr;
     std::string graph_key, last_key;
 
+    // Wait for everything enqueued on `stream`.  A batch worker BLOCKS (an event created with hipEventBlockingSync: the thread sleeps
+    // until the interrupt) where hipStreamSynchronize busy-waits: sixteen workers that spin while the PCIe link - the bottleneck -
+    // moves their frames burn sixteen CPUs for nothing, which is all a 16-CPU container has.  The single-image path keeps the spin:
+    // it is 10-20 us faster per wait and one thread.
+    hipEvent_t blocking_done = nullptr;
+    hipError_t wait_stream() {
+        static const bool spin = JPEGENC_DIAG_ENV("JPEGENC_SPIN_WAITS") != nullptr;        // diagnosis: the round-3 behaviour
+        if (!batch_worker || spin) return hipStreamSynchronize(stream);
+        if (!blocking_done) {
+            const hipError_t e = hipEventCreateWithFlags(&blocking_done, hipEventDisableTiming | hipEventBlockingSync);
+            if (e != hipSuccess) { blocking_done = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(stream); }
+        }
+        hipError_t e = hipEventRecord(blocking_done, stream);
+        if (e == hipSuccess) e = hipEventSynchronize(blocking_done);
+        return e;
+    }
+
     int open(int dev) {
         if (device == dev && stream) {        // (the calling thread may have used another device in between)
             JPEGENC_HIP(hipSetDevice(dev));
@@ -324,7 +380,9 @@ struct DeviceCtx {
     }
     int allocate_fixed() {
         JPEGENC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        for (auto &e : chunk_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        // (a batch worker's events block instead of spinning: see wait_stream)
+        static const bool spin = JPEGENC_DIAG_ENV("JPEGENC_SPIN_WAITS") != nullptr;
+        for (auto &e : chunk_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | (batch_worker && !spin ? hipEventBlockingSync : 0u)));
         JPEGENC_HIP(hipMalloc(&d_freq, sizeof(uint32_t) * 2 * 2 * 257));
         JPEGENC_HIP(hipHostMalloc((void **)&h_freq, sizeof(uint32_t) * 2 * 2 * 257, hipHostMallocDefault));
         JPEGENC_HIP(hipMalloc((void **)&d_scan_len, sizeof(uint32_t) * kMaxScans));
@@ -416,6 +474,7 @@ struct DeviceCtx {
         (void)hipSetDevice(device);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
         for (auto &e : chunk_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (blocking_done) { (void)hipEventDestroy(blocking_done); blocking_done = nullptr; }
         for (auto &e : uploaded) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (kernel_stream) (void)hipStreamDestroy(kernel_stream);
         if (download_stream) (void)hipStreamDestroy(download_stream);
@@ -436,7 +495,9 @@ struct DeviceCtx {
         if (d_chain) (void)hipFree(d_chain);
         if (h_words) (void)hipHostFree((void *)h_words);
         if (h_scan_out) (void)hipHostFree(h_scan_out);
+        const bool was_worker = batch_worker;
         *this = DeviceCtx();
+        batch_worker = was_worker;
     }
     ~DeviceCtx() { close(); }
     DeviceCtx() = default;

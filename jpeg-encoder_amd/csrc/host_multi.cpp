@@ -119,8 +119,7 @@ static int encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_de
         if (!frames[i]) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
     if ((int)e->shards.size() > num_devices) e->shards.resize((size_t)num_devices);
     while ((int)e->shards.size() < num_devices) e->shards.emplace_back(nullptr);
-    unsigned hw = std::thread::hardware_concurrency();
-    if (!hw) hw = 4;
+    const unsigned hw = (unsigned)usable_cpus();
     int per_shard = (int)(hw / (unsigned)num_devices);
     if (per_shard < 4) per_shard = 4;
     if (per_shard > 16) per_shard = 16;

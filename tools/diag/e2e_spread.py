@@ -120,12 +120,28 @@ def main():
 
     def run():
         b.check(b.lib().jpegenc_encoder_encode_batch_to_buffers(enc._h, ptrs, arrs[0].size, n, w, h, b.RGB, optrs, caps, lens))
+    def cpu_stat():
+        out = {}
+        try:
+            for line in open("/sys/fs/cgroup/cpu.stat"):
+                k, v = line.split()
+                out[k] = int(v)
+        except Exception:
+            pass
+        return out
     run()
-    times = []
+    run()
+    times, cpus_used, throttled = [], [], []
     for _ in range(args.runs):
+        c0 = cpu_stat()
         t = time.perf_counter()
         run()
-        times.append(time.perf_counter() - t)
+        dt = time.perf_counter() - t
+        c1 = cpu_stat()
+        times.append(dt)
+        if "usage_usec" in c0:
+            cpus_used.append(round((c1["usage_usec"] - c0["usage_usec"]) / 1e6 / dt, 1))
+            throttled.append(c1.get("nr_throttled", 0) - c0.get("nr_throttled", 0))
     link = h2d_rate(dev)
     ts = sorted(times)
     rate = [n * fb / t / 1e9 for t in times]
@@ -139,7 +155,9 @@ def main():
            "spread": round((ts[-1] - ts[0]) / ts[len(ts) // 2], 3), "jpeg_bytes_per_frame": int(sum(lens) / n),
            "source_pages": hostinfo.merge_counts([hostinfo.array_nodes(a, 16) for a in arrs[:len(distinct)]]),
            "output_pages": hostinfo.merge_counts([hostinfo.array_nodes(o, 8) for o in outs[:64]]),
-           "gpu_numa_node": gpu_node, "caller_affinity": hostinfo.affinity_summary(nodes)}
+           "gpu_numa_node": gpu_node, "caller_affinity": hostinfo.affinity_summary(nodes),
+           "cpus_busy_per_batch": cpus_used, "cfs_throttled_periods_per_batch": throttled, "cpu_max": (open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None),
+           "workers": len(enc.batch_worker_info())}
     print(json.dumps(rec), flush=True)
     if pinned_buf is not None:
         del frames, arrs, views

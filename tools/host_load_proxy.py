@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""What does one rank's host side do when seven more ranks load the same two-socket host?  (one GPU is enough to ask)
+"""What does one rank's host side do when more ranks load the same two-socket host?  (one GPU is enough to ask)
 
-The 1000-frame batch of BASELINE config 3 is bound by the host on an 8-GPU node: every rank stages 53 GB/s of
-pageable frames into page-locked memory (a read + a streaming write per byte) which the DMA engine then reads - three moves
-per frame byte, 8 x 160 GB/s against ~1.15 TB/s of DDR5 on the two sockets.  This tool runs the REAL rank (the c3 batch through
-jpegenc_encoder_encode_batch_to_buffers on the one GPU of the box) next to K in {0, 1, 3, 7} GPU-less dummy ranks, each of which
-runs 16 threads of the library's own staging copy (jpegenc_host_copy) at the byte rate a real rank moves:
-  * mode `staging` (ranks with pageable frames): copies at 1.5 x the rank's upload rate - read + write = the three moves of a
-    real rank's byte (the dummy has no DMA engine to make the third);
-  * mode `dma` (ranks with page-locked frames): reads only, at the upload rate;
-and reports the real rank's frames/s for pageable and page-locked frames, its workers unbound and bound to the GPU's NUMA node,
-the dummies unbound or dealt round-robin onto the NUMA nodes the way ranks are on a two-socket node.
+The 1000-frame batch of BASELINE config 3 is bound by the host on an 8-GPU node.  A round-3 rank STAGED its pageable
+frames - 16 worker threads, a read + a streaming write per frame byte, then the DMA engine's read: three DRAM moves per byte at
+53 GB/s of upload = 160 GB/s per rank, 8 x 160 against ~1.15 TB/s of DDR5.  A round-4 rank uploads the frames IN PLACE (the runtime
+pins them piece by piece): one DRAM move per byte, and 4 worker threads reach the rate 16 did (profiles/r04_host_upload_paths.txt).
+This tool runs the REAL rank (the c3 batch through jpegenc_encoder_encode_batch_to_buffers on the one GPU of the box) next to
+K in {0, 1, 3, 7} GPU-less dummy ranks that move a rank's bytes through host memory with the library's own copy (jpegenc_host_copy):
+  * mode `in_place` (round-4 ranks): reads only, at the upload rate;
+  * mode `staging` (round-3 ranks): the staging copy, at 1.5 x the upload rate (read + write standing in for the three moves);
+and reports the real rank's frames/s - pageable frames, its workers unbound and bound to the GPU's NUMA node - the dummies
+unbound or dealt round-robin onto the NUMA nodes, with the CPUs the whole job kept busy and the CFS periods it was throttled in.
 
-  python tools/host_load_proxy.py [--ranks 0,1,3,7] [--passes 5] [--frames 1000] > profiles/r04_host_load.jsonl
+WHAT THIS BOX CAN ANSWER.  The pool's boxes confine a container to 16 CPUs (cgroup cpu.max = "1600000 100000", printed in the
+first record): a dummy is given --dummy-threads threads (default 1: as much as one core moves, ~10-25 GB/s, NOT a rank's 53-160)
+so that the real rank's 8 workers + K dummies stay inside the quota - what the curve then shows is whether the real rank keeps
+its rate beside K busy neighbours, not what 8 x 160 GB/s do to two sockets' DRAM (sixteen cores cannot generate that load; with
+16 threads per dummy the quota is exceeded at K = 1 and the curve shows CPU starvation: --dummy-threads 16 reproduces it).
+
+  python tools/host_load_proxy.py [--ranks 0,1,3,7] [--passes 5] [--frames 1000] [--dummy-threads 1] > profiles/r04_host_load.jsonl
 """
 import argparse
 import ctypes as C
@@ -44,7 +50,7 @@ def dummy(args):
     libc = C.CDLL(None)
     libc.memchr.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     libc.memchr.restype = C.c_void_p
-    nthreads = 16
+    nthreads = args.dummy_threads
     rng = np.random.default_rng(os.getpid())
     per_thread = 4                                            # distinct source frames per thread (100 MB per thread in all: far beyond any cache share)
     srcs = [[rng.integers(1, 256, FRAME, dtype=np.uint8) for _ in range(per_thread)] for _ in range(nthreads)]   # (no zero byte: memchr reads it all)
@@ -57,7 +63,7 @@ def dummy(args):
         k, t0 = 0, time.perf_counter()
         while not stop.is_set():
             src = srcs[t][k % per_thread]
-            if args.mode == "staging":
+            if args.mode == "staging":                       # (in_place: read only)
                 lib.jpegenc_host_copy(dsts[t].ctypes.data, src.ctypes.data, FRAME)
             else:
                 libc.memchr(src.ctypes.data, 0, FRAME)
@@ -87,6 +93,7 @@ def main():
     ap.add_argument("--mode", default="staging")
     ap.add_argument("--rate", type=float, default=80.0)
     ap.add_argument("--bind-node", type=int, default=-1)
+    ap.add_argument("--dummy-threads", type=int, default=1)
     args = ap.parse_args()
     if args.dummy:
         return dummy(args)
@@ -105,36 +112,51 @@ def main():
     pool = batch.ShardFrames(synth, torch=torch, device=dev)
     pool.materialise(range(n))
     pageable = [pool(k) for k in range(n)]
-    pinned_buf = b.HostBuffer(n * FRAME)
-    for i in range(n):
-        pinned_buf.array[i * FRAME:(i + 1) * FRAME] = pageable[i].reshape(-1)
-    pinned = [pinned_buf.array[i * FRAME:(i + 1) * FRAME] for i in range(n)]
     outs = [np.ones(1 << 20, dtype=np.uint8) for _ in range(n)]
     enc = b.Encoder(batch.C3_QUALITY, device=0)
+
+    def cpu_stat():
+        out = {}
+        try:
+            for line in open("/sys/fs/cgroup/cpu.stat"):
+                k, v = line.split()
+                out[k] = int(v)
+        except Exception:
+            pass
+        return out
 
     def rate(frames, bind):
         enc.set_numa_bind(bind)
         enc.encode_batch_into(frames[:128], batch.C3_W, batch.C3_H, b.RGB, outs)
         ts = []
+        c0, t0 = cpu_stat(), time.perf_counter()
         for _ in range(args.passes):
             t = time.perf_counter()
             enc.encode_batch_into(frames, batch.C3_W, batch.C3_H, b.RGB, outs)
             ts.append(time.perf_counter() - t)
+        c1, t1 = cpu_stat(), time.perf_counter()
         ts.sort()
-        return {"min": round(n / ts[-1], 1), "median": round(n / ts[len(ts) // 2], 1), "max": round(n / ts[0], 1)}
+        out = {"min": round(n / ts[-1], 1), "median": round(n / ts[len(ts) // 2], 1), "max": round(n / ts[0], 1)}
+        if "usage_usec" in c0:
+            out["cpus_busy_whole_job"] = round((c1["usage_usec"] - c0["usage_usec"]) / 1e6 / (t1 - t0), 1)
+            out["cfs_throttled_periods"] = c1.get("nr_throttled", 0) - c0.get("nr_throttled", 0)
+        return out
+    cpu_max = open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else None
+    print(json.dumps({"host": hostinfo.host_summary(torch, 0), "cpu_max": cpu_max, "frames": n, "passes": args.passes, "dummy_threads": args.dummy_threads,
+                      "real_rank_workers": len(enc.batch_worker_info()) or "8 (default pool)",
+                      "what": "real rank = c3 batch on the box's GPU, pageable frames, frames/s; dummies = GPU-less ranks moving bytes through host memory"}), flush=True)
     base = None
-    print(json.dumps({"host": hostinfo.host_summary(torch, 0), "frames": n, "passes": args.passes,
-                      "what": "real rank = c3 batch on the box's GPU, frames/s; dummies = GPU-less ranks moving a rank's bytes through host memory"}), flush=True)
     for k in [int(x) for x in args.ranks.split(",")]:
-        for mode, rate_gbps in (("staging", 80.0), ("dma", 53.0)):
+        for mode, rate_gbps in (("in_place", 53.0), ("staging", 80.0)):
             for bind_dummies in ((False, True) if k else (False,)):
-                if k == 0 and mode == "dma":
+                if k == 0 and mode == "staging":
                     continue
                 procs = []
                 for d in range(k):
                     node = nodes[(d + 1) % len(nodes)] if bind_dummies and nodes else -1
                     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--dummy", "--mode", mode, "--rate", str(rate_gbps),
-                                                   "--bind-node", str(node)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+                                                   "--bind-node", str(node), "--dummy-threads", str(args.dummy_threads)],
+                                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
                 for p in procs:
                     assert p.stdout.readline().strip() == "READY"
                 time.sleep(0.5)
@@ -142,11 +164,8 @@ def main():
                     p.stdin.write("MARK\n"); p.stdin.flush(); p.stdout.readline()
                 rec = {"other_ranks": k, "their_mode": mode if k else None, "their_target_GBps_each": rate_gbps if k else None,
                        "dummies_dealt_onto_numa_nodes": bind_dummies}
-                # the real rank's frames in pageable memory when the others stage, in page-locked memory when the others only DMA
-                frames = pageable if mode == "staging" else pinned
-                rec["real_rank_frames"] = "pageable" if mode == "staging" else "page-locked"
-                rec["frames_per_s"] = rate(frames, False)
-                rec["frames_per_s_workers_bound_to_gpu_node"] = rate(frames, True)
+                rec["frames_per_s"] = rate(pageable, False)
+                rec["frames_per_s_workers_bound_to_gpu_node"] = rate(pageable, True)
                 got = []
                 for p in procs:
                     p.stdin.write("MARK\n"); p.stdin.flush()
@@ -158,18 +177,8 @@ def main():
                     p.wait(timeout=30)
                 if k == 0:
                     base = rec["frames_per_s"]["median"]
-                    rec_p = dict(rec, real_rank_frames="page-locked", frames_per_s=rate(pinned, False), frames_per_s_workers_bound_to_gpu_node=rate(pinned, True))
-                    rec["vs_alone"] = 1.0
-                    print(json.dumps(rec), flush=True)
-                    base_pinned = rec_p["frames_per_s"]["median"]
-                    rec_p["vs_alone"] = 1.0
-                    print(json.dumps(rec_p), flush=True)
-                    continue
-                ref = base if mode == "staging" else base_pinned
-                rec["vs_alone"] = round(rec["frames_per_s"]["median"] / ref, 3) if ref else None
+                rec["vs_alone"] = round(rec["frames_per_s"]["median"] / base, 3) if base else None
                 print(json.dumps(rec), flush=True)
-    pinned = None
-    pinned_buf.close()
 
 
 if __name__ == "__main__":
