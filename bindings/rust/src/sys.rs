@@ -115,6 +115,7 @@ extern "C" {
     pub fn jpegenc_encoder_set_device(e: *mut jpegenc_encoder, device: c_int) -> c_int;
     pub fn jpegenc_encoder_set_fdct_variant(e: *mut jpegenc_encoder, variant: c_int) -> c_int;
     pub fn jpegenc_encoder_set_device_entropy(e: *mut jpegenc_encoder, enable: c_int) -> c_int;
+    pub fn jpegenc_encoder_set_register_cache(e: *mut jpegenc_encoder, bytes: usize) -> c_int;
     pub fn jpegenc_encoder_set_numa_bind(e: *mut jpegenc_encoder, enable: c_int) -> c_int;
     pub fn jpegenc_encoder_set_batch_round_frames(e: *mut jpegenc_encoder, frames: c_int) -> c_int;
     pub fn jpegenc_encoder_set_density(e: *mut jpegenc_encoder, unit: c_int, x: u16, y: u16) -> c_int;

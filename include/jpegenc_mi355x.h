@@ -257,6 +257,13 @@ int  jpegenc_encoder_set_fdct_variant(jpegenc_encoder *e, int variant);  /* defa
 /* 1 (default): every scan is entropy-coded on the GPU and only compressed bytes cross PCIe;
  * 0: coefficients come back and the host codes them.  The emitted bytes are identical either way. */
 int  jpegenc_encoder_set_device_entropy(jpegenc_encoder *e, int enable);
+/* Opt-in for callers that encode from / into the SAME ordinary (malloc'ed) buffers call after call, as the reference's own
+ * benchmark loop does (criterion/benches/encode.rs:57-188): jpegenc_encoder_encode_to_buffer page-locks the pixel range and the
+ * output buffer in place the first time it sees them and keeps up to `bytes` of such ranges locked (least recently used out
+ * first; everything unlocked by 0 and by jpegenc_encoder_free).  With both buffers page-locked a large baseline frame goes through
+ * upload, kernel and download stripe by stripe instead of one after the other.  Default 0 (off).  A buffer must not be freed
+ * while it may still be in the cache (pass 0 first); ranges the caller page-locked itself are left alone. */
+int  jpegenc_encoder_set_register_cache(jpegenc_encoder *e, size_t bytes);
 /* 1: the host threads the batch calls spawn for this handle (and for its per-device children in
  * jpegenc_encoder_encode_batch_multi) run on the NUMA node of the device's PCIe root complex - their pinned staging
  * memory is then first touched there and uploads do not cross the socket interconnect.  Best effort (sysfs), the
@@ -387,9 +394,9 @@ int  jpegenc_packed_planes(int surface_format, const void *const *d_planes, cons
  * f -> sink(users[f], ...), one complete file each (sink threading: see jpegenc_encoder_encode_batch).  The device
  * work of the whole batch shares its launches as in jpegenc_encoder_encode_batch_device when the descriptors of each
  * component agree in pixel_stride, invert, shift and the byte they start at inside an interleaved group over the frames (address and pitch are per frame); otherwise - and with optimised Huffman tables, the
- * host entropy coder or sampling factors of 4 - the frames are encoded ONE AT A TIME on the handle's own stream, strictly in
- * sequence (no worker pool as for pixel frames: expect ~280 us per 4K frame instead of ~30; a sink error returns with the
- * earlier frames already delivered).  Same bytes either way. */
+ * host entropy coder or sampling factors of 4 - every frame is its own launch sequence, sixteen of them in flight on a pool of host
+ * threads (frames are handed out in order; a failing frame stops the hand-out, the frames before it are delivered, and the call
+ * returns that frame's status with its index in jpegenc_last_error()).  Same bytes either way. */
 int  jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
                                                 const jpegenc_plane *planes, int num_frames, int planes_subsampled,
                                                 jpegenc_write_fn sink, void *const *users);

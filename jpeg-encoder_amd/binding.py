@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_histogram_device",
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
     "jpegenc_pixels_scan_fused", "jpegenc_pixels_scan_device",
-    "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_numa_bind", "jpegenc_encoder_set_batch_round_frames",
+    "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_register_cache", "jpegenc_encoder_set_numa_bind", "jpegenc_encoder_set_batch_round_frames",
     "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
     "jpegenc_encoder_set_fdct_variant", "jpegenc_encoder_set_density", "jpegenc_encoder_density",
     "jpegenc_encoder_set_sampling_factor", "jpegenc_encoder_sampling_factor",
@@ -448,6 +448,10 @@ class Encoder:
 
     def optimized_huffman_tables(self):
         return bool(lib().jpegenc_encoder_optimized_huffman_tables(self._h))
+
+    def set_register_cache(self, nbytes):
+        lib().jpegenc_encoder_set_register_cache.argtypes = [C.c_void_p, C.c_size_t]
+        check(lib().jpegenc_encoder_set_register_cache(self._h, nbytes))
 
     def set_device_entropy(self, enable):
         check(lib().jpegenc_encoder_set_device_entropy(self._h, 1 if enable else 0))

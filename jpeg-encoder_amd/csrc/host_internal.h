@@ -653,9 +653,41 @@ inline bool numa_bind_default() {
 
 using namespace jpegenc;
 
+// jpegenc_encoder_set_register_cache: caller buffers this handle page-locked on the fly (and unlocks when they fall out of the
+// budget, when the budget is set to 0, or when the handle is freed), least recently used first
+struct RegisterCache {
+    struct Entry { void *p; size_t n; uint64_t used; };
+    std::vector<Entry> entries;
+    size_t budget = 0, held = 0;
+    uint64_t tick = 0;
+    void drop(size_t i) { (void)hipHostUnregister(entries[i].p); (void)hipGetLastError(); held -= entries[i].n; entries[i] = entries.back(); entries.pop_back(); }
+    void clear() { while (!entries.empty()) drop(entries.size() - 1); }
+    // makes [p, p + n) page-locked if the budget allows; a range that already is (by the caller, or by an entry) is left alone
+    void touch(void *p, size_t n) {
+        if (!budget || !p || n < ((size_t)1 << 20) || n > budget) return;
+        for (size_t i = 0; i < entries.size(); i++)
+            if (entries[i].p == p && entries[i].n == n) {
+                if (is_pinned_host_range(p, n)) { entries[i].used = ++tick; return; }
+                drop(i);                                            // (freed and mapped again since: the registration went with the mapping)
+                break;
+            }
+        if (is_pinned_host((const uint8_t *)p) || is_pinned_host((const uint8_t *)p + n - 1)) return;    // the caller's own registration (whole or part): not ours to touch
+        while (held + n > budget && !entries.empty()) {
+            size_t lru = 0;
+            for (size_t i = 1; i < entries.size(); i++) if (entries[i].used < entries[lru].used) lru = i;
+            drop(lru);
+        }
+        if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+        entries.push_back(Entry{p, n, ++tick});
+        held += n;
+    }
+    ~RegisterCache() { clear(); }
+};
+
 struct jpegenc_encoder {
     Config cfg;
     int device = 0;
+    RegisterCache reg_cache;
     DeviceCtx ctx;
     std::vector<std::unique_ptr<DeviceCtx>> workers;   // batch API: one per in-flight frame, kept across calls
     BatchBuffers batch;                                  // device-resident batch API

@@ -664,3 +664,54 @@ def test_dense_frames_are_routed_to_the_two_kernels_and_back(binding, oracle, sy
             assert files == [want[id(a)] for a in order]
             files = e.encode_batch_device(d.data_ptr(), w * h * 3, len(order), w, h, binding.RGB)      # (this call starts with what the last one learnt)
             assert files == [want[id(a)] for a in order]
+
+
+def test_planes_pool_that_cannot_share_launches_goes_through_the_worker_pool(binding, oracle, synth):
+    """A pool of surfaces that mixes sample strides (NV12 frames among I420 frames) - or asks for optimised tables - cannot share
+    its launches: the frames go one per launch sequence through the pool of host workers, handed out in order.  Same files; and a
+    sink that fails on frame 13 of 24 makes the call return JPEGENC_ERR_WRITE naming that frame with every frame before it delivered
+    complete."""
+    import ctypes as C
+    import torch
+    w, h, n = 640, 360, 24
+    cw, ch = w // 2, h // 2
+    rng = np.random.default_rng(23)
+    smooth = lambda a: (a.astype(np.int16) // 4 + np.add.outer(np.arange(a.shape[0]), np.arange(a.shape[1])) // 3).clip(0, 255).astype(np.uint8)
+    keep, frames, want = [], [], []
+    for f in range(n):
+        y, cb, cr = (smooth(rng.integers(0, 256, s, dtype=np.uint8)) for s in ((h, w), (ch, cw), (ch, cw)))
+        full = np.stack([y, _replicated(cb, 2, 2, w, h), _replicated(cr, 2, 2, w, h)], axis=-1)
+        want.append(oracle.encode_jpeg(full, w, h, oracle.YCBCR, 85, sampling=(2, 2)))
+        d_y = torch.from_numpy(y).cuda()
+        if f % 3 == 1:                                              # an NV12 surface among the I420 ones
+            d_uv = torch.from_numpy(np.ascontiguousarray(np.stack([cb, cr], axis=-1))).cuda()
+            keep += [d_y, d_uv]
+            frames.append([(d_y.data_ptr(), w, 1, 0), (d_uv.data_ptr(), 2 * cw, 2, 0), (d_uv.data_ptr() + 1, 2 * cw, 2, 0)])
+        else:
+            d_cb, d_cr = torch.from_numpy(cb).cuda(), torch.from_numpy(cr).cuda()
+            keep += [d_y, d_cb, d_cr]
+            frames.append([(d_y.data_ptr(), w, 1, 0), (d_cb.data_ptr(), cw, 1, 0), (d_cr.data_ptr(), cw, 1, 0)])
+    with binding.Encoder(85) as e:
+        e.set_sampling_factor(binding.F_2_2)
+        assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, frames, planes_subsampled=True) == want
+        # the failing sink, through the C ABI
+        arr = (binding.Plane * (4 * n))()
+        for f, planes in enumerate(frames):
+            for i, t in enumerate(planes):
+                arr[4 * f + i] = binding._plane(t)
+        got = [bytearray() for _ in range(n)]
+
+        def sink(user, ptr, nbytes):
+            k = user or 0
+            if k == 13:
+                return 1
+            got[k] += C.string_at(ptr, nbytes)
+            return 0
+        cb_ = binding.WRITE_FN(sink)
+        users = (C.c_void_p * n)(*range(n))
+        fn = binding.lib().jpegenc_encoder_encode_planes_batch_device
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(binding.Plane), C.c_int, C.c_int, binding.WRITE_FN, C.POINTER(C.c_void_p)]
+        rc = fn(e._h, binding.J_YCBCR, w, h, arr, n, 1, cb_, users)
+        assert rc == binding.ERR_WRITE and b"frame 13" in binding.lib().jpegenc_last_error()
+        assert [bytes(g) for g in got[:13]] == want[:13]
+        assert all(bytes(g) in (b"", want[k]) for k, g in enumerate(got) if k > 13)      # later frames: delivered whole or not at all

@@ -1184,3 +1184,39 @@ def test_encode_batch_of_small_frames(binding, oracle, synth, kw):
     assert len(got) == n
     for i in (0, 1, 2, 511, 1023, 1024, 1025, 1099):
         assert got[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, **kw), i
+
+
+def test_register_cache_locks_reused_buffers_and_lets_go_of_them(binding, oracle, synth):
+    """jpegenc_encoder_set_register_cache: the same ordinary pixel and output buffers call after call are page-locked in place by
+    the handle (a large baseline frame then takes the striped path) - same file every call, other buffers evict the least recently
+    used range within the budget, a buffer the caller page-locked itself is left alone, and 0 / jpegenc_encoder_free unlock
+    everything (a caller's own hipHostRegister of the same range succeeds afterwards)."""
+    w, h = 2000, 1800
+    px = [np.ascontiguousarray(np.roll(synth.criterion_pattern(w, h), 32 * k, axis=1)).reshape(-1) for k in range(3)]
+    want = [oracle.encode_jpeg(p.reshape(h, w, 3), w, h, oracle.RGB, 100) for p in px]
+    out = np.empty(32 << 20, dtype=np.uint8)
+    with binding.Encoder(100) as e:
+        e.set_register_cache(48 << 20)                                  # room for the output buffer and one frame
+        for rounds in range(3):
+            for k in range(3):
+                n = e.encode_to_buffer(px[k], w, h, binding.RGB, out)
+                assert out[:n].tobytes() == want[k], (rounds, k)
+        mine = np.ascontiguousarray(px[0].copy())
+        binding.host_register(mine)                                     # the caller's own registration is not the cache's to drop
+        try:
+            for _ in range(2):
+                n = e.encode_to_buffer(mine, w, h, binding.RGB, out)
+                assert out[:n].tobytes() == want[0]
+        finally:
+            binding.host_unregister(mine)
+        e.set_register_cache(0)
+        binding.host_register(out)                                      # nothing of ours is left on it
+        binding.host_unregister(out)
+        n = e.encode_to_buffer(px[1], w, h, binding.RGB, out)
+        assert out[:n].tobytes() == want[1]
+    e2 = binding.Encoder(90)
+    e2.set_register_cache(64 << 20)
+    n = e2.encode_to_buffer(px[2], w, h, binding.RGB, out)
+    e2.close()                                                          # frees the handle: unlocks
+    binding.host_register(px[2])
+    binding.host_unregister(px[2])
