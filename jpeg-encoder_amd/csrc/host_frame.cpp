@@ -37,6 +37,10 @@ void staging_copy(void *dst, const void *src, size_t n) {
 // (begin_sequence, enqueue_blocks_and_statistics, enqueue_scans, launch_and_wait) and what comes back
 // (emit_device_coded: compressed bytes; collect_host_coded: coefficients for the host coder).
 constexpr int kFinishGaveUp = -1001;        // (internal) launch_and_wait: code the frame again through the ordinary sequence
+// large single frames (more than kFinishBigRuns runs) through the pixels -> bits kernel right now, per device (plan_scans)
+constexpr uint32_t kFinishBigRuns = 256;
+constexpr int kFinishBigInFlight = 1;
+static std::atomic<int> g_big_finishing[64];
 
 struct FrameRun {
     struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap, ws_off, ws; };
@@ -66,6 +70,8 @@ struct FrameRun {
     FusedSource fused_src = {};
     int stripes = 0;                    // > 0: a large frame between page-locked buffers, through run_striped in that many stripes
     bool self_finishing = false;        // ... and its workgroups put the scan together themselves: the launch sequence is that one kernel
+    bool holds_finish_slot = false;     // counted in g_big_finishing until this run ends
+    ~FrameRun() { if (holds_finish_slot) g_big_finishing[ctx.device & 63].fetch_sub(1); }
     bool fused = false;                 // interleaved baseline scan of an RGB-family image: ONE kernel from the pixels to the coded runs
     std::vector<Job> jobs;
     bool supported = false;
@@ -186,10 +192,7 @@ struct FrameRun {
             first_piece = out_total < DeviceCtx::kFirstPiece ? out_total : DeviceCtx::kFirstPiece;
             fused = supported && mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() &&
                     (ctx.external_planes ? fused_planes_supported(p, ctx.external_planes, ctx.external_planes_subsampled) : fused_supported(p));
-            // (dense content takes the two kernels - DeviceCtx::dense_last_time; frames of up to 1 MB of pixels keep the one kernel
-            // that finishes the scan itself: their time is launches, not walks)
-            static const bool route_off = JPEGENC_DIAG_ENV("JPEGENC_NO_DENSE_ROUTING") != nullptr;
-            if (fused && !route_off && pixel_bytes > ((size_t)1 << 20) && ctx.dense_last_time((uint64_t)width << 32 | (uint32_t)height, L.total_blocks)) fused = false;
+
             if (supported) {
                 // The scans of a sequential / progressive frame are independent: coded in shared launches they cost
                 // ~10 launches per 8 scans instead of ~10 per scan (a 4K progressive frame: 12 scans; such frames were
@@ -244,6 +247,29 @@ struct FrameRun {
         if (self_finishing && !stripes && fused_runs(p) > kFinishOneLaunchRuns) {
             self_finishing = false;
             fused_src.chain = nullptr; fused_src.finish_abort = nullptr; fused_src.finish_done = nullptr;
+        }
+        // Dense content takes the two kernels (DeviceCtx::dense_last_time) - except frames of up to 1 MB of pixels, whose time is
+        // launches, not walks (they keep the one kernel that finishes the scan itself), and striped frames, whose kernel time
+        // hides behind their copies (2000x1800 at quality 100 between page-locked buffers: 0.46 ms striped, 0.57 through the two
+        // kernels one after the other).
+        static const bool route_off = JPEGENC_DIAG_ENV("JPEGENC_NO_DENSE_ROUTING") != nullptr;
+        if (fused && !stripes && !route_off && pixel_bytes > ((size_t)1 << 20) && ctx.dense_last_time((uint64_t)width << 32 | (uint32_t)height, L.total_blocks)) {
+            fused = false; self_finishing = false;
+            fused_src.chain = nullptr; fused_src.finish_abort = nullptr; fused_src.finish_done = nullptr;
+        }
+        // The kernel that finishes the scan itself is a LATENCY path: its workgroups wait - on their CU slots - for the runs before
+        // them.  One frame at a time that costs nothing; several large frames in flight at once (concurrent callers, each on its
+        // own handle) stand in each other's way: 4K device-resident frames from 8 threads 28 000 frames/s against 39 500 through
+        // the launched k_push / k_stuff sequence, where frames of up to 1080p (127 runs) gain at every thread count
+        // (csrc/tools/concurrent_callers.cpp, profiles/r04_concurrent_callers.jsonl; letting two such frames finish themselves
+        // beside ordinary ones was worse than either: 21 500 at 4 threads).  So a frame of more than 256 runs finishes itself only
+        // when no other such frame of this process is in flight on the device; every one of them is counted while it runs.
+        if (fused && !stripes && fused_runs(p) > kFinishBigRuns) {
+            holds_finish_slot = true;
+            if (g_big_finishing[ctx.device & 63].fetch_add(1) >= kFinishBigInFlight && self_finishing) {
+                self_finishing = false;
+                fused_src.chain = nullptr; fused_src.finish_abort = nullptr; fused_src.finish_done = nullptr;
+            }
         }
         return rc;
 
