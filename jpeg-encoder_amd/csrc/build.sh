@@ -3,7 +3,7 @@
 # sources with -DJPEGENC_DIAG, the only build that reads the diagnostic environment switches (diag_env.h) - the tests that
 # force a rare code path load it.  Outputs land next to the Python binding so that they travel with the tree.
 #   JPEGENC_OUT / JPEGENC_BUILD_DIR / EXTRA_HIPCC_FLAGS: one variant build somewhere else (tools/diag A/B libraries)
-#   JPEGENC_SKIP_DIAG=1: the shipping library only
+#   JPEGENC_SKIP_DIAG=1: the shipping library only;  JPEGENC_ALLOW_SPILLS=1: link although tools/check_spills.py objects (A/B experiments)
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
@@ -31,7 +31,7 @@ build_variant() {
   done
   # warnings of the compiles just run, then the spill guard over every translation unit's kernels
   for o in "${objs[@]}"; do if [[ -f "${o}.resources" ]]; then grep -E "warning:|error:" "${o}.resources" >&2 || true; fi; done
-  python3 "${here}/../../tools/check_spills.py" "${bdir}"/*.resources
+  python3 "${here}/../../tools/check_spills.py" "${bdir}"/*.resources || [[ -n "${JPEGENC_ALLOW_SPILLS:-}" ]]      # (JPEGENC_ALLOW_SPILLS=1: experiment builds only)
   "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${out}" "${objs[@]}" -lpthread
   echo "built ${out}"
 }

@@ -574,13 +574,14 @@ def test_randomised_planar_sources(binding, oracle, synth):
             e.set_fdct_variant(binding.FDCT_SIMD)
         ypad, cpad = int(rng.integers(0, 40)), int(rng.integers(0, 9))
         mixed_pitches = bool(rng.integers(0, 2))                      # a pool whose surfaces differ in pitch (per-frame pitch table)
-        frames, want, keep = [], [], []
+        frames, want, keep, full_list = [], [], [], []
         for f in range(nframes):
             if mixed_pitches and f:
                 ypad, cpad = int(rng.integers(0, 40)), int(rng.integers(0, 9))
             noisy = trial % 3 != 0
             mk = (lambda s: rng.integers(0, 256, s, dtype=np.uint8)) if noisy else (lambda s: (np.add.outer(np.arange(s[0]), np.arange(s[1])) // 3 + f).astype(np.uint8))
             y, cb, cr = mk((h, w)), mk((ch, cw)), mk((ch, cw))
+            full_list.append((y, cb, cr))
             full = np.stack([y, _replicated(cb, hs, vs, w, h) if subsampled else cb, _replicated(cr, hs, vs, w, h) if subsampled else cr], axis=-1)
             want.append(oracle.encode_jpeg(np.ascontiguousarray(full), w, h, oracle.YCBCR, variant=variant, **kw))
             d_y = torch.zeros((h, w + ypad), dtype=torch.uint8, device="cuda"); d_y[:, :w] = torch.from_numpy(y).cuda()
@@ -599,6 +600,41 @@ def test_randomised_planar_sources(binding, oracle, synth):
             print(what, flush=True)
         assert e.encode_planes_device(binding.J_YCBCR, w, h, frames[0], planes_subsampled=subsampled) == want[0], what
         assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, frames, planes_subsampled=subsampled) == want, what
+        # ---- the same pictures with every plane in a random packed / deep layout: samples 1, 2 or 4 bytes apart starting at any
+        # byte of the group, or eight bits (any shift) of 16-bit little-endian words - one layout per component for the whole pool
+        factor4 = hs == 4 or vs == 4
+        if factor4 and not subsampled:
+            continue                                                   # (strides above 1 are not decimated by 4 on the device)
+        layout = []
+        for c in range(3):
+            stride = int(rng.choice([1, 2, 4]))
+            deep = stride > 1 and bool(rng.integers(0, 2))
+            shift = (8 if stride == 4 or factor4 else int(rng.choice([8, 8, 2, 4, 6, 1, 7]))) if deep else 0
+            off = int(rng.integers(0, stride // 2)) * 2 if deep else int(rng.integers(0, stride))
+            layout.append((stride, shift, off))
+        frames2 = []
+        for f in range(nframes):
+            planes = []
+            comps = [np.ascontiguousarray(a) for a in (full_list[f][0], full_list[f][1], full_list[f][2])]
+            for c, (stride, shift, off) in enumerate(layout):
+                a = comps[c]
+                rows, cols = a.shape
+                pitch = cols * stride + int(rng.integers(0, 5)) * 4 + (4 if stride > 1 else 0)
+                buf = rng.integers(0, 256, (rows, pitch), dtype=np.uint8)
+                if shift:
+                    word = (a.astype(np.uint32) << shift) | rng.integers(0, 1 << shift, a.shape).astype(np.uint32)
+                    word = (word | (rng.integers(0, 256, a.shape).astype(np.uint32) << (shift + 8))) & 0xFFFF
+                    buf[:, off:off + cols * stride:stride] = (word & 0xFF).astype(np.uint8)
+                    buf[:, off + 1:off + 1 + cols * stride:stride] = (word >> 8).astype(np.uint8)
+                else:
+                    buf[:, off:off + cols * stride:stride] = a
+                t = torch.from_numpy(buf).cuda()
+                keep.append(t)
+                planes.append((t.data_ptr() + off, pitch, stride, 0, shift))
+            frames2.append(planes)
+        what2 = what + (layout,)
+        assert e.encode_planes_device(binding.J_YCBCR, w, h, frames2[0], planes_subsampled=subsampled) == want[0], what2
+        assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, frames2, planes_subsampled=subsampled) == want, what2
 
 
 def test_planar_source_launch_sequence_is_replayed_correctly(binding, oracle, synth):

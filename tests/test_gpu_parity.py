@@ -628,12 +628,12 @@ def test_randomised_configurations(binding, oracle, synth):
     # (JPEGENC_FUZZ_MAX_W / _H: larger frames reach the multi-tile prefix sums and thousands of runs per scan)
     max_w, max_h = int(os.environ.get("JPEGENC_FUZZ_MAX_W", "200")), int(os.environ.get("JPEGENC_FUZZ_MAX_H", "120"))
     for trial in range(int(os.environ.get("JPEGENC_FUZZ_TRIALS", "60"))):     # longer soaks: set the two variables
-        ct = int(rng.integers(0, 9))
+        ct = int(rng.integers(0, 11))                        # 9, 10: the 16-bit packed RGB extensions (unpacked on the device)
         w, h = int(rng.integers(1, max_w)), int(rng.integers(1, max_h))
         px = rng.integers(0, 256, (h, w, binding.BPP[ct]), dtype=np.uint8)
         if trial % 3 == 0:                                   # smooth content: long zero runs, EOBs
             px = (np.add.outer(np.arange(h), np.arange(w))[..., None] // 3 + np.arange(binding.BPP[ct])).astype(np.uint8)
-        kw = dict(quality=int(rng.integers(1, 101)), sampling=samplings[int(rng.integers(0, 8))])
+        kw = dict(quality=int(rng.integers(1, 101)), sampling=samplings[int(rng.integers(0, 8 if ct < 9 else 4))])      # (565: factors 1 and 2)
         mode = int(rng.integers(0, 4))
         if mode == 1:
             kw["progressive_scans"] = int(rng.integers(2, 20))
@@ -654,7 +654,14 @@ def test_randomised_configurations(binding, oracle, synth):
             okw["qpresets"] = (oracle.Q_CUSTOM, e.quantization_tables()[1])
             okw["qcustoms"] = (cust, None)
         got = e.encode(px, w, h, ct)
-        want = oracle.encode_jpeg(px, w, h, ct, variant=variant, **okw)
+        if ct >= 9:                                          # the oracle sees the words unpacked by the header's definition
+            wd = np.ascontiguousarray(px).view(np.uint16).reshape(h, w).astype(np.uint32)
+            hi, g6, lo = (wd >> 11) & 31, (wd >> 5) & 63, wd & 31
+            r5, b5 = (hi, lo) if ct == binding.RGB565 else (lo, hi)
+            rgb = np.stack([(r5 << 3) | (r5 >> 2), (g6 << 2) | (g6 >> 4), (b5 << 3) | (b5 >> 2)], axis=-1).astype(np.uint8)
+            want = oracle.encode_jpeg(rgb, w, h, oracle.RGB, variant=variant, **okw)
+        else:
+            want = oracle.encode_jpeg(px, w, h, ct, variant=variant, **okw)
         assert got == want, (trial, ct, w, h, kw, variant)
 
 
