@@ -83,13 +83,15 @@ def main():
             ts.append(time.perf_counter() - t)
         return sorted(ts)[len(ts) // 2]
 
-    def planes_case(name, sampling, frames):
+    def planes_case(name, sampling, frames, optimized=False):
         arr = (b.Plane * (4 * N))()
         for f, planes in enumerate(frames):
             for i, t in enumerate(planes):
                 arr[4 * f + i] = b._plane(t)
         e = b.Encoder(Q)
         e.set_sampling_factor(sampling)
+        if optimized:
+            e.set_optimized_huffman_tables(True)
         t_batch = timed(lambda: b.check(fpb(e._h, b.J_YCBCR, W, H, arr, N, 1, cb_, users)))
         mb = nbytes[0] / N / 1e6
 
@@ -117,6 +119,9 @@ def main():
         e.close()
 
     planes_case("I420", b.F_2_2, sets["i420"])
+    planes_case("I420, optimised Huffman tables (per-frame tables: the pool of host workers, one launch sequence per frame)", b.F_2_2, sets["i420"], optimized=True)
+    mixed = [sets["nv12"][f] if f % 3 == 1 else sets["i420"][f] for f in range(N)]
+    planes_case("I420 pool with NV12 frames in it (cannot share launches: the pool of host workers)", b.F_2_2, mixed)
     planes_case("NV12", b.F_2_2, sets["nv12"])
     planes_case("P010 (16-bit words, high byte)", b.F_2_2, sets["p010"])
     pixels_case("RGB (interleaved)", b.RGB, d_rgb, 3, b.F_2_2)
