@@ -150,7 +150,10 @@ int jpegenc_layout_init(jpegenc_layout *out, int width, int height, int color_ty
  * `d_coeffs` receives, per frame, layout.total_blocks blocks of 64 little-endian i16 in zig-zag
  * order (writer.rs:64-68), `coeff_frame_stride` BLOCKS apart (>= total_blocks).  Launches on
  * `hip_stream` (a hipStream_t, NULL = default stream) and returns without synchronising.
- * Bit-exact with the reference for every ColorType / SamplingFactor / order. */
+ * Bit-exact with the reference for every ColorType / SamplingFactor / order.
+ * Exactly the frames' width * height * bpp bytes are read and exactly total_blocks * 128 bytes per frame written - here and
+ * in every entry point that takes device buffers (the scan entry points: the sizes their size functions return): no load or
+ * store leaves the caller's buffers by a single byte (tests/test_gpu_guard_pages.py runs them against unmapped pages). */
 int jpegenc_blocks_device(const void *d_pixels, size_t pixel_frame_stride, int num_frames,
                           int width, int height, int color_type, int h_sampling, int v_sampling,
                           const jpegenc_qtable tables[2], int order, int fdct_variant,
@@ -363,6 +366,10 @@ int  jpegenc_encoder_encode_image(jpegenc_encoder *e, int jpeg_color_type, int w
  * One launch covers all planes - every wave reads its own plane (address, pitch, size and sample stride come from the
  * wave's record) - and an interleaved baseline scan goes from the samples to the coded runs in ONE kernel, like the
  * interleaved pixel formats; sampling factors of 4 take one block-kernel launch per plane.
+ * What is read: nothing but the rows described; with pixel_stride 2 or 4 the kernels take the whole 2- / 4-byte groups the
+ * samples lie in (groups aligned to pixel_stride BY ADDRESS: the pair a Cr byte of NV12 shares with its Cb byte), never a
+ * byte before the group of a row's first sample nor after the group of its last one, and nothing at all after the last sample
+ * of the plane's last row (tests/test_gpu_guard_pages.py: every plane against unmapped addresses on both sides).
  * The planes must stay valid and unmodified until the call returns.  Every Encoder mode applies (progressive,
  * optimised tables, restart intervals ...).  Sampling factors of 4 are not taken for pixel strides above 1 unless the
  * planes arrive subsampled, nor with a shift of 1 .. 7. */

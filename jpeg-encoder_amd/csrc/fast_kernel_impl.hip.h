@@ -154,10 +154,12 @@ __device__ __forceinline__ uint32_t edge_sample(gbytes px, int role, int c, cons
         if (k.shift[c]) v = ((v | ((uint32_t)px[k.byte_index[c] + 1] << 8)) >> k.shift[c]) & 0xFFu;
         return k.invert[c] ? 255u - v : v;
     }
-    int r = px[k.o_r], g = px[k.o_g], b = px[k.o_b];
-    if (k.packed565) {
+    int r, g, b;
+    if (k.packed565) {         // (two bytes per pixel: nothing past px[1] may be read - the frame's last pixel ends the buffer)
         const uint32_t w = unpack565((uint32_t)px[0] | ((uint32_t)px[1] << 8), k.packed565 & 0xFFu, (k.packed565 >> 8) & 0xFFu);
         r = (int)(w & 0xFFu); g = (int)((w >> 8) & 0xFFu); b = (int)((w >> 16) & 0xFFu);
+    } else {
+        r = px[k.o_r]; g = px[k.o_g]; b = px[k.o_b];
     }
     if (role == ROLE_Y) return (uint32_t)((19595 * r + 38470 * g + 7471 * b + 0x7FFF) >> 16);
     if (role == ROLE_CB) return (uint32_t)((-11059 * r - 21709 * g + 32768 * b + kBias) >> 16);
@@ -440,7 +442,11 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     }
     if (false)
 #endif
-    if (me.x0 + 8 * sxc <= width) {
+    // (samples 2 or 4 bytes apart: the row loads below take whole pixels, up to 3 bytes past a block's last SAMPLE - inside the
+    //  plane everywhere but at the end of its last row, where that may be past the caller's allocation: the one block there takes
+    //  the clamped path)
+    const int row_guard = PLANES && lg_stride != 0u && me.y0 + 7 * syc >= hlim ? 1 : 0;
+    if (me.x0 + 8 * sxc + row_guard <= width) {
         if (CONV && BPP == 2) {                                     // 16-bit r5 g6 b5 pixels: unpacked, then converted like Rgb
             const uint32_t rs = Wv[12] & 0xFFu, bs = (Wv[12] >> 8) & 0xFFu;
             if (role == ROLE_Y) {

@@ -565,7 +565,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
-    const bool staged = JPEGENC_DIAG_ENV("JPEGENC_BATCH_PAGEABLE_H2D") == nullptr;
+    const bool staged = true;      // batch frames: uploaded by the worker (in place; host_frame.cpp encode_pixels), never read by the kernel over the link
     auto body = [&](int w) {
         if (w > 0) bind_thread_near_device(e->device, e->numa_bind);   // (opt-in) spawned workers; the caller's own affinity is left alone
         DeviceCtx &ctx = *e->workers[(size_t)w];

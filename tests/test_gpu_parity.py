@@ -623,6 +623,7 @@ def test_randomised_configurations(binding, oracle, synth):
     configuration must also be byte-identical to the oracle): size, ColorType, sampling factor,
     quality, scan mode, restart interval, custom tables, FDCT build, entropy coder."""
     import os
+    import sys
     rng = np.random.default_rng(int(os.environ.get("JPEGENC_FUZZ_SEED", "20261002")))
     samplings = [(1, 1), (2, 1), (1, 2), (2, 2), (4, 1), (4, 2), (1, 4), (2, 4)]
     # (JPEGENC_FUZZ_MAX_W / _H: larger frames reach the multi-tile prefix sums and thousands of runs per scan)
@@ -645,7 +646,8 @@ def test_randomised_configurations(binding, oracle, synth):
         if rng.integers(0, 3) == 0 and not kw.get("optimize"):
             kw["restart_interval"] = int(rng.integers(1, 40))
         variant = int(rng.integers(0, 2))
-        e = _encoder(binding, kw, device_entropy=bool(rng.integers(0, 2)))
+        on_device = bool(rng.integers(0, 2))
+        e = _encoder(binding, kw, device_entropy=on_device)
         e.set_fdct_variant(variant)
         okw = dict(kw)
         if rng.integers(0, 4) == 0:
@@ -653,6 +655,9 @@ def test_randomised_configurations(binding, oracle, synth):
             e.set_quantization_tables(binding.Q_CUSTOM, int(rng.integers(0, 9)), cust, None)
             okw["qpresets"] = (oracle.Q_CUSTOM, e.quantization_tables()[1])
             okw["qcustoms"] = (cust, None)
+        if os.environ.get("JPEGENC_FUZZ_VERBOSE"):          # (a device fault kills the process: the last line names the configuration)
+            print("trial", trial, dict(ct=ct, w=w, h=h, variant=variant, device_entropy=on_device, smooth=trial % 3 == 0, custom="qcustoms" in okw, **kw),
+                  file=sys.stderr, flush=True)
         got = e.encode(px, w, h, ct)
         if ct >= 9:                                          # the oracle sees the words unpacked by the header's definition
             wd = np.ascontiguousarray(px).view(np.uint16).reshape(h, w).astype(np.uint32)

@@ -15,4 +15,4 @@ enc.encode_batch_into(frames[:64], 1920, 1080, b.RGB, outs)
 ts = []
 for _ in range(5):
     t = time.perf_counter(); enc.encode_batch_into(frames, 1920, 1080, b.RGB, outs); ts.append(time.perf_counter() - t)
-print(json.dumps({"workers": os.environ.get("JPEGENC_BATCH_WORKERS", "16"), "pageable": os.environ.get("JPEGENC_BATCH_PAGEABLE_H2D"), "fps_median": round(n / sorted(ts)[2], 1), "fps_best": round(n / min(ts), 1)}))
+print(json.dumps({"workers": os.environ.get("JPEGENC_BATCH_WORKERS", "16"), "staging_copy": os.environ.get("JPEGENC_STAGING_COPY"), "fps_median": round(n / sorted(ts)[2], 1), "fps_best": round(n / min(ts), 1)}))

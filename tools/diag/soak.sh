@@ -6,7 +6,7 @@ out=gpurun_out
 mkdir -p $out
 run() {  # name, env..., then pytest -k expr
   local name=$1; shift
-  ( env "$@" timeout 1500 python3 -m pytest tests/test_gpu_parity.py -q -x -k test_randomised_configurations 2>&1 | tail -3; echo "rc=$?" ) > $out/${tag}_soak_$name.log 2>&1
+  ( env "$@" timeout 1500 python3 -m pytest tests/test_gpu_parity.py -q -x -k test_randomised_configurations 2>&1 | tail -60; echo "rc=${PIPESTATUS[0]}" ) > $out/${tag}_soak_$name.log 2>&1
   tail -2 $out/${tag}_soak_$name.log
 }
 S=${SOAK_SEED:-100}
