@@ -751,6 +751,8 @@ bool launch_bytes_s4(const BlockKernelParams &p, const ColourConsts &k, int sx, 
                      hipStream_t stream, hipError_t *err);
 // fast_kernels_565.hip: 16-bit packed RGB (BPP = 2 with the conversion roles)
 bool launch_conv_565(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant, hipStream_t stream, hipError_t *err);
+// fast_kernels_444.hip: the RGB family without decimation, one wave per 64 MCUs for all three components
+bool launch_conv_444(const BlockKernelParams &p, const ColourConsts &k, int num_frames, int variant, hipStream_t stream, hipError_t *err);
 // fast_kernels_bytes.hip
 bool launch_bytes_family(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant,
                          hipStream_t stream, hipError_t *err);

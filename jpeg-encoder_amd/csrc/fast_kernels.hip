@@ -78,6 +78,9 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
     const bool conv = p.xform == XF_RGB2YCC || p.xform == XF_CMYK2YCCK;
     if (!conv) return launch_bytes_family(p, k, sx, sy, num_frames, variant, stream, err);
     if (p.packed565) return p.bpp == 2 && launch_conv_565(p, k, sx, sy, num_frames, variant, stream, err);
+    // 4:4:4 of the RGB family: one wave per 64 MCUs codes all three components (fast_kernels_444.hip)
+    static const bool no_trio = JPEGENC_DIAG_ENV("JPEGENC_NO_TRIO") != nullptr;
+    if (!no_trio && sx == 1 && sy == 1 && launch_conv_444(p, k, num_frames, variant, stream, err)) return true;
 #define JPEGENC_CASE(B, X, Y) if (p.bpp == B && sx == X && sy == Y) { *err = launch_fast<B, X, Y, true>(p, k, num_frames, variant, stream); return true; }
     JPEGENC_CASE(3, 1, 1) JPEGENC_CASE(3, 2, 1) JPEGENC_CASE(3, 1, 2) JPEGENC_CASE(3, 2, 2)
     JPEGENC_CASE(4, 1, 1) JPEGENC_CASE(4, 2, 1) JPEGENC_CASE(4, 1, 2) JPEGENC_CASE(4, 2, 2)

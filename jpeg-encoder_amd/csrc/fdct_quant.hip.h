@@ -113,6 +113,19 @@ __device__ __forceinline__ int odd(uint32_t d01, uint32_t d32, Lin4 c, uint32_t 
 __device__ __forceinline__ uint32_t pack_lo(int a, int b) {
     return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x05040100u);
 }
+// (a >> N, b >> N) as one packed i16 pair in two instructions: a's shift, then b's as an SDWA shift that writes only the high
+// word of the same register (the low halves of both results are all pass 2 reads) - instead of two shifts and a v_perm.
+#ifndef JPEGENC_NO_SDWA_PACK
+template <int N>
+__device__ __forceinline__ uint32_t pack_shifted(int a, int b) {
+    int r = a >> N;
+    asm("v_ashrrev_i32_sdwa %0, %2, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(r) : "v"(b), "n"(N));
+    return (uint32_t)r;
+}
+#else
+template <int N>
+__device__ __forceinline__ uint32_t pack_shifted(int a, int b) { return pack_lo(a >> N, b >> N); }
+#endif
 // high halves of two ints -> one packed pair (lo = a >> 16, hi = b >> 16)
 __device__ __forceinline__ uint32_t pack_hi(int a, int b) {
     return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x07060302u);
@@ -136,14 +149,17 @@ __device__ __forceinline__ void islow_pass(uint32_t a, uint32_t b, uint32_t c, u
     const uint32_t ts = pk_sub(s01, s32);      // (tmp13, tmp12)
     if (PASS == 1) {
         constexpr int n = CONST_BITS - PASS1_BITS, r = 1 << (n - 1);
+        // (outputs 1, 2, 3, 5, 6, 7 are returned BEFORE their rounding shift by kPass1Shift: the caller shifts while it packs
+        //  two rows' values for pass 2, pack_shifted)
+        (void)n;
         out[0] = dot2_first(ta, K.p1_0, -4096);   // fdct.rs:137: (tmp10 + tmp11) << 2, minus 8*128*4
         out[4] = dot2_first_imm<0>(ta, K.p1_4);   // fdct.rs:138
-        out[2] = dot2_first(ts, K.k2, r) >> n;
-        out[6] = dot2_first(ts, K.k6, r) >> n;
-        out[1] = odd(d01, d32, ODD1, K.o1, r) >> n;
-        out[3] = odd(d01, d32, ODD3, K.o3, r) >> n;
-        out[5] = odd(d01, d32, ODD5, K.o5, r) >> n;
-        out[7] = odd(d01, d32, ODD7, K.o7, r) >> n;
+        out[2] = dot2_first(ts, K.k2, r);
+        out[6] = dot2_first(ts, K.k6, r);
+        out[1] = odd(d01, d32, ODD1, K.o1, r);
+        out[3] = odd(d01, d32, ODD3, K.o3, r);
+        out[5] = odd(d01, d32, ODD5, K.o5, r);
+        out[7] = odd(d01, d32, ODD7, K.o7, r);
     } else {
         constexpr int n = CONST_BITS + PASS1_BITS, r = 1 << (n - 1);
         constexpr int r2 = SIMD_ODD_LANE ? 0 : (1 << (PASS1_BITS - 1));   // avx2/fdct.rs:196-209,:291
@@ -185,8 +201,15 @@ __device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], qcon
     int prod[64];   // 2 * quantiser product of natural coefficient n; its high half is the result
 #pragma unroll
     for (int x = 0; x < 8; x++) {
-        const uint32_t a = pack_lo(mid[0][x], mid[1][x]), b = pack_lo(mid[3][x], mid[2][x]);
-        const uint32_t c = pack_lo(mid[7][x], mid[6][x]), d = pack_lo(mid[4][x], mid[5][x]);
+        constexpr int n1 = CONST_BITS - PASS1_BITS;      // pass 1's rounding shift (fdct.rs:139-170), pending on every output but 0 and 4
+        uint32_t a, b, c, d;
+        if (x == 0 || x == 4) {
+            a = pack_lo(mid[0][x], mid[1][x]); b = pack_lo(mid[3][x], mid[2][x]);
+            c = pack_lo(mid[7][x], mid[6][x]); d = pack_lo(mid[4][x], mid[5][x]);
+        } else {
+            a = pack_shifted<n1>(mid[0][x], mid[1][x]); b = pack_shifted<n1>(mid[3][x], mid[2][x]);
+            c = pack_shifted<n1>(mid[7][x], mid[6][x]); d = pack_shifted<n1>(mid[4][x], mid[5][x]);
+        }
         int col[8];
         if (VARIANT == 1 && (x & 1)) islow_pass<2, true>(a, b, c, d, K, col);
         else islow_pass<2, false>(a, b, c, d, K, col);

@@ -11,7 +11,7 @@ out, cfg = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(float); cnt = collections.Counter()
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_blocks_fast" not in r["Kernel_Name"]: continue
+        if "k_blocks_" not in r["Kernel_Name"]: continue
         acc[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
 v = {k: acc[k] / cnt[k] for k in acc}
 w = v.get("SQ_WAVES", 1)
