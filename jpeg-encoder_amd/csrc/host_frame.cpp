@@ -69,6 +69,7 @@ struct FrameRun {
     bool optimize = false;
     FusedSource fused_src = {};
     int stripes = 0;                    // > 0: a large frame between page-locked buffers, through run_striped in that many stripes
+    bool stripe_timed = false;          // the call's duration goes to the handle's StripeTuner
     bool self_finishing = false;        // ... and its workgroups put the scan together themselves: the launch sequence is that one kernel
     bool holds_finish_slot = false;     // counted in g_big_finishing until this run ends
     ~FrameRun() { if (holds_finish_slot) g_big_finishing[ctx.device & 63].fetch_sub(1); }
@@ -231,12 +232,15 @@ struct FrameRun {
         if (self_finishing && !host_gather && host_pixels && sink == buffer_sink && pixel_bytes >= striped_from && pixel_bytes < (1ull << 31)) {
             const BufferSink *bs = (const BufferSink *)user;
             const uint32_t mcu_rows = (uint32_t)((L.mcus + p.mcus_x - 1) / p.mcus_x);
-            stripes = pixel_bytes >= ((size_t)8 << 20) ? 4 : 2;                 // (tools/diag/stripes_ab.sh: 3-4 stripes of 2.7-6 MB are the best of 1 ... 8)
             static const int forced = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_STRIPES"); return e ? atoi(e) : 0; }();
-            if (forced) stripes = forced;
-            if (stripes > DeviceCtx::kChunks) stripes = DeviceCtx::kChunks;
-            if ((uint32_t)stripes > mcu_rows) stripes = (int)mcu_rows;
-            if (stripes < 2 || !is_pinned_host_range(host_pixels, pixel_bytes) || !bs->out || !is_pinned_host_range(bs->out, bs->cap)) stripes = 0;
+            if (mcu_rows >= 2 && is_pinned_host_range(host_pixels, pixel_bytes) && bs->out && is_pinned_host_range(bs->out, bs->cap)) {
+                // 4, 2 or 1 (= the ordinary sequence): whichever this handle measured as the fastest (DeviceCtx::StripeTuner)
+                stripes = forced ? forced : ctx.stripe_tuner.choose(((uint64_t)width << 32 | (uint32_t)height) ^ ((uint64_t)L.total_blocks << 40));
+                stripe_timed = !forced;
+                if (stripes > DeviceCtx::kChunks) stripes = DeviceCtx::kChunks;
+                if ((uint32_t)stripes > mcu_rows) stripes = (int)mcu_rows;
+                if (stripes < 2) stripes = 0;
+            }
         }
         if (stripes) fused_src.stripe_ends = (uint32_t *)(ctx.h_words + 4);
         // In ONE launch the kernel finishes the scan itself only while all of the frame's workgroups are resident together (two per
@@ -599,17 +603,24 @@ struct FrameRun {
         // the finished part of the scan, stripe by stripe, to its place behind the headers
         const size_t room = bs->cap > at ? bs->cap - at : 0;
         size_t prev = 0;
+        const auto t_enqueued = now();
+        long t_stripe[DeviceCtx::kChunks] = {0}, t_copy[DeviceCtx::kChunks] = {0};
         for (int k = 0; k < launched && rc == JPEGENC_OK && he == hipSuccess; k++) {
             he = hipEventSynchronize(ctx.chunk_done[k]);
+            if (trace) t_stripe[k] = us(t_begin, now());
             const size_t end = ends[k];
             if (he == hipSuccess && end > prev && end <= room)               // (a buffer that is too small is left alone; the caller learns the size)
                 he = hipMemcpyAsync(bs->out + at + prev, (const uint8_t *)ctx.d_gather + kGatherHeader + prev, end - prev, hipMemcpyDeviceToHost, ctx.download_stream);
+            if (trace) t_copy[k] = us(t_begin, now()) - t_stripe[k];
             if (end > prev) prev = end;
         }
         (void)hipStreamSynchronize(ctx.kernel_stream);
         (void)hipStreamSynchronize(ctx.stream);
+        const auto t_kernels = now();
         const hipError_t de = hipStreamSynchronize(ctx.download_stream);
         ctx.unsynchronised = 0;
+        if (trace) fprintf(stderr, "[jpegenc]   stripes: enqueued after %ld us; stripe k coded after %ld / %ld / %ld / %ld us; streams idle after %ld, downloads after %ld us; inside the download calls %ld / %ld / %ld / %ld us\n",
+                           us(t_begin, t_enqueued), t_stripe[0], t_stripe[1], t_stripe[2], t_stripe[3], us(t_begin, t_kernels), us(t_begin, now()), t_copy[0], t_copy[1], t_copy[2], t_copy[3]);
         // (a failure after some stripes were launched leaves READY words and a part-way counter in the look-back chain: the last
         // workgroup's zeroing never ran, and the next self-finishing frame of this handle would read them)
         if ((rc != JPEGENC_OK || he != hipSuccess || de != hipSuccess) && launched > 0) (void)reset_chain();
@@ -797,7 +808,9 @@ static int encode_frame_once(const Config &c, DeviceCtx &ctx, int jct, int width
     run.choose_replay();
     rc = run.begin_sequence();
     if (rc) return rc;
-    if (run.stripes) return run.run_striped();
+    // (a frame that could have gone in stripes tells the handle's tuner how long it took, whichever way it went)
+    auto timed = [&](int r) { if (run.stripe_timed && r == JPEGENC_OK) ctx.stripe_tuner.record((float)FrameRun::us(run.t_begin, FrameRun::now())); return r; };
+    if (run.stripes) return timed(run.run_striped());
     rc = run.enqueue_blocks_and_statistics();
     if (rc) return rc;
     if (!(c.device_entropy && run.supported)) return run.collect_host_coded();
@@ -805,7 +818,7 @@ static int encode_frame_once(const Config &c, DeviceCtx &ctx, int jct, int width
     if (rc) return rc;
     rc = run.launch_and_wait();
     if (rc) return rc;
-    return run.emit_device_coded();
+    return timed(run.emit_device_coded());
 }
 
 int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,

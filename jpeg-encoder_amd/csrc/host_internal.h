@@ -329,6 +329,36 @@ struct DeviceCtx {
     bool dense_last_time(uint64_t geometry, uint64_t total_blocks) const {
         return last_file_geometry == geometry && total_blocks && (uint64_t)last_scan_bytes * 8u > kDenseBitsPerBlock * total_blocks;
     }
+    // In how many stripes a large baseline frame between page-locked buffers goes (host_frame.cpp, run_striped): MEASURED per handle.
+    // Stripes overlap the download of a large file with the upload (Criterion's 14.4 MB quality-100 file: 0.45 ms in four stripes,
+    // 0.58 in one piece), cost fixed times per copy (a 2.7 MB file of the same frame: 0.30 in two stripes, 0.32 in one piece, 0.34
+    // in four; a 4K frame with a 6 MB file: 0.64 in one piece, 0.76 in two, 0.89 in four) - and depend on which hardware queues
+    // the runtime gave the handle's three streams: with many streams alive in the process two of them can share a queue, and the
+    // same 14.4 MB frame then takes 1.02 ms in four stripes (tools/diag/stripes_policy.py, profiles/r04_stripes_policy.txt).  No
+    // rule on sizes captures that, so the handle times its own calls: each of {4, 2, 1} twice, then the fastest, with one of the
+    // others tried again every 32nd call (content, quality and the process's streams change).  Same bytes whichever is taken.
+    struct StripeTuner {
+        uint64_t key = 0;
+        uint32_t calls = 0, seen[3] = {0, 0, 0};
+        float cost[3] = {0, 0, 0};             // microseconds per call, smoothed
+        int current = 0;
+        static int stripes_of(int option) { return option == 0 ? 4 : option == 1 ? 2 : 1; }
+        int choose(uint64_t k) {
+            if (k != key) { key = k; calls = 0; for (int i = 0; i < 3; i++) { seen[i] = 0; cost[i] = 0; } }
+            if (calls < 6) current = (int)(calls % 3u);
+            else {
+                int best = 0;
+                for (int i = 1; i < 3; i++) if (cost[i] < cost[best]) best = i;
+                current = calls % 32u == 0 ? (best + 1 + (int)((calls / 32u) & 1u)) % 3 : best;
+            }
+            calls++;
+            return stripes_of(current);
+        }
+        void record(float us) {                // (the first call of an option pays for its streams, events and graphs: the second replaces it)
+            seen[current]++;
+            cost[current] = seen[current] <= 2 ? us : 0.5f * cost[current] + 0.5f * us;
+        }
+    } stripe_tuner;
     size_t last_scan_bytes = 0;        // coded bytes of the handle's last device-coded frame and its size: a mid-size frame whose file was
     uint64_t last_file_geometry = 0;   // small is coded straight into pinned host memory the next time (host_frame.cpp, plan_scans)
     int last_cpu = -1;                 // the CPU the worker that owns this context ran on when it last finished a frame (jpegenc_encoder_batch_worker_info)
