@@ -576,6 +576,35 @@ def main():
                                       "block_kernel_ms": round(ms_simd, 4), "vs_scalar": round(kernel_ms / ms_simd, 4)}
         except Exception as exc:
             result["simd_variant"] = {"error": str(exc)}
+        # ---- the block kernel on the reference's DEFAULT sampling factor (F_1_1 = 4:4:4, encoder.rs:224-236) in BASELINE config 5's
+        # shape (4K RGB, planar order, 9 algorithmic bytes per pixel): a kernel of its own (fast_kernels_444.hip), same roofline
+        try:
+            f444 = min(16, F)
+            L444 = binding.layout(W, H, binding.RGB, 1, 1, binding.ORDER_PLANAR)
+            nb444 = int(L444.total_blocks)
+            d_co444 = torch.empty((f444, nb444 * 64), dtype=torch.int16, device=dev)
+
+            def step444():
+                binding.blocks_device(d_px.data_ptr(), frame_bytes, f444, W, H, binding.RGB, 1, 1, q, binding.ORDER_PLANAR, binding.FDCT_SCALAR,
+                                      d_co444.data_ptr(), nb444, stream.cuda_stream)
+            t_in = time.perf_counter()
+            while time.perf_counter() - t_in < 0.15:                # run-in (profiles/r01_k_step_series.txt)
+                for _ in range(8):
+                    step444()
+                torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(200):
+                step444()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms444 = e0.elapsed_time(e1) / 200
+            bytes444 = f444 * (frame_bytes + nb444 * 128)
+            result["layout_444"] = {"block_kernel_frac": round(bytes444 / (ms444 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "block_kernel_ms": round(ms444, 4),
+                                    "Mpixels_per_s": round(f444 * W * H / ms444 / 1e3, 1), "workload": f"{f444} x {W}x{H} RGB q={QUALITY} 4:4:4 planar order"}
+            del d_co444
+        except Exception as exc:
+            result["layout_444"] = {"error": str(exc)}
         # side figure (never `value`): the north-star stream pipeline, jpegenc_blocks_stream — pinned host
         # frames -> H2D -> fused kernel -> D2H of the coefficient tiles into pinned memory -> callback
         # (no entropy coding here), one stream per direction + one for the kernel

@@ -37,6 +37,7 @@ struct BatchRun {
     int per_round = 1;
     std::vector<std::thread> pools[2];                  // the threads assembling the files of the round staged in h_out[slot]
     std::atomic<int> failed{0};
+    std::atomic<int> first_bad{0x7FFFFFFF};             // lowest frame whose sink reported an error (every frame before it is delivered whole)
     bool stop = false;
 
     BatchRun(const Config &c_, DeviceCtx &ctx_, BatchBuffers &b_, int device_, const void *d_frames_, size_t frame_stride_, int num_frames_,
@@ -226,7 +227,11 @@ struct BatchRun {
             }
             o.marker(0xD9);
             o.drain(true);
-            if (o.failed) failed.store(1);
+            if (o.failed) {
+                int seen = first_bad.load();
+                while (f0 + f < seen && !first_bad.compare_exchange_weak(seen, f0 + f)) { }
+                failed.store(1);
+            }
         }
     }
 
@@ -304,8 +309,9 @@ struct BatchRun {
     }
 };
 
+// failed_frame (optional): the lowest frame whose sink failed, where that is why the call failed (else untouched)
 int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b, int device, const void *d_frames, size_t frame_stride, int num_frames,
-                        int width, int height, int color_type, jpegenc_write_fn sink, void *const *users, const PlaneBatch *pb) {
+                        int width, int height, int color_type, jpegenc_write_fn sink, void *const *users, const PlaneBatch *pb, int *failed_frame) {
     BatchRun run(c, ctx, b, device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users, pb);
     int rc = run.prepare();
     if (rc) return rc;
@@ -313,7 +319,9 @@ int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b, int de
     if (rc) return rc;
     rc = run.size_rounds_and_reserve();
     if (rc) return rc;
-    return run.run();
+    rc = run.run();
+    if (rc == JPEGENC_ERR_WRITE && failed_frame && run.first_bad.load() != 0x7FFFFFFF) *failed_frame = run.first_bad.load();
+    return rc;
 }
 
 }  // namespace jpegenc
@@ -349,10 +357,7 @@ static int encode_device_frames_pooled(jpegenc_encoder *e, const void *d_frames,
             if (status.compare_exchange_strong(expected, r)) messages[(size_t)w] = jpegenc_last_error();
         }
     };
-    std::vector<std::thread> pool;
-    for (int w = 1; w < workers; w++) pool.emplace_back(body, w);
-    body(0);
-    for (auto &th : pool) th.join();
+    e->threads.run(workers, body);
     if (status.load() != JPEGENC_OK) {
         for (const auto &m : messages) if (!m.empty()) { set_last_error(m); break; }
         return status.load();
@@ -366,7 +371,7 @@ static int encode_device_frames_pooled(jpegenc_encoder *e, const void *d_frames,
 // after it that were already in flight may be as well), and its status - the one of the LOWEST failing frame - is what the call
 // returns.  (Until round 4 this was a loop on the handle's own stream: ~280 us per 4K frame.)
 static int encode_planes_frames_pooled(jpegenc_encoder *e, int jct, int width, int height, const jpegenc_plane *planes, int num_frames,
-                                       bool planes_subsampled, jpegenc_write_fn sink, void *const *users) {
+                                       bool planes_subsampled, jpegenc_write_fn sink, void *const *users, int *failed_frame = nullptr) {
     const int workers = batch_pool_size(e->max_batch_workers, num_frames);
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
     const int ncomp = jct == JPEGENC_J_LUMA ? 1 : jct == JPEGENC_J_YCBCR ? 3 : 4;
@@ -397,11 +402,12 @@ static int encode_planes_frames_pooled(jpegenc_encoder *e, int jct, int width, i
             }
         }
     };
-    std::vector<std::thread> pool;
-    for (int w = 1; w < workers; w++) pool.emplace_back(body, w);
-    body(0);
-    for (auto &th : pool) th.join();
-    if (bad_status != JPEGENC_OK) { set_last_error("frame " + std::to_string(first_bad.load()) + ": " + bad_message); return bad_status; }
+    e->threads.run(workers, body);
+    if (bad_status != JPEGENC_OK) {
+        if (failed_frame) { *failed_frame = first_bad.load(); set_last_error(bad_message); }      // (the caller names the frame in its own numbering)
+        else set_last_error("frame " + std::to_string(first_bad.load()) + ": " + bad_message);
+        return bad_status;
+    }
     return JPEGENC_OK;
 }
 
@@ -422,6 +428,39 @@ int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames
     const int rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
     if (rc != kBatchNeedsPerFrame) return rc;
     return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
+}
+
+// A pool of described surfaces of ONE layout (sample strides, inversion, shifts and byte lanes agree): shared launches.
+// failed_frame: the lowest frame whose delivery failed (-1 where the failure is not a frame's).
+static int encode_planes_uniform(jpegenc_encoder *e, int jct, int width, int height, int ncomp, const jpegenc_plane *planes, int num_frames,
+                                 bool planes_subsampled, jpegenc_write_fn sink, void *const *users, int *failed_frame) {
+    int rc = e->ctx.open(e->device);
+    if (rc) return rc;
+    // (the second byte of an interleaved pair is addressed through its pair: the kernels pick byte 1 of each two-byte sample,
+    // as jpegenc_encoder_encode_planes_device does)
+    // table[frame][8] = {4 plane addresses, 4 pitches}: the frames of a pool may differ in both (what they share - sample
+    // stride, inversion, byte of the pair - is in the launch's wave records, set up from `rep`: frame 0's descriptors with
+    // the LARGEST pitch of each component, which is what the launchers' 32-bit offset checks look at)
+    rc = e->batch.reserve_plane_table((size_t)num_frames * 8 * sizeof(uint64_t));
+    if (rc) return rc;
+    uint64_t *table = e->batch.h_plane_table;
+    jpegenc_plane rep[4];
+    memset(rep, 0, sizeof rep);
+    for (int i = 0; i < ncomp; i++) rep[i] = planes[i];
+    for (int f = 0; f < num_frames; f++)
+        for (int i = 0; i < 4; i++) {
+            if (i >= ncomp) { table[(size_t)f * 8 + i] = table[(size_t)f * 8 + 4 + i] = 0; continue; }
+            const jpegenc_plane &pl = planes[(size_t)f * 4 + i];
+            const uintptr_t ptr = (uintptr_t)pl.d_data;
+            table[(size_t)f * 8 + i] = (uint64_t)(ptr - (ptr & (uintptr_t)(pl.pixel_stride - 1)));
+            table[(size_t)f * 8 + 4 + i] = (uint64_t)pl.pitch;
+            if (pl.pitch > rep[i].pitch) rep[i].pitch = pl.pitch;
+        }
+    JPEGENC_HIP(hipMemcpyAsync(e->batch.d_plane_table, table, (size_t)num_frames * 8 * sizeof(uint64_t), hipMemcpyHostToDevice, e->ctx.stream));
+    const PlaneBatch pb = {rep, planes_subsampled, (const uint64_t *)e->batch.d_plane_table, jct};
+    rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, nullptr, 0, num_frames, width, height, 0, sink, users, &pb, failed_frame);
+    if (rc != kBatchNeedsPerFrame) return rc;
+    return encode_planes_frames_pooled(e, jct, width, height, planes, num_frames, planes_subsampled, sink, users, failed_frame);
 }
 
 // A batch of described planar surfaces (decoder / camera pools of I420 or NV12 frames): the launches of the whole batch are
@@ -448,39 +487,57 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
                 (((uintptr_t)pl.d_data ^ (uintptr_t)p0.d_data) & (uintptr_t)(pl.pixel_stride - 1)))
                 uniform = false;
         }
-    auto one_by_one = [&]() -> int {        // (one image per call of the frame engine - through the worker pool)
-        if (num_frames == 1) return jpegenc_encoder_encode_planes_device(e, jct, width, height, planes, planes_subsampled, sink, users[0]);
-        return encode_planes_frames_pooled(e, jct, width, height, planes, num_frames, planes_subsampled != 0, sink, users);
-    };
     const bool per_frame_tables = e->cfg.optimize && select_mode(e->cfg) != MODE_INTERLEAVED;
-    if (!uniform || !e->cfg.device_entropy || per_frame_tables || hs == 4 || vs == 4 || num_frames == 1) return one_by_one();
-    int rc = e->ctx.open(e->device);
-    if (rc) return rc;
-    // (the second byte of an interleaved pair is addressed through its pair: the kernels pick byte 1 of each two-byte sample,
-    // as jpegenc_encoder_encode_planes_device does)
-    // table[frame][8] = {4 plane addresses, 4 pitches}: the frames of a pool may differ in both (what they share - sample
-    // stride, inversion, byte of the pair - is in the launch's wave records, set up from `rep`: frame 0's descriptors with
-    // the LARGEST pitch of each component, which is what the launchers' 32-bit offset checks look at)
-    rc = e->batch.reserve_plane_table((size_t)num_frames * 8 * sizeof(uint64_t));
-    if (rc) return rc;
-    uint64_t *table = e->batch.h_plane_table;
-    jpegenc_plane rep[4];
-    memset(rep, 0, sizeof rep);
-    for (int i = 0; i < ncomp; i++) rep[i] = planes[i];
-    for (int f = 0; f < num_frames; f++)
-        for (int i = 0; i < 4; i++) {
-            if (i >= ncomp) { table[(size_t)f * 8 + i] = table[(size_t)f * 8 + 4 + i] = 0; continue; }
-            const jpegenc_plane &pl = planes[(size_t)f * 4 + i];
-            const uintptr_t ptr = (uintptr_t)pl.d_data;
-            table[(size_t)f * 8 + i] = (uint64_t)(ptr - (ptr & (uintptr_t)(pl.pixel_stride - 1)));
-            table[(size_t)f * 8 + 4 + i] = (uint64_t)pl.pitch;
-            if (pl.pitch > rep[i].pitch) rep[i].pitch = pl.pitch;
+    const bool shareable = e->cfg.device_entropy && !per_frame_tables && hs != 4 && vs != 4;
+    if (num_frames == 1) return jpegenc_encoder_encode_planes_device(e, jct, width, height, planes, planes_subsampled, sink, users[0]);
+    if (!shareable) return encode_planes_frames_pooled(e, jct, width, height, planes, num_frames, planes_subsampled != 0, sink, users);
+    if (uniform) {
+        int bad = -1;
+        const int rc = encode_planes_uniform(e, jct, width, height, ncomp, planes, num_frames, planes_subsampled != 0, sink, users, &bad);
+        if (rc != JPEGENC_OK && bad >= 0) set_last_error("frame " + std::to_string(bad) + ": " + jpegenc_last_error());
+        return rc;
+    }
+    // A pool that MIXES layouts (NV12 surfaces among I420 ones, an inverted plane here and there): the frames of each layout share
+    // their launches among themselves - 32 us per 4K frame instead of 70 through one launch sequence per frame
+    // (profiles/r04_surfaces.jsonl).  Groups go one after the other; when a frame fails, the groups still to come deliver the
+    // frames BEFORE it (and only those): what the caller is told is the lowest failing frame, with every frame before it whole.
+    std::vector<int> group_of((size_t)num_frames, -1);
+    std::vector<int> leaders;
+    for (int f = 0; f < num_frames; f++) {
+        for (size_t g = 0; g < leaders.size() && group_of[(size_t)f] < 0; g++) {
+            bool same = true;
+            for (int i = 0; i < ncomp && same; i++) {
+                const jpegenc_plane &pl = planes[(size_t)f * 4 + i], &p0 = planes[(size_t)leaders[g] * 4 + i];
+                same = pl.pixel_stride == p0.pixel_stride && (pl.invert != 0) == (p0.invert != 0) && pl.shift == p0.shift &&
+                       !(((uintptr_t)pl.d_data ^ (uintptr_t)p0.d_data) & (uintptr_t)(pl.pixel_stride - 1));
+            }
+            if (same) group_of[(size_t)f] = (int)g;
         }
-    JPEGENC_HIP(hipMemcpyAsync(e->batch.d_plane_table, table, (size_t)num_frames * 8 * sizeof(uint64_t), hipMemcpyHostToDevice, e->ctx.stream));
-    const PlaneBatch pb = {rep, planes_subsampled != 0, (const uint64_t *)e->batch.d_plane_table, jct};
-    rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, nullptr, 0, num_frames, width, height, 0, sink, users, &pb);
-    if (rc != kBatchNeedsPerFrame) return rc;
-    return one_by_one();
+        if (group_of[(size_t)f] < 0) { group_of[(size_t)f] = (int)leaders.size(); leaders.push_back(f); }
+    }
+    int bad_frame = num_frames, bad_status = JPEGENC_OK;
+    std::string bad_message;
+    for (size_t g = 0; g < leaders.size(); g++) {
+        std::vector<jpegenc_plane> sub;
+        std::vector<void *> sub_users;
+        std::vector<int> ids;
+        for (int f = 0; f < bad_frame; f++)
+            if (group_of[(size_t)f] == (int)g) {
+                for (int i = 0; i < 4; i++) sub.push_back(planes[(size_t)f * 4 + i]);
+                sub_users.push_back(users[f]);
+                ids.push_back(f);
+            }
+        if (ids.empty()) continue;
+        int bad = -1, rc;
+        if (ids.size() == 1) { rc = jpegenc_encoder_encode_planes_device(e, jct, width, height, sub.data(), planes_subsampled, sink, sub_users[0]); bad = 0; }
+        else rc = encode_planes_uniform(e, jct, width, height, ncomp, sub.data(), (int)ids.size(), planes_subsampled != 0, sink, sub_users.data(), &bad);
+        if (rc != JPEGENC_OK) {
+            const int k = ids[(size_t)(bad >= 0 ? bad : 0)];
+            if (k < bad_frame) { bad_frame = k; bad_status = rc; bad_message = jpegenc_last_error(); }
+        }
+    }
+    if (bad_status != JPEGENC_OK) { set_last_error("frame " + std::to_string(bad_frame) + ": " + bad_message); return bad_status; }
+    return JPEGENC_OK;
 }
 
 int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len, int num_frames,
@@ -583,10 +640,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
             }
         }
     };
-    std::vector<std::thread> pool;
-    for (int w = 1; w < workers; w++) pool.emplace_back(body, w);
-    if (workers > 0) body(0);
-    for (auto &th : pool) th.join();
+    e->threads.run(workers, body);
     if (status.load() != JPEGENC_OK) {
         for (const auto &m : messages) if (!m.empty()) { set_last_error(m); break; }
         return status.load();

@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -714,12 +715,77 @@ struct RegisterCache {
     ~RegisterCache() { clear(); }
 };
 
+namespace jpegenc {
+// The host threads of a handle's batch calls, kept between calls.  A thread that is new to the HIP runtime pays for its first call
+// (per-thread state: ~100 us), and a pool of sixteen device-resident 4K frames is 0.5 ms of GPU work in all: threads created per
+// call made such pools no faster than one call after the other (77 us per frame in the pool, 81 one at a time; persistent: see
+// profiles/r04_surfaces.jsonl).  run(n, body): body(0) on the caller's thread, body(1 .. n-1) on the pool's, returns when all are done.
+class WorkerThreads {
+  public:
+    ~WorkerThreads() { stop(); }
+    void run(int n, const std::function<void(int)> &body) {
+        if (n <= 1) { if (n == 1) body(0); return; }
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            while ((int)threads_.size() < n - 1) {
+                const int index = (int)threads_.size() + 1;
+                threads_.emplace_back([this, index] { loop(index); });
+            }
+            job_ = &body; width_ = n; pending_ = n - 1; generation_++;
+        }
+        start_.notify_all();
+        body(0);
+        std::unique_lock<std::mutex> lock(m_);
+        done_.wait(lock, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    void stop() {
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            quit_ = true;
+        }
+        start_.notify_all();
+        for (auto &t : threads_) if (t.joinable()) t.join();
+        threads_.clear();
+        quit_ = false;
+    }
+
+  private:
+    void loop(int index) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                start_.wait(lock, [&] { return quit_ || (generation_ != seen && index < width_); });
+                if (quit_) return;
+                seen = generation_;
+                job = job_;
+            }
+            (*job)(index);
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::mutex m_;
+    std::condition_variable start_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)> *job_ = nullptr;
+    uint64_t generation_ = 0;
+    int width_ = 0, pending_ = 0;
+    bool quit_ = false;
+};
+}  // namespace jpegenc
+
 struct jpegenc_encoder {
     Config cfg;
     int device = 0;
     RegisterCache reg_cache;
     DeviceCtx ctx;
     std::vector<std::unique_ptr<DeviceCtx>> workers;   // batch API: one per in-flight frame, kept across calls
+    jpegenc::WorkerThreads threads;                    // ... and the threads that drive them (declared after `workers`: joined before the contexts go)
     BatchBuffers batch;                                  // device-resident batch API
     SmallBatchBuffers small;                             // batches of small frames
     int max_batch_workers = 16;                          // host threads of jpegenc_encoder_encode_batch
@@ -796,7 +862,7 @@ constexpr int kBatchNeedsPerFrame = -1000;
 // stride and inversion (planes = frame 0's descriptors with each component's largest pitch); every frame's plane addresses and pitches are a device table [frame][8].
 struct PlaneBatch { const jpegenc_plane *planes; bool subsampled; const uint64_t *d_table; int jct; };
 int encode_device_batch(const Config &c, DeviceCtx &ctx, BatchBuffers &b, int device, const void *d_frames, size_t frame_stride, int num_frames,
-                        int width, int height, int color_type, jpegenc_write_fn sink, void *const *users, const PlaneBatch *pb = nullptr);
+                        int width, int height, int color_type, jpegenc_write_fn sink, void *const *users, const PlaneBatch *pb = nullptr, int *failed_frame = nullptr);
 
 // one descriptor of a device-resident planar source (jpegenc_encoder_encode_planes_device and its batch form)
 inline int validate_plane(const jpegenc_plane &pl, int hs, int vs, bool planes_subsampled) {
