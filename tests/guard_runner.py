@@ -64,6 +64,12 @@ def pixels():
                         region.upload(ptr, px)
                         got = e.encode_device(ptr, w, h, ct)
                         assert got == want, (ct, w, h, sampling, mode, where)
+                    if mode in ("baseline", "progressive") and variant == 0 and px.nbytes * 3 <= region.size:
+                        # three frames back to back, the last one ending at the end of the mapping: the shared launches of a batch
+                        ptr = region.tail(3 * px.nbytes)
+                        for k in range(3):
+                            region.upload(ptr + k * px.nbytes, px)
+                        assert e.encode_batch_device(ptr, px.nbytes, 3, w, h, ct) == [want] * 3, (ct, w, h, sampling, mode, "batch")
                     e.close()
             ok(f"pixels ct={ct} {w}x{h}")
     region.close()
