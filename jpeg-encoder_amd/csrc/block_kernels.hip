@@ -174,7 +174,10 @@ __global__ void __launch_bounds__(256) k_histogram(const HistKernelParams p) {
 // counter, 256 adders per address at most), and counts the DC categories of its slice of the side array - DC differences chain
 // through the whole component with no restart reset (encoder.rs:1104-1116): block b against block b - 1.
 constexpr uint32_t kHistFinishGroups = 256;          // workgroups of k_hist_finish: kHistCopies / 256 partials each
-__global__ void __launch_bounds__(256) k_hist_finish(const HistFinishParams p) {
+__global__ void __launch_bounds__(256) k_hist_finish(HistFinishParams p) {
+    p.partials += (size_t)blockIdx.y * p.partials_frame_stride;          // (blockIdx.y = frame of the launch)
+    p.dc_side += (size_t)blockIdx.y * p.dc_frame_stride;
+    p.freq += (size_t)blockIdx.y * p.freq_frame_stride;
     __shared__ uint32_t dcl[2 * 16];
     if (threadIdx.x < 32) dcl[threadIdx.x] = 0;
     __syncthreads();
@@ -207,8 +210,8 @@ __global__ void __launch_bounds__(256) k_hist_finish(const HistFinishParams p) {
     if (blockIdx.x == 0 && (int)threadIdx.x < 2 * max_tables) atomicAdd(&p.freq[threadIdx.x * 257u + 256u], 1u);
 }
 
-hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_hist_finish, dim3(kHistFinishGroups), dim3(256), 0, stream, p);
+hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream, int frames) {
+    hipLaunchKernelGGL(k_hist_finish, dim3(kHistFinishGroups, (unsigned)(frames > 0 ? frames : 1)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

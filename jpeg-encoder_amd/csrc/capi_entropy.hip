@@ -295,11 +295,15 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
 int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                 const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
                 size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st,
-                std::string *stored_params, const FusedSource *fused) {
+                std::string *stored_params, const FusedSource *fused, bool lut_per_frame) {
     EntropyParams p, *d_params = nullptr;
     const int rc = fill_scan(d_coeffs, coeff_frame_stride, frames, L, sc, tables, d_lut, d_out, out_frame_stride, d_out_lengths,
                              d_ws, ws_bytes, st, &p, &d_params, fused);
     if (rc) return rc;
+    if (lut_per_frame) {                // d_lut = `frames` table sets, kLutDeviceBytes apart (a batch with per-frame optimised tables)
+        if (!d_lut || fused) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "per-frame tables need prepared tables and the coefficient-fed coder");
+        p.fused_prefix |= kLutPerFrame;
+    }
     const hipError_t e = launch_entropy_scans(&p, 1, d_params, frames, st, stored_params, fused);
     if (e != hipSuccess) return hip_fail(e, "entropy kernels");
     return JPEGENC_OK;

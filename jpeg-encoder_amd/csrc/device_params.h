@@ -137,6 +137,9 @@ struct HistFinishParams {
     uint32_t nblocks[4];
     uint64_t comp_off[4];
     int32_t table[4];
+    // several frames in one launch (grid.y; a batch with per-frame optimised tables): frame f's partials, side array and
+    // table start f * these strides (in elements of the respective pointer) behind frame 0's; 0 = one frame
+    uint64_t partials_frame_stride, dc_frame_stride, freq_frame_stride;
 };
 
 }  // namespace jpegenc

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
     const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
     // every load of the wave's life in one queue: tables, DC predecessor, the block (clamped for lanes past the end)
     LutRegs l;
-    lut_fetch(p, l);
+    lut_fetch(p, l, f);
     const uint32_t bc = min(b, p.nblocks - 1u);
     const BlockPlace where = place_of(p, bc);
     const int prev_raw = ((const __attribute__((address_space(1))) int16_t *)frame)[where.prev_block * 64u];
@@ -803,7 +803,7 @@ hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyPar
     for (int first = 0; first < njobs; first += (int)kScansPerStore) {
         ParamPack pack;
         pack.n = (uint32_t)min(njobs - first, (int)kScansPerStore);
-        for (uint32_t j = 0; j < pack.n; j++) { pack.p[j] = jobs[first + j]; pack.p[j].fused_prefix = shape.fused_prefix; }
+        for (uint32_t j = 0; j < pack.n; j++) { pack.p[j] = jobs[first + j]; pack.p[j].fused_prefix = shape.fused_prefix | (jobs[first + j].fused_prefix & kLutPerFrame); }
         hipLaunchKernelGGL(k_store_params, dim3(1), dim3(256), 0, st, pack, d_params + first);
     }
     if (stored) stored->swap(now);

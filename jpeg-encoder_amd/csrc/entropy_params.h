@@ -19,6 +19,7 @@ constexpr uint32_t kMaxScansPerLaunch = 16;                      // scans coded 
 constexpr uint32_t kLutWords = 4u * 256u;
 constexpr uint32_t kLutCompactBytes = 2u * (16u + 16u * 11u) * 8u;
 constexpr uint32_t kLutDeviceBytes = kLutWords * 4u + kLutCompactBytes;
+constexpr uint32_t kLutPerFrame = 4u;       // EntropyParams::fused_prefix bit 2: `lut` holds one table set per FRAME of the launch (kLutDeviceBytes apart)
 
 // k_gather_scans: the coded scans of one frame, collected behind a header of their lengths
 constexpr uint32_t kGatherMaxScans = 256;
@@ -83,7 +84,7 @@ struct EntropyParams {
     uint8_t *raw;                    // [frames][raw_stride]   unstuffed bits, every interval 16-byte aligned
     uint64_t raw_stride;             // bytes, multiple of 16
     uint32_t max_chunks;             // raw_stride / 16
-    uint32_t fused_prefix;           // no restart markers and bit 0: few runs / bit 1: few tiles - k_push / k_stuff add up the run lengths /
+    uint32_t fused_prefix;           // bit 2 (kLutPerFrame): per-frame code tables; no restart markers and bit 0: few runs / bit 1: few tiles - k_push / k_stuff add up the run lengths /
                                      // tile counts before their own themselves and the two prefix-sum launches are skipped
     uint32_t window_words;           // bit-packer runs up to this many words go through the LDS window (<= kPackWindowWords;
                                      // JPEGENC_PACK_WINDOW_WORDS lowers it so that tests reach the direct path)

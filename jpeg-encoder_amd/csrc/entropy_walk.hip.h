@@ -149,8 +149,9 @@ __device__ __forceinline__ BlockPlace place_of(Params p, uint32_t b) {
 // The code tables go to LDS in two steps: fetch (first in the load queue, so waiting for it waits for nothing
 // else), then the kernel requests its own data, then commit.  256 threads, 4 entries each.
 struct LutRegs { uint32_t v[4]; };
-__device__ __forceinline__ void lut_fetch(Params p, LutRegs &l) {
-    const hbm_word *src = (const hbm_word *)p.lut;
+__device__ __forceinline__ void lut_fetch(Params p, LutRegs &l, uint32_t frame) {
+    // (kLutPerFrame: a batch whose frames each have their own optimised tables - one table set per frame, kLutDeviceBytes apart)
+    const hbm_word *src = (const hbm_word *)p.lut + ((p.fused_prefix & kLutPerFrame) ? (size_t)frame * (kLutDeviceBytes / 4u) : (size_t)0);
 #pragma unroll
     for (int i = 0; i < 4; i++) l.v[i] = src[i * 256 + threadIdx.x];
 }

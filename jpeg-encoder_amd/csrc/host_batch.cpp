@@ -29,6 +29,12 @@ struct BatchRun {
     const PlaneBatch *const pb;
 
     Tables t;
+    // optimised Huffman tables (encoder.rs:1086-1200): every frame gets its own, in the SAME launches - the block kernel counts
+    // the symbols of all frames of a round, one host step per round builds the tables, and the coder reads frame f's table set
+    // (EntropyParams: kLutPerFrame).  Sixteen device-resident 4K I420 surfaces: 105 us per frame through one launch sequence
+    // each (eight workers), see profiles/r04_final_surfaces.jsonl for this path.
+    bool optimize = false;
+    std::vector<Tables> frame_tables;
     Mode mode = MODE_INTERLEAVED;
     int jct = 0, order = JPEGENC_ORDER_MCU;
     jpegenc_layout L;
@@ -44,6 +50,10 @@ struct BatchRun {
              int width_, int height_, int color_type_, jpegenc_write_fn sink_, void *const *users_, const PlaneBatch *pb_)
         : c(c_), ctx(ctx_), b(b_), device(device_), d_frames(d_frames_), frame_stride(frame_stride_), num_frames(num_frames_), width(width_),
           height(height_), color_type(color_type_), sink(sink_), users(users_), pb(pb_) {}
+    static int declined(const char *why) {             // the shared launches cannot take this batch: the caller goes frame by frame
+        if (getenv("JPEGENC_TRACE")) fprintf(stderr, "[jpegenc] batch: shared launches declined (%s)\n", why);
+        return kBatchNeedsPerFrame;
+    }
     void join(int slot) { for (auto &th : pools[slot]) th.join(); pools[slot].clear(); }
     ~BatchRun() { join(0); join(1); }                   // also on an early return
 
@@ -67,7 +77,9 @@ struct BatchRun {
         order = mode == MODE_INTERLEAVED ? JPEGENC_ORDER_MCU : JPEGENC_ORDER_PLANAR;
         rc = jpegenc_layout_init(&L, width, height, pb ? 100 + pb->jct : color_type, hs, vs, order);
         if (rc) return rc;
-
+        optimize = c.optimize && mode != MODE_INTERLEAVED;
+        if (optimize && L.total_blocks >= (1ull << 32)) return declined("too many blocks for the statistics");
+        if (optimize) frame_tables.assign((size_t)num_frames, t);
         return JPEGENC_OK;
     }
 
@@ -95,7 +107,7 @@ struct BatchRun {
         for (auto &j : jobs) {
             if (!j.sc.with_dc && j.sc.ac_end == j.sc.ac_start) continue;          // empty band: nothing to code
             j.cap = scan_max_bytes(L, j.sc);
-            if (!j.cap) return kBatchNeedsPerFrame;                               // (before any device work)
+            if (!j.cap) return declined("a scan the device coder does not take");   // (before any device work)
             j.off = out_total;
             out_total += j.cap;
         }
@@ -113,7 +125,10 @@ struct BatchRun {
         // copy out of pinned memory, ~as long as the round's download) while the GPU codes and delivers the next - what is
         // exposed is the first round's coding and the last round's assembly, so the rounds should be short (32 4K frames:
         // 42.4 Gpixel/s in four rounds, 44.1 in eight)
-        if (coeff_bytes >= ((size_t)4 << 20) && num_frames >= 8) {
+        // (per-frame optimised tables: every round has a host step the GPU waits for - few large rounds instead: 16 4K surfaces
+        //  98 us per frame in four rounds, see profiles/r04_final_surfaces.jsonl for one or two)
+        if (optimize) { if (per_round > 32) per_round = 32; }
+        else if (coeff_bytes >= ((size_t)4 << 20) && num_frames >= 8) {
             const int eighth = (num_frames + 7) / 8;
             if (eighth < per_round) per_round = std::min(per_round, eighth < 4 ? 4 : eighth);   // (never above the footprint / the caller's bound)
         }
@@ -122,12 +137,16 @@ struct BatchRun {
         for (auto &j : jobs) {
             if (!j.cap) continue;
             const size_t w = scan_workspace_size(L, j.sc, per_round);
-            if (!w) return kBatchNeedsPerFrame;
+            if (!w) return declined("scan workspace");
             if (w > ws) ws = w;
         }
         nlen = jobs.size() * (size_t)per_round;
         int rc = b.reserve(coeff_bytes * (size_t)per_round, out_total * (size_t)per_round, ws, nlen);
         if (rc) return rc;
+        if (optimize) {
+            rc = b.reserve_opt((size_t)per_round, (size_t)L.total_blocks, kLutDeviceBytes);
+            if (rc) return rc;
+        }
 
         jpegenc_huffman_spec specs[2][2];
         for (int d = 0; d < 2; d++)
@@ -163,22 +182,97 @@ struct BatchRun {
         const bool dense = !route_off && b.dense_geometry == ((uint64_t)width << 32 | (uint32_t)height) && b.dense_bits_per_block > DeviceCtx::kDenseBitsPerBlock;
         const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() && !dense &&
                            (pb ? fused_planes_supported(p, pb->planes, pb->subsampled) : fused_supported(p));
+        if (optimize) {                                  // the block kernel counts the symbols of every frame (host_frame.cpp does this for one)
+            p.hist_partials = (uint32_t *)b.d_opt_partials;
+            p.dc_side = (int16_t *)b.d_opt_dc;
+            p.hist_total_blocks = (uint32_t)L.total_blocks;
+            p.hist_band_mask = 0;
+            if (c.progressive_scans) {                                           // AC bands of encode_image_progressive (encoder.rs:1123-1134)
+                const int scans = c.progressive_scans - 1, per = 64 / scans;
+                for (int sidx = 1; sidx < scans; sidx++)
+                    if (sidx * per > 1 && sidx * per < 64) p.hist_band_mask |= 1ull << (sidx * per);
+            }
+            JPEGENC_HIP(hipMemsetAsync(b.d_opt_partials, 0, (size_t)n * BatchBuffers::kOptPartialsStride, ctx.stream));
+            JPEGENC_HIP(hipMemsetAsync(b.d_opt_freq, 0, (size_t)n * BatchBuffers::kOptFreqStride, ctx.stream));
+        }
         if (!fused) {
             hipError_t err = hipSuccess;
             if (pb) {
-                if (!launch_blocks_planes_once(p, pb->planes, pb->subsampled, n, c.fdct_variant, ctx.stream, &err)) return kBatchNeedsPerFrame;   // (sampling factors of 4)
+                if (!launch_blocks_planes_once(p, pb->planes, pb->subsampled, n, c.fdct_variant, ctx.stream, &err)) return declined("plane layout for one launch");   // (sampling factors of 4)
             } else if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) {
+                if (optimize) return declined("statistics need a tuned block kernel");   // (only the tuned kernels count symbols; nothing was launched: round 0)
                 err = launch_blocks_generic(p, n, c.fdct_variant, ctx.stream);
             }
             if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+        }
+        if (optimize) {
+            {
+                HistFinishParams hf;                                             // all frames of the round in one launch (grid.y)
+                memset(&hf, 0, sizeof hf);
+                hf.partials = (const uint32_t *)b.d_opt_partials;
+                hf.dc_side = (const int16_t *)b.d_opt_dc;
+                hf.freq = (uint32_t *)b.d_opt_freq;
+                hf.partials_frame_stride = BatchBuffers::kOptPartialsStride / sizeof(uint32_t);
+                hf.dc_frame_stride = L.total_blocks;
+                hf.freq_frame_stride = BatchBuffers::kOptFreqStride / sizeof(uint32_t);
+                hf.ncomp = L.num_components;
+                uint64_t off = 0;
+                for (int i = 0; i < L.num_components; i++) { hf.nblocks[i] = (uint32_t)L.blocks[i]; hf.comp_off[i] = off; off += L.blocks[i]; hf.table[i] = L.table[i]; }
+                const hipError_t he = launch_hist_finish(hf, ctx.stream, n);
+                if (he != hipSuccess) return hip_fail(he, "histogram finish kernel launch");
+            }
+            JPEGENC_HIP(hipMemcpyAsync(b.h_opt_freq, b.d_opt_freq, (size_t)n * BatchBuffers::kOptFreqStride, hipMemcpyDeviceToHost, ctx.stream));
+            static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));                        // the round's one host step: tables from the counts
+            const auto t1 = std::chrono::steady_clock::now();
+            // (Figure K.1 / K.2 per frame: ~20 us each - a round's worth on a few threads, the GPU waits for it)
+            const int max_tables = L.num_components < 2 ? L.num_components : 2;
+            std::atomic<int> next_frame(0), too_long(0);
+            auto build = [&]() {
+                for (;;) {
+                    const int f = next_frame.fetch_add(1);
+                    if (f >= n) break;
+                    Tables &tf = frame_tables[(size_t)(f0 + f)];
+                    const uint32_t *freq = (const uint32_t *)((const uint8_t *)b.h_opt_freq + (size_t)f * BatchBuffers::kOptFreqStride);
+                    for (int d = 0; d < max_tables; d++)
+                        for (int k = 0; k < 2; k++)
+                            if (!tf.h[d][k].assign_optimized(freq + (d * 2 + k) * 257)) too_long.store(1);
+                }
+            };
+            {
+                int nthreads = usable_cpus() - 1;
+                if (nthreads > 8) nthreads = 8;
+                if (nthreads > n / 2) nthreads = n / 2;
+                if (nthreads < 1) nthreads = 1;
+                if (b.helpers) b.helpers->run(nthreads, [&](int) { build(); });   // the handle's persistent threads
+                else build();
+            }
+            if (too_long.load()) return fail_code_too_long();
+            if (trace) fprintf(stderr, "[jpegenc] batch round of %d frames with their own tables: statistics on the host after %ld us, tables built in %ld us\n", n,
+                               (long)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count(),
+                               (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count());
+            for (int f = 0; f < n; f++) {
+                const Tables &tf = frame_tables[(size_t)(f0 + f)];
+                jpegenc_huffman_spec specs[2][2];
+                for (int d = 0; d < 2; d++)
+                    for (int k = 0; k < 2; k++) {
+                        memset(&specs[d][k], 0, sizeof specs[d][k]);
+                        memcpy(specs[d][k].bits, tf.h[d][k].bits, 16);
+                        memcpy(specs[d][k].values, tf.h[d][k].vals, (size_t)tf.h[d][k].nvals);
+                        specs[d][k].num_values = tf.h[d][k].nvals;
+                    }
+                const int rl = upload_huffman_luts(specs, (uint8_t *)b.d_opt_luts + (size_t)f * kLutDeviceBytes, ctx.stream);
+                if (rl) return rl;
+            }
         }
         uint32_t *d_len = b.d_len + (size_t)half * nlen;
         JPEGENC_HIP(hipMemsetAsync(d_len, 0, nlen * sizeof(uint32_t), ctx.stream));
         for (size_t k = 0; k < jobs.size(); k++) {
             const Job &j = jobs[k];
             if (!j.cap) continue;
-            e = scan_device(b.d_coeffs, L.total_blocks, n, L, j.sc, nullptr, ctx.d_lut, (uint8_t *)b.d_out + (size_t)half * round_out + j.off,
-                            out_total, d_len + k * (size_t)per_round, b.d_ws, ws, ctx.stream, nullptr, fused ? &fused_src : nullptr);
+            e = scan_device(b.d_coeffs, L.total_blocks, n, L, j.sc, nullptr, optimize ? b.d_opt_luts : ctx.d_lut, (uint8_t *)b.d_out + (size_t)half * round_out + j.off,
+                            out_total, d_len + k * (size_t)per_round, b.d_ws, ws, ctx.stream, nullptr, fused ? &fused_src : nullptr, optimize);
             if (e) return e;
         }
         JPEGENC_HIP(hipMemcpyAsync(b.h_len + (size_t)half * nlen, d_len, nlen * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
@@ -209,7 +303,7 @@ struct BatchRun {
             Out o;
             o.sink = sink; o.user = users[f0 + f];
             write_prologue(o, c, jct);
-            write_frame_header(o, c, width, height, L, t);
+            write_frame_header(o, c, width, height, L, optimize ? frame_tables[(size_t)(f0 + f)] : t);
             for (size_t k = 0; k < jobs.size(); k++) {
                 const Job &j = jobs[k];
                 write_scan_header(o, L, j.first, j.n, j.ss, j.se);
@@ -420,11 +514,11 @@ int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames
     if (width < 0 || height < 0 || width > 65535 || height > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "width/height must fit u16");
     if (width == 0 || height == 0) return fail(JPEGENC_ERR_ZERO_IMAGE_DIMENSIONS, "Image dimensions must be non zero");
     if (num_frames == 0) return JPEGENC_OK;
-    const bool per_frame_tables = e->cfg.optimize && select_mode(e->cfg) != MODE_INTERLEAVED;
-    if (!e->cfg.device_entropy || per_frame_tables) {
-        // host entropy coding was asked for, or every frame gets its own Huffman tables: one image at a time per worker
+    if (!e->cfg.device_entropy) {
+        // host entropy coding was asked for: one image at a time per worker
         return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
     }
+    e->batch.helpers = &e->threads;
     const int rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
     if (rc != kBatchNeedsPerFrame) return rc;
     return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
@@ -458,8 +552,10 @@ static int encode_planes_uniform(jpegenc_encoder *e, int jct, int width, int hei
         }
     JPEGENC_HIP(hipMemcpyAsync(e->batch.d_plane_table, table, (size_t)num_frames * 8 * sizeof(uint64_t), hipMemcpyHostToDevice, e->ctx.stream));
     const PlaneBatch pb = {rep, planes_subsampled, (const uint64_t *)e->batch.d_plane_table, jct};
+    e->batch.helpers = &e->threads;
     rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, nullptr, 0, num_frames, width, height, 0, sink, users, &pb, failed_frame);
     if (rc != kBatchNeedsPerFrame) return rc;
+    if (getenv("JPEGENC_TRACE")) fprintf(stderr, "[jpegenc] pool of %d surfaces: the shared launches declined, one launch sequence per frame\n", num_frames);
     return encode_planes_frames_pooled(e, jct, width, height, planes, num_frames, planes_subsampled, sink, users, failed_frame);
 }
 
@@ -487,8 +583,7 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
                 (((uintptr_t)pl.d_data ^ (uintptr_t)p0.d_data) & (uintptr_t)(pl.pixel_stride - 1)))
                 uniform = false;
         }
-    const bool per_frame_tables = e->cfg.optimize && select_mode(e->cfg) != MODE_INTERLEAVED;
-    const bool shareable = e->cfg.device_entropy && !per_frame_tables && hs != 4 && vs != 4;
+    const bool shareable = e->cfg.device_entropy && hs != 4 && vs != 4;      // (per-frame optimised tables share launches too: BatchRun)
     if (num_frames == 1) return jpegenc_encoder_encode_planes_device(e, jct, width, height, planes, planes_subsampled, sink, users[0]);
     if (!shareable) return encode_planes_frames_pooled(e, jct, width, height, planes, num_frames, planes_subsampled != 0, sink, users);
     if (uniform) {

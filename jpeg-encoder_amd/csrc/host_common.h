@@ -35,7 +35,7 @@ int build_block_params_planes(BlockKernelParams *p, const jpegenc_layout &L, int
 // block_kernels.hip
 hipError_t launch_blocks_generic(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream);
 hipError_t launch_histogram(const HistKernelParams &p, hipStream_t stream);
-hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream);
+hipError_t launch_hist_finish(const HistFinishParams &p, hipStream_t stream, int frames = 1);
 // fast_kernels.hip: returns false when the configuration has no specialised kernel
 bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant, hipStream_t stream,
                         hipError_t *err);
@@ -81,7 +81,7 @@ hipError_t launch_gather_scans(const GatherArgs &a, const void *d_src, const uin
 int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,
                 const jpegenc_scan &sc, const jpegenc_huffman_spec (*tables)[2], const void *d_lut, void *d_out,
                 size_t out_frame_stride, uint32_t *d_out_lengths, void *d_ws, size_t ws_bytes, hipStream_t st,
-                std::string *stored_params = nullptr, const FusedSource *fused = nullptr);
+                std::string *stored_params = nullptr, const FusedSource *fused = nullptr, bool lut_per_frame = false);
 // only fills and (unless `stored_params` says they are there) stores the scan's parameter blocks: what a replayed launch
 // sequence needs done outside of it
 int scan_store_params(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,

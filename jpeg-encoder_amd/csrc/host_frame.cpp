@@ -861,24 +861,25 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
         ctx.external_pixels = nullptr;
         return rc;
     }
-    // Batch workers and PAGEABLE frames: a plain hipMemcpyAsync from the caller's memory - the runtime page-locks the range in
-    // place, piece by piece, and the DMA engine reads the caller's pages - instead of a copy into the worker's own page-locked
-    // buffer first (rounds 2-3).  Measured in the pool (tools/diag/r04_quota.sh, profiles/r04_host_upload_paths.txt): 128 4K frames
-    // 17.4 Gpixel/s = 0.93 of the link against 15.2-15.7 staged, 1000 1080p frames 9 230 frames/s against 8 770-9 080; and the
-    // host's DRAM moves every frame byte ONCE (the DMA's read) instead of three times (read, streaming write, DMA read) - the
-    // resource eight ranks on one host run out of first.  The call blocks its worker while the frame crosses the
-    // link; the other workers' kernels and downloads overlap it, which is all the staging copy bought.
+    // Batch workers: a frame the caller has PAGE-LOCKED is uploaded where it lies (a true asynchronous DMA); a PAGEABLE frame is
+    // copied into this worker's page-locked buffer first (streaming stores, staging_copy) and uploaded from there.
+    // Round 4 measured the alternative - a plain hipMemcpyAsync from the caller's pageable memory, the runtime pinning the range
+    // piece by piece - as the faster one: 128 4K frames 18.4 against 17.0 Gpixel/s, 1000 1080p frames 9 240 against 9 110
+    // frames/s, and one DRAM move per frame byte instead of three (profiles/r04_host_upload_paths.txt).  It is not what ships:
+    // with eight workers inside the runtime's pageable-copy path at once the process dies with a SIGSEGV inside the runtime in 5
+    // of 8 runs of `rocprofv3 --kernel-trace -- python3 bench.py` (0 of 8 with one worker, 0 of 8 with the copies serialised - at
+    // -16 % - and 0 of 8 with the staging copy; never seen in ~1 500 unprofiled batches, profiles/r04_pageable_upload_crash.txt).
+    // Whoever's race that is, a library must not bring a profiled application down: the workers keep to page-locked sources.
+    // JPEGENC_IN_PLACE_UPLOADS=1 in the diagnostic build selects the in-place upload for measurements.
     // (Tried as well: hipHostRegister of the frame + async DMA + hipHostUnregister by the worker - one thread reaches 52 GB/s at
     // 119 us of CPU per 6.2 MB frame, csrc/tools/host_register_rates.cpp, but in the pool it is 3-5 % slower than the staging copy,
     // and it cannot tell a range the CALLER has partly registered from its own registration: not kept.)
-    // JPEGENC_STAGING_COPY=1 (diagnostic build): the staging copy.
-    static const bool always_stage = JPEGENC_DIAG_ENV("JPEGENC_STAGING_COPY") != nullptr;
-    // (a frame the caller has page-locked only in part - a registration that ends inside it - is staged: the runtime's own
-    // pinning of the range would replace the caller's registration of the same base address, and the caller's unregister fail)
+    static const bool in_place = JPEGENC_DIAG_ENV("JPEGENC_IN_PLACE_UPLOADS") != nullptr;
+    const bool caller_locked = staged && bytes && is_pinned_host((const uint8_t *)data) && is_pinned_host((const uint8_t *)data + bytes - 1);
+    // (a frame the caller has page-locked only in part - a registration that ends inside it - is staged like a pageable one)
     const bool partly_locked = staged && bytes && is_pinned_host((const uint8_t *)data) != is_pinned_host((const uint8_t *)data + bytes - 1);
     auto upload = [&](DeviceCtx &cx) -> int {
-        if (staged && !always_stage && !partly_locked) {
-            // (page-locked by the caller or pageable: either way the DMA engine reads the frame where it lies)
+        if (staged && (caller_locked || (in_place && !partly_locked))) {
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
         } else if (staged) {       // a copy into this worker's pinned buffer, then a true async DMA
             if (bytes > cx.h_pixels_cap) {
@@ -889,7 +890,7 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
             }
             staging_copy(cx.h_pixels, data, bytes);
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, cx.h_pixels, bytes, hipMemcpyHostToDevice, cx.stream));
-        } else {
+        } else {                   // (one image at a time on the caller's thread: the runtime's own path for pageable memory)
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
         }
         return JPEGENC_OK;

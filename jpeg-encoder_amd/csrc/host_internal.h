@@ -592,7 +592,9 @@ struct SmallBatchBuffers {
 
 // Buffers of the device-resident batch path (jpegenc_encoder_encode_batch_device), kept in the handle
 // across calls and only ever grown: pinned allocations of a few hundred MB cost tens of milliseconds.
+class WorkerThreads;
 struct BatchBuffers {
+    WorkerThreads *helpers = nullptr;     // the handle's persistent host threads (set by the batch entry points), for a round's host step
     void *d_coeffs = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_packed = nullptr;      // d_packed: a round's scans back to back
     uint64_t *d_pos = nullptr;
     uint32_t *d_len = nullptr, *h_len = nullptr;
@@ -618,6 +620,28 @@ struct BatchBuffers {
         JPEGENC_HIP(hipMalloc(&d_plane_table, bytes));
         JPEGENC_HIP(hipHostMalloc((void **)&h_plane_table, bytes, hipHostMallocDefault));
         plane_table_cap = bytes;
+        return JPEGENC_OK;
+    }
+    // Per-frame optimised Huffman tables in shared launches (BatchRun, host_batch.cpp): every frame of a round has its own
+    // statistics (AC partial histograms + DC side array, as DeviceCtx::d_hist / d_dc_side hold them for one frame), its
+    // frequency table on the host and its own table set on the device.
+    void *d_opt_partials = nullptr, *d_opt_freq = nullptr, *d_opt_dc = nullptr, *d_opt_luts = nullptr;
+    uint32_t *h_opt_freq = nullptr;
+    size_t opt_partials_cap = 0, opt_freq_cap = 0, opt_dc_cap = 0, opt_luts_cap = 0, h_opt_freq_cap = 0;
+    static constexpr size_t kOptFreqStride = 4352;                 // bytes per frame: [2][2][257] uint32 and padding (DeviceCtx::kHistFreqBytes)
+    static constexpr size_t kOptPartialsStride = (size_t)1024 * 2 * 256 * sizeof(uint32_t);   // kHistCopies partial tables per frame
+    int reserve_opt(size_t frames, size_t total_blocks, size_t lut_bytes) {
+        int rc = grow_device(&d_opt_partials, &opt_partials_cap, frames * kOptPartialsStride);
+        if (!rc) rc = grow_device(&d_opt_freq, &opt_freq_cap, frames * kOptFreqStride);
+        if (!rc) rc = grow_device(&d_opt_dc, &opt_dc_cap, frames * total_blocks * sizeof(int16_t));
+        if (!rc) rc = grow_device(&d_opt_luts, &opt_luts_cap, frames * lut_bytes);
+        if (rc) return rc;
+        if (frames * kOptFreqStride > h_opt_freq_cap) {
+            if (h_opt_freq) (void)hipHostFree(h_opt_freq);
+            h_opt_freq = nullptr; h_opt_freq_cap = 0;
+            JPEGENC_HIP(hipHostMalloc((void **)&h_opt_freq, frames * kOptFreqStride, hipHostMallocDefault));
+            h_opt_freq_cap = frames * kOptFreqStride;
+        }
         return JPEGENC_OK;
     }
     // d_out, d_len and h_len hold TWO rounds (halves): one is downloaded while the next is coded
@@ -664,6 +688,8 @@ struct BatchBuffers {
         if (d_packed) (void)hipFree(d_packed);
         if (d_plane_table) (void)hipFree(d_plane_table);
         if (h_plane_table) (void)hipHostFree(h_plane_table);
+        for (void *q : {d_opt_partials, d_opt_freq, d_opt_dc, d_opt_luts}) if (q) (void)hipFree(q);
+        if (h_opt_freq) (void)hipHostFree(h_opt_freq);
         if (d_pos) (void)hipFree(d_pos);
         if (d_len) (void)hipFree(d_len);
         if (h_len) (void)hipHostFree(h_len);

@@ -751,3 +751,45 @@ def test_planes_pool_that_cannot_share_launches_goes_through_the_worker_pool(bin
         assert rc == binding.ERR_WRITE and b"frame 13" in binding.lib().jpegenc_last_error()
         assert [bytes(g) for g in got[:13]] == want[:13]
         assert all(bytes(g) in (b"", want[k]) for k, g in enumerate(got) if k > 13)      # later frames: delivered whole or not at all
+
+
+@pytest.mark.parametrize("kw", [dict(quality=85, sampling=(2, 2), optimize=True), dict(quality=70, sampling=(2, 1), progressive_scans=5, optimize=True),
+                                dict(quality=92, sampling=(1, 1), optimize=True, restart_interval=11)],
+                         ids=["sequential", "progressive", "444-restart"])
+def test_pools_with_per_frame_optimised_tables_share_their_launches(binding, oracle, synth, kw):
+    """optimize_huffman_table gives every image its own tables (encoder.rs:1086-1200).  A pool of device-resident frames or
+    described surfaces still shares its launches: the block kernel counts the symbols of every frame of a round, one host step
+    builds the tables, the coder reads frame f's table set (EntropyParams: kLutPerFrame).  Frames with very different
+    statistics (noise, a gradient, flat) in rounds of 3 of 11: every file equals the oracle's for THAT frame."""
+    import torch
+    w, h, n = 328, 200, 11
+    hs, vs = kw["sampling"]
+    rng = np.random.default_rng(5)
+    frames, want, keep, surfaces = [], [], [], []
+    for f in range(n):
+        kind = f % 3
+        px = (rng.integers(0, 256, (h, w, 3), dtype=np.uint8) if kind == 0 else
+              synth.test_img_rgb(w, h) if kind == 1 else np.full((h, w, 3), 17 * f, dtype=np.uint8))
+        px = np.ascontiguousarray(np.roll(px, 5 * f, axis=1))
+        frames.append(px)
+        want.append(oracle.encode_jpeg(px, w, h, oracle.YCBCR, **kw))
+    d = torch.from_numpy(np.stack(frames)).cuda()
+
+    def enc():
+        e = binding.Encoder(kw["quality"])
+        e.set_sampling_factor(binding.sampling_factor(hs, vs))
+        if kw.get("progressive_scans"):
+            e.set_progressive_scans(kw["progressive_scans"])
+        if kw.get("restart_interval"):
+            e.set_restart_interval(kw["restart_interval"])
+        e.set_optimized_huffman_tables(True)
+        e.set_batch_round_frames(3)
+        return e
+    with enc() as e:
+        assert e.encode_batch_device(d.data_ptr(), w * h * 3, n, w, h, binding.YCBCR) == want
+        # the same frames as full-resolution planes of a pool of described surfaces
+        planar = torch.from_numpy(np.ascontiguousarray(np.stack(frames).transpose(0, 3, 1, 2))).cuda()
+        pool = [[(planar[f, c].data_ptr(), w, 1, 0) for c in range(3)] for f in range(n)]
+        assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, pool) == want
+        # and one at a time: same files
+        assert e.encode_device(d.data_ptr() + 4 * w * h * 3, w, h, binding.YCBCR) == want[4]

@@ -133,7 +133,7 @@ def main():
         e.close()
 
     planes_case("I420", b.F_2_2, sets["i420"])
-    planes_case("I420, optimised Huffman tables (per-frame tables: the pool of host workers, one launch sequence per frame)", b.F_2_2, sets["i420"], optimized=True)
+    planes_case("I420, optimised Huffman tables (every frame its own tables, in shared launches)", b.F_2_2, sets["i420"], optimized=True)
     mixed = [sets["nv12"][f] if f % 3 == 1 else sets["i420"][f] for f in range(N)]
     planes_case("I420 pool with NV12 frames in it (two layouts: the frames of each share their launches)", b.F_2_2, mixed)
     planes_case("NV12", b.F_2_2, sets["nv12"])

@@ -10,9 +10,9 @@ timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee "$out/pyte
 D=$PWD/jpeg-encoder_amd/libjpegenc_mi355x_diag.so
 for what in e2e4k c3; do
   runs=11; [ $what = c3 ] && runs=7
-  timeout 300 python tools/diag/e2e_spread.py --what $what --runs $runs --label "$what default: uploaded in place, pool sized by the quota" 2>&1 | grep -v amdgpu.ids | tee -a "$out/quota.jsonl"
-  JPEGENC_LIB=$D JPEGENC_STAGING_COPY=1 timeout 300 python tools/diag/e2e_spread.py --what $what --runs $runs --label "$what staging copy, pool sized by the quota" 2>&1 | grep -v amdgpu.ids | tee -a "$out/quota.jsonl"
-  JPEGENC_LIB=$D JPEGENC_STAGING_COPY=1 JPEGENC_SPIN_WAITS=1 JPEGENC_BATCH_WORKERS=16 timeout 300 python tools/diag/e2e_spread.py --what $what --runs $runs --label "$what round-3 behaviour: staging copy, 16 workers, spinning waits" 2>&1 | grep -v amdgpu.ids | tee -a "$out/quota.jsonl"
+  JPEGENC_LIB=$D JPEGENC_IN_PLACE_UPLOADS=1 timeout 300 python tools/diag/e2e_spread.py --what $what --runs $runs --label "$what uploaded in place (mid-round default; diagnostic switch now), pool sized by the quota" 2>&1 | grep -v amdgpu.ids | tee -a "$out/quota.jsonl"
+  JPEGENC_LIB=$D timeout 300 python tools/diag/e2e_spread.py --what $what --runs $runs --label "$what staging copy (what ships), pool sized by the quota" 2>&1 | grep -v amdgpu.ids | tee -a "$out/quota.jsonl"
+  JPEGENC_LIB=$D JPEGENC_SPIN_WAITS=1 JPEGENC_BATCH_WORKERS=16 timeout 300 python tools/diag/e2e_spread.py --what $what --runs $runs --label "$what round-3 behaviour: staging copy, 16 workers, spinning waits" 2>&1 | grep -v amdgpu.ids | tee -a "$out/quota.jsonl"
   for wk in 16 12 10 8 6 4 3 2; do
     JPEGENC_LIB=$D JPEGENC_BATCH_WORKERS=$wk timeout 300 python tools/diag/e2e_spread.py --what $what --runs $runs --label "$what uploaded in place, $wk workers" 2>&1 | grep -v amdgpu.ids | tee -a "$out/quota.jsonl"
   done
