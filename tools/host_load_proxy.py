@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """What does one rank's host side do when more ranks load the same two-socket host?  (one GPU is enough to ask)
 
-The 1000-frame batch of BASELINE config 3 is bound by the host on an 8-GPU node.  A round-3 rank STAGED its pageable
-frames - 16 worker threads, a read + a streaming write per frame byte, then the DMA engine's read: three DRAM moves per byte at
-53 GB/s of upload = 160 GB/s per rank, 8 x 160 against ~1.15 TB/s of DDR5.  A round-4 rank uploads the frames IN PLACE (the runtime
-pins them piece by piece): one DRAM move per byte, and 4 worker threads reach the rate 16 did (profiles/r04_host_upload_paths.txt).
+The 1000-frame batch of BASELINE config 3 is bound by the host on an 8-GPU node.  A rank STAGES its pageable
+frames - worker threads, a read + a streaming write per frame byte, then the DMA engine's read: three DRAM moves per byte at
+53 GB/s of upload = 160 GB/s per rank, 8 x 160 against ~1.15 TB/s of DDR5.  (Round 4 built the in-place upload - one DRAM move
+per byte - and withdrew it: profiles/r04_pageable_upload_crash.txt.  Frames the caller page-locked are uploaded in place.)
 This tool runs the REAL rank (the c3 batch through jpegenc_encoder_encode_batch_to_buffers on the one GPU of the box) next to
 K in {0, 1, 3, 7} GPU-less dummy ranks that move a rank's bytes through host memory with the library's own copy (jpegenc_host_copy):
-  * mode `in_place` (round-4 ranks): reads only, at the upload rate;
-  * mode `staging` (round-3 ranks): the staging copy, at 1.5 x the upload rate (read + write standing in for the three moves);
+  * mode `in_place` (ranks whose frames the caller page-locked): reads only, at the upload rate;
+  * mode `staging` (ranks fed pageable frames): the staging copy, at 1.5 x the upload rate (read + write standing in for the three moves);
 and reports the real rank's frames/s - pageable frames, its workers unbound and bound to the GPU's NUMA node - the dummies
 unbound or dealt round-robin onto the NUMA nodes, with the CPUs the whole job kept busy and the CFS periods it was throttled in.
 
