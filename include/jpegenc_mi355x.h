@@ -320,10 +320,12 @@ int  jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int
  * frame i -> sink(users[i], ...), one complete file each, each file's bytes in order (sink threading: see
  * jpegenc_encoder_encode_batch).  The device work of the whole batch
  * shares its launches (one fused block-encode launch, one launch sequence per scan for all frames);
- * only the compressed bytes come back.  With optimised Huffman tables (per-frame tables), the host
- * entropy coder, or frames too large for the device entropy coder (jpegenc_scan_max_bytes == 0: about
- * 2.45 M blocks and more) every frame takes the single-image path instead, up to 16 of them in flight on
- * as many host workers (each with its own stream and buffers) - same bytes either way. */
+ * only the compressed bytes come back.  Optimised Huffman tables are per frame (optimize_huffman_table,
+ * encoder.rs:1086-1200) and share the launches too: the block kernel counts the symbols of every frame of a
+ * round, one host step builds the tables, the coder reads frame i's table set.  With the host entropy coder,
+ * or frames too large for the device entropy coder (jpegenc_scan_max_bytes == 0: about 2.45 M blocks and
+ * more), every frame takes the single-image path instead, several of them in flight on the handle's worker
+ * threads (each with its own stream and buffers) - same bytes either way. */
 int  jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride,
                                          int num_frames, int width, int height, int color_type,
                                          jpegenc_write_fn sink, void *const *users);
@@ -399,11 +401,13 @@ int  jpegenc_packed_planes(int surface_format, const void *const *d_planes, cons
 /* A batch of such surfaces of one geometry (a decoder's or camera pipeline's frame pool): planes = num_frames x 4
  * descriptors, frame-major (frame f, component c at planes[4 * f + c]), the surfaces anywhere in device memory.  Frame
  * f -> sink(users[f], ...), one complete file each (sink threading: see jpegenc_encoder_encode_batch).  The device
- * work of the whole batch shares its launches as in jpegenc_encoder_encode_batch_device when the descriptors of each
- * component agree in pixel_stride, invert, shift and the byte they start at inside an interleaved group over the frames (address and pitch are per frame); otherwise - and with optimised Huffman tables, the
- * host entropy coder or sampling factors of 4 - every frame is its own launch sequence, sixteen of them in flight on a pool of host
- * threads (frames are handed out in order; a failing frame stops the hand-out, the frames before it are delivered, and the call
- * returns that frame's status with its index in jpegenc_last_error()).  Same bytes either way. */
+ * work of the whole batch shares its launches as in jpegenc_encoder_encode_batch_device (per-frame optimised tables
+ * included): frames whose descriptors agree, component by component, in pixel_stride, invert, shift and the byte they
+ * start at inside an interleaved group form one LAYOUT (address and pitch are per frame), and a pool that mixes layouts
+ * - NV12 surfaces among I420 ones - takes one set of launches per layout.  With the host entropy coder or sampling
+ * factors of 4 every frame is its own launch sequence, several of them in flight on the handle's worker threads.
+ * Errors: the call returns the status of the LOWEST failing frame with its index in jpegenc_last_error() ("frame K:
+ * ..."); every frame before it has been delivered whole, later ones whole or not at all.  Same bytes either way. */
 int  jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jpeg_color_type, int width, int height,
                                                 const jpegenc_plane *planes, int num_frames, int planes_subsampled,
                                                 jpegenc_write_fn sink, void *const *users);
