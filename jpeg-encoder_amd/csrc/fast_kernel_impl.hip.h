@@ -433,19 +433,19 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     __builtin_amdgcn_sched_barrier(0);
 #endif
 
-#if defined(JPEGENC_PROBE_MEMORY_ONLY) && JPEGENC_PROBE_MEMORY_ONLY == 5   // stores only
-    {
+    // (samples 2 or 4 bytes apart: the row loads below take whole pixels, up to 3 bytes past a block's last SAMPLE - inside the
+    //  plane everywhere but at the end of its last row, where that may be past the caller's allocation: the one block there takes
+    //  the clamped path)
+    const int row_guard = PLANES && lg_stride != 0u && me.y0 + 7 * syc >= hlim ? 1 : 0;
+#if defined(JPEGENC_PROBE_MEMORY_ONLY) && (JPEGENC_PROBE_MEMORY_ONLY == 5 || JPEGENC_PROBE_MEMORY_ONLY == 6)   // 5: stores only; 6: chroma waves load nothing
+    {                                                                     // (6 = the ceiling of a kernel whose chroma waves shared their pixels with the luma waves)
 #pragma unroll
         for (int y = 0; y < 8; y++)
 #pragma unroll
             for (int i = 0; i < 4; i++) rows[y][i] = lane * 33u + y * 4u + i;
     }
-    if (false)
+    if (JPEGENC_PROBE_MEMORY_ONLY == 6 && role == ROLE_Y)
 #endif
-    // (samples 2 or 4 bytes apart: the row loads below take whole pixels, up to 3 bytes past a block's last SAMPLE - inside the
-    //  plane everywhere but at the end of its last row, where that may be past the caller's allocation: the one block there takes
-    //  the clamped path)
-    const int row_guard = PLANES && lg_stride != 0u && me.y0 + 7 * syc >= hlim ? 1 : 0;
     if (me.x0 + 8 * sxc + row_guard <= width) {
         if (CONV && BPP == 2) {                                     // 16-bit r5 g6 b5 pixels: unpacked, then converted like Rgb
             const uint32_t rs = Wv[12] & 0xFFu, bs = (Wv[12] >> 8) & 0xFFu;
