@@ -47,6 +47,49 @@ __global__ void __launch_bounds__(1024) k_build_lut(const LutSpecs specs, uint32
 }
 static_assert(kLoopLutBytes == kLutCompactBytes, "entropy_params.h sizes the compact tables");
 
+// The same for a batch whose frames each have their own tables (per-frame optimised Huffman tables in shared launches,
+// host_batch.cpp): workgroup f builds frame f's table set from specs[f] in device memory - one launch instead of one per frame
+// (1 024 thumbnails: 5 ms of launches).
+__global__ void __launch_bounds__(1024) k_build_lut_batch(const LutSpecs *specs, uint32_t *luts) {
+    const uint32_t id = threadIdx.x >> 8, k = threadIdx.x & 255u;
+    uint32_t *lut = luts + (size_t)blockIdx.x * (kLutDeviceBytes / 4u);
+    const uint8_t *s = reinterpret_cast<const uint8_t *>(specs + blockIdx.x) + id * sizeof(jpegenc_huffman_spec);
+    lut[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t num_values = *reinterpret_cast<const uint32_t *>(s + __builtin_offsetof(jpegenc_huffman_spec, num_values));
+    if (k < num_values) {
+        uint32_t code = 0, first = 0;
+#pragma unroll
+        for (uint32_t len = 1; len <= 16; len++) {
+            const uint32_t n = s[__builtin_offsetof(jpegenc_huffman_spec, bits) + len - 1];
+            if (k < first + n) {
+                const uint32_t sym = s[__builtin_offsetof(jpegenc_huffman_spec, values) + k];
+                lut[id * 256u + sym] = (len << 16) | (code + (k - first));
+                break;
+            }
+            code = (code + n) << 1;
+            first += n;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kLoopLutEntries)
+        reinterpret_cast<u32x2 *>(lut + kLutWords)[threadIdx.x] = loop_lut_entry(threadIdx.x, lut[loop_lut_source(threadIdx.x)]);
+}
+size_t huffman_lut_batch_spec_bytes() { return sizeof(LutSpecs); }
+// h_specs: page-locked, frames x huffman_lut_batch_spec_bytes(), filled by fill_huffman_lut_spec; d_specs / d_luts: device
+void fill_huffman_lut_spec(void *h_specs, int frame, const jpegenc_huffman_spec (*tables)[2]) {
+    LutSpecs &dst = reinterpret_cast<LutSpecs *>(h_specs)[frame];
+    for (int d = 0; d < 2; d++)
+        for (int c = 0; c < 2; c++) dst.t[d][c] = tables[d][c];
+}
+int upload_huffman_luts_batch(const void *h_specs, void *d_specs, void *d_luts, int frames, hipStream_t st) {
+    JPEGENC_HIP(hipMemcpyAsync(d_specs, h_specs, (size_t)frames * sizeof(LutSpecs), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_build_lut_batch, dim3((unsigned)frames), dim3(1024), 0, st, (const LutSpecs *)d_specs, (uint32_t *)d_luts);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_build_lut_batch");
+    return JPEGENC_OK;
+}
+
 struct ScanPlan {
     uint32_t max_blocks, max_chunks, max_tiles, max_waves, max_fftiles, slot_words;
     uint64_t raw_stride;

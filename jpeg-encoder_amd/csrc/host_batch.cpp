@@ -127,7 +127,10 @@ struct BatchRun {
         // 42.4 Gpixel/s in four rounds, 44.1 in eight)
         // (per-frame optimised tables: every round has a host step the GPU waits for - few large rounds instead: 16 4K surfaces
         //  98 us per frame in four rounds, see profiles/r04_final_surfaces.jsonl for one or two)
-        if (optimize) { if (per_round > 32) per_round = 32; }
+        if (optimize) {                                                        // (2 MiB of partial histograms per frame of a round: at most 512 MiB)
+            const int cap = coeff_bytes >= ((size_t)4 << 20) ? 32 : 256;
+            if (per_round > cap) per_round = cap;
+        }
         else if (coeff_bytes >= ((size_t)4 << 20) && num_frames >= 8) {
             const int eighth = (num_frames + 7) / 8;
             if (eighth < per_round) per_round = std::min(per_round, eighth < 4 ? 4 : eighth);   // (never above the footprint / the caller's bound)
@@ -144,7 +147,7 @@ struct BatchRun {
         int rc = b.reserve(coeff_bytes * (size_t)per_round, out_total * (size_t)per_round, ws, nlen);
         if (rc) return rc;
         if (optimize) {
-            rc = b.reserve_opt((size_t)per_round, (size_t)L.total_blocks, kLutDeviceBytes);
+            rc = b.reserve_opt((size_t)per_round, (size_t)L.total_blocks, kLutDeviceBytes, huffman_lut_batch_spec_bytes());
             if (rc) return rc;
         }
 
@@ -252,6 +255,7 @@ struct BatchRun {
             if (trace) fprintf(stderr, "[jpegenc] batch round of %d frames with their own tables: statistics on the host after %ld us, tables built in %ld us\n", n,
                                (long)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count(),
                                (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count());
+            // (the specs of round r - 1 have been consumed: this stream was synchronised above)
             for (int f = 0; f < n; f++) {
                 const Tables &tf = frame_tables[(size_t)(f0 + f)];
                 jpegenc_huffman_spec specs[2][2];
@@ -262,9 +266,10 @@ struct BatchRun {
                         memcpy(specs[d][k].values, tf.h[d][k].vals, (size_t)tf.h[d][k].nvals);
                         specs[d][k].num_values = tf.h[d][k].nvals;
                     }
-                const int rl = upload_huffman_luts(specs, (uint8_t *)b.d_opt_luts + (size_t)f * kLutDeviceBytes, ctx.stream);
-                if (rl) return rl;
+                fill_huffman_lut_spec(b.h_opt_specs, f, specs);
             }
+            const int rl = upload_huffman_luts_batch(b.h_opt_specs, b.d_opt_specs, b.d_opt_luts, n, ctx.stream);      // one copy, one launch
+            if (rl) return rl;
         }
         uint32_t *d_len = b.d_len + (size_t)half * nlen;
         JPEGENC_HIP(hipMemsetAsync(d_len, 0, nlen * sizeof(uint32_t), ctx.stream));
@@ -650,8 +655,10 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     // round overlaps the encoding of the current one.
     const size_t frame_bytes = (size_t)width * (size_t)height * (size_t)jpegenc_bytes_per_pixel(color_type);
     static const bool small_off = JPEGENC_DIAG_ENV("JPEGENC_NO_SMALL_BATCH") != nullptr;
+    // (per-frame optimised tables ride along: the device-resident batch path builds them round by round)
+    static const bool small_opt_off = JPEGENC_DIAG_ENV("JPEGENC_NO_SMALL_BATCH_OPTIMISED") != nullptr;     // diagnosis: such batches through one launch sequence per frame
     const bool per_frame_tables = e->cfg.optimize && select_mode(e->cfg) != MODE_INTERLEAVED;
-    if (!small_off && frame_bytes <= ((size_t)2 << 20) && num_frames >= 16 && e->cfg.device_entropy && !per_frame_tables) {
+    if (!small_off && frame_bytes <= ((size_t)2 << 20) && num_frames >= 16 && e->cfg.device_entropy && !(per_frame_tables && small_opt_off)) {
         for (int i = 0; i < num_frames; i++)
             if (!frames[i]) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
         static const size_t round_mb = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_SMALL_BATCH_ROUND_MB"); return v && atoi(v) > 0 ? (size_t)atoi(v) : (size_t)64; }();   // (diagnostic sweep)
@@ -717,7 +724,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
-    const bool staged = true;      // batch frames: uploaded by the worker (in place; host_frame.cpp encode_pixels), never read by the kernel over the link
+    const bool staged = true;      // batch frames: uploaded by the worker (through its page-locked staging, or in place where the caller page-locked them), never read by the kernel over the link
     auto body = [&](int w) {
         if (w > 0) bind_thread_near_device(e->device, e->numa_bind);   // (opt-in) spawned workers; the caller's own affinity is left alone
         DeviceCtx &ctx = *e->workers[(size_t)w];

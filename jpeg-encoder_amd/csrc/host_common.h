@@ -95,6 +95,10 @@ struct ScanJob {                 // one scan of scan_device_multi
 int scan_device_multi(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L, const ScanJob *jobs,
                       int njobs, const void *d_lut, hipStream_t st);
 int upload_huffman_luts(const jpegenc_huffman_spec (*tables)[2], void *d_lut, hipStream_t st);
+// one table set per frame of a batch in one launch (h_specs page-locked: frames x huffman_lut_batch_spec_bytes())
+size_t huffman_lut_batch_spec_bytes();
+void fill_huffman_lut_spec(void *h_specs, int frame, const jpegenc_huffman_spec (*tables)[2]);
+int upload_huffman_luts_batch(const void *h_specs, void *d_specs, void *d_luts, int frames, hipStream_t st);
 size_t scan_workspace_size(const jpegenc_layout &L, const jpegenc_scan &sc, int frames);
 size_t scan_max_bytes(const jpegenc_layout &L, const jpegenc_scan &sc);
 

@@ -625,17 +625,25 @@ struct BatchBuffers {
     // Per-frame optimised Huffman tables in shared launches (BatchRun, host_batch.cpp): every frame of a round has its own
     // statistics (AC partial histograms + DC side array, as DeviceCtx::d_hist / d_dc_side hold them for one frame), its
     // frequency table on the host and its own table set on the device.
-    void *d_opt_partials = nullptr, *d_opt_freq = nullptr, *d_opt_dc = nullptr, *d_opt_luts = nullptr;
+    void *d_opt_partials = nullptr, *d_opt_freq = nullptr, *d_opt_dc = nullptr, *d_opt_luts = nullptr, *d_opt_specs = nullptr;
     uint32_t *h_opt_freq = nullptr;
-    size_t opt_partials_cap = 0, opt_freq_cap = 0, opt_dc_cap = 0, opt_luts_cap = 0, h_opt_freq_cap = 0;
+    void *h_opt_specs = nullptr;
+    size_t opt_partials_cap = 0, opt_freq_cap = 0, opt_dc_cap = 0, opt_luts_cap = 0, opt_specs_cap = 0, h_opt_freq_cap = 0, h_opt_specs_cap = 0;
     static constexpr size_t kOptFreqStride = 4352;                 // bytes per frame: [2][2][257] uint32 and padding (DeviceCtx::kHistFreqBytes)
     static constexpr size_t kOptPartialsStride = (size_t)1024 * 2 * 256 * sizeof(uint32_t);   // kHistCopies partial tables per frame
-    int reserve_opt(size_t frames, size_t total_blocks, size_t lut_bytes) {
+    int reserve_opt(size_t frames, size_t total_blocks, size_t lut_bytes, size_t spec_bytes) {
         int rc = grow_device(&d_opt_partials, &opt_partials_cap, frames * kOptPartialsStride);
         if (!rc) rc = grow_device(&d_opt_freq, &opt_freq_cap, frames * kOptFreqStride);
         if (!rc) rc = grow_device(&d_opt_dc, &opt_dc_cap, frames * total_blocks * sizeof(int16_t));
         if (!rc) rc = grow_device(&d_opt_luts, &opt_luts_cap, frames * lut_bytes);
+        if (!rc) rc = grow_device(&d_opt_specs, &opt_specs_cap, frames * spec_bytes);
         if (rc) return rc;
+        if (frames * spec_bytes > h_opt_specs_cap) {
+            if (h_opt_specs) (void)hipHostFree(h_opt_specs);
+            h_opt_specs = nullptr; h_opt_specs_cap = 0;
+            JPEGENC_HIP(hipHostMalloc(&h_opt_specs, frames * spec_bytes, hipHostMallocDefault));
+            h_opt_specs_cap = frames * spec_bytes;
+        }
         if (frames * kOptFreqStride > h_opt_freq_cap) {
             if (h_opt_freq) (void)hipHostFree(h_opt_freq);
             h_opt_freq = nullptr; h_opt_freq_cap = 0;
@@ -688,8 +696,9 @@ struct BatchBuffers {
         if (d_packed) (void)hipFree(d_packed);
         if (d_plane_table) (void)hipFree(d_plane_table);
         if (h_plane_table) (void)hipHostFree(h_plane_table);
-        for (void *q : {d_opt_partials, d_opt_freq, d_opt_dc, d_opt_luts}) if (q) (void)hipFree(q);
+        for (void *q : {d_opt_partials, d_opt_freq, d_opt_dc, d_opt_luts, d_opt_specs}) if (q) (void)hipFree(q);
         if (h_opt_freq) (void)hipHostFree(h_opt_freq);
+        if (h_opt_specs) (void)hipHostFree(h_opt_specs);
         if (d_pos) (void)hipFree(d_pos);
         if (d_len) (void)hipFree(d_len);
         if (h_len) (void)hipHostFree(h_len);
