@@ -560,7 +560,7 @@ def test_randomised_planar_sources(binding, oracle, synth):
         if rng.integers(0, 3) == 0:
             kw["restart_interval"] = int(rng.integers(1, 40))
         variant = oracle.FDCT_SIMD if rng.integers(0, 4) == 0 else oracle.FDCT_SCALAR
-        nframes = int(rng.integers(1, 4))
+        nframes = int(rng.integers(1, 6))
         cw, ch = (-(-w // hs), -(-h // vs)) if subsampled else (w, h)
         e = binding.Encoder(kw["quality"])
         e.set_sampling_factor(binding.sampling_factor(hs, vs))
@@ -574,8 +574,12 @@ def test_randomised_planar_sources(binding, oracle, synth):
             e.set_fdct_variant(binding.FDCT_SIMD)
         ypad, cpad = int(rng.integers(0, 40)), int(rng.integers(0, 9))
         mixed_pitches = bool(rng.integers(0, 2))                      # a pool whose surfaces differ in pitch (per-frame pitch table)
+        nv12_allowed = subsampled or (hs < 4 and vs < 4)
+        mixed_layouts = nv12_allowed and rng.integers(0, 4) == 0        # ... and in layout: NV12 surfaces among I420 ones (one set of launches per layout)
         frames, want, keep, full_list = [], [], [], []
         for f in range(nframes):
+            if mixed_layouts:
+                nv12 = bool(rng.integers(0, 2))
             if mixed_pitches and f:
                 ypad, cpad = int(rng.integers(0, 40)), int(rng.integers(0, 9))
             noisy = trial % 3 != 0
