@@ -778,7 +778,7 @@ def main():
                                          "upload_GBps_per_batch": [round(n * frame_bytes / t / 1e9, 1) for t in times],
                                          "what": "pageable host RGB (Criterion pattern) -> JPEG bytes in host buffers: "
                                                  "H2D + fused kernel + device entropy coding + D2H of compressed bytes, "
-                                                 f"{n} frames per batch, {len(times)} timed batches after two warm-up batches, one GPU, up to 16 host threads of {os.cpu_count()}",
+                                                 f"{n} frames per batch, {len(times)} timed batches after two warm-up batches, one GPU, {len(enc.batch_worker_info()) or 8} batch workers (pageable frames through their page-locked staging) on a host of {os.cpu_count()} hardware threads",
                                          "jpeg_bytes_per_frame": int(sum(lens) / n),
                                          "placement": placement(hostinfo, enc, arrs[:args.e2e_frames], outs, gpu_node),
                                          "roofline": pcie_roofline("pcie_h2d", n * frame_bytes, dt, link),
