@@ -17,6 +17,8 @@ run large JPEGENC_FUZZ_SEED=$((S + 3)) JPEGENC_FUZZ_TRIALS=1500 JPEGENC_FUZZ_MAX
 # (the switches below exist in the diagnostic build only: diag_env.h)
 DIAG=$PWD/jpeg-encoder_amd/libjpegenc_mi355x_diag.so
 run two_kernels JPEGENC_LIB=$DIAG JPEGENC_FUSED=0 JPEGENC_FUZZ_SEED=$((S + 4)) JPEGENC_FUZZ_TRIALS=6000
+# 4:4:4 frames of the RGB family through the general block kernel (three waves per 64 MCUs) instead of k_blocks_444
+run general_444_kernel JPEGENC_LIB=$DIAG JPEGENC_NO_TRIO=1 JPEGENC_FUZZ_SEED=$((S + 14)) JPEGENC_FUZZ_TRIALS=6000
 run dma_only JPEGENC_LIB=$DIAG JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES=0 JPEGENC_ZERO_COPY_IN_MAX_PIXEL_BYTES=0 JPEGENC_FUZZ_SEED=$((S + 6)) JPEGENC_FUZZ_TRIALS=6000
 # the pixels -> bits kernel's second walk (runs coded again chunk by chunk out of the LDS images): every workgroup takes it with a
 # window of 8 words per wave, chunks of 8 x bpm words
