@@ -183,10 +183,13 @@ __global__ void __launch_bounds__(256) k_hist_finish(HistFinishParams p) {
     __syncthreads();
     constexpr uint32_t per = kHistCopies / kHistFinishGroups;
     uint32_t n0 = 0, n1 = 0;                            // bins threadIdx.x and threadIdx.x + 256 of this group's partials: all loads up front
+    const uint32_t copies = p.copies > 0 ? (uint32_t)p.copies : kHistCopies;      // (the rest was neither cleared nor written)
 #pragma unroll
     for (uint32_t k = 0; k < per; k++) {
-        const uint32_t *src = p.partials + ((size_t)blockIdx.x * per + k) * 512u;
-        n0 += src[threadIdx.x]; n1 += src[threadIdx.x + 256u];
+        if (blockIdx.x * per + k < copies) {
+            const uint32_t *src = p.partials + ((size_t)blockIdx.x * per + k) * 512u;
+            n0 += src[threadIdx.x]; n1 += src[threadIdx.x + 256u];
+        }
     }
     if (n0) atomicAdd(&p.freq[257u + threadIdx.x], n0);                // table 0, AC
     if (n1) atomicAdd(&p.freq[514u + 257u + threadIdx.x], n1);         // table 1, AC

@@ -104,6 +104,8 @@ struct BlockKernelParams {
     int16_t *dc_side;                 // [frame][total planar blocks] DC of every block
     uint64_t hist_band_mask;          // bit k (2..63): a progressive AC band starts at zig-zag position k (encoder.rs:1123-1134)
     uint32_t hist_total_blocks;       // planar blocks per frame (stride of dc_side)
+    uint32_t hist_copy_mask;          // partial histograms a frame's waves use, minus 1: a power of two up to kHistCopies (small frames have few waves: only
+                                      // what is used has to be cleared and summed); frame f's partials start f * (hist_copy_mask + 1) partials behind frame 0's
     // One launch per component plane of a device-resident planar source (jpegenc_encoder_encode_planes_device): only the
     // waves of the components in comp_mask (0 = all), reading `pixels` as that plane with its own pitch; a plane that is
     // already decimated has its own MCU size in plane samples.
@@ -133,7 +135,7 @@ struct HistFinishParams {
     const uint32_t *partials;         // [kHistCopies][2][256]
     const int16_t *dc_side;           // planar-order DC values of ONE frame
     uint32_t *freq;                   // [2][2][257], zeroed by the caller
-    int32_t ncomp, reserved;
+    int32_t ncomp, copies;            // copies: partial histograms in use (hist_copy_mask + 1); 0 = all kHistCopies
     uint32_t nblocks[4];
     uint64_t comp_off[4];
     int32_t table[4];

@@ -558,8 +558,8 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
     const bool sub = (w.bits >> FW_SUB_SHIFT) & 1u;
 #endif
     if (p.hist_partials && order != 0) {                                         // wave-uniform: optimised-Huffman statistics
-        const uint32_t wave_id = (grp * (blockDim.x >> 6) + wave) & (kHistCopies - 1u);
-        uint32_t *partial = p.hist_partials + (((size_t)frm * kHistCopies + wave_id) * 2u + (uint32_t)qsel) * 256u;
+        const uint32_t wave_id = (grp * (blockDim.x >> 6) + wave) & p.hist_copy_mask;
+        uint32_t *partial = p.hist_partials + (((size_t)frm * (p.hist_copy_mask + 1u) + wave_id) * 2u + (uint32_t)qsel) * 256u;
         ac_histogram(packed, inside, smem + wave * kStageBytes, lane, p.hist_band_mask, partial);
         if (inside) {
             const uint32_t bx = (ux << lg) + sub_k, by = (uy << lgv) + vrow;

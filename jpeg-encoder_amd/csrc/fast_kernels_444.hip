@@ -49,8 +49,8 @@ __device__ __forceinline__ void trio_component(const BlockKernelParams &p, uint8
     bool in_plane = inside;
     if (order != 0) in_plane = in_plane && ux < Wv[2] && uy < Wv[13];
     if (p.hist_partials && order != 0) {                                        // wave-uniform: optimised-Huffman statistics
-        const uint32_t wave_id = (grp * 3u + (uint32_t)c) & (kHistCopies - 1u);
-        uint32_t *partial = p.hist_partials + (((size_t)frm * kHistCopies + wave_id) * 2u + (uint32_t)w.qsel) * 256u;
+        const uint32_t wave_id = (grp * 3u + (uint32_t)c) & p.hist_copy_mask;
+        uint32_t *partial = p.hist_partials + (((size_t)frm * (p.hist_copy_mask + 1u) + wave_id) * 2u + (uint32_t)w.qsel) * 256u;
         ac_histogram(packed, in_plane, stage, lane, p.hist_band_mask, partial);
         if (in_plane) {
             const uint64_t comp_off = ((uint64_t)Wv[8] << 32) | Wv[7];

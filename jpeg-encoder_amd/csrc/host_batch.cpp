@@ -189,13 +189,15 @@ struct BatchRun {
             p.hist_partials = (uint32_t *)b.d_opt_partials;
             p.dc_side = (int16_t *)b.d_opt_dc;
             p.hist_total_blocks = (uint32_t)L.total_blocks;
+            p.hist_copy_mask = DeviceCtx::hist_copies(L.total_blocks) - 1u;
             p.hist_band_mask = 0;
             if (c.progressive_scans) {                                           // AC bands of encode_image_progressive (encoder.rs:1123-1134)
                 const int scans = c.progressive_scans - 1, per = 64 / scans;
                 for (int sidx = 1; sidx < scans; sidx++)
                     if (sidx * per > 1 && sidx * per < 64) p.hist_band_mask |= 1ull << (sidx * per);
             }
-            JPEGENC_HIP(hipMemsetAsync(b.d_opt_partials, 0, (size_t)n * BatchBuffers::kOptPartialsStride, ctx.stream));
+            // (only the partials the frames' waves use: copies x 2 KiB per frame, back to back)
+            JPEGENC_HIP(hipMemsetAsync(b.d_opt_partials, 0, (size_t)n * (p.hist_copy_mask + 1u) * 2048u, ctx.stream));
             JPEGENC_HIP(hipMemsetAsync(b.d_opt_freq, 0, (size_t)n * BatchBuffers::kOptFreqStride, ctx.stream));
         }
         if (!fused) {
@@ -215,10 +217,11 @@ struct BatchRun {
                 hf.partials = (const uint32_t *)b.d_opt_partials;
                 hf.dc_side = (const int16_t *)b.d_opt_dc;
                 hf.freq = (uint32_t *)b.d_opt_freq;
-                hf.partials_frame_stride = BatchBuffers::kOptPartialsStride / sizeof(uint32_t);
+                hf.partials_frame_stride = (uint64_t)(p.hist_copy_mask + 1u) * 512u;
                 hf.dc_frame_stride = L.total_blocks;
                 hf.freq_frame_stride = BatchBuffers::kOptFreqStride / sizeof(uint32_t);
                 hf.ncomp = L.num_components;
+                hf.copies = (int32_t)(p.hist_copy_mask + 1u);
                 uint64_t off = 0;
                 for (int i = 0; i < L.num_components; i++) { hf.nblocks[i] = (uint32_t)L.blocks[i]; hf.comp_off[i] = off; off += L.blocks[i]; hf.table[i] = L.table[i]; }
                 const hipError_t he = launch_hist_finish(hf, ctx.stream, n);

@@ -363,6 +363,7 @@ struct FrameRun {
                 p.hist_partials = (uint32_t *)((uint8_t *)ctx.d_hist + DeviceCtx::kHistFreqBytes);
                 p.dc_side = (int16_t *)ctx.d_dc_side;
                 p.hist_total_blocks = (uint32_t)L.total_blocks;
+                p.hist_copy_mask = DeviceCtx::hist_copies(L.total_blocks) - 1u;
                 p.hist_band_mask = 0;
                 if (c.progressive_scans) {                                   // AC bands of encode_image_progressive (encoder.rs:1123-1134)
                     const int scans = c.progressive_scans - 1, per = 64 / scans;
@@ -373,7 +374,7 @@ struct FrameRun {
         }
         if (enqueue && !fused) {
             hipError_t err = hipSuccess;
-            if (p.hist_partials) JPEGENC_HIP(hipMemsetAsync(ctx.d_hist, 0, DeviceCtx::kHistBytes, ctx.stream));
+            if (p.hist_partials) JPEGENC_HIP(hipMemsetAsync(ctx.d_hist, 0, DeviceCtx::kHistFreqBytes + (size_t)(p.hist_copy_mask + 1u) * 2048u, ctx.stream));
             if (ctx.external_planes) {
                 err = launch_blocks_planes(p, ctx.external_planes, ctx.external_planes_subsampled, c.fdct_variant, ctx.stream);
                 if (err == hipErrorInvalidValue) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane layout not supported on the device (pixel stride 2 with a sampling factor of 4, or a plane of 2 GiB)");
@@ -391,6 +392,7 @@ struct FrameRun {
                 HistFinishParams hf;
                 memset(&hf, 0, sizeof hf);
                 hf.partials = p.hist_partials; hf.dc_side = p.dc_side; hf.freq = (uint32_t *)ctx.d_hist; hf.ncomp = L.num_components;
+                hf.copies = (int32_t)(p.hist_copy_mask + 1u);
                 uint64_t off = 0;
                 for (int i = 0; i < L.num_components; i++) {
                     hf.nblocks[i] = (uint32_t)L.blocks[i]; hf.comp_off[i] = off; off += L.blocks[i]; hf.table[i] = L.table[i];

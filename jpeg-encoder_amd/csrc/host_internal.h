@@ -300,6 +300,13 @@ struct DeviceCtx {
     void *d_hist = nullptr, *d_dc_side = nullptr;
     size_t d_dc_side_cap = 0;
     static constexpr size_t kHistFreqBytes = 4352, kHistBytes = kHistFreqBytes + (size_t)kHistCopies * 2 * 256 * sizeof(uint32_t);
+    // partial histograms a frame of `total_blocks` blocks spreads its waves' counts over: one per wave where that is fewer than
+    // kHistCopies (a 256x256 frame has 48 waves: clearing and summing 1 024 partials of 2 KiB was most of its statistics' cost)
+    static uint32_t hist_copies(uint64_t total_blocks) {
+        uint32_t c = 64;
+        while (c < kHistCopies && (uint64_t)c * 64u < total_blocks + 1024u) c <<= 1;
+        return c;
+    }
     const void *external_pixels = nullptr;   // device-resident input: use the caller's buffer, no upload
     const jpegenc_plane *external_planes = nullptr;   // device-resident planar input (jpegenc_encoder_encode_planes_device)
     bool external_planes_subsampled = false;
