@@ -156,6 +156,23 @@ def raw():
                 b.blocks_device(g_px, w * h * bpp, n, w, h, ct, hs, vs, q, order, variant, g_co, nblk)
                 torch.cuda.synchronize()
                 assert r_co.download(g_co, n * nblk * 128).tobytes() == want, ("blocks", ct, w, h, order, variant)
+        # symbol statistics of the planar-order coefficients (jpegenc_histogram_device): coefficients and the [2][2][257] table both
+        # end where their mappings end
+        Lp = b.layout(w, h, ct, hs, vs, b.ORDER_PLANAR)
+        nblk_p = int(Lp.total_blocks)
+        d_px1 = torch.from_numpy(px[:1]).cuda()
+        d_co1 = torch.zeros(nblk_p * 64, dtype=torch.int16, device="cuda")
+        b.blocks_device(d_px1.data_ptr(), w * h * bpp, 1, w, h, ct, hs, vs, b.qtables(90), b.ORDER_PLANAR, b.FDCT_SCALAR, d_co1.data_ptr(), nblk_p)
+        torch.cuda.synchronize()
+        for scans in (0, 4):
+            d_fr = torch.zeros(2 * 2 * 257, dtype=torch.int32, device="cuda")
+            b.histogram_device(d_co1.data_ptr(), Lp, scans, d_fr.data_ptr(), 0)
+            torch.cuda.synchronize()
+            g_c, g_f = r_co.tail(nblk_p * 128), r_len.tail(2 * 2 * 257 * 4)
+            r_co.upload(g_c, d_co1.cpu().numpy())
+            b.histogram_device(g_c, Lp, scans, g_f, 0)
+            torch.cuda.synchronize()
+            assert r_len.download(g_f, 2 * 2 * 257 * 4).tobytes() == d_fr.cpu().numpy().tobytes(), ("histogram", ct, w, h, scans)
         # coded scans: the two-kernel pair and the pixels -> bits kernel
         L = b.layout(w, h, ct, hs, vs, b.ORDER_MCU)
         nblk = int(L.total_blocks)
