@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--runs", type=int, default=11)
     ap.add_argument("--label", default="")
+    ap.add_argument("--register-cycles", type=int, default=0, help="before the batches: hipHostRegister / hipHostUnregister N scratch arrays of 32 MB and free them (what a process that used "
+                                                                      "jpegenc_host_register earlier looks like: tools/diag/r04_in_place_crash_hunt.sh)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -75,6 +77,12 @@ def main():
         print(json.dumps({"scenario": "link steadiness: 60 x 16 pinned 25 MB copies", "h2d_GBps": up, "d2h_GBps": down,
                           "h2d_min_median_max": [min(up), sorted(up)[30], max(up)], "d2h_min_median_max": [min(down), sorted(down)[30], max(down)]}), flush=True)
         return
+    for _ in range(args.register_cycles):
+        scratch = np.empty(32 << 20, dtype=np.uint8)
+        scratch[::4096] = 1
+        b.host_register(scratch)
+        b.host_unregister(scratch)
+        del scratch
     nodes = hostinfo.numa_nodes()
     gpu_node = hostinfo.gpu_numa_node(hostinfo.torch_gpu_bus_id(torch, 0))
     before = os.sched_getaffinity(0)
