@@ -603,6 +603,21 @@ __device__ __forceinline__ void block_wave(const BlockKernelParams &p, const Col
 #endif
 }
 
+// Which (group, frame) a workgroup takes.  Workgroups are dispatched round-robin over the eight XCDs in the order of their linear
+// index: with JPEGENC_XCD_MAP the workgroups of one XCD walk one contiguous eighth of the launch's groups (frames included), so that
+// each XCD's L2 streams a dense range of pixels in and of coefficients out (tools/store_shapes.hip: what that does to the write stream).
+__device__ __forceinline__ void launch_item(uint32_t &grp, uint32_t &frm) {
+    grp = blockIdx.x; frm = blockIdx.y;
+#ifdef JPEGENC_XCD_MAP
+    const uint32_t G = gridDim.x, T = G * gridDim.y, per = T >> 3;
+    const uint32_t L = blockIdx.y * G + blockIdx.x;
+    if (L < per * 8u) {
+        const uint32_t item = (L & 7u) * per + (L >> 3);
+        frm = item / G; grp = item - frm * G;
+    }
+#endif
+}
+
 template <int BPP, int SX, int SY, int VARIANT, bool CONV, bool PLANES = false>
 __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY <= 4 ? 384 : 640) k_blocks_fast(const BlockKernelParams p, const ColourConsts k) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -615,7 +630,9 @@ __global__ void JPEGENC_WAVES_ATTR __launch_bounds__(BPP == 3 && CONV && SX * SY
         block_wave<BPP, SX, SY, VARIANT, CONV, PLANES>(p, k, smem, item - frm * p.groups, frm);
     }
 #else
-    block_wave<BPP, SX, SY, VARIANT, CONV, PLANES>(p, k, smem, blockIdx.x, blockIdx.y);
+    uint32_t grp, frm;
+    launch_item(grp, frm);
+    block_wave<BPP, SX, SY, VARIANT, CONV, PLANES>(p, k, smem, grp, frm);
 #endif
 }
 
@@ -753,6 +770,8 @@ bool launch_bytes_s4(const BlockKernelParams &p, const ColourConsts &k, int sx, 
 bool launch_conv_565(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant, hipStream_t stream, hipError_t *err);
 // fast_kernels_444.hip: the RGB family without decimation, one wave per 64 MCUs for all three components
 bool launch_conv_444(const BlockKernelParams &p, const ColourConsts &k, int num_frames, int variant, hipStream_t stream, hipError_t *err);
+// fast_kernels_420.hip: the RGB family at 4:2:0, lane = half an MCU, one wave per 32 MCUs
+bool launch_conv_420(const BlockKernelParams &p, const ColourConsts &k, int num_frames, int variant, hipStream_t stream, hipError_t *err);
 // fast_kernels_bytes.hip
 bool launch_bytes_family(const BlockKernelParams &p, const ColourConsts &k, int sx, int sy, int num_frames, int variant,
                          hipStream_t stream, hipError_t *err);

@@ -81,6 +81,10 @@ bool launch_blocks_fast(const BlockKernelParams &p, int num_frames, int variant,
     // 4:4:4 of the RGB family: one wave per 64 MCUs codes all three components (fast_kernels_444.hip)
     static const bool no_trio = JPEGENC_DIAG_ENV("JPEGENC_NO_TRIO") != nullptr;
     if (!no_trio && sx == 1 && sy == 1 && launch_conv_444(p, k, num_frames, variant, stream, err)) return true;
+    // 4:2:0 of the RGB family with lane = half an MCU, every pixel loaded once (fast_kernels_420.hip): built and measured in round 5,
+    // slower than the general kernel (profiles/r05_headline_kernel_probes.txt) - diagnostic builds only, behind JPEGENC_DUO=1
+    static const bool duo = JPEGENC_DIAG_ENV("JPEGENC_DUO") != nullptr;
+    if (duo && sx == 2 && sy == 2 && launch_conv_420(p, k, num_frames, variant, stream, err)) return true;
 #define JPEGENC_CASE(B, X, Y) if (p.bpp == B && sx == X && sy == Y) { *err = launch_fast<B, X, Y, true>(p, k, num_frames, variant, stream); return true; }
     JPEGENC_CASE(3, 1, 1) JPEGENC_CASE(3, 2, 1) JPEGENC_CASE(3, 1, 2) JPEGENC_CASE(3, 2, 2)
     JPEGENC_CASE(4, 1, 1) JPEGENC_CASE(4, 2, 1) JPEGENC_CASE(4, 1, 2) JPEGENC_CASE(4, 2, 2)

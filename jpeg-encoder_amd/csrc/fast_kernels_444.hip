@@ -183,7 +183,9 @@ __device__ __forceinline__ void trio_wave(const BlockKernelParams &p, const Colo
 template <int BPP, int VARIANT>
 __global__ void __attribute__((amdgpu_waves_per_eu(JPEGENC_TRIO_WAVES))) __launch_bounds__(64) k_blocks_444(const BlockKernelParams p, const ColourConsts k) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    trio_wave<BPP, VARIANT>(p, k, smem, blockIdx.x, blockIdx.y);
+    uint32_t grp, frm;
+    launch_item(grp, frm);
+    trio_wave<BPP, VARIANT>(p, k, smem, grp, frm);
 }
 
 template <int BPP>

@@ -191,7 +191,12 @@ __device__ __forceinline__ qconst_ptr quant_table(int table) {
 // little-endian i16.
 // (Tried and rejected on hardware: feeding (kq, aq) through broadcast LDS reads to avoid the 64
 // SGPR->VGPR accumulator moves made the 4K bench 8 % slower.)
-template <int VARIANT>
+// COLS_AHEAD > 0: the scalar load of column x's quantiser constants may not be issued before column x - COLS_AHEAD has been
+// quantised (an empty asm ties the load's address to one of that column's products).  Left alone the scheduler of hipcc 7.2
+// issues six or seven of the eight 64-byte loads in one burst in the multi-block kernels (fast_kernels_420.hip): 112 SGPRs of
+// constants in flight, every column parked in VGPR lanes with v_writelane and fetched back with v_readlane - 280 extra VALU
+// instructions per wave.
+template <int VARIANT, int COLS_AHEAD = 0>
 __device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], qconst_ptr qc, uint32_t out[32]) {
     const ChainConsts K = chain_consts();
     int mid[8][8];
@@ -216,9 +221,15 @@ __device__ __forceinline__ void fdct_quant_block(const uint32_t rows[8][4], qcon
         // the column's 8 (kq, aq) pairs as ONE 64-byte scalar load (left as 16 dword loads the compiler
         // does not always merge them: 128 s_load_dword per block after the table-driven prologue)
         typedef uint32_t u32x16q __attribute__((ext_vector_type(16)));
-        const u32x16q qv = *reinterpret_cast<const u32x16q __attribute__((address_space(4))) *>(qc + x * 16);
+        qconst_ptr qcx = qc + x * 16;
+        if (COLS_AHEAD > 0 && x >= COLS_AHEAD) asm volatile("" : "+s"(qcx) : "v"(prod[x - COLS_AHEAD]));
+        if (COLS_AHEAD > 0 && x < COLS_AHEAD) asm volatile("" : "+s"(qcx) : "v"(mid[7 - x][7]));      // (the first ones: not before pass 1 is nearly done)
+        const u32x16q qv = *reinterpret_cast<const u32x16q __attribute__((address_space(4))) *>(qcx);
 #pragma unroll
         for (int k = 0; k < 8; k++) prod[k * 8 + x] = dot2((uint32_t)col[k], qv[2 * k], (int)qv[2 * k + 1]);
+        // (... and no instruction moves from one column into another: a column's sixteen constants die with it.  CDNA issues a
+        //  wave's dependent VALU instructions back to back, there is nothing to gain from interleaving columns.)
+        if (COLS_AHEAD > 0) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < 32; j++) out[j] = pack_hi(prod[kZigzag[2 * j]], prod[kZigzag[2 * j + 1]]);

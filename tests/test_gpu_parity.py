@@ -1232,3 +1232,42 @@ def test_register_cache_locks_reused_buffers_and_lets_go_of_them(binding, oracle
     e2.close()                                                          # frees the handle: unlocks
     binding.host_register(px[2])
     binding.host_unregister(px[2])
+
+
+def test_half_mcu_kernel_experiment(binding):
+    """fast_kernels_420.hip (round 5): the 4:2:0 block kernel with lane = half an MCU - slower than the general kernel and therefore
+    only in the diagnostic build behind JPEGENC_DUO=1, but the measurements in profiles/r05_headline_kernel_probes.txt refer to it,
+    so it stays bit-exact: a child process runs it against the oracle - both block orders, both FDCT variants, 3- and 4-byte pixels,
+    ragged widths and heights (right-edge MCUs take the clamped path, bottom rows repeat), fewer MCUs than a wave holds, a wave that
+    wraps from one MCU row into the next, and the statistics of optimised Huffman tables counted by its waves."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "ge.load_package()\n"
+        "from jpeg_encoder_amd import binding as b, synth\n"
+        "from oracle import pyoracle as o\n"
+        "n = 0\n"
+        "for (w, h) in ((16, 16), (37, 21), (258, 128), (515, 64), (520, 40), (1030, 77), (3840, 32)):\n"
+        "    for ct in (b.RGB, b.BGRA):\n"
+        "        px = synth.lcg_image(w, h, b.BPP[ct], w + ct)\n"
+        "        for order in (0, 1):\n"
+        "            for variant in (b.FDCT_SCALAR, b.FDCT_SIMD):\n"
+        "                got = b.blocks_host(px, w, h, ct, 2, 2, 83, order, variant)\n"
+        "                want = o.encode_blocks(px, w, h, ct, 2, 2, 83, order, variant)\n"
+        "                assert np.array_equal(got, want), (w, h, ct, order, variant)\n"
+        "                n += 1\n"
+        "for (w, h), kw in (((200, 120), dict(quality=90, sampling=(2, 2), optimize=True)), ((333, 500), dict(quality=75, sampling=(2, 2), progressive_scans=4, optimize=True))):\n"
+        "    px = synth.lcg_image(w, h, 3, 5)\n"
+        "    e = b.Encoder(kw['quality'])\n"
+        "    e.set_sampling_factor(b.sampling_factor(2, 2))\n"
+        "    e.set_optimized_huffman_tables(True)\n"
+        "    if kw.get('progressive_scans'): e.set_progressive_scans(kw['progressive_scans'])\n"
+        "    assert e.encode(px, w, h, b.RGB) == o.encode_jpeg(px, w, h, o.RGB, **kw), kw\n"
+        "print('ok', n)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JPEGENC_DUO="1", JPEGENC_LIB=binding.DIAG_LIB_PATH)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok 56" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

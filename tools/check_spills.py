@@ -44,12 +44,12 @@ def main(paths):
     bad, noted, scratchy = [], [], []
     for n in names:
         k, name = kernels[n], pretty[n]
-        if "k_group_code" not in name and "k_blocks_fast" not in name and "k_blocks_444" not in name:
+        if "k_group_code" not in name and "k_blocks_fast" not in name and "k_blocks_444" not in name and "k_blocks_420" not in name:
             continue
         sg, vg, sc = k.get("SGPRs Spill", 0), k.get("VGPRs Spill", 0), k.get("ScratchSize [bytes/lane]", 0)
         # CONV = true (5th template argument), in the demangled or - without a demangler - the mangled name
         rgb_family = (re.search(r"<\d+, \d+, \d+, \d+, true", name) is not None or re.search(r"ILi\d+ELi\d+ELi\d+ELi\d+ELb1ELb[01]EE", n) is not None
-                      or "k_blocks_444" in name)                               # (the 4:4:4 kernel of the RGB family: no scratch either)
+                      or "k_blocks_444" in name or "k_blocks_420" in name)                               # (the 4:4:4 kernel of the RGB family: no scratch either)
         m = re.search(r"<\d+, (\d+), (\d+), \d+, (?:true|false)", name) or re.search(r"ILi\d+ELi(\d+)ELi(\d+)ELi\d+ELb[01]ELb[01]EE", n)
         six_wave_layout = bool(m) and int(m.group(1)) * int(m.group(2)) == 4
         if sg and vg:
@@ -60,7 +60,7 @@ def main(paths):
             noted.append(f"{name}: {sc} B scratch per lane at the 6-wave budget of the six-wave layouts ({vg} VGPRs spilled outside the loops; measured faster than 5 waves without)")
         elif "k_group_code" in name and sc:
             noted.append(f"{name}: {sc} B scratch per lane")
-    checked = sum(1 for n in names if "k_group_code" in pretty[n] or "k_blocks_fast" in pretty[n] or "k_blocks_444" in pretty[n])
+    checked = sum(1 for n in names if "k_group_code" in pretty[n] or "k_blocks_fast" in pretty[n] or "k_blocks_444" in pretty[n] or "k_blocks_420" in pretty[n])
     for line in noted:
         print("check_spills: note: " + line)
     if bad:
