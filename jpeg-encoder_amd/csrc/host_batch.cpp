@@ -182,7 +182,7 @@ struct BatchRun {
         // (dense content - the last collected round of frames of this size coded to more than kDenseBitsPerBlock - takes the two
         // kernels: host_internal.h)
         static const bool route_off = JPEGENC_DIAG_ENV("JPEGENC_NO_DENSE_ROUTING") != nullptr;
-        const bool dense = !route_off && b.dense_geometry == ((uint64_t)width << 32 | (uint32_t)height) && b.dense_bits_per_block > DeviceCtx::kDenseBitsPerBlock;
+        const bool dense = !route_off && b.dense_geometry == content_key(c, width, height, color_type) && b.dense_bits_per_block > DeviceCtx::kDenseBitsPerBlock;
         const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() && !dense &&
                            (pb ? fused_planes_supported(p, pb->planes, pb->subsampled) : fused_supported(p));
         if (optimize) {                                  // the block kernel counts the symbols of every frame (host_frame.cpp does this for one)
@@ -306,7 +306,9 @@ struct BatchRun {
         std::atomic<int> *next = &next_v;
         for (;;) {
             const int f = next->fetch_add(1);
-            if (f >= n || failed.load()) break;
+            // (rounds r and r + 1 are assembled at the same time: a failure in round r + 1 must not stop round r's frames - every
+            //  frame BELOW the lowest failing one is delivered whole; `failed` only keeps further rounds from starting)
+            if (f >= n || f0 + f > first_bad.load()) break;
             size_t pos = (*frame_at)[(size_t)f];
             Out o;
             o.sink = sink; o.user = users[f0 + f];
@@ -360,7 +362,7 @@ struct BatchRun {
         if (jobs.size() == 1 && n > 0 && L.total_blocks) {                     // what the next rounds (and calls) of this size can expect
             uint64_t bytes = 0;
             for (int f = 0; f < n; f++) bytes += (*lens)[(size_t)f];
-            b.dense_geometry = (uint64_t)width << 32 | (uint32_t)height;
+            b.dense_geometry = content_key(c, width, height, color_type);
             b.dense_bits_per_block = bytes * 8u / ((uint64_t)n * L.total_blocks);
         }
         int rc = b.reserve_host(need, slot);
@@ -527,8 +529,12 @@ int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames
         return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
     }
     e->batch.helpers = &e->threads;
-    const int rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
-    if (rc != kBatchNeedsPerFrame) return rc;
+    int bad = -1;
+    const int rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users, nullptr, &bad);
+    if (rc != kBatchNeedsPerFrame) {
+        if (rc != JPEGENC_OK && bad >= 0) set_last_error("frame " + std::to_string(bad) + ": " + jpegenc_last_error());      // (every frame below it: delivered whole)
+        return rc;
+    }
     return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
 }
 
@@ -634,12 +640,18 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
         int bad = -1, rc;
         if (ids.size() == 1) { rc = jpegenc_encoder_encode_planes_device(e, jct, width, height, sub.data(), planes_subsampled, sink, sub_users[0]); bad = 0; }
         else rc = encode_planes_uniform(e, jct, width, height, ncomp, sub.data(), (int)ids.size(), planes_subsampled != 0, sink, sub_users.data(), &bad);
+        if (rc != JPEGENC_OK && bad < 0) {
+            // not a frame's own failure (a HIP error, an allocation, a code that came out too long): no frame is invented for it -
+            // the pool stops here with the status as it is; what a group before this one has reported stays the lower frame
+            if (bad_status == JPEGENC_OK) { bad_status = rc; bad_message = jpegenc_last_error(); bad_frame = -1; }
+            break;
+        }
         if (rc != JPEGENC_OK) {
-            const int k = ids[(size_t)(bad >= 0 ? bad : 0)];
+            const int k = ids[(size_t)bad];
             if (k < bad_frame) { bad_frame = k; bad_status = rc; bad_message = jpegenc_last_error(); }
         }
     }
-    if (bad_status != JPEGENC_OK) { set_last_error("frame " + std::to_string(bad_frame) + ": " + bad_message); return bad_status; }
+    if (bad_status != JPEGENC_OK) { set_last_error(bad_frame >= 0 ? "frame " + std::to_string(bad_frame) + ": " + bad_message : bad_message); return bad_status; }
     return JPEGENC_OK;
 }
 

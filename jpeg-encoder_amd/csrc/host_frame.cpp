@@ -209,7 +209,7 @@ struct FrameRun {
                 static const size_t zero_copy_max = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_ZERO_COPY_MAX_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)1 << 20); }();
                 // (Larger frames whose files are small - the handle's last file of this geometry fitted the first copy - take the same
                 // way while that lasts: 720p 113 -> 108 us, 1080p 178 -> 175; at 1440p and beyond the copy engine wins again.)
-                const bool small_file_again = ctx.last_file_geometry == ((uint64_t)width << 32 | (uint32_t)height) && ctx.last_scan_bytes &&
+                const bool small_file_again = ctx.last_file_geometry == content_key(c, width, height, color_type_or_planes) && ctx.last_scan_bytes &&
                                               ctx.last_scan_bytes <= DeviceCtx::kFirstPiece && pixel_bytes <= ((size_t)13 << 19) && jobs.size() == 1;
                 if (out_total && (pixel_bytes <= zero_copy_max || (small_file_again && zero_copy_max))) {   // (several scans: the gather kernel writes there)
                     rc = ctx.reserve_scan_host(kGatherHeader + out_total);
@@ -235,7 +235,7 @@ struct FrameRun {
             static const int forced = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_STRIPES"); return e ? atoi(e) : 0; }();
             if (mcu_rows >= 2 && is_pinned_host_range(host_pixels, pixel_bytes) && bs->out && is_pinned_host_range(bs->out, bs->cap)) {
                 // 4, 2 or 1 (= the ordinary sequence): whichever this handle measured as the fastest (DeviceCtx::StripeTuner)
-                stripes = forced ? forced : ctx.stripe_tuner.choose(((uint64_t)width << 32 | (uint32_t)height) ^ ((uint64_t)L.total_blocks << 40));
+                stripes = forced ? forced : ctx.stripe_tuner.choose(content_key(c, width, height, color_type_or_planes));
                 stripe_timed = !forced;
                 if (stripes > DeviceCtx::kChunks) stripes = DeviceCtx::kChunks;
                 if ((uint32_t)stripes > mcu_rows) stripes = (int)mcu_rows;
@@ -257,7 +257,7 @@ struct FrameRun {
         // hides behind their copies (2000x1800 at quality 100 between page-locked buffers: 0.46 ms striped, 0.57 through the two
         // kernels one after the other).
         static const bool route_off = JPEGENC_DIAG_ENV("JPEGENC_NO_DENSE_ROUTING") != nullptr;
-        if (fused && !stripes && !route_off && pixel_bytes > ((size_t)1 << 20) && ctx.dense_last_time((uint64_t)width << 32 | (uint32_t)height, L.total_blocks)) {
+        if (fused && !stripes && !route_off && pixel_bytes > ((size_t)1 << 20) && ctx.dense_last_time(content_key(c, width, height, color_type_or_planes), L.total_blocks)) {
             fused = false; self_finishing = false;
             fused_src.chain = nullptr; fused_src.finish_abort = nullptr; fused_src.finish_done = nullptr;
         }
@@ -544,7 +544,7 @@ struct FrameRun {
         for (size_t k = 0; k < jobs.size(); k++) { scan_len[k] = reinterpret_cast<const uint32_t *>(ctx.h_scan_out)[k]; nbytes += scan_len[k]; }
         for (size_t k = 1; merged && k < jobs.size(); k++) nbytes += scan_header_bytes[k];
         ctx.last_scan_bytes = nbytes;
-        ctx.last_file_geometry = (uint64_t)width << 32 | (uint32_t)height;
+        ctx.last_file_geometry = content_key(c, width, height, color_type_or_planes);
         return JPEGENC_OK;
     }
 

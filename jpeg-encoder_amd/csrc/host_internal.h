@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -242,35 +243,92 @@ struct Restart {
     }
 };
 
-// The CPUs this process may actually use at once: the smallest of the hardware threads, the calling thread's affinity mask and the
-// container's CPU-time quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  hardware_concurrency() alone says 256
-// inside a container that is throttled to 16 CPUs' worth - sixteen busy-waiting batch workers plus the caller then run into the
-// quota, the kernel freezes the whole process until the next 100 ms period, and a batch takes half as long again
-// (profiles/r04_cpu_quota.txt: the 9-16 Gpixel/s spread of the host -> JPEG leg).
+// The CPUs this process may actually use at once: the smallest of the hardware threads, the PROCESS's affinity mask (the thread-group
+// leader's: a caller that pins its own thread for a moment must not shrink every handle's pools) and the container's CPU-time quota
+// (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  hardware_concurrency() alone says 256 inside a container that is
+// throttled to 16 CPUs' worth - sixteen busy-waiting batch workers plus the caller then run into the quota, the kernel freezes the
+// whole process until the next 100 ms period, and a batch takes half as long again (profiles/r04_cpu_quota.txt: the 9-16 Gpixel/s
+// spread of the host -> JPEG leg).  Read afresh when the last answer is older than a second (a few file reads: microseconds per
+// batch call): masks and quotas change under a running process.
+inline int usable_cpus_now() {
+    long cpus = (long)std::thread::hardware_concurrency();
+    if (cpus <= 0) cpus = 4;
+    cpu_set_t set;
+    if (sched_getaffinity(getpid(), sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < cpus) cpus = CPU_COUNT(&set);
+    long long quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // "max 100000" or "1600000 100000"
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+    }
+    if (quota > 0 && period > 0) {
+        const long q = (long)((quota + period - 1) / period);
+        if (q >= 1 && q < cpus) cpus = q;
+    }
+    return (int)(cpus < 1 ? 1 : cpus);
+}
 inline int usable_cpus() {
-    static const int n = [] {
-        long cpus = (long)std::thread::hardware_concurrency();
-        if (cpus <= 0) cpus = 4;
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < cpus) cpus = CPU_COUNT(&set);
-        long long quota = -1, period = 100000;
-        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // "max 100000" or "1600000 100000"
-            char q[32] = {0};
-            if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
-            fclose(f);
-        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
-            fclose(g);
-            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
-        }
-        if (quota > 0 && period > 0) {
-            const long q = (long)((quota + period - 1) / period);
-            if (q >= 1 && q < cpus) cpus = q;
-        }
-        return (int)(cpus < 1 ? 1 : cpus);
-    }();
+    static std::atomic<int> cached{0};
+    static std::atomic<long long> stamp_ms{0};
+    const long long now = (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    int n = cached.load(std::memory_order_relaxed);
+    if (n == 0 || now - stamp_ms.load(std::memory_order_relaxed) > 1000) {
+        n = usable_cpus_now();
+        cached.store(n, std::memory_order_relaxed);
+        stamp_ms.store(now, std::memory_order_relaxed);
+    }
     return n;
 }
+// "0-31,128-159" (a sysfs cpulist) -> CPU set; false when nothing could be read
+inline bool parse_cpulist(const char *list, cpu_set_t *out) {
+    CPU_ZERO(out);
+    for (const char *c = list; c && *c;) {
+        char *end = nullptr;
+        const long a = strtol(c, &end, 10);
+        if (end == c) break;
+        long b = a;
+        c = end;
+        if (*c == '-') { b = strtol(c + 1, &end, 10); c = end; }
+        for (long i = a; i <= b && i < CPU_SETSIZE; i++) if (i >= 0) CPU_SET((int)i, out);
+        if (*c == ',') c++; else break;
+    }
+    return CPU_COUNT(out) > 0;
+}
+// What a thread remembers about having been placed near a device (bind_thread_near_device; one per thread).  The batch workers
+// PERSIST between calls and re-apply their handle's (device, switch) at the top of every batch body: the switch going off, or the
+// handle being re-made for another device, has to take a bound worker back to the mask it started with first - intersecting
+// the next node's CPUs with the mask of the previous node would be empty, and the worker would stay where the old device was.
+struct ThreadBinding {
+    bool bound = false;
+    int device = -1;
+    cpu_set_t original;                // the thread's mask before the library first narrowed it
+    // lookup(device, cpu_set_t *) -> bool: the CPUs of the device's NUMA node
+    template <class Lookup>
+    void apply(int dev, bool on, Lookup &&lookup) {
+        if (!on) { restore(); return; }
+        if (bound && device == dev) return;
+        cpu_set_t base, want, both;
+        if (bound) base = original;
+        else if (sched_getaffinity(0, sizeof base, &base) != 0) return;
+        if (!lookup(dev, &want)) { restore(); return; }
+        CPU_AND(&both, &want, &base);
+        if (CPU_COUNT(&both) > 0 && sched_setaffinity(0, sizeof both, &both) == 0) {
+            if (!bound) original = base;
+            bound = true; device = dev;
+        } else {
+            restore();                 // nothing of that node is open to this thread: unbound rather than on the wrong node
+        }
+    }
+    void restore() {
+        if (bound) (void)sched_setaffinity(0, sizeof original, &original);
+        bound = false; device = -1;
+    }
+};
+
 // Host threads of a batch's worker pool: at most `cap` (16 per device: what saturates the link, csrc/tools/h2d_staging.cpp), and
 // two fewer than the CPUs the process may use - the caller's thread and the runtime's own need theirs.
 inline int batch_pool_size(int cap, int num_frames) {
@@ -355,9 +413,15 @@ struct DeviceCtx {
             if (k != key) { key = k; calls = 0; for (int i = 0; i < 3; i++) { seen[i] = 0; cost[i] = 0; } }
             if (calls < 6) current = (int)(calls % 3u);
             else {
-                int best = 0;
-                for (int i = 1; i < 3; i++) if (cost[i] < cost[best]) best = i;
-                current = calls % 32u == 0 ? (best + 1 + (int)((calls / 32u) & 1u)) % 3 : best;
+                // (an option none of whose trial calls was recorded - they failed, or gave up and were retried another way - has
+                //  no cost yet: it is tried again instead of winning with its initial 0)
+                int best = -1, untimed = -1;
+                for (int i = 0; i < 3; i++) {
+                    if (!seen[i]) { if (untimed < 0) untimed = i; continue; }
+                    if (best < 0 || cost[i] < cost[best]) best = i;
+                }
+                if (best < 0) best = 0;
+                current = untimed >= 0 ? untimed : calls % 32u == 0 ? (best + 1 + (int)((calls / 32u) & 1u)) % 3 : best;
             }
             calls++;
             return stripes_of(current);
@@ -558,6 +622,15 @@ struct Config {                      // the fields of struct Encoder, encoder.rs
     int batch_round_frames = 0;      // jpegenc_encoder_set_batch_round_frames: frames of a device-resident batch in flight together (0 = by footprint)
     std::vector<std::pair<uint8_t, std::vector<uint8_t>>> app_segments;
 };
+
+// What a handle's per-content memories (stripe tuner, dense-content routing, small-file path) are keyed on: the frame's size AND
+// the settings that decide how many bits it makes - a handle whose quality, sampling factor or colour type changes starts afresh
+// instead of applying what it learnt about other content.
+inline uint64_t content_key(const Config &c, int width, int height, int color_type) {
+    const uint64_t qsum = (uint64_t)(c.qtype[0] * 31 + c.qtype[1]) & 0xFFu;
+    return (uint64_t)(uint32_t)width << 32 | (uint64_t)(uint32_t)height | (uint64_t)(c.quality & 0xFF) << 16 | (uint64_t)(c.sampling & 0xFF) << 24 |
+           (uint64_t)(color_type & 0xF) << 48 | (uint64_t)(c.fdct_variant & 1) << 52 | qsum << 53 | (uint64_t)(c.progressive_scans != 0) << 61 | (uint64_t)c.optimize << 62;
+}
 
 // Staging of the small-frame batch path (jpegenc_encoder_encode_batch): two rounds of frames in pinned
 // host memory and on the device, so that copying / uploading one round overlaps encoding the other.
@@ -921,6 +994,6 @@ inline int validate_plane(const jpegenc_plane &pl, int hs, int vs, bool planes_s
 }
 
 // ---- host_multi.cpp ------------------------------------------------------------------------------------------------------------
-void bind_thread_near_device(int device, bool on);            // (opt-in) the calling thread onto the NUMA node of the device
+void bind_thread_near_device(int device, bool on);            // (opt-in) the calling thread onto the NUMA node of the device; off / another device: back out first (ThreadBinding)
 
 }  // namespace jpegenc

@@ -33,16 +33,7 @@ static bool device_cpus(int device, cpu_set_t *out) {
                 if (FILE *f = fopen(path, "r")) { len = fread(list, 1, sizeof list - 1, f); fclose(f); }
                 cpu_set_t want;
                 CPU_ZERO(&want);
-                for (const char *c = list; len && *c;) {                    // "0-31,128-159"
-                    char *end = nullptr;
-                    const long a = strtol(c, &end, 10);
-                    if (end == c) break;
-                    long b = a;
-                    c = end;
-                    if (*c == '-') { b = strtol(c + 1, &end, 10); c = end; }
-                    for (long i = a; i <= b && i < CPU_SETSIZE; i++) if (i >= 0) CPU_SET((int)i, &want);
-                    if (*c == ',') c++; else break;
-                }
+                if (len) (void)parse_cpulist(list, &want);                  // "0-31,128-159"
                 if (CPU_COUNT(&want) > 0) { sets[device] = want; state[device] = 1; }
             }
         }
@@ -53,12 +44,8 @@ static bool device_cpus(int device, cpu_set_t *out) {
 }
 
 void bind_thread_near_device(int device, bool on) {
-    if (!on) return;
-    cpu_set_t want, have, both;
-    if (!device_cpus(device, &want)) return;
-    if (sched_getaffinity(0, sizeof have, &have) != 0) return;
-    CPU_AND(&both, &want, &have);
-    if (CPU_COUNT(&both) > 0) (void)sched_setaffinity(0, sizeof both, &both);
+    thread_local ThreadBinding binding;                                     // (persistent workers: remembered from batch to batch)
+    binding.apply(device, on, device_cpus);
 }
 
 
@@ -137,7 +124,9 @@ static int encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_de
     std::vector<int> status((size_t)num_devices, JPEGENC_OK);
     std::vector<std::string> messages((size_t)num_devices);
     auto shard_body = [&](int d) {
-        bind_thread_near_device(devices[d], e->numa_bind);                  // the workers this thread spawns inherit the mask
+        // (this driving thread only - it ends with the call; the child's persistent workers place themselves at the top of every
+        //  batch body, host_batch.cpp, and un-place themselves when the switch is off or the child is re-made for another device)
+        bind_thread_near_device(devices[d], e->numa_bind);
         const int n = jpegenc_shard_frames(num_frames, num_devices, d, nullptr, 0);
         if (n <= 0) { status[(size_t)d] = n < 0 ? -n : JPEGENC_OK; return; }
         std::vector<int> idx((size_t)n);

@@ -4,6 +4,8 @@
 #include <atomic>
 #include <cstdio>
 #include <set>
+#include <string>
+#include <vector>
 
 #include "host_internal.h"
 
@@ -73,7 +75,76 @@ static int worker_threads() {
     return 0;
 }
 
+// ThreadBinding (bind_thread_near_device): a persistent worker follows its handle's (device, switch) - on, off, another device -
+// with a fake "sysfs": device 0 sits on the first half of the CPUs this process may use, device 1 on the second half, device 2 on
+// CPUs the process does not have.
+static int thread_binding() {
+    cpu_set_t start;
+    CHECK(sched_getaffinity(0, sizeof start, &start) == 0);
+    std::vector<int> cpus;
+    for (int i = 0; i < CPU_SETSIZE; i++) if (CPU_ISSET(i, &start)) cpus.push_back(i);
+    if (cpus.size() < 2) { printf("thread binding: one CPU only, skipped\n"); return 0; }
+    std::string lists[2];
+    for (size_t i = 0; i < cpus.size(); i++) {
+        std::string &l = lists[i < cpus.size() / 2 ? 0 : 1];
+        if (!l.empty()) l += ",";
+        l += std::to_string(cpus[i]);
+    }
+    auto lookup = [&](int device, cpu_set_t *out) {
+        if (device == 2) { CPU_ZERO(out); CPU_SET(CPU_SETSIZE - 1, out); return true; }      // a node whose CPUs are closed to us
+        if (device < 0 || device > 2) return false;
+        return jpegenc::parse_cpulist(lists[device].c_str(), out);
+    };
+    auto mask = [] { cpu_set_t m; CPU_ZERO(&m); (void)sched_getaffinity(0, sizeof m, &m); return m; };
+    auto same = [](const cpu_set_t &a, const cpu_set_t &b) { return CPU_EQUAL(&a, &b) != 0; };
+    cpu_set_t node[2];
+    CHECK(jpegenc::parse_cpulist(lists[0].c_str(), &node[0]) && jpegenc::parse_cpulist(lists[1].c_str(), &node[1]));
+    cpu_set_t ranges;
+    CHECK(jpegenc::parse_cpulist("0-2,5,7-8", &ranges) && CPU_COUNT(&ranges) == 6 && CPU_ISSET(5, &ranges) && !CPU_ISSET(6, &ranges));
+    jpegenc::ThreadBinding b;
+    b.apply(0, false, lookup);                                   // off and never bound: nothing happens
+    CHECK(!b.bound && same(mask(), start));
+    b.apply(0, true, lookup);
+    CHECK(b.bound && b.device == 0 && same(mask(), node[0]));
+    b.apply(0, true, lookup);                                    // the same again: still there
+    CHECK(b.bound && same(mask(), node[0]));
+    b.apply(0, false, lookup);                                   // the switch goes off: back to where the thread started
+    CHECK(!b.bound && same(mask(), start));
+    b.apply(1, true, lookup);
+    CHECK(b.bound && b.device == 1 && same(mask(), node[1]));
+    b.apply(0, true, lookup);                                    // the handle now serves another device: straight over, not an empty intersection
+    CHECK(b.bound && b.device == 0 && same(mask(), node[0]));
+    b.apply(2, true, lookup);                                    // a node with none of our CPUs: unbound, not left on the old node
+    CHECK(!b.bound && same(mask(), start));
+    b.apply(1, true, lookup);
+    b.apply(7, true, lookup);                                    // a device without a known node: unbound as well
+    CHECK(!b.bound && same(mask(), start));
+    b.apply(1, true, lookup);
+    b.restore();
+    CHECK(same(mask(), start));
+    return 0;
+}
+
+// StripeTuner: an option whose trial calls were never recorded has no cost - it is tried again, it does not win with 0
+static int stripe_tuner_untimed_option() {
+    DeviceCtx::StripeTuner t;
+    for (int i = 0; i < 6; i++) {
+        const int s = t.choose(5);
+        if (s != 2) t.record(s == 4 ? 700.f : 650.f);               // the two-stripe calls "failed": nothing recorded
+    }
+    CHECK(t.choose(5) == 2);                                     // still owed a measurement
+    t.record(900.f);
+    for (int i = 0; i < 20; i++) {
+        const int s = t.choose(5);
+        if (t.calls % 32u != 1u) CHECK(s == 1);                  // the measured best, not the option that cost "0"
+        t.record(s == 4 ? 700.f : s == 2 ? 900.f : 650.f);
+    }
+    return 0;
+}
+
 int main() {
+    if (thread_binding()) return 1;
+    if (stripe_tuner_untimed_option()) return 1;
     if (stripe_tuner()) return 1;
     if (worker_threads()) return 1;
     printf("host units ok\n");

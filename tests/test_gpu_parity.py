@@ -963,6 +963,41 @@ def test_device_batch_sink_failure_in_a_later_round(binding, oracle, synth):
         assert got[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, 85), i
 
 
+def test_device_batch_sink_failure_while_the_round_before_is_still_being_assembled(binding, oracle, synth):
+    """Rounds r and r + 1 of a device-resident batch are assembled at the same time.  A sink that fails on a frame of round r + 1
+    while round r's files are still going out (a slow sink) must not cut round r short: the header's contract is that every
+    frame below the reported one has been delivered whole."""
+    import ctypes as C
+    import time
+    import torch
+    w, h, n = 96, 80, 24
+    frames = np.stack([synth.lcg_image(w, h, 3, 300 + i) for i in range(n)])
+    d = torch.from_numpy(frames.reshape(n, -1).copy()).to("cuda:0")
+    e = binding.Encoder(85)
+    got = {}
+
+    def sink(user, ptr, nbytes):
+        u = user or 0
+        if u == 9:
+            return 3                                             # round 1 (frames 8..15) fails at once ...
+        if u < 8:
+            time.sleep(0.02)                                     # ... while round 0 is still being written
+        got.setdefault(u, bytearray()).extend(C.string_at(ptr, nbytes))
+        return 0
+
+    cb = binding.WRITE_FN(sink)
+    users = (C.c_void_p * n)(*range(n))
+    fn = binding.lib().jpegenc_encoder_encode_batch_device
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, binding.WRITE_FN, C.POINTER(C.c_void_p)]
+    e.set_batch_round_frames(8)
+    rc = fn(e._h, d.data_ptr(), w * h * 3, n, w, h, binding.RGB, cb, users)
+    assert rc == binding.ERR_WRITE
+    assert "frame 9" in binding.lib().jpegenc_last_error().decode()
+    for i in range(9):                                           # every frame below the failing one: whole and right
+        assert bytes(got[i]) == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, 85), i
+    assert all(k < 9 or k > 9 for k in got)
+
+
 def test_replayed_sequence_after_a_single_other_frame(binding, oracle, synth):
     """A, A, A captures and replays A's launch sequence; ONE frame of another geometry in between is enqueued
     directly and leaves A's sequence in place - but not A's scan parameters or the workspace contents: the next A
