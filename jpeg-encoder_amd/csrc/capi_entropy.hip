@@ -93,7 +93,7 @@ int upload_huffman_luts_batch(const void *h_specs, void *d_specs, void *d_luts, 
 struct ScanPlan {
     uint32_t max_blocks, max_chunks, max_tiles, max_waves, max_fftiles, slot_words;
     uint64_t raw_stride;
-    size_t off_params, off_lut, off_bits, off_wsum, off_woff, off_partials, off_scalars, off_intervals, off_slots, off_raw, off_fftile, off_fftile_off, total;
+    size_t off_params, off_lut, off_bits, off_wsum, off_woff, off_ffstat, off_partials, off_scalars, off_intervals, off_slots, off_raw, off_fftile, off_fftile_off, total;
 };
 
 // Worst-case code bytes of one block of a scan: DC <= 16 + 11 bits, each AC coefficient <= 16 + 11,
@@ -138,6 +138,7 @@ static void plan_scan(uint64_t max_blocks, uint64_t bound, int frames, ScanPlan 
     pl->off_bits = take(F * pl->max_blocks * 4);
     pl->off_wsum = take(F * pl->max_waves * 4);
     pl->off_woff = take(F * pl->max_waves * 4);
+    pl->off_ffstat = take(F * pl->max_waves * 4);
     pl->off_partials = take(F * pl->max_tiles * 4);
     pl->off_scalars = take(F * 5 * 4);
     pl->off_intervals = take(F * (size_t)pl->max_blocks * 5 * 4);
@@ -279,6 +280,7 @@ static int fill_scan(const void *d_coeffs, size_t coeff_frame_stride, int frames
     p.nwaves = (p.nblocks + 63u) / 64u;
     p.wsum = (uint32_t *)(ws + pl.off_wsum);
     p.woff = (uint32_t *)(ws + pl.off_woff);
+    p.ffstat = (uint32_t *)(ws + pl.off_ffstat);
     p.partials = (uint32_t *)(ws + pl.off_partials);
     p.max_tiles = pl.max_tiles;
     uint32_t *scalars = (uint32_t *)(ws + pl.off_scalars);

@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
     if (valid && p.nintervals > 1u) p.bits[(size_t)f * p.nblocks + b] = at;      // (interval offsets need them, k_interval_len)
     const uint32_t total = (uint32_t)__shfl((int)upto, 63);
     const uint32_t w = b >> 6;
-    if (lane == 0) p.wsum[(size_t)f * p.nwaves + w] = total;
+    if (lane == 0) { p.wsum[(size_t)f * p.nwaves + w] = total; p.ffstat[(size_t)f * p.nwaves + w] = 0; }      // (k_finish_runs' look-back word of this run)
     const uint32_t nwords = (total + 31u) >> 5;
     uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)w * p.slot_words;
     uint32_t *win = area[wave];
@@ -500,6 +500,7 @@ __global__ void __launch_bounds__(256) k_place(const EntropyParams *params) {
 __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
     if (p.nintervals != 1) return;               // k_place
+    if (p.fused_prefix & kRunsFinishThemselves) return;   // k_finish_runs
     const uint32_t f = blockIdx.y, lane = threadIdx.x & 63u;
     const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (w >= p.nwaves) return;
@@ -599,14 +600,295 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
     }
 }
 
+// ---- scans without restart markers, in ONE launch: every run puts itself into the finished scan ----------------------
+// What k_push + the prefix sum over the tiles' 0xFF counts + k_stuff do in three or four launches and two trips of the scan through
+// HBM (slots -> raw -> out), done by the run's own wave in one (slots -> out): the same steps the pixels -> bits kernel takes when it
+// finishes a small frame itself (finish_run.hip.h) - but as a kernel of its own, after the coder, so that no coder workgroup sits
+// on its CU slot waiting for the runs before it (which is what costs a batch a third of its throughput there), and with the runs'
+// lengths all known: only the 0xFF counts are looked back over.
+//   1. lo = bits of the runs before this one (the lengths are complete: summed by the wave itself, or read from the prefix sum
+//      where a frame has more than kFusedPrefixRuns runs); r = lo % 8 bits of the previous run open this run's first byte.
+//      A byte of the stream belongs to the run that holds its LAST bit; the last run also owns the 1-padded final byte
+//      (finalize_bit_buffer, writer.rs:138-154).
+//   2. count the 0xFF bytes among the bytes the run owns; publish ffstat[g] = AGGREGATE | count.
+//   3. look back (decoupled, Merrill & Garland) - per WORKGROUP of kFinishRunsPerWg runs, so that 16 runs share one look-back and one
+//      sum of the lengths before them: a wave reads the 64 words before its workgroup's at once, adds counts up to the nearest
+//      INCLUSIVE word, steps further back while there is none, waits for words that are still empty (workgroups start in blockIdx
+//      order: a predecessor is running or done); then publishes INCLUSIVE | (count of all runs up to and including its own).
+//   4. stuff (0xFF -> 0xFF 0x00, writer.rs:157-167) in LDS, phase-aligned with the destination, copy out as whole dwords; the
+//      partial words at the two ends are shared with the neighbouring runs and go out byte by byte.  The last run stores the length.
+// A wave that waits longer than kStatSpinTicks for a predecessor's word (never observed) counts that run's bytes itself.
+constexpr uint32_t kStatAggregate = 0x40000000u, kStatInclusive = 0x80000000u, kStatValue = 0x3FFFFFFFu;
+constexpr uint64_t kStatSpinTicks = 200000;                                  // 2 ms of the 100 MHz clock
+
+struct RunBytes {                     // run g of frame f as the bytes it owns in the finished (unstuffed) stream
+    const uint32_t *run;              // its slot: bits from bit 0 of word 0, a zero word behind them (16-byte aligned)
+    uint32_t nwords, r, carry, nbytes, pad_word, pad_mask, first_byte;
+    // the four words of chunk q of [r carried bits][the run], MSB first, and how many of their bytes are 0xFF (the bytes after the
+    // ones the run owns never count: an unfinished byte's bits are followed by zeros)
+    __device__ __forceinline__ uint32_t chunk(uint32_t q, uint32_t (&w)[4]) const {
+        const uint32_t j0 = q * 4u;
+        const u32x4a4 v = *reinterpret_cast<const u32x4a4 *>(run + j0);       // (a slot is a multiple of 16 bytes: whole chunks are its own memory)
+        uint32_t m[5] = {j0 ? __builtin_bswap32(run[j0 - 1u]) : carry, __builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z), __builtin_bswap32(v.w)};
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++)                                       // words past the zero word behind the run are stale: they read as zero
+            m[k + 1u] &= ~(uint32_t)((int32_t)(nwords - (j0 + k)) >> 31);
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            w[k] = r ? (m[k] << (32u - r)) | (m[k + 1u] >> r) : m[k + 1u];
+            if (j0 + k == pad_word) w[k] |= pad_mask;
+        }
+        return ff_count4(w[0]) + ff_count4(w[1]) + ff_count4(w[2]) + ff_count4(w[3]);
+    }
+};
+// lo = bits before run g, total = its own bits (wave-uniform); slots / wsum = the frame's
+__device__ __forceinline__ RunBytes run_bytes(Params p, const uint32_t *slots, const uint32_t *wsum, uint32_t g, uint32_t lo, uint32_t total) {
+    RunBytes b;
+    b.run = slots + (size_t)g * p.slot_words;
+    b.nwords = (total + 31u) >> 5;
+    b.r = lo & 7u;
+    b.carry = 0;
+    if (b.r && g) {                   // the last r bits of the run before (every run but a scan's last holds at least 64 blocks: never shorter than 8 bits)
+        const uint32_t *prev = slots + (size_t)(g - 1u) * p.slot_words;
+        const uint32_t o = wsum[g - 1u] - b.r, j = o >> 5, s = o & 31u;
+        const uint32_t a = __builtin_bswap32(prev[j]), c = __builtin_bswap32(prev[j + 1u]);      // (a zero word follows every run)
+        b.carry = ((s ? (a << s) | (c >> (32u - s)) : a) >> (32u - b.r));
+    }
+    const bool last = g + 1u == p.nwaves;
+    const uint32_t vbits = b.r + total;
+    b.nbytes = last ? (vbits + 7u) >> 3 : vbits >> 3;
+    const uint32_t ones = b.nbytes * 8u > vbits ? b.nbytes * 8u - vbits : 0u;                     // (last run only) the padding
+    b.pad_word = vbits >> 5;
+    b.pad_mask = ones ? ((1u << ones) - 1u) << (32u - (vbits & 31u) - ones) : 0u;
+    b.first_byte = lo >> 3;
+    return b;
+}
+// 0xFF bytes of a run (whole wave); the first round's words and count stay with the caller
+__device__ __forceinline__ uint32_t run_ff_count(const RunBytes &b, uint32_t lane, uint32_t (&w0)[4], uint32_t &c0) {
+    uint32_t w[4], n = 0;
+    c0 = 0;
+    w0[0] = w0[1] = w0[2] = w0[3] = 0;
+    if (lane * 16u < b.nbytes) { c0 = b.chunk(lane, w0); n = c0; }
+    for (uint32_t q = lane + 64u; q * 16u < b.nbytes; q += 64u) n += b.chunk(q, w);
+    return wave_sum(n);
+}
+
+#ifndef JPEGENC_FINISH_X      // ablation builds (tools/diag/r05_finish_x.sh): 1 no look-back, 2 no global stores, 4 no stuffing step, 8 no counting loads
+#define JPEGENC_FINISH_X 0
+#endif
+constexpr uint32_t kFinishRunsPerWg = 16;        // runs a workgroup of k_finish_runs takes (four per wave): what they share - the bits before them, the look-back - is paid once
+
+// bits before run `first` of the frame (whole wave)
+__device__ __forceinline__ uint32_t bits_before_run(Params p, uint32_t f, const uint32_t *wsum, uint32_t first, uint32_t lane) {
+    if (!(p.fused_prefix & 1u)) return (p.woff + (size_t)f * p.nwaves)[first];
+    uint32_t before = 0;
+    for (uint32_t i = lane; i < first; i += 64u) before += wsum[i];
+    return wave_sum(before);
+}
+// 0xFF bytes of the runs of workgroup `wg` counted by ONE wave (a predecessor that never reported: nothing but complete data is needed)
+__device__ __forceinline__ uint32_t group_ff_count(Params p, uint32_t f, const uint32_t *slots, const uint32_t *wsum, uint32_t wg, uint32_t lane) {
+    const uint32_t g0 = wg * kFinishRunsPerWg, n = min(kFinishRunsPerWg, p.nwaves - g0);
+    uint32_t lo = bits_before_run(p, f, wsum, g0, lane), sum = 0, w0[4], c0;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t total = wsum[g0 + k];
+        sum += run_ff_count(run_bytes(p, slots, wsum, g0 + k, lo, total), lane, w0, c0);
+        lo += total;
+    }
+    return sum;
+}
+
+__global__ void __launch_bounds__(256) k_finish_runs(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
+    if (p.nintervals != 1) return;               // k_place / k_stuff
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[4][64 * 32 + 48];
+    __shared__ uint32_t sh_len[kFinishRunsPerWg + 1], sh_lo[kFinishRunsPerWg + 1], sh_ff[kFinishRunsPerWg], sh_red[4], sh_base;
+    const uint32_t f = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t wg = blockIdx.x, g0 = wg * kFinishRunsPerWg;
+    if (g0 >= p.nwaves) return;                  // (the whole workgroup)
+    const uint32_t nruns = min(kFinishRunsPerWg, p.nwaves - g0);
+    const uint32_t *wsum = p.wsum + (size_t)f * p.nwaves;
+    const uint32_t *slots = reinterpret_cast<const uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride);
+    uint32_t *stat = p.ffstat + (size_t)f * p.nwaves;          // (one word per WORKGROUP is used: the first nwaves / 16 of the frame's)
+    // The kernel's time is its chain of dependent memory round trips (every workgroup of a 16-frame launch is resident at once, so
+    // the launch lasts as long as one workgroup does): each step below issues all of its loads before it looks at any.
+    // ---- 1. where the runs' bits begin: the lengths before the workgroup (one batch of loads), its own 16 + the run before them
+    {
+        uint32_t before = 0;
+        if (p.fused_prefix & 1u) for (uint32_t i = tid; i < g0; i += 256u) before += wsum[i];
+        if (tid <= nruns) sh_len[tid] = tid == 0 ? (g0 ? wsum[g0 - 1u] : 0u) : wsum[g0 + tid - 1u];      // [0] = the run before, [1 + k] = run k
+        before = wave_sum(before);
+        if (lane == 0) sh_red[wv] = before;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t at = (p.fused_prefix & 1u) ? sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3] : (p.woff + (size_t)f * p.nwaves)[g0];
+        for (uint32_t k = 0; k < nruns; k++) { sh_lo[k] = at; at += sh_len[1u + k]; }
+        sh_lo[nruns] = at;
+    }
+    __syncthreads();
+    // ---- 2. this wave's four runs side by side: the carried bits, the first 64 chunks (kept for step 4) and the 0xFF counts
+    constexpr uint32_t kPerWave = kFinishRunsPerWg / 4u;
+    RunBytes rb[kPerWave];
+    uint32_t cw[kPerWave][4], nff[kPerWave], most = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kPerWave; j++) {
+        const uint32_t k = min(wv * kPerWave + j, nruns - 1u);                  // (waves past the last run look at it again and store nothing)
+        const uint32_t lo = sh_lo[k], total = sh_len[1u + k], g = g0 + k;
+        RunBytes &b = rb[j];
+        b.run = slots + (size_t)g * p.slot_words;
+        b.nwords = (total + 31u) >> 5;
+        b.r = lo & 7u;
+        b.carry = 0;
+        if (b.r && g) {               // the last r bits of the run before (every run but a scan's last holds at least 64 blocks: never shorter than 8 bits)
+            const uint32_t *prev = slots + (size_t)(g - 1u) * p.slot_words;
+            const uint32_t o = sh_len[k] - b.r, jw = o >> 5, sft = o & 31u;
+            const uint32_t a = __builtin_bswap32(prev[jw]), c = __builtin_bswap32(prev[jw + 1u]);      // (a zero word follows every run)
+            b.carry = ((sft ? (a << sft) | (c >> (32u - sft)) : a) >> (32u - b.r));
+        }
+        const bool last = g + 1u == p.nwaves;
+        const uint32_t vbits = b.r + total;
+        b.nbytes = last ? (vbits + 7u) >> 3 : vbits >> 3;
+        const uint32_t ones = b.nbytes * 8u > vbits ? b.nbytes * 8u - vbits : 0u;                 // (last run only) the padding
+        b.pad_word = vbits >> 5;
+        b.pad_mask = ones ? ((1u << ones) - 1u) << (32u - (vbits & 31u) - ones) : 0u;
+        b.first_byte = lo >> 3;
+        most = max(most, b.nbytes);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kPerWave; j++) {
+        nff[j] = 0;
+        cw[j][0] = cw[j][1] = cw[j][2] = cw[j][3] = 0;
+        if (!(JPEGENC_FINISH_X & 8) && lane * 16u < rb[j].nbytes) nff[j] = rb[j].chunk(lane, cw[j]);
+    }
+    for (uint32_t q = lane + 64u; (q - lane) * 16u < most; q += 64u) {          // (wave-uniform trip count; runs of more than 1 KiB)
+#pragma unroll
+        for (uint32_t j = 0; j < kPerWave; j++) {
+            uint32_t w[4];
+            if (q * 16u < rb[j].nbytes) nff[j] += rb[j].chunk(q, w);
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kPerWave; j++) {
+        const uint32_t n = wave_sum(nff[j]), k = wv * kPerWave + j;
+        if (lane == 0 && k < nruns) sh_ff[k] = n;
+    }
+    __syncthreads();
+    // ---- 3. those of the workgroups before this one: publish, look back, publish
+    if (wv == 0) {
+        const uint32_t mine_ff = wave_sum(lane < nruns ? sh_ff[lane] : 0u);
+        if (lane == 0) __hip_atomic_store(stat + wg, kStatAggregate | mine_ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t before_ff = 0;
+        for (uint32_t end = (JPEGENC_FINISH_X & 1) ? 0u : wg; end > 0;) {      // the window [end - 64, end) of workgroups, lane i looking at workgroup end - 1 - i
+            const bool have = lane < end;
+            const uint32_t idx = have ? end - 1u - lane : 0u;
+            uint32_t v = have ? __hip_atomic_load(stat + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatAggregate;
+            if (__builtin_amdgcn_ballot_w64(have && !(v & (kStatAggregate | kStatInclusive))) != 0) {
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {                       // some predecessor has not counted yet
+                    __builtin_amdgcn_s_sleep(1);
+                    if (have && !(v & (kStatAggregate | kStatInclusive))) v = __hip_atomic_load(stat + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t missing = __builtin_amdgcn_ballot_w64(have && !(v & (kStatAggregate | kStatInclusive)));
+                    if (missing == 0) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kStatSpinTicks) {
+                        // a workgroup that never reported: its runs' bytes are counted here (everything this needs is complete)
+                        const uint32_t who = (uint32_t)__builtin_ctzll(missing);
+                        const uint32_t n = group_ff_count(p, f, slots, wsum, end - 1u - who, lane);
+                        if (lane == who) v = kStatAggregate | n;
+                    }
+                }
+            }
+            // the nearest workgroup with an inclusive count: the lanes up to it add up, nothing beyond it matters
+            const uint64_t incl = __builtin_amdgcn_ballot_w64(have && (v & kStatInclusive));
+            const uint32_t stop = incl ? (uint32_t)__builtin_ctzll(incl) : 64u;
+            before_ff += wave_sum(have && lane <= stop ? (v & kStatValue) : 0u);
+            if (incl) break;
+            end = end > 64u ? end - 64u : 0u;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(stat + wg, kStatInclusive | (before_ff + mine_ff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_base = before_ff;
+        }
+    }
+    __syncthreads();
+    // ---- 4. stuff and copy out: 64 chunks of each of the wave's runs per round, the rounds' loads issued together
+    uint8_t *out = p.out + (size_t)f * p.out_stride;
+    uint8_t *stage = stage_all[wv];
+    uint32_t base[kPerWave];
+    {
+        uint32_t ff_before = sh_base;
+        for (uint32_t k = 0; k < wv * kPerWave && k < nruns; k++) ff_before += sh_ff[k];
+#pragma unroll
+        for (uint32_t j = 0; j < kPerWave; j++) {
+            const uint32_t k = wv * kPerWave + j;
+            base[j] = rb[j].first_byte + ff_before;                              // where the run's first byte goes
+            if (k < nruns) ff_before += sh_ff[k];
+        }
+    }
+    for (uint32_t q0 = 0; q0 * 16u < ((JPEGENC_FINISH_X & 4) ? 0u : most); q0 += 64u) {
+        const uint32_t q = q0 + lane;
+        if (q0) {
+#pragma unroll
+            for (uint32_t j = 0; j < kPerWave; j++) {
+                cw[j][0] = cw[j][1] = cw[j][2] = cw[j][3] = 0;
+                if (q * 16u < rb[j].nbytes) (void)rb[j].chunk(q, cw[j]);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kPerWave; j++) {
+            const RunBytes &me = rb[j];
+            if (wv * kPerWave + j >= nruns || q0 * 16u >= me.nbytes) continue;  // (wave-uniform)
+            const bool active = q * 16u < me.nbytes;
+            const uint32_t valid = active ? min(16u, me.nbytes - q * 16u) : 0u;
+            const uint32_t b[4] = {__builtin_bswap32(cw[j][0]), __builtin_bswap32(cw[j][1]), __builtin_bswap32(cw[j][2]), __builtin_bswap32(cw[j][3])};   // stream byte order
+            const uint32_t m = ff_mask16(b, valid), c = (uint32_t)__builtin_popcount(m);
+            const uint32_t inc = wave_inclusive_dpp(c);
+            const uint32_t round_ff = (uint32_t)__shfl((int)inc, 63);
+            const uint32_t phase = (uint32_t)((uintptr_t)(out + base[j]) & 15u); // the LDS image shares the destination's alignment
+            if (active) stuff16(stage + phase + lane * 16u + inc - c, b, m, valid);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t round_raw = min(64u * 16u, me.nbytes - q0 * 16u), len = round_raw + round_ff, span = phase + len;
+            // out in whole 16-byte pieces (one global_store_dwordx4 per lane: dword by dword the stores were a third of the kernel's
+            // time); the partial pieces at the two ends are shared with the neighbouring runs (or rounds) and go out as 8 + 4 + 2 + 1 bytes
+            uint8_t *gdst = out + base[j] - phase;                               // 16-byte aligned
+            const uint32_t first_full = (phase + 15u) >> 4, last_full = span >> 4;
+            if (!(JPEGENC_FINISH_X & 2)) {
+                for (uint32_t u = first_full + lane; u < last_full; u += 64u)
+                    *reinterpret_cast<uint4 *>(gdst + u * 16u) = *reinterpret_cast<const uint4 *>(stage + u * 16u);
+                const uint32_t head_n = phase ? min(16u, span) - phase : 0u;
+                const uint32_t tail_n = (last_full > 0u || phase == 0u) ? span - last_full * 16u : 0u;
+                if (lane == 62u && head_n) copy_small(gdst + phase, stage + phase, head_n);
+                if (lane == 63u && tail_n) copy_small(gdst + last_full * 16u, stage + last_full * 16u, tail_n);
+            }
+            base[j] += len;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kPerWave; j++) {
+        const uint32_t k = wv * kPerWave + j;
+        if (k < nruns && g0 + k + 1u == p.nwaves && lane == 0) {
+            p.out_bytes[f] = base[j];
+            p.total_bits[f] = sh_lo[k + 1u];
+            // (a launch that also holds scans WITH restart markers goes on to the tile prefix sum and k_stuff over every scan of the
+            //  launch: this one has no tiles and no chunks left for them)
+            p.nfftiles[f] = 0; p.raw_chunks[f] = 0; p.raw_bytes[f] = 0;
+        }
+    }
+}
+
 // Stuffing scatter.  A workgroup takes 256 consecutive chunks; their output is one contiguous byte
 // range, so the bytes (with the inserted 0x00 and the RSTn markers) are laid out in LDS first -
 // phase-aligned with the destination - and then copied out as whole dwords; only the partial words
 // at the two ends, which neighbouring workgroups also touch, are written byte by byte.
 __global__ void __launch_bounds__(256) k_stuff(const EntropyParams *params) {
     Params p = JPEGENC_JOB(params);
-    __shared__ __attribute__((aligned(16))) uint8_t stage[256 * 34 + 32];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[256 * 34 + 48];
     __shared__ uint32_t tile_begin, tile_end, part[4];
+    if (p.nintervals == 1 && (p.fused_prefix & kRunsFinishThemselves)) return;   // k_finish_runs has written the scan
     const uint32_t f = blockIdx.y, n = p.raw_chunks[f];
     const uint32_t *ichunk = p.ichunk + (size_t)f * p.nintervals;
     uint8_t *out = p.out + (size_t)f * p.out_stride;
@@ -645,19 +927,14 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams *params) {
         if (threadIdx.x == 0) tile_begin = pos;
         __syncthreads();
         const uint32_t begin = tile_begin;
-        const uint32_t phase = (uint32_t)((uintptr_t)(out + begin) & 3u);          // LDS image shares the destination's alignment
+        const uint32_t phase = (uint32_t)((uintptr_t)(out + begin) & 15u);         // LDS image shares the destination's alignment
         if (active) {
             uint8_t *dst = stage + phase + (pos - begin);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             const uint32_t valid = ilen - j * 16u < 16u ? ilen - j * 16u : 16u;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                if ((uint32_t)i < valid) {
-                    const uint8_t byte = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
-                    dst[o++] = byte;
-                    if (byte == 0xFF) dst[o++] = 0;          // flush_byte_from_bit_buffer, writer.rs:157-167
-                }
-            }
+            const uint32_t m = ff_mask16(w, valid);
+            stuff16(dst, w, m, valid);                // flush_byte_from_bit_buffer, writer.rs:157-167
+            o = valid + (uint32_t)__builtin_popcount(m);
             if (j + 1 == nchunks) {
                 if (iv + 1 < p.nintervals) {      // RSTn between intervals (encoder.rs:748-752): n = interval index mod 8
                     dst[o++] = 0xFF;
@@ -672,17 +949,16 @@ __global__ void __launch_bounds__(256) k_stuff(const EntropyParams *params) {
         __syncthreads();
         const uint32_t end = tile_end;
         const uint32_t len = end - begin;
-        uint8_t *gdst = out + begin - phase;                                     // 4-byte aligned
+        // out in whole 16-byte pieces; the partial pieces at the two ends are shared with the neighbouring workgroups' tiles
+        uint8_t *gdst = out + begin - phase;                                     // 16-byte aligned
         const uint32_t total = phase + len;
-        for (uint32_t wd = threadIdx.x; wd * 4u < total; wd += 256u) {
-            const uint32_t b0 = wd * 4u;
-            if (b0 >= phase && b0 + 4u <= total) {
-                *reinterpret_cast<uint32_t *>(gdst + b0) = *reinterpret_cast<const uint32_t *>(stage + b0);
-            } else {
-                for (uint32_t k = 0; k < 4u; k++)
-                    if (b0 + k >= phase && b0 + k < total) gdst[b0 + k] = stage[b0 + k];
-            }
-        }
+        const uint32_t first_full = (phase + 15u) >> 4, last_full = total >> 4;
+        for (uint32_t u = first_full + threadIdx.x; u < last_full; u += 256u)
+            *reinterpret_cast<uint4 *>(gdst + u * 16u) = *reinterpret_cast<const uint4 *>(stage + u * 16u);
+        const uint32_t head_n = phase ? min(16u, total) - phase : 0u;
+        const uint32_t tail_n = (last_full > 0u || phase == 0u) ? total - last_full * 16u : 0u;
+        if (threadIdx.x == 254u && head_n) copy_small(gdst + phase, stage + phase, head_n);
+        if (threadIdx.x == 255u && tail_n) copy_small(gdst + last_full * 16u, stage + last_full * 16u, tail_n);
         __syncthreads();
     }
 }
@@ -785,6 +1061,11 @@ static LaunchShape shape_of(const EntropyParams *jobs, int njobs) {
     // 0.8-1.6 us on noise, and per-64-tile counters kept by k_push to shorten the sum cost 2-3 us in contended atomics.
     static const uint32_t allow = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_FUSED_PREFIX_MASK"); return e ? (uint32_t)atoi(e) : 3u; }();   // diagnostic
     if (!s.any_multi) s.fused_prefix = ((s.nwaves <= kFusedPrefixRuns ? 1u : 0u) | (s.fftiles <= kFusedPrefixTiles ? 2u : 0u)) & allow;
+    // JPEGENC_FINISH_KERNEL=1 in the diagnostic build: scans without restart markers are put together by k_finish_runs - ONE launch
+    // instead of k_push / prefix sum / k_stuff.  Built and measured in round 5 (profiles/r05_finish_kernel.txt): byte-identical, and no
+    // faster - 39.8 us against 39.8 for 16 photo-like 4K frames, 148 against 133 on noise - so the three-launch sequence stays.
+    static const bool finish_kernel = JPEGENC_DIAG_ENV("JPEGENC_FINISH_KERNEL") != nullptr;
+    if (s.any_single && finish_kernel) s.fused_prefix |= kRunsFinishThemselves;
     return s;
 }
 
@@ -819,6 +1100,7 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
     const uint32_t nblocks = shape.nblocks, nwaves = shape.nwaves, nintervals = shape.nintervals, fftiles = shape.fftiles;
     const bool any_single = shape.any_single, any_multi = shape.any_multi;
     const bool fused_runs_prefix = shape.fused_prefix & 1u, fused_tiles_prefix = shape.fused_prefix & 2u;
+    const bool runs_finish = shape.fused_prefix & kRunsFinishThemselves;
     const uint32_t bgrid = (nblocks + 255u) / 256u;
     if (fused) {
         const int restart = jobs[0].nintervals > 1 ? (int)(jobs[0].interval_blocks / jobs[0].bpm) : 0;
@@ -841,7 +1123,9 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
         if (e != hipSuccess) return e;
     }
     const uint32_t cgrid = min(fftiles, kChunkGrid);
-    if (any_single) hipLaunchKernelGGL(k_push, dim3((nwaves + 3u) / 4u, frames, njobs), dim3(256), 0, st, d_params);
+    if (any_single && runs_finish) hipLaunchKernelGGL(k_finish_runs, dim3((nwaves + kFinishRunsPerWg - 1u) / kFinishRunsPerWg, frames, njobs), dim3(256), 0, st, d_params);
+    else if (any_single) hipLaunchKernelGGL(k_push, dim3((nwaves + 3u) / 4u, frames, njobs), dim3(256), 0, st, d_params);
+    if (runs_finish && !any_multi) return hipGetLastError();                     // nothing left to place, add up or stuff
     if (any_multi)
         hipLaunchKernelGGL(k_place, dim3(min((fftiles + kPlaceSub - 1u) / kPlaceSub, kChunkGrid), frames, njobs), dim3(256), 0, st, d_params);
     if (!fused_tiles_prefix) {

@@ -20,6 +20,8 @@ constexpr uint32_t kLutWords = 4u * 256u;
 constexpr uint32_t kLutCompactBytes = 2u * (16u + 16u * 11u) * 8u;
 constexpr uint32_t kLutDeviceBytes = kLutWords * 4u + kLutCompactBytes;
 constexpr uint32_t kLutPerFrame = 4u;       // EntropyParams::fused_prefix bit 2: `lut` holds one table set per FRAME of the launch (kLutDeviceBytes apart)
+constexpr uint32_t kRunsFinishThemselves = 8u;   // EntropyParams::fused_prefix bit 3: scans without restart markers are put together by k_finish_runs (one launch: runs
+                                            // shifted into place, 0xFF bytes counted, looked back over and stuffed) instead of k_push + prefix sum + k_stuff
 
 // k_gather_scans: the coded scans of one frame, collected behind a header of their lengths
 constexpr uint32_t kGatherMaxScans = 256;
@@ -91,6 +93,7 @@ struct EntropyParams {
     uint32_t max_fftiles;            // ceil(max_chunks / 256)
     uint32_t *fftile;                // [frames][max_fftiles]  0xFF bytes per tile of 256 chunks
     uint32_t *fftile_off;            // [frames][max_fftiles]  its exclusive prefix sum
+    uint32_t *ffstat;                // [frames][nwaves]       k_finish_runs' look-back words: state << 30 | 0xFF bytes (of the run / of all runs up to it); zeroed by the coder
     uint32_t *total_ff;              // [frames]
     uint32_t *nfftiles;              // [frames] ceil(raw_chunks / 256)
     uint8_t *out;                    // [frames][out_stride]   stuffed segment incl. RSTn markers

@@ -65,6 +65,60 @@ __device__ __forceinline__ uint32_t wg_exclusive(uint32_t x, uint32_t *part, uin
     return base + inc - x;
 }
 
+// ---- 0xFF stuffing of 16 bytes (flush_byte_from_bit_buffer, writer.rs:157-167) without a loop over the bytes --------------
+// 0xFF bytes are rare in entropy-coded data (one byte in 256): 94 % of all 16-byte chunks hold none, and a chunk that does
+// holds one.  So every chunk is first written as it is - ONE unaligned 16-byte LDS store (gfx950 has unaligned DS access:
+// hipcc emits a single ds_write_b128 for an align-1 pointer) - and only the lanes with a 0xFF go on, once per 0xFF: a zero byte
+// behind it and everything after it written again one byte further, as 8 + 4 + 2 + 1 bytes.  The byte-by-byte form this replaces
+// was ~130 instructions per chunk whether there was a 0xFF or not and the larger part of k_stuff's time.
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_a1;
+typedef uint64_t __attribute__((aligned(1))) u64_a1;
+typedef uint32_t __attribute__((aligned(1))) u32_a1;
+typedef uint16_t __attribute__((aligned(1))) u16_a1;
+// bit i of the result: byte i of w (bits 8 i ...) is 0xFF.  Exact: ~w has a zero byte there; (x & 0x7F..) + 0x7F.. carries into bit 7 of
+// every byte whose low seven bits are not all zero, | x brings in its own bit 7.
+__device__ __forceinline__ uint32_t ff_mask4(uint32_t w) {
+    const uint32_t x = ~w;
+    const uint32_t y = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);      // 0x80 in every byte of w that is 0xFF
+    return (((y >> 7) * 0x01020408u) >> 24) & 0xFu;                                  // bits 0, 8, 16, 24 -> 0, 1, 2, 3 (no carries meet)
+}
+__device__ __forceinline__ void write_tail(uint8_t *p, uint64_t lo, uint64_t hi, uint32_t n) {     // the low n < 16 bytes of hi:lo
+    if (n & 8u) { *reinterpret_cast<u64_a1 *>(p) = lo; p += 8; lo = hi; }
+    if (n & 4u) { *reinterpret_cast<u32_a1 *>(p) = (uint32_t)lo; p += 4; lo >>= 32; }
+    if (n & 2u) { *reinterpret_cast<u16_a1 *>(p) = (uint16_t)lo; p += 2; lo >>= 16; }
+    if (n & 1u) *p = (uint8_t)lo;
+}
+__device__ __forceinline__ void copy_small(uint8_t *dst, const uint8_t *src, uint32_t n) {          // n < 16 bytes, any alignment on both sides
+    if (n & 8u) { *reinterpret_cast<u64_a1 *>(dst) = *reinterpret_cast<const u64_a1 *>(src); dst += 8; src += 8; }
+    if (n & 4u) { *reinterpret_cast<u32_a1 *>(dst) = *reinterpret_cast<const u32_a1 *>(src); dst += 4; src += 4; }
+    if (n & 2u) { *reinterpret_cast<u16_a1 *>(dst) = *reinterpret_cast<const u16_a1 *>(src); dst += 2; src += 2; }
+    if (n & 1u) *dst = *src;
+}
+// dst: where the chunk's first byte goes (any alignment; LDS).  b[0..3]: the chunk in stream byte order (byte i of the stream = bits
+// 8 (i & 3) ... of b[i >> 2]); valid <= 16 of its bytes count.  Returns the mask of its 0xFF bytes among the valid ones.
+__device__ __forceinline__ uint32_t ff_mask16(const uint32_t (&b)[4], uint32_t valid) {
+    const uint32_t m = ff_mask4(b[0]) | (ff_mask4(b[1]) << 4) | (ff_mask4(b[2]) << 8) | (ff_mask4(b[3]) << 12);
+    return valid >= 16u ? m : m & ((1u << valid) - 1u);
+}
+__device__ __forceinline__ void stuff16(uint8_t *dst, const uint32_t (&b)[4], uint32_t m, uint32_t valid) {
+    uint64_t lo = (uint64_t)b[1] << 32 | b[0], hi = (uint64_t)b[3] << 32 | b[2];
+    if (valid >= 16u) *reinterpret_cast<u32x4_a1 *>(dst) = u32x4_a1{b[0], b[1], b[2], b[3]};
+    else write_tail(dst, lo, hi, valid);          // (the last chunk of a run or interval: nothing past its end may be touched)
+    uint32_t k = 0;
+    while (m) {                                   // one trip per 0xFF byte of the chunk
+        const uint32_t i = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        k++;
+        const uint32_t s = i + 1u, n = valid - s;  // s bytes are in place; n follow the 0xFF
+        dst[i + k] = 0;
+        // hi:lo >> 8 s (s = 1 .. 16)
+        uint64_t tl, th;
+        if (s >= 8u) { tl = s == 16u ? 0 : hi >> (8u * (s - 8u)); th = 0; }
+        else { tl = (lo >> (8u * s)) | (hi << (64u - 8u * s)); th = hi >> (8u * s); }
+        write_tail(dst + s + k, tl, th, n);
+    }
+}
+
 // bit offset of block b in the scan: its run's offset + the block's offset inside the run (what the coder kernels leave in
 // `bits` for scans with restart intervals)
 __device__ __forceinline__ uint32_t block_bit_offset(Params p, uint32_t f, uint32_t b) {

@@ -169,31 +169,23 @@ __device__ __forceinline__ void finish_run(Params p, uint32_t g, uint32_t tid, u
             __syncthreads();
             uint32_t before = 0, round_ff = 0;
             for (uint32_t i = 0; i < nwaves_wg; i++) { const uint32_t v = sh[4u + i]; if (i < wave) before += v; round_ff += v; }
-            const uint32_t phase = (uint32_t)((uintptr_t)(out + base) & 3u);    // the LDS image shares the destination's alignment
+            const uint32_t phase = (uint32_t)((uintptr_t)(out + base) & 15u);   // the LDS image shares the destination's alignment
             if (active) {
-                uint8_t *dst = stage + phase + tid * 16u + before + inc - c;
-                uint32_t o = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < 16u; i++) {
-                    if (i < valid) {
-                        const uint8_t byte = (uint8_t)(w[i >> 2] >> (24u - 8u * (i & 3u)));
-                        dst[o++] = byte;
-                        if (byte == 0xFFu) dst[o++] = 0;                        // flush_byte_from_bit_buffer, writer.rs:157-167
-                    }
-                }
+                // (stuff16, below: the chunk as it is in one unaligned 16-byte LDS store, then one trip per 0xFF byte - not one per byte)
+                const uint32_t b[4] = {__builtin_bswap32(w[0]), __builtin_bswap32(w[1]), __builtin_bswap32(w[2]), __builtin_bswap32(w[3])};   // stream byte order
+                stuff16(stage + phase + tid * 16u + before + inc - c, b, ff_mask16(b, valid), valid);   // flush_byte_from_bit_buffer, writer.rs:157-167
             }
             __syncthreads();
             const uint32_t round_raw = min(nthreads * 16u, nbytes - q0 * 16u), len = round_raw + round_ff, span = phase + len;
-            uint8_t *gdst = out + base - phase;                                  // 4-byte aligned
-            for (uint32_t wd = tid; wd * 4u < span; wd += nthreads) {
-                const uint32_t b = wd * 4u;
-                if (b >= phase && b + 4u <= span) {
-                    *reinterpret_cast<uint32_t *>(gdst + b) = *reinterpret_cast<const uint32_t *>(stage + b);
-                } else {                                                        // the partial words at the ends are shared with the neighbouring runs
-                    for (uint32_t k = 0; k < 4u; k++)
-                        if (b + k >= phase && b + k < span) gdst[b + k] = stage[b + k];
-                }
-            }
+            // out in whole 16-byte pieces; the partial pieces at the two ends are shared with the neighbouring runs (or rounds)
+            uint8_t *gdst = out + base - phase;                                  // 16-byte aligned
+            const uint32_t first_full = (phase + 15u) >> 4, last_full = span >> 4;
+            for (uint32_t u = first_full + tid; u < last_full; u += nthreads)
+                *reinterpret_cast<uint4 *>(gdst + u * 16u) = *reinterpret_cast<const uint4 *>(stage + u * 16u);
+            const uint32_t head_n = phase ? min(16u, span) - phase : 0u;
+            const uint32_t tail_n = (last_full > 0u || phase == 0u) ? span - last_full * 16u : 0u;
+            if (tid == nthreads - 2u && head_n) copy_small(gdst + phase, stage + phase, head_n);
+            if (tid == nthreads - 1u && tail_n) copy_small(gdst + last_full * 16u, stage + last_full * 16u, tail_n);
             base += len;
             __syncthreads();
         }

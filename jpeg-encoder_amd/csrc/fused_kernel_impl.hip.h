@@ -236,7 +236,7 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
     const uint32_t upto = wave_inclusive_dpp(mcu_bits);
     const uint32_t total = (uint32_t)__shfl((int)upto, 63);
     at += (uint32_t)__shfl((int)(upto - mcu_bits), (int)(mcu_local & 63u));
-    if (tid == 0 && !finish) p.wsum[(size_t)f * p.nwaves + grp] = total;
+    if (tid == 0 && !finish) { p.wsum[(size_t)f * p.nwaves + grp] = total; p.ffstat[(size_t)f * p.nwaves + grp] = 0; }      // (k_finish_runs' look-back word of this run)
     if (p.nintervals > 1u && mine_valid) p.bits[(size_t)f * p.nblocks + (size_t)group_first * bpm + s] = at;   // (interval offsets need them, k_interval_len)
     const uint32_t nwords = (total + 31u) >> 5;
     uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)grp * p.slot_words;

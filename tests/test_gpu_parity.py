@@ -1306,3 +1306,47 @@ def test_half_mcu_kernel_experiment(binding):
     env = dict(os.environ, JPEGENC_DUO="1", JPEGENC_LIB=binding.DIAG_LIB_PATH)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "ok 56" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_finish_kernel_experiment(binding):
+    """k_finish_runs (round 5): scans without restart markers put together in ONE launch after the coder - runs shifted into place,
+    0xFF bytes counted, looked back over (decoupled, per workgroup of 16 runs) and stuffed.  Byte-identical but no faster than
+    k_push / prefix sum / k_stuff (profiles/r05_finish_kernel.txt), so it is only taken with JPEGENC_FINISH_KERNEL=1 in the
+    diagnostic build; this keeps it honest: baseline, sequential, progressive and optimised files, binary noise at quality 100
+    (0xFF-rich scans, runs of several KiB), a frame with more runs than the folded prefix sum takes, a scan with restart markers next
+    to scans without in one launch, device-resident batches."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "ge.load_package()\n"
+        "from jpeg_encoder_amd import binding as b, synth\n"
+        "from oracle import pyoracle as o\n"
+        "n = 0\n"
+        "for (w, h), kw in (((64, 48), dict(quality=90)), ((640, 480), dict(quality=100, sampling=(2, 2))), ((1000, 700), dict(quality=75, sampling=(2, 1))),\n"
+        "                   ((333, 201), dict(quality=80, progressive_scans=4)), ((500, 300), dict(quality=85, sampling=(4, 1))),\n"
+        "                   ((16, 16), dict(quality=80, sampling=(4, 1), restart_interval=3)), ((264, 200), dict(quality=92, optimize=True)),\n"
+        "                   ((4096, 2304), dict(quality=90, sampling=(2, 2))), ((2048, 1032), dict(quality=91))):\n"
+        "    for content in ('photo', 'binary'):\n"
+        "        px = synth.lcg_image(w, h, 3, n) if content == 'photo' else (synth.noise_image(w, h, 3, n) >> 7) * np.uint8(255)\n"
+        "        e = b.Encoder(kw['quality'])\n"
+        "        if 'sampling' in kw: e.set_sampling_factor(b.sampling_factor(*kw['sampling']))\n"
+        "        if kw.get('restart_interval'): e.set_restart_interval(kw['restart_interval'])\n"
+        "        if kw.get('progressive_scans'): e.set_progressive_scans(kw['progressive_scans'])\n"
+        "        if kw.get('optimize'): e.set_optimized_huffman_tables(True)\n"
+        "        assert e.encode(px, w, h, b.RGB) == o.encode_jpeg(px, w, h, o.RGB, **kw), (w, h, kw, content)\n"
+        "        n += 1\n"
+        "w, h, k = 200, 120, 12\n"
+        "frames = np.stack([synth.lcg_image(w, h, 3, 50 + i) for i in range(k)])\n"
+        "d = torch.from_numpy(frames.reshape(k, -1).copy()).to('cuda:0')\n"
+        "e = b.Encoder(88)\n"
+        "e.set_batch_round_frames(5)\n"
+        "got = e.encode_batch_device(d.data_ptr(), w * h * 3, k, w, h, b.RGB)\n"
+        "assert got == [o.encode_jpeg(frames[i], w, h, o.RGB, 88) for i in range(k)]\n"
+        "print('ok', n)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JPEGENC_FINISH_KERNEL="1", JPEGENC_LIB=binding.DIAG_LIB_PATH)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "ok 18" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
