@@ -434,6 +434,8 @@ def main():
     ap.add_argument("--e2e-batches", type=int, default=11, help="timed batches of the end-to-end side figure (min / median / max are reported)")
     ap.add_argument("--c3-frames", type=int, default=1000, help="frames of the config-3 batch (whole job, all ranks); 0 disables")
     ap.add_argument("--c3-passes", type=int, default=7, help="timed passes of the config-3 batch (min / median / max are reported)")
+    ap.add_argument("--c3-register-ahead", action="store_true",
+                    help="also time the config-3 batch with jpegenc_encoder_set_batch_upload(REGISTER_AHEAD) (not under rocprofv3: see profiles/r05_upload_modes.txt)")
     ap.add_argument("--numa-bind", type=int, default=0, choices=(0, 1),
                     help="headline variant of the config-3 leg: batch worker threads bound to the NUMA node of the rank's GPU "
                          "(jpegenc_encoder_set_numa_bind); the other setting is timed beside it (c3_batch.variants)")
@@ -965,10 +967,12 @@ def main():
             # on its shard; the bookkeeping all-reduce inside per_rank_report is unconditional (a rank whose variant failed
             # contributes a negative time), so ranks cannot part ways
             variants = {}
-            for v_pinned in (False, True):
-                for v_bind in (False, True):
-                    name = ("pinned" if v_pinned else "pageable") + ("_numa_bind" if v_bind else "")
-                    is_primary = (v_pinned == (primary_frames is pinned)) and (v_bind == bool(args.numa_bind))
+            # (the register-ahead variant only on request: two threads inside hipHostRegister / hipHostUnregister beside the workers bring
+            #  a process under rocprofv3 down - 11 of 16 runs of tools/diag/r05_upload_modes.py, profiles/r05_upload_modes.txt)
+            for v_pinned, v_bind, v_ahead in ((False, False, 0), (False, True, 0), (True, False, 0), (True, True, 0)) + (((False, False, 1),) if args.c3_register_ahead else ()):
+                if True:
+                    name = ("pinned" if v_pinned else "pageable") + ("_numa_bind" if v_bind else "") + ("_register_ahead" if v_ahead else "")
+                    is_primary = (v_pinned == (primary_frames is pinned)) and (v_bind == bool(args.numa_bind)) and not v_ahead
                     frames_v = pinned if v_pinned else pageable
                     dtv, same, err_v = -1.0, True, None
                     if is_primary:
@@ -978,6 +982,7 @@ def main():
                     else:
                         try:
                             enc3.set_numa_bind(v_bind)
+                            enc3.set_batch_upload(binding.UPLOAD_REGISTER_AHEAD if v_ahead else binding.UPLOAD_STAGED)
                             if frames_v:
                                 enc3.encode_batch_into(frames_v[:64], batch.C3_W, batch.C3_H, binding.RGB, outs3)   # warm-up
                         except Exception as exc:
@@ -1001,12 +1006,14 @@ def main():
                                       if ok and slowest > 0 else {"error": err_v or "failed on another rank"})
             try:
                 enc3.set_numa_bind(bool(args.numa_bind))
+                enc3.set_batch_upload(binding.UPLOAD_STAGED)
             except Exception:
                 pass
             c3["variants"] = variants
             c3["variants_what"] = ("the same sharded batch with the frames in pageable / page-locked host memory (jpegenc_host_alloc: DMA reads them in place, "
                                    "no staging copy by the workers) and the batch worker threads unbound / bound to the NUMA node of the rank's GPU "
-                                   "(jpegenc_encoder_set_numa_bind); seconds = MAX over ranks; per_rank.frac = the rank's upload rate over the h2d rate "
+                                   "(jpegenc_encoder_set_numa_bind); pageable_register_ahead: the pageable frames page-locked a few ahead of the workers by one thread of the handle and uploaded in place "
+                                   "(jpegenc_encoder_set_batch_upload); seconds = MAX over ranks; per_rank.frac = the rank's upload rate over the h2d rate "
                                    "it measured for plain pinned copies while every rank was copying")
             if "pinned" in variants and "error" not in variants["pinned"]:
                 c3["pinned_frames"] = {k: variants["pinned"][k] for k in ("frames_per_s", "seconds", "identical_files")}
@@ -1015,7 +1022,8 @@ def main():
             details["c3_batch"] = c3
             to_bytes["c3_frames_per_s"] = dict({k: c3["frames_per_s_passes"][k] for k in ("min", "median", "max")},
                                                frac_of_h2d=(c3.get("roofline") or {}).get("frac"), per_rank_frac_min_max=[c3["per_rank_min_max"]["frac_min"], c3["per_rank_min_max"]["frac_max"]],
-                                               pinned_frames_per_s=(c3.get("pinned_frames") or {}).get("frames_per_s"), digest=c3.get("digest"))
+                                               pinned_frames_per_s=(c3.get("pinned_frames") or {}).get("frames_per_s"),
+                                               register_ahead_frames_per_s=(variants.get("pageable_register_ahead") or {}).get("frames_per_s"), digest=c3.get("digest"))
         if pinned_buf is not None:
             pinned = primary_frames = None
             try:

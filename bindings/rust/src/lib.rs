@@ -616,6 +616,12 @@ impl<W: JfifWrite> Encoder<W> {
         unsafe { sys::jpegenc_encoder_set_numa_bind(self.h, enable as c_int) };
     }
 
+    /// `true`: one thread of the handle page-locks the pageable frames of a batch a few ahead of the workers, which then upload
+    /// them where they lie (one DRAM move per byte instead of three); `false` (default): every worker stages its frame.
+    pub fn set_register_ahead_uploads(&mut self, enable: bool) {
+        unsafe { sys::jpegenc_encoder_set_batch_upload(self.h, enable as c_int) };
+    }
+
     /// Upper bound on the frames of a device-resident batch in flight together (0 = sized by device memory footprint).
     pub fn set_batch_round_frames(&mut self, frames: u32) {
         unsafe { sys::jpegenc_encoder_set_batch_round_frames(self.h, frames as c_int) };

@@ -117,6 +117,7 @@ extern "C" {
     pub fn jpegenc_encoder_set_device_entropy(e: *mut jpegenc_encoder, enable: c_int) -> c_int;
     pub fn jpegenc_encoder_set_register_cache(e: *mut jpegenc_encoder, bytes: usize) -> c_int;
     pub fn jpegenc_encoder_set_numa_bind(e: *mut jpegenc_encoder, enable: c_int) -> c_int;
+    pub fn jpegenc_encoder_set_batch_upload(e: *mut jpegenc_encoder, mode: c_int) -> c_int;
     pub fn jpegenc_encoder_set_batch_round_frames(e: *mut jpegenc_encoder, frames: c_int) -> c_int;
     pub fn jpegenc_encoder_set_density(e: *mut jpegenc_encoder, unit: c_int, x: u16, y: u16) -> c_int;
     pub fn jpegenc_encoder_density(e: *const jpegenc_encoder, unit: *mut c_int, x: *mut u16, y: *mut u16) -> c_int;

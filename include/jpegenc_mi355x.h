@@ -58,7 +58,7 @@ typedef enum jpegenc_color_type {
      * is widened by bit replication (r8 = r5 << 3 | r5 >> 2, g8 = g6 << 2 | g6 >> 4) and then converted like Rgb: the device
      * form of a user ImageBuffer whose fill_buffers unpacks the words (image_buffer.rs:40-98) - same bytes as that host
      * callback gives (tests/test_gpu_packed_formats.py), no host code, half the upload.  Accepted wherever a colour type is
-     * (host and device-resident entry points, batches); sampling factors 1 and 2, frames below 2 GiB. */
+     * (host and device-resident entry points, batches), at every sampling factor; frames below 2 GiB. */
     JPEGENC_RGB565 = 9, JPEGENC_BGR565 = 10
 } jpegenc_color_type;
 
@@ -272,6 +272,19 @@ int  jpegenc_encoder_set_register_cache(jpegenc_encoder *e, size_t bytes);
  * memory is then first touched there and uploads do not cross the socket interconnect.  Best effort (sysfs), the
  * caller's own thread is left alone.  Default 0, or 1 when JPEGENC_NUMA_BIND is set in the environment. */
 int  jpegenc_encoder_set_numa_bind(jpegenc_encoder *e, int enable);
+/* How jpegenc_encoder_encode_batch (and the calls built on it) bring PAGEABLE frames of more than 2 MB to the device.
+ *   JPEGENC_UPLOAD_STAGED (default): every worker copies its frame into its own page-locked buffer and uploads from there - three
+ *     DRAM moves per frame byte (read, write, DMA read), one busy CPU per worker while it copies;
+ *   JPEGENC_UPLOAD_REGISTER_AHEAD: one thread of the handle page-locks the frames a few ahead of the workers (hipHostRegister of
+ *     whole pages, in frame order), the workers upload them where they lie (a true asynchronous DMA: one DRAM move per byte) and
+ *     a second thread releases them behind the workers (two busy CPUs beside the workers).  Worth it for frames on transparent
+ *     huge pages (they lock at > 1 TB/s: +6-8 % over staging at 4K and 1080p); frames on 4 KB pages lock at 9-13 GB/s, a quarter of
+ *     the link - the locking thread times itself and hands the rest of such a batch to the staged path after three frames.  The frames must stay mapped for the duration of the call (they must
+ *     anyway); a frame that is already page-locked by the caller, in whole or in part, or that cannot be registered is handled as
+ *     in the default mode.  The reference reads the caller's slice in place (encoder.rs:440-454): this is its closest equivalent.
+ * Files do not depend on the mode. */
+typedef enum jpegenc_upload_mode { JPEGENC_UPLOAD_STAGED = 0, JPEGENC_UPLOAD_REGISTER_AHEAD = 1 } jpegenc_upload_mode;
+int  jpegenc_encoder_set_batch_upload(jpegenc_encoder *e, int mode);
 /* Upper bound on the frames of a device-resident batch (jpegenc_encoder_encode_batch_device and the calls built on it) whose
  * device work is in flight together: a round of n frames occupies n x (coefficients + worst-case scan bytes) of device
  * memory.  0 (default): rounds are sized for a 6 GiB footprint, at most 1024 frames.  The files do not depend on it. */
@@ -365,6 +378,11 @@ int  jpegenc_encoder_encode_image(jpegenc_encoder *e, int jpeg_color_type, int w
  *   planes_subsampled = 1: a component the sampling factor decimates by (sx, sy) is given as ceil(width / sx) x
  *     ceil(height / sy) samples (4:2:0 / 4:2:2 surfaces as decoders produce them).  Same bytes as an ImageBuffer that
  *     repeats each such sample sx x sy times: get_block reads exactly one sample per repeat.
+ *   planes_subsampled = 2: a component the sampling factor decimates is given with ceil(width / sx) samples per row and ALL
+ *     height rows - the chroma of packed 4:2:2 surfaces (YUYV / UYVY) - and the sampling factor may decimate vertically as well
+ *     (F_2_2 from a YUYV camera frame): the kernel takes every sy-th row, as get_block does of the rows a fill_buffers
+ *     delivers (encoder.rs:1232-1237), and bottom-edge rows repeat the surface's LAST row.  Same bytes as an ImageBuffer that
+ *     repeats each sample sx times along its row.  Sampling factors 1 and 2.
  * One launch covers all planes - every wave reads its own plane (address, pitch, size and sample stride come from the
  * wave's record) - and an interleaved baseline scan goes from the samples to the coded runs in ONE kernel, like the
  * interleaved pixel formats; sampling factors of 4 take one block-kernel launch per plane.
@@ -392,7 +410,8 @@ int  jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jpeg_color_typ
  * surface's own planes in their usual order (I420, YV12: 3; NV12, NV21, P010, P016: 2 - luma, interleaved chroma; YUYV, UYVY:
  * 1; I010 = planar 10-bit 4:2:0 with the value in the low bits: 3).  Fills planes[0 .. 2] (Y, Cb, Cr; planes[3] zeroed) and
  * returns the sampling factor the layout is subsampled for (JPEGENC_F_2_2 or JPEGENC_F_2_1; pass planes_subsampled = 1 and set
- * that sampling factor on the encoder), or -JPEGENC_ERR_INVALID_ARGUMENT.  Pure arithmetic: no device work. */
+ * that sampling factor on the encoder - or, for the packed 4:2:2 layouts, planes_subsampled = 2 with JPEGENC_F_2_2: 4:2:0 files
+ * from YUYV / UYVY frames), or -JPEGENC_ERR_INVALID_ARGUMENT.  Pure arithmetic: no device work. */
 typedef enum jpegenc_surface_format {
     JPEGENC_SURFACE_I420 = 0, JPEGENC_SURFACE_YV12 = 1, JPEGENC_SURFACE_NV12 = 2, JPEGENC_SURFACE_NV21 = 3,
     JPEGENC_SURFACE_YUYV = 4, JPEGENC_SURFACE_UYVY = 5, JPEGENC_SURFACE_P010 = 6, JPEGENC_SURFACE_P016 = 7, JPEGENC_SURFACE_I010 = 8

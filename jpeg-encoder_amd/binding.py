@@ -21,6 +21,8 @@ RGB565, BGR565 = 9, 10          # extensions: 16-bit packed RGB, unpacked on the
 J_LUMA, J_YCBCR, J_CMYK, J_YCCK = range(4)
 ORDER_MCU, ORDER_PLANAR = 0, 1
 FDCT_SCALAR, FDCT_SIMD = 0, 1
+UPLOAD_STAGED, UPLOAD_REGISTER_AHEAD = 0, 1
+PLANES_FULL, PLANES_SUBSAMPLED, PLANES_SUBSAMPLED_H = 0, 1, 2        # planes_subsampled of the described-surface calls
 (Q_DEFAULT, Q_FLAT, Q_CUSTOM_MS_SSIM, Q_CUSTOM_PSNR_HVS, Q_IMAGE_MAGICK, Q_KLEIN_SILVERSTEIN_CARNEY,
  Q_DENTAL_XRAYS, Q_VISUAL_DETECTION_MODEL, Q_IMPROVED_DETECTION_MODEL, Q_CUSTOM) = range(10)
 DENSITY_PIXEL_ASPECT_RATIO, DENSITY_INCHES, DENSITY_CENTIMETERS = range(3)
@@ -45,7 +47,7 @@ ABI_SYMBOLS = [
     "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_histogram_device",
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
     "jpegenc_pixels_scan_fused", "jpegenc_pixels_scan_device",
-    "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_register_cache", "jpegenc_encoder_set_numa_bind", "jpegenc_encoder_set_batch_round_frames",
+    "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_register_cache", "jpegenc_encoder_set_numa_bind", "jpegenc_encoder_set_batch_upload", "jpegenc_encoder_set_batch_round_frames",
     "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
     "jpegenc_encoder_set_fdct_variant", "jpegenc_encoder_set_density", "jpegenc_encoder_density",
     "jpegenc_encoder_set_sampling_factor", "jpegenc_encoder_sampling_factor",
@@ -449,6 +451,11 @@ class Encoder:
     def optimized_huffman_tables(self):
         return bool(lib().jpegenc_encoder_optimized_huffman_tables(self._h))
 
+    def set_batch_upload(self, mode):
+        """UPLOAD_STAGED (default) or UPLOAD_REGISTER_AHEAD: how batch calls bring pageable frames of more than 2 MB to the device."""
+        lib().jpegenc_encoder_set_batch_upload.argtypes = [C.c_void_p, C.c_int]
+        check(lib().jpegenc_encoder_set_batch_upload(self._h, int(mode)))
+
     def set_register_cache(self, nbytes):
         lib().jpegenc_encoder_set_register_cache.argtypes = [C.c_void_p, C.c_size_t]
         check(lib().jpegenc_encoder_set_register_cache(self._h, nbytes))
@@ -561,7 +568,7 @@ class Encoder:
             return 0
 
         cb = WRITE_FN(sink)
-        check(lib().jpegenc_encoder_encode_planes_device(self._h, jpeg_color_type, width, height, arr, 1 if planes_subsampled else 0, cb, None))
+        check(lib().jpegenc_encoder_encode_planes_device(self._h, jpeg_color_type, width, height, arr, int(planes_subsampled), cb, None))
         return b"".join(chunks)
 
     def encode_planes_batch_device(self, jpeg_color_type, width, height, frames, planes_subsampled=False):
@@ -582,7 +589,7 @@ class Encoder:
         users = (C.c_void_p * max(n, 1))(*[i for i in range(n)])
         fn = lib().jpegenc_encoder_encode_planes_batch_device
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Plane), C.c_int, C.c_int, WRITE_FN, C.POINTER(C.c_void_p)]
-        check(fn(self._h, jpeg_color_type, width, height, arr, n, 1 if planes_subsampled else 0, cb, users))
+        check(fn(self._h, jpeg_color_type, width, height, arr, n, int(planes_subsampled), cb, users))
         return [b"".join(o) for o in outs]
 
     def encode_batch_device(self, d_frames_ptr, frame_stride, num_frames, width, height, color_type):

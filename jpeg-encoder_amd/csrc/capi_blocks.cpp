@@ -142,7 +142,6 @@ int build_block_params(BlockKernelParams *p, const jpegenc_layout &L, int width,
         // 16-bit packed pixels: unpacked to an RGB-order word on the device, then the Rgb conversion (tuned kernels only)
         p->xform = XF_RGB2YCC;
         p->packed565 = 0x10000u | (color_type == JPEGENC_RGB565 ? 11u : 0u) | ((color_type == JPEGENC_RGB565 ? 0u : 11u) << 8);
-        if (L.max_h > 2 || L.max_v > 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "RGB565 / BGR565 frames take sampling factors 1 and 2");
         if ((uint64_t)width * (uint64_t)height * 2u >= (1ull << 31)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "RGB565 / BGR565 frames must be smaller than 2 GiB");
         break;
     default: return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown colour type");

@@ -114,6 +114,9 @@ struct BlockKernelParams {
     uint32_t plane_mcu_w, plane_mcu_h;   // 0 = 8 * hmax / 8 * vmax
     uint32_t plane_byte_index, plane_invert;
     uint32_t packed565;               // != 0: the pixels are 16-bit r5 g6 b5 words (bpp 2): bit 16 set, bits 0..7 / 8..15 = bit position of the red / blue field
+    uint32_t plane_last_extra[4];     // described planes that are subsampled horizontally ONLY (packed 4:2:2 at F_2_2: planes_subsampled = 2): the plane is read
+                                      // with sy x its pitch, and rows past its last one repeat source row height - 1 (encoder.rs:738-744) - this many bytes
+                                      // behind the start of plane row ceil(height / sy) - 1
     QuantDev q[2];
     FastHeader fast_hdr;
     FastWave fast_wave[10];

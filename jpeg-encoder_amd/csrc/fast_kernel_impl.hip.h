@@ -425,7 +425,15 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
     me.y0 = (int)(uy * mcu_h + vrow * 8u * (uint32_t)syc);
     const bool aligned4 = (((uintptr_t)frame | pitch) & 3u) == 0;   // wave-uniform
     const uint32_t first = (uint32_t)me.y0 * pitch + (uint32_t)me.x0 * (uint32_t)bpp;
-    const uint32_t last = (uint32_t)hlim * pitch + (uint32_t)me.x0 * (uint32_t)bpp;
+    // (described planes subsampled horizontally only: the row that bottom-edge rows repeat lies `extra` bytes behind the last plane row)
+    uint32_t last_extra = 0;
+    if (PLANES) {
+        const uint32_t __attribute__((address_space(4))) *ex = (const uint32_t __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)
+            __builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(BlockKernelParams, plane_last_extra));
+        last_extra = ex[c];
+    }
+    const uint32_t last_row = (uint32_t)hlim * pitch + last_extra;
+    const uint32_t last = last_row + (uint32_t)me.x0 * (uint32_t)bpp;
     uint32_t rows[8][4];
 #ifdef JPEGENC_WAVE_TIMING
     __builtin_amdgcn_sched_barrier(0);
@@ -507,7 +515,7 @@ __device__ __forceinline__ bool block_compute(const ColourConsts &k, const uint3
 #pragma nounroll
         for (int i = 0; i < 64; i++) {
             const int y = i >> 3, x = i & 7;
-            const gbytes row = frame + (size_t)min(me.y0 + y * syc, hlim) * pitch;
+            const gbytes row = frame + min((uint32_t)(me.y0 + y * syc) * pitch, last_row);
             mine[i] = (uint8_t)edge_sample(row + (size_t)min(me.x0 + x * sxc, width - 1) * (size_t)bpp, role, c, k);
         }
 #pragma unroll
@@ -720,6 +728,7 @@ static inline bool fill_fast_params(BlockKernelParams &q, const ColourConsts &k,
         f.byte_pack = 0x0C040C00u | b | (b << 16);     // byte b of each pixel word -> zero-extended 16-bit pair
         if (conv && k.packed565) f.byte_pack = k.packed565 & 0xFFFFu;            // (no byte role in these kernels: the slot carries the field positions)
         f.plane_lo = (uint32_t)k.plane_offset[c]; f.plane_hi = (uint32_t)(k.plane_offset[c] >> 32);
+        if (planes && w == wave_first[c]) q.plane_last_extra[c] = (uint32_t)planes[c].reserved;      // (normalize_planes, host_internal.h)
         if (planes) {
             const bool own_size = planes_subsampled && decimated;
             const uint32_t pw = own_size ? (uint32_t)((q.width + q.sx[c] - 1) / q.sx[c]) : (uint32_t)q.width;

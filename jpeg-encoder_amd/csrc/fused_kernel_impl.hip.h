@@ -147,7 +147,14 @@ k_group_code(const BlockKernelParams bp, const ColourConsts k, const EntropyPara
         const int by = (int)(pmy * mcu_h + ((1u << lgv) - 1u) * 8u * (uint32_t)csy) + (int)(lane >> 3) * csy;
         const int c = (int)((wbits >> FW_COMP_SHIFT) & 3u), role = (int)((wbits >> FW_ROLE_SHIFT) & 3u);
         const gbytes frame = frame_base<PLANES>(H, Wv, f, (uint32_t)c, ppitch);
-        pred_sample = edge_sample(frame + (size_t)min(by, ph - 1) * ppitch + (size_t)min(bx, pw - 1) * pbpp, role, c, k);
+        // (described planes subsampled horizontally only: bottom-edge rows repeat a source row `extra` bytes behind the last plane row - block_compute)
+        uint32_t last_extra = 0;
+        if (PLANES) {
+            const uint32_t __attribute__((address_space(4))) *ex = (const uint32_t __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)
+                __builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(BlockKernelParams, plane_last_extra));
+            last_extra = ex[c];
+        }
+        pred_sample = edge_sample(frame + min((uint32_t)by * ppitch, (uint32_t)(ph - 1) * ppitch + last_extra) + (size_t)min(bx, pw - 1) * pbpp, role, c, k);
     }
 
     // ---- the AC symbols of the block, into the lane's strip from bit 32 (before the barrier: the other waves still fetch) ----

@@ -587,22 +587,32 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
     const int ncomp = jct == JPEGENC_J_LUMA ? 1 : jct == JPEGENC_J_YCBCR ? 3 : 4;
     int hs, vs;
     sampling_hv(e->cfg.sampling, &hs, &vs);
+    if (planes_subsampled < 0 || planes_subsampled > 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "planes_subsampled must be 0, 1 or 2");
+    if (planes_subsampled == 2 && (hs > 2 || vs > 2)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "horizontally subsampled planes are taken at sampling factors 1 and 2");
+    for (int f = 0; f < num_frames; f++)
+        for (int i = 0; i < ncomp; i++) {
+            const int rc_plane = validate_plane(planes[(size_t)f * 4 + i], hs, vs, planes_subsampled != 0);
+            if (rc_plane) return rc_plane;
+        }
+    // (horizontally subsampled planes - mode 2 - become ordinary subsampled ones with a longer pitch: normalize_planes; from here
+    //  on `planes` are the normalised descriptors and the mode is a yes / no)
+    std::vector<jpegenc_plane> norm;
+    const bool subsampled = normalize_planes(planes_subsampled, planes, num_frames, jct, e->cfg.sampling, width, height, norm);
+    planes = norm.data();
     bool uniform = true;
     for (int f = 0; f < num_frames; f++)
         for (int i = 0; i < ncomp; i++) {
             const jpegenc_plane &pl = planes[(size_t)f * 4 + i], &p0 = planes[i];
-            const int rc_plane = validate_plane(pl, hs, vs, planes_subsampled != 0);
-            if (rc_plane) return rc_plane;
-            if (pl.pixel_stride != p0.pixel_stride || (pl.invert != 0) != (p0.invert != 0) || pl.shift != p0.shift ||
+            if (pl.pixel_stride != p0.pixel_stride || (pl.invert != 0) != (p0.invert != 0) || pl.shift != p0.shift || pl.reserved != p0.reserved ||
                 (((uintptr_t)pl.d_data ^ (uintptr_t)p0.d_data) & (uintptr_t)(pl.pixel_stride - 1)))
                 uniform = false;
         }
     const bool shareable = e->cfg.device_entropy && hs != 4 && vs != 4;      // (per-frame optimised tables share launches too: BatchRun)
-    if (num_frames == 1) return jpegenc_encoder_encode_planes_device(e, jct, width, height, planes, planes_subsampled, sink, users[0]);
-    if (!shareable) return encode_planes_frames_pooled(e, jct, width, height, planes, num_frames, planes_subsampled != 0, sink, users);
+    if (num_frames == 1) return encode_planes_one(e, jct, width, height, planes, subsampled, sink, users[0]);
+    if (!shareable) return encode_planes_frames_pooled(e, jct, width, height, planes, num_frames, subsampled, sink, users);
     if (uniform) {
         int bad = -1;
-        const int rc = encode_planes_uniform(e, jct, width, height, ncomp, planes, num_frames, planes_subsampled != 0, sink, users, &bad);
+        const int rc = encode_planes_uniform(e, jct, width, height, ncomp, planes, num_frames, subsampled, sink, users, &bad);
         if (rc != JPEGENC_OK && bad >= 0) set_last_error("frame " + std::to_string(bad) + ": " + jpegenc_last_error());
         return rc;
     }
@@ -617,7 +627,7 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
             bool same = true;
             for (int i = 0; i < ncomp && same; i++) {
                 const jpegenc_plane &pl = planes[(size_t)f * 4 + i], &p0 = planes[(size_t)leaders[g] * 4 + i];
-                same = pl.pixel_stride == p0.pixel_stride && (pl.invert != 0) == (p0.invert != 0) && pl.shift == p0.shift &&
+                same = pl.pixel_stride == p0.pixel_stride && (pl.invert != 0) == (p0.invert != 0) && pl.shift == p0.shift && pl.reserved == p0.reserved &&
                        !(((uintptr_t)pl.d_data ^ (uintptr_t)p0.d_data) & (uintptr_t)(pl.pixel_stride - 1));
             }
             if (same) group_of[(size_t)f] = (int)g;
@@ -638,8 +648,8 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
             }
         if (ids.empty()) continue;
         int bad = -1, rc;
-        if (ids.size() == 1) { rc = jpegenc_encoder_encode_planes_device(e, jct, width, height, sub.data(), planes_subsampled, sink, sub_users[0]); bad = 0; }
-        else rc = encode_planes_uniform(e, jct, width, height, ncomp, sub.data(), (int)ids.size(), planes_subsampled != 0, sink, sub_users.data(), &bad);
+        if (ids.size() == 1) { rc = encode_planes_one(e, jct, width, height, sub.data(), subsampled, sink, sub_users[0]); bad = 0; }
+        else rc = encode_planes_uniform(e, jct, width, height, ncomp, sub.data(), (int)ids.size(), subsampled, sink, sub_users.data(), &bad);
         if (rc != JPEGENC_OK && bad < 0) {
             // not a frame's own failure (a HIP error, an allocation, a code that came out too long): no frame is invented for it -
             // the pool stops here with the status as it is; what a group before this one has reported stays the lower frame
@@ -654,6 +664,182 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
     if (bad_status != JPEGENC_OK) { set_last_error(bad_frame >= 0 ? "frame " + std::to_string(bad_frame) + ": " + bad_message : bad_message); return bad_status; }
     return JPEGENC_OK;
 }
+
+}  // extern "C"
+
+namespace jpegenc {
+
+// JPEGENC_UPLOAD_REGISTER_AHEAD: one thread page-locks the batch's pageable frames a few ahead of the workers and a second one
+// releases them behind the workers - never more than one thread inside hipHostRegister and one inside hipHostUnregister, never a
+// pageable hipMemcpyAsync from a worker (eight workers inside the runtime's pageable-copy path crashed profiled processes:
+// profiles/r04_pageable_upload_crash.txt).
+// Whole pages are registered, in frame order; frames that share a page (a contiguous array of frames whose size is not a multiple
+// of the page) split it: the page belongs to the range registered first, the later frame's range starts behind it (or ends before
+// it), and a range is released only when the frame AFTER it is done as well.
+struct RegisterAhead {
+    const uint8_t *const *frames;
+    const size_t bytes;
+    const int n, depth, device;
+    std::atomic<int> &taken;                       // frames handed to workers so far (the batch's own counter)
+    std::unique_ptr<std::atomic<int>[]> state;     // 0 = not looked at yet, 1 = page-locked here, 2 = to be staged (the caller's in part, or not lockable), 3 = the caller's as a whole: in place
+    std::unique_ptr<std::atomic<int>[]> done;
+    std::atomic<bool> finished{false};
+    std::atomic<int> reg_count{0};                 // frames the registrar has looked at
+    std::thread releaser;                          // (two_threads) the unregistering half on a thread of its own
+    std::atomic<uint64_t> registered_bytes{0}, register_ns{0}, unregister_ns{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread th;
+    struct Range { void *p; size_t len; };
+    std::vector<Range> ranges;
+    struct Pieces { size_t n[3]; };                // bytes of frame i that lie in the registration before its own / in its own / in the one after
+    std::vector<Pieces> pieces;
+    RegisterAhead(const uint8_t *const *f, size_t b, int count, int ahead, int dev, std::atomic<int> &next)
+        : frames(f), bytes(b), n(count), depth(ahead), device(dev), taken(next), state(new std::atomic<int>[(size_t)count]), done(new std::atomic<int>[(size_t)count]),
+          ranges((size_t)count, Range{nullptr, 0}), pieces((size_t)count, Pieces{{0, 0, 0}}) {
+        for (int i = 0; i < count; i++) { state[i].store(0); done[i].store(0); }
+        // Two threads: one locks ahead of the workers, one releases behind them.  Locking is cheap (1 000 1080p frames: 5 ms in all),
+        // RELEASING is what costs (110 ms for the same frames, 56 GB/s): with both halves on one thread the workers wait for frames
+        // that are not locked yet because the thread is busy unlocking (6 700 against 7 500 frames/s staged; two threads: 8 100).
+        // Never more than one thread inside hipHostRegister and one inside hipHostUnregister.  JPEGENC_REGISTER_AHEAD_THREADS=1
+        // (diagnostic build): both halves on one thread, profiles/r05_upload_modes.txt.
+        static const bool one = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_REGISTER_AHEAD_THREADS"); return v && atoi(v) == 1; }();
+        two_threads = !one;
+        th = std::thread([this] { run(); });
+        if (two_threads) releaser = std::thread([this] { release_loop(); });
+    }
+    bool two_threads = false;
+    ~RegisterAhead() { finish(); }
+    void finish() {                                 // every worker is done (or has given up): release what is still locked
+        if (!th.joinable()) return;
+        finished.store(true);
+        { std::lock_guard<std::mutex> lock(mu); }
+        cv.notify_all();
+        th.join();
+        if (releaser.joinable()) releaser.join();
+    }
+    // the releasing half: ranges of frames [unreg, limit) where limit lags one frame behind the finished prefix
+    int release_some(int unreg, int done_prefix_out[1]) {
+        int dp = done_prefix_out[0];
+        while (dp < n && done[dp].load(std::memory_order_acquire)) dp++;
+        done_prefix_out[0] = dp;
+        const bool fin = finished.load();
+        const int reg = reg_count.load(std::memory_order_acquire);
+        int can_unreg = fin ? reg : (dp >= n ? n : dp - 1);     // (a range may hold the first or last page of the frame after it)
+        if (can_unreg > reg) can_unreg = reg;
+        auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        while (unreg < can_unreg) {
+            if (ranges[(size_t)unreg].len) {
+                const uint64_t t0 = now_ns();
+                if (hipHostUnregister(ranges[(size_t)unreg].p) != hipSuccess) (void)hipGetLastError();
+                unregister_ns += now_ns() - t0;
+            }
+            unreg++;
+        }
+        return unreg;
+    }
+    void release_loop() {
+        if (hipSetDevice(device) != hipSuccess) (void)hipGetLastError();
+        int unreg = 0, dp[1] = {0};
+        for (;;) {
+            const bool fin = finished.load();
+            const bool registrar_gone = reg_done.load();
+            const int before = unreg;
+            unreg = release_some(unreg, dp);
+            if (fin ? (registrar_gone && unreg >= reg_count.load()) : unreg >= n) break;
+            if (unreg == before) {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait_for(lock, std::chrono::microseconds(200));
+            }
+        }
+    }
+    std::atomic<bool> reg_done{false};
+    bool gave_up = false;                          // (registrar thread only; read by the caller after finish())
+    void wait_ready(int i) {                        // worker: frame i has been looked at
+        if (state[i].load(std::memory_order_acquire)) return;
+        std::unique_lock<std::mutex> lock(mu);
+        cv.notify_all();                            // (the registrar may be waiting for `taken` to move)
+        cv.wait(lock, [&] { return state[i].load(std::memory_order_acquire) != 0 || finished.load(); });
+    }
+    void frame_done(int i) {
+        done[i].store(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> lock(mu); }
+        cv.notify_all();
+    }
+    void run() {
+        if (hipSetDevice(device) != hipSuccess) (void)hipGetLastError();
+        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+        uintptr_t prev_a = 0, prev_b = 0;           // the range registered last
+        int reg = 0, unreg = 0, dp[1] = {0};
+        auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        for (;;) {
+            bool progressed = false;
+            const bool fin = finished.load();
+            if (!two_threads) {
+                const int before = unreg;
+                unreg = release_some(unreg, dp);
+                progressed = unreg != before;
+                if (fin ? unreg >= reg : unreg >= n) break;
+            } else if (fin || reg >= n) {
+                break;                              // (the releaser sees to the rest)
+            }
+            if (!fin && reg < n && reg < taken.load() + depth) {
+                const uint8_t *p = frames[reg];
+                int st = 2;
+                // How fast pages can be locked depends on what backs them: frames on transparent huge pages lock at > 1 TB/s (5 ms
+                // for 6.2 GB), frames on 4 KB pages at 9-13 GB/s - a quarter of what the link moves (profiles/r05_upload_modes.txt).
+                // The thread times itself: once at least three frames and 16 MB are on record at under 30 GB/s, it stops locking and
+                // the rest of the batch is staged by the workers as in the default mode.
+                if (!gave_up && reg >= 3 && registered_bytes.load() >= ((uint64_t)16 << 20) &&
+                    (double)registered_bytes.load() / (double)(register_ns.load() ? register_ns.load() : 1) < 30.0) gave_up = true;
+                if (p && bytes && !gave_up) {
+                    const uintptr_t first = (uintptr_t)p, end = first + bytes;
+                    uintptr_t a = first & ~(page - 1), b = (end + page - 1) & ~(page - 1);
+                    Pieces pc = {{0, bytes, 0}};
+                    if (a < prev_b && b > prev_a) {             // shares a page with the range registered last
+                        if (a >= prev_a) { a = prev_b; pc.n[0] = a > first ? (size_t)(std::min(a, end) - first) : 0; pc.n[1] = bytes - pc.n[0]; }
+                        else { b = prev_a; pc.n[2] = end > b ? (size_t)(end - std::max(b, first)) : 0; pc.n[1] = bytes - pc.n[2]; }
+                    }
+                    // (page-locked by someone else - the caller - in whole or in part: left as it is.  Looked at OUTSIDE the range
+                    //  registered last: a neighbour's page that this thread locked itself says nothing about the caller)
+                    const bool pinned_head = b > a && is_pinned_host((const uint8_t *)std::max(a, first)), pinned_tail = b > a && is_pinned_host((const uint8_t *)std::min(b, end) - 1);
+                    if (pinned_head || pinned_tail) {
+                        st = pinned_head && pinned_tail && pc.n[1] == bytes ? 3 : 2;      // the caller's, as a whole (uploaded where it lies) / in part (staged)
+                    } else if (b > a) {
+                        const uint64_t t0 = now_ns();
+                        if (hipHostRegister((void *)a, b - a, hipHostRegisterDefault) == hipSuccess) {
+                            ranges[(size_t)reg] = Range{(void *)a, b - a};
+                            prev_a = a; prev_b = b;
+                            registered_bytes += b - a; register_ns += now_ns() - t0;
+                            st = 1;
+                        } else {
+                            (void)hipGetLastError();              // (someone else's registration in the way, a limit: the worker stages this frame)
+                        }
+                    } else {
+                        st = 1;                                   // wholly inside the page(s) the frame before brought along
+                    }
+                    pieces[(size_t)reg] = pc;
+                }
+                state[reg].store(st, std::memory_order_release);
+                reg++; progressed = true;
+                reg_count.store(reg, std::memory_order_release);
+                { std::lock_guard<std::mutex> lock(mu); }
+                cv.notify_all();
+            }
+            if (!progressed) {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait_for(lock, std::chrono::microseconds(200));
+            }
+        }
+        reg_done.store(true);
+        { std::lock_guard<std::mutex> lock(mu); }
+        cv.notify_all();
+    }
+};
+
+}  // namespace jpegenc
+
+extern "C" {
 
 int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len, int num_frames,
                                  int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
@@ -740,6 +926,11 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
     const bool staged = true;      // batch frames: uploaded by the worker (through its page-locked staging, or in place where the caller page-locked them), never read by the kernel over the link
+    // register-ahead (jpegenc_encoder_set_batch_upload; JPEGENC_REGISTER_AHEAD=0/1 in the diagnostic build overrides the handle)
+    static const char *ra_env = JPEGENC_DIAG_ENV("JPEGENC_REGISTER_AHEAD");
+    const bool register_ahead = ra_env ? atoi(ra_env) != 0 : e->batch_upload == JPEGENC_UPLOAD_REGISTER_AHEAD;
+    std::unique_ptr<RegisterAhead> ahead;
+    if (register_ahead) ahead.reset(new RegisterAhead(frames, frame_bytes, num_frames, workers + 4, e->device, next));
     auto body = [&](int w) {
         if (w > 0) bind_thread_near_device(e->device, e->numa_bind);   // (opt-in) spawned workers; the caller's own affinity is left alone
         DeviceCtx &ctx = *e->workers[(size_t)w];
@@ -747,8 +938,12 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= num_frames || status.load() != JPEGENC_OK) break;
-            int r = frames[i] ? encode_pixels(e->cfg, ctx, e->device, frames[i], frame_len, width, height, color_type, sink, users[i], staged)
+            if (ahead) ahead->wait_ready(i);                           // page-locked by now (or left as it is): encode_pixels uploads a locked frame where it lies
+            const int st = ahead ? ahead->state[i].load(std::memory_order_acquire) : 0;
+            const size_t *locked = st == 1 ? ahead->pieces[(size_t)i].n : nullptr;
+            int r = frames[i] ? encode_pixels(e->cfg, ctx, e->device, frames[i], frame_len, width, height, color_type, sink, users[i], staged, locked, st >= 2 ? st : 0)
                               : fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
+            if (ahead) ahead->frame_done(i);
             ctx.last_cpu = sched_getcpu();
             if (r != JPEGENC_OK) {
                 int expected = JPEGENC_OK;
@@ -758,6 +953,14 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
         }
     };
     e->threads.run(workers, body);
+    if (ahead) {
+        ahead->finish();
+        static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[jpegenc] register-ahead: %.1f MB page-locked in %.2f ms (%.1f GB/s), released in %.2f ms%s\n",
+                           (double)ahead->registered_bytes.load() / 1e6, (double)ahead->register_ns.load() / 1e6,
+                           ahead->register_ns.load() ? (double)ahead->registered_bytes.load() / (double)ahead->register_ns.load() : 0.0, (double)ahead->unregister_ns.load() / 1e6,
+                           ahead->gave_up ? "; too slow for the link: the rest of the batch was staged" : "");
+    }
     if (status.load() != JPEGENC_OK) {
         for (const auto &m : messages) if (!m.empty()) { set_last_error(m); break; }
         return status.load();

@@ -68,6 +68,12 @@ int jpegenc_encoder_set_numa_bind(jpegenc_encoder *e, int enable) {
     e->numa_bind = enable != 0;
     return JPEGENC_OK;
 }
+int jpegenc_encoder_set_batch_upload(jpegenc_encoder *e, int mode) {
+    REQUIRE(e);
+    if (mode != JPEGENC_UPLOAD_STAGED && mode != JPEGENC_UPLOAD_REGISTER_AHEAD) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown upload mode");
+    e->batch_upload = mode;
+    return JPEGENC_OK;
+}
 
 int jpegenc_encoder_set_fdct_variant(jpegenc_encoder *e, int variant) {
     REQUIRE(e);
@@ -310,6 +316,23 @@ int jpegenc_encoder_encode_image(jpegenc_encoder *e, int jct, int width, int hei
     return encode_frame(e->cfg, e->ctx, jct, width, height, 100 + jct, bytes, upload, sink, sink_user);
 }
 
+}  // extern "C"
+namespace jpegenc {
+// one described surface whose descriptors have been checked and normalised (normalize_planes)
+int encode_planes_one(jpegenc_encoder *e, int jct, int width, int height, const jpegenc_plane *planes, bool subsampled, jpegenc_write_fn sink, void *user) {
+    const int ncomp = jct == JPEGENC_J_LUMA ? 1 : jct == JPEGENC_J_YCBCR ? 3 : 4;
+    int rc = e->ctx.open(e->device);
+    if (rc) return rc;
+    e->ctx.external_planes = planes;
+    e->ctx.external_planes_subsampled = subsampled;
+    auto upload = [&](DeviceCtx &) -> int { return JPEGENC_OK; };
+    rc = encode_frame(e->cfg, e->ctx, jct, width, height, 100 + jct, (size_t)width * (size_t)height * (size_t)ncomp, upload, sink, user);
+    e->ctx.external_planes = nullptr;
+    return rc;
+}
+}  // namespace jpegenc
+extern "C" {
+
 int jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jct, int width, int height, const jpegenc_plane planes[4],
                                          int planes_subsampled, jpegenc_write_fn sink, void *user) {
     REQUIRE(e);
@@ -320,19 +343,16 @@ int jpegenc_encoder_encode_planes_device(jpegenc_encoder *e, int jct, int width,
     const int ncomp = jct == JPEGENC_J_LUMA ? 1 : jct == JPEGENC_J_YCBCR ? 3 : 4;
     int hs, vs;
     sampling_hv(e->cfg.sampling, &hs, &vs);
+    if (planes_subsampled < 0 || planes_subsampled > 2) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "planes_subsampled must be 0, 1 or 2");
+    if (planes_subsampled == 2 && (hs > 2 || vs > 2)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "horizontally subsampled planes are taken at sampling factors 1 and 2");
     for (int i = 0; i < ncomp; i++) {
         if (!planes[i].d_data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null plane");
         const int rc_plane = validate_plane(planes[i], hs, vs, planes_subsampled != 0);
         if (rc_plane) return rc_plane;
     }
-    int rc = e->ctx.open(e->device);
-    if (rc) return rc;
-    e->ctx.external_planes = planes;
-    e->ctx.external_planes_subsampled = planes_subsampled != 0;
-    auto upload = [&](DeviceCtx &) -> int { return JPEGENC_OK; };
-    rc = encode_frame(e->cfg, e->ctx, jct, width, height, 100 + jct, (size_t)width * (size_t)height * (size_t)ncomp, upload, sink, user);
-    e->ctx.external_planes = nullptr;
-    return rc;
+    std::vector<jpegenc_plane> norm;
+    const bool subsampled = normalize_planes(planes_subsampled, planes, 1, jct, e->cfg.sampling, width, height, norm);
+    return jpegenc::encode_planes_one(e, jct, width, height, norm.data(), subsampled, sink, user);
 }
 
 

@@ -300,7 +300,7 @@ struct FrameRun {
             if (ctx.external_planes) {                                        // a described planar source: its descriptors are part of what the sequence bakes in
                 for (int i = 0; i < L.num_components; i++) {
                     const jpegenc_plane &pl = ctx.external_planes[i];
-                    const int64_t d[] = {(int64_t)(uintptr_t)pl.d_data, (int64_t)pl.pitch, pl.pixel_stride, pl.invert, pl.shift, (int64_t)ctx.external_planes_subsampled};
+                    const int64_t d[] = {(int64_t)(uintptr_t)pl.d_data, (int64_t)pl.pitch, pl.pixel_stride, pl.invert, pl.shift, (int64_t)ctx.external_planes_subsampled, (int64_t)pl.reserved};
                     put(d, sizeof d);
                 }
             }
@@ -835,7 +835,7 @@ int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height
 }
 
 int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *data, size_t len, int width,
-                         int height, int color_type, jpegenc_write_fn sink, void *user, bool staged) {
+                         int height, int color_type, jpegenc_write_fn sink, void *user, bool staged, const size_t *locked_pieces, int upload_hint) {
     int rc = validate_image(len, width, height, color_type);      // before any device work
     if (rc) return rc;
     if (!sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null sink");
@@ -877,11 +877,18 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
     // 119 us of CPU per 6.2 MB frame, csrc/tools/host_register_rates.cpp, but in the pool it is 3-5 % slower than the staging copy,
     // and it cannot tell a range the CALLER has partly registered from its own registration: not kept.)
     static const bool in_place = JPEGENC_DIAG_ENV("JPEGENC_IN_PLACE_UPLOADS") != nullptr;
-    const bool caller_locked = staged && bytes && is_pinned_host((const uint8_t *)data) && is_pinned_host((const uint8_t *)data + bytes - 1);
+    const bool caller_locked = upload_hint == 3 || (upload_hint == 0 && staged && bytes && is_pinned_host((const uint8_t *)data) && is_pinned_host((const uint8_t *)data + bytes - 1));
     // (a frame the caller has page-locked only in part - a registration that ends inside it - is staged like a pageable one)
-    const bool partly_locked = staged && bytes && is_pinned_host((const uint8_t *)data) != is_pinned_host((const uint8_t *)data + bytes - 1);
+    const bool partly_locked = upload_hint == 2 || (upload_hint == 0 && staged && bytes && is_pinned_host((const uint8_t *)data) != is_pinned_host((const uint8_t *)data + bytes - 1));
     auto upload = [&](DeviceCtx &cx) -> int {
-        if (staged && (caller_locked || (in_place && !partly_locked))) {
+        if (staged && locked_pieces) {                 // page-locked by the handle's registrar, in up to three registrations
+            size_t at = 0;
+            for (int k = 0; k < 3; k++) {
+                const size_t n = locked_pieces[k] < bytes - at ? locked_pieces[k] : bytes - at;
+                if (n) JPEGENC_HIP(hipMemcpyAsync((uint8_t *)cx.d_pixels + at, data + at, n, hipMemcpyHostToDevice, cx.stream));
+                at += n;
+            }
+        } else if (staged && (caller_locked || (in_place && !partly_locked))) {
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
         } else if (staged) {       // a copy into this worker's pinned buffer, then a true async DMA
             if (bytes > cx.h_pixels_cap) {

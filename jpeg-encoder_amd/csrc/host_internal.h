@@ -905,6 +905,7 @@ struct jpegenc_encoder {
     SmallBatchBuffers small;                             // batches of small frames
     int max_batch_workers = 16;                          // host threads of jpegenc_encoder_encode_batch
     bool numa_bind = jpegenc::numa_bind_default();      // those threads run on the NUMA node of the device (jpegenc_encoder_set_numa_bind)
+    int batch_upload = 0;                               // jpegenc_encoder_set_batch_upload: 0 staged, 1 register-ahead
     // jpegenc_encoder_encode_batch_multi: one child encoder per entry of `devices` (its own workers, streams,
     // pinned staging and device buffers), kept across calls
     std::vector<std::unique_ptr<jpegenc_encoder>> shards;
@@ -965,8 +966,13 @@ int buffer_sink(void *user, const uint8_t *data, size_t n);
 // The whole of encode_image_internal for one frame; `upload` copies the source into ctx.d_pixels on ctx.stream.
 int encode_frame(const Config &c, DeviceCtx &ctx, int jct, int width, int height, int color_type_or_planes, size_t pixel_bytes,
                  const std::function<int(DeviceCtx &)> &upload, jpegenc_write_fn sink, void *user, const uint8_t *host_pixels = nullptr);
+// locked_pieces (batch workers, register-ahead): the frame has been page-locked by the handle's registrar as up to three
+// registrations - {bytes in the registration before the frame's own, bytes in its own, bytes in the one after}; one copy per piece
+// (the runtime takes a page-locked source as ONE registration: a copy that runs from one into the next is refused).
+// upload_hint (the same callers): 0 = look at the frame yourself, 2 = stage it whatever its ends look like (they may lie in pages the
+// registrar locked for its neighbours), 3 = page-locked by the caller as a whole: upload it where it lies.
 int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *data, size_t len, int width, int height, int color_type,
-                  jpegenc_write_fn sink, void *user, bool staged = false);
+                  jpegenc_write_fn sink, void *user, bool staged = false, const size_t *locked_pieces = nullptr, int upload_hint = 0);
 
 // ---- host_batch.cpp: device-resident batches --------------------------------------------------------------------------------
 // encode_device_batch returns this (before any device work) for frames whose scans the device entropy coder declines
@@ -992,6 +998,34 @@ inline int validate_plane(const jpegenc_plane &pl, int hs, int vs, bool planes_s
     if (pl.pitch > 0x7FFFFFFFu) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane pitch too large");
     return JPEGENC_OK;
 }
+
+// planes_subsampled as the API takes it: 0 full-resolution planes, 1 planes subsampled like the sampling factor says, 2 planes
+// subsampled HORIZONTALLY only - the chroma of packed 4:2:2 surfaces (YUYV / UYVY: half the columns, every row) coded at a sampling
+// factor that also decimates vertically (F_2_2): get_block takes every sy-th row (encoder.rs:1232-1237), so component c is handed on
+// as a plane of ceil(height / sy) rows sy pitches apart - mode 1 to everything downstream - whose bottom-edge repeats are source row
+// height - 1 (encoder.rs:738-744; NOT the last row taken, which is height - 2 for an even height): how far that row lies behind the
+// plane's last one travels in `reserved` (BlockKernelParams::plane_last_extra).  Returns what to pass on as planes_subsampled.
+inline bool normalize_planes(int mode, const jpegenc_plane *in, int frames, int jct, int sampling, int width, int height, std::vector<jpegenc_plane> &out) {
+    out.assign(in, in + (size_t)frames * 4);
+    if (mode != 2) return mode != 0;
+    int hs = 1, vs = 1;
+    sampling_hv(sampling, &hs, &vs);
+    jpegenc_layout L;
+    if (jpegenc_layout_init(&L, width, height, 100 + jct, hs, vs, JPEGENC_ORDER_MCU) != JPEGENC_OK) return true;      // (the caller's own checks report it)
+    for (int f = 0; f < frames; f++)
+        for (int c = 0; c < L.num_components; c++) {
+            const int sy = L.max_v / (L.v[c] > 0 ? L.v[c] : 1);
+            if (sy <= 1) continue;
+            jpegenc_plane &pl = out[(size_t)f * 4 + c];
+            const size_t pitch = pl.pitch;
+            const int rows = (height + sy - 1) / sy;
+            pl.reserved = (int32_t)((size_t)(height - 1 - sy * (rows - 1)) * pitch);
+            pl.pitch = pitch * (size_t)sy;
+        }
+    return true;
+}
+
+int encode_planes_one(jpegenc_encoder *e, int jct, int width, int height, const jpegenc_plane *planes, bool subsampled, jpegenc_write_fn sink, void *user);   // host_encoder.cpp
 
 // ---- host_multi.cpp ------------------------------------------------------------------------------------------------------------
 void bind_thread_near_device(int device, bool on);            // (opt-in) the calling thread onto the NUMA node of the device; off / another device: back out first (ThreadBinding)

@@ -797,3 +797,57 @@ def test_pools_with_per_frame_optimised_tables_share_their_launches(binding, ora
         assert e.encode_planes_batch_device(binding.J_YCBCR, w, h, pool) == want
         # and one at a time: same files
         assert e.encode_device(d.data_ptr() + 4 * w * h * 3, w, h, binding.YCBCR) == want[4]
+
+
+def test_register_ahead_uploads(binding, oracle, synth):
+    """jpegenc_encoder_set_batch_upload(REGISTER_AHEAD): one thread of the handle page-locks the batch's pageable frames ahead of the
+    workers, which upload them where they lie.  Same files as the staged default for frames that are slices of ONE array (their size
+    is no multiple of the page: neighbours share pages), given in reverse order, allocated one by one, partly or wholly page-locked by
+    the caller already; a sink failure in the middle ends the call with ERR_WRITE and nothing stays page-locked behind the call."""
+    import ctypes as C
+    w, h, n = 1000, 701, 12                                     # 2 103 000 bytes per frame: above the 2 MB small-frame path, not a page multiple
+    fb = w * h * 3
+    block = np.empty(n * fb + 64, dtype=np.uint8)
+    frames = [block[5 + i * fb: 5 + (i + 1) * fb] for i in range(n)]       # unaligned slices of one allocation
+    for i, f in enumerate(frames):
+        f[:] = synth.lcg_image(w, h, 3, 700 + i).reshape(-1)
+    want = [oracle.encode_jpeg(f, w, h, oracle.RGB, 85) for f in frames]
+    e = binding.Encoder(85)
+    staged = e.encode_batch(frames, w, h, binding.RGB)
+    assert staged == want
+    e.set_batch_upload(binding.UPLOAD_REGISTER_AHEAD)
+    assert e.encode_batch(frames, w, h, binding.RGB) == want
+    assert e.encode_batch(frames[::-1], w, h, binding.RGB) == want[::-1]
+    singles = [np.ascontiguousarray(f.copy()) for f in frames]
+    assert e.encode_batch(singles, w, h, binding.RGB) == want
+    lib = binding.lib()
+    lib.jpegenc_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.jpegenc_host_unregister.argtypes = [C.c_void_p]
+    # the caller has page-locked frame 3 wholly and the first half of frame 7: left as they are (in place / staged)
+    assert lib.jpegenc_host_register(singles[3].ctypes.data, fb) == 0
+    assert lib.jpegenc_host_register(singles[7].ctypes.data, fb // 2) == 0
+    try:
+        assert e.encode_batch(singles, w, h, binding.RGB) == want
+    finally:
+        assert lib.jpegenc_host_unregister(singles[3].ctypes.data) == 0
+        assert lib.jpegenc_host_unregister(singles[7].ctypes.data) == 0
+    # nothing of ours is still locked: the caller can lock every frame itself now
+    for f in singles:
+        assert lib.jpegenc_host_register(f.ctypes.data, fb) == 0
+        assert lib.jpegenc_host_unregister(f.ctypes.data) == 0
+    # a failing sink
+    seen = []
+
+    def sink(user, ptr, nbytes):
+        seen.append(user or 0)
+        return 3 if (user or 0) == 5 else 0
+    cb = binding.WRITE_FN(sink)
+    ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+    users = (C.c_void_p * n)(*range(n))
+    fn = lib.jpegenc_encoder_encode_batch
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, binding.WRITE_FN, C.POINTER(C.c_void_p)]
+    assert fn(e._h, ptrs, fb, n, w, h, binding.RGB, cb, users) == binding.ERR_WRITE
+    assert lib.jpegenc_host_register(block.ctypes.data, block.nbytes) == 0       # (whole array: fails if any page of it were still locked)
+    assert lib.jpegenc_host_unregister(block.ctypes.data) == 0
+    e.set_batch_upload(binding.UPLOAD_STAGED)
+    assert e.encode_batch(frames, w, h, binding.RGB) == want

@@ -108,13 +108,34 @@ def test_rgb565_files_match_the_host_unpacking_image_buffer(binding, oracle, w, 
             e.close()
 
 
+@pytest.mark.parametrize("sampling", [(4, 1), (4, 2), (1, 4), (2, 4)])
+def test_rgb565_sampling_factors_of_four(binding, oracle, sampling):
+    """16-bit packed RGB at the sampling factors of 4 (sequential files, encoder.rs:558-559): coefficients in both block orders and
+    whole files - host pixels, device-resident pixels, a batch - against the oracle fed the host-unpacked RGB image."""
+    import torch
+    for (w, h) in ((37, 21), (258, 128), (515, 301)):
+        rng = np.random.default_rng(w + h)
+        words = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+        raw = np.ascontiguousarray(words).view(np.uint8).reshape(h, w * 2)
+        for bgr in (False, True):
+            ct = binding.BGR565 if bgr else binding.RGB565
+            rgb = unpack565(words, bgr)
+            for order in (binding.ORDER_MCU, binding.ORDER_PLANAR):
+                for variant in (binding.FDCT_SCALAR, binding.FDCT_SIMD):
+                    assert np.array_equal(binding.blocks_host(raw, w, h, ct, sampling[0], sampling[1], 85, order, variant),
+                                          oracle.encode_blocks(rgb, w, h, oracle.RGB, sampling[0], sampling[1], 85, order, variant)), (w, h, bgr, order, variant)
+            for kw in (dict(quality=85, sampling=sampling), dict(quality=77, sampling=sampling, restart_interval=5, optimize=True)):
+                want = oracle.encode_jpeg(rgb, w, h, oracle.RGB, **kw)
+                e = _encoder(binding, kw)
+                assert e.encode(raw, w, h, ct) == want
+                d = torch.from_numpy(raw.copy()).cuda()
+                assert e.encode_device(d.data_ptr(), w, h, ct) == want
+                assert e.encode_batch([raw] * 2, w, h, ct) == [want] * 2
+                e.close()
+
+
 def test_rgb565_rejects_what_the_tuned_kernels_do_not_take(binding):
     raw = np.zeros((16, 32), dtype=np.uint8)
-    with binding.Encoder(80) as e:
-        e.set_sampling_factor(binding.F_4_1)
-        with pytest.raises(binding.JpegEncError) as err:
-            e.encode(raw, 16, 16, binding.RGB565)
-        assert err.value.status == binding.ERR_INVALID_ARGUMENT
     with pytest.raises(binding.JpegEncError) as err:
         binding.Encoder(80).encode(raw[:, :30], 16, 16, binding.BGR565)       # 2 bytes per pixel: too short
     assert err.value.status == binding.ERR_BAD_IMAGE_DATA
@@ -169,6 +190,77 @@ def test_packed_422_yuyv_and_uyvy(binding, oracle, w, h, kw):
             want2 = oracle.encode_jpeg(full[::-1].copy(), w, h, oracle.YCBCR, **okw)
             assert files == [want, want2, want, want2]
             e.close()
+
+
+@pytest.mark.parametrize("w,h", [(16, 8), (16, 16), (37, 21), (37, 22), (258, 128), (515, 301), (514, 300), (1920, 1080)])
+@pytest.mark.parametrize("kw", [dict(quality=85, sampling=(2, 2)), dict(quality=92, sampling=(2, 2), restart_interval=4),
+                                dict(quality=80, sampling=(2, 2), progressive_scans=4, optimize=True), dict(quality=77, sampling=(2, 2), variant=1),
+                                dict(quality=88, sampling=(1, 2))],
+                         ids=["420", "420-restart", "420-progressive-optimised", "420-simd", "440"])
+def test_packed_422_coded_as_420(binding, oracle, w, h, kw):
+    """planes_subsampled = 2: YUYV / UYVY frames (chroma at half the columns, EVERY row) coded at F_2_2 - the device takes every
+    second chroma row, and the rows below an image whose height is no multiple of 16 repeat its LAST row (even heights: a row
+    the decimation itself never takes).  Same file as the oracle fed the interleaved YCbCr image with each chroma sample repeated
+    twice along its row, and as the ImageBuffer path unpacking the rows on the host (the reference's extension point,
+    image_buffer.rs:86-98).  F_1_2 from the same surface: luma and chroma at full width, chroma rows halved - only where the chroma
+    planes are full width, i.e. not from a packed 4:2:2 surface: there the test describes three planar planes of full width."""
+    import torch
+    rng = np.random.default_rng(7 * w + h)
+    okw = {k: v for k, v in kw.items() if k != "variant"}
+    if kw.get("variant"):
+        okw["variant"] = oracle.FDCT_SIMD
+    if kw["sampling"] == (1, 2):
+        # (vertical decimation only: full-width planes, mode 2 == mode 0 for them - the kernel decimates the rows itself either way)
+        planes_px = [_smooth(rng.integers(0, 256, (h, w), dtype=np.uint8)) for _ in range(3)]
+        full = np.stack(planes_px, axis=-1)
+        want = oracle.encode_jpeg(full, w, h, oracle.YCBCR, **okw)
+        d = [torch.from_numpy(p.copy()).cuda() for p in planes_px]
+        planes = [(t.data_ptr(), w, 1, 0) for t in d]
+        e = _encoder(binding, kw)
+        assert e.encode_planes_device(binding.J_YCBCR, w, h, planes, planes_subsampled=binding.PLANES_SUBSAMPLED_H) == want
+        assert e.encode_planes_device(binding.J_YCBCR, w, h, planes, planes_subsampled=binding.PLANES_FULL) == want
+        e.close()
+        return
+    cw = -(-w // 2)
+    y = _smooth(rng.integers(0, 256, (h, 2 * cw), dtype=np.uint8))
+    cb = _smooth(rng.integers(0, 256, (h, cw), dtype=np.uint8))
+    cr = _smooth(rng.integers(0, 256, (h, cw), dtype=np.uint8))
+    cb[-1] ^= 0x55                                                      # the last row differs from the one above it: the bottom edge shows which one is repeated
+    cr[-1] ^= 0x2A
+    full = np.stack([y[:, :w], _rep(cb, 2, 1, w, h), _rep(cr, 2, 1, w, h)], axis=-1)
+    want = oracle.encode_jpeg(full, w, h, oracle.YCBCR, **okw)
+    pitch = 4 * cw + 20
+    for fmt in (binding.SURFACE_YUYV, binding.SURFACE_UYVY):
+        packed = np.zeros((h, pitch), dtype=np.uint8)
+        quad = [y[:, 0::2], cb, y[:, 1::2], cr] if fmt == binding.SURFACE_YUYV else [cb, y[:, 0::2], cr, y[:, 1::2]]
+        packed[:, :4 * cw] = np.stack(quad, axis=-1).reshape(h, 4 * cw)
+        d = torch.from_numpy(packed).cuda()
+        planes, _ = binding.packed_planes(fmt, [d.data_ptr()], [pitch])
+        for device_entropy in (True, False):
+            e = _encoder(binding, kw)
+            e.set_device_entropy(device_entropy)
+            assert e.encode_planes_device(binding.J_YCBCR, w, h, planes, planes_subsampled=binding.PLANES_SUBSAMPLED_H) == want, (fmt, device_entropy)
+            if w * h <= 40000:
+                assert e.encode_image(binding.J_YCBCR, w, h, lambda r: [full[r, :, 0], full[r, :, 1], full[r, :, 2]]) == want
+            # a pool: two distinct buffers, the second with another pitch (its bottom-edge row lies elsewhere: a layout of its own)
+            pitch2 = pitch + 16
+            packed2 = np.zeros((h, pitch2), dtype=np.uint8)
+            packed2[:, :4 * cw] = packed[::-1, :4 * cw]
+            d2 = torch.from_numpy(packed2).cuda()
+            planes2, _ = binding.packed_planes(fmt, [d2.data_ptr()], [pitch2])
+            files = e.encode_planes_batch_device(binding.J_YCBCR, w, h, [planes, planes2, planes, planes2], planes_subsampled=binding.PLANES_SUBSAMPLED_H)
+            want2 = oracle.encode_jpeg(full[::-1].copy(), w, h, oracle.YCBCR, **okw)
+            assert files == [want, want2, want, want2]
+            e.close()
+    # what the call refuses
+    with binding.Encoder(80) as e:
+        e.set_sampling_factor(binding.F_4_1)
+        with pytest.raises(binding.JpegEncError) as err:
+            e.encode_planes_device(binding.J_YCBCR, w, h, planes, planes_subsampled=binding.PLANES_SUBSAMPLED_H)
+        assert err.value.status == binding.ERR_INVALID_ARGUMENT
+        e.set_sampling_factor(binding.F_2_2)
+        with pytest.raises(binding.JpegEncError):
+            e.encode_planes_device(binding.J_YCBCR, w, h, planes, planes_subsampled=3)
 
 
 @pytest.mark.parametrize("w,h", [(16, 16), (37, 21), (258, 128), (1920, 1080)])
