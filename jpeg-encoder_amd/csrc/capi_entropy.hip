@@ -362,7 +362,7 @@ int scan_store_params(const void *d_coeffs, size_t coeff_frame_stride, int frame
     const int rc = fill_scan(d_coeffs, coeff_frame_stride, frames, L, sc, nullptr, d_lut, d_out, out_frame_stride, d_out_lengths,
                              d_ws, ws_bytes, st, &p, &d_params, fused);
     if (rc) return rc;
-    const hipError_t e = store_entropy_params(&p, 1, d_params, st, stored_params);
+    const hipError_t e = store_entropy_params(&p, 1, d_params, frames, st, stored_params);
     if (e != hipSuccess) return hip_fail(e, "entropy parameter store");
     return JPEGENC_OK;
 }
@@ -370,19 +370,36 @@ int scan_store_params(const void *d_coeffs, size_t coeff_frame_stride, int frame
 // Several scans of the same frames (the per-component / per-band scans of a sequential or progressive file)
 // in shared launches, kMaxScansPerLaunch at a time.  Every scan brings its own workspace and output.
 int scan_device_multi(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L, const ScanJob *jobs,
-                      int njobs, const void *d_lut, hipStream_t st) {
+                      int njobs, const void *d_lut, hipStream_t st, bool lut_per_frame) {
     if (!d_lut) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "scan_device_multi needs prepared tables");
-    for (int first = 0; first < njobs; first += (int)kMaxScansPerLaunch) {
-        const int n = njobs - first < (int)kMaxScansPerLaunch ? njobs - first : (int)kMaxScansPerLaunch;
+    // The scans of a progressive frame come component by component, round after round (DC of c0, c1, c2, band 1 of c0, c1, c2 ...):
+    // job g + s * G is scan s of component g.  Where the jobs have that shape the coder takes all scans of a component in one pass
+    // over its blocks (k_block_code_group); launches then hold whole rounds (a multiple of G scans).
+    static const bool group_off = JPEGENC_DIAG_ENV("JPEGENC_NO_SCAN_GROUPS") != nullptr;
+    int G = 0;
+    if (!group_off && njobs >= 2 && jobs[0].sc.component >= 0) {
+        G = 1;
+        while (G < njobs && jobs[G].sc.component != jobs[0].sc.component) G++;
+        bool shaped = G < njobs && njobs % G == 0 && G <= (int)kMaxScansPerLaunch / 2;
+        for (int j = 0; shaped && j < njobs; j++)
+            shaped = jobs[j].sc.component >= 0 && jobs[j].sc.component == jobs[j % G].sc.component && jobs[j].sc.restart_interval == jobs[j % G].sc.restart_interval;
+        for (int g = 0; shaped && g < G; g++)
+            for (int h = 0; h < g; h++) if (jobs[g].sc.component == jobs[h].sc.component) shaped = false;
+        if (!shaped) G = 0;
+    }
+    const int per_launch = G ? ((int)kMaxScansPerLaunch / G) * G : (int)kMaxScansPerLaunch;
+    for (int first = 0; first < njobs; first += per_launch) {
+        const int n = njobs - first < per_launch ? njobs - first : per_launch;
         EntropyParams p[kMaxScansPerLaunch], *d_params = nullptr, *d_first = nullptr;
         for (int j = 0; j < n; j++) {
             const ScanJob &job = jobs[first + j];
             const int rc = fill_scan(d_coeffs, coeff_frame_stride, frames, L, job.sc, nullptr, d_lut, job.d_out, job.out_frame_stride,
                                      job.d_out_lengths, job.d_ws, job.ws_bytes, st, &p[j], &d_params);
             if (rc) return rc;
+            if (lut_per_frame) p[j].fused_prefix |= kLutPerFrame;     // d_lut = `frames` table sets, kLutDeviceBytes apart (per-frame optimised tables)
             if (j == 0) d_first = d_params;
         }
-        const hipError_t e = launch_entropy_scans(p, n, d_first, frames, st);
+        const hipError_t e = launch_entropy_scans(p, n, d_first, frames, st, nullptr, nullptr, G && n > G && n % G == 0 ? G : 0);
         if (e != hipSuccess) return hip_fail(e, "entropy kernels");
     }
     return JPEGENC_OK;

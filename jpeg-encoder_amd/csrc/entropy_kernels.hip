@@ -220,27 +220,11 @@ __global__ void __launch_bounds__(256) k_scan_apply_fused(const EntropyParams *p
 // bits straight into the zeroed slot.  (A workgroup's 256 blocks as ONE run - the pixels -> bits kernel's finding that k_push
 // likes few long runs - was tried: k_push 33 -> 14 us per 16 photo-like 4K frames, but the two barriers it takes cost
 // k_block_code as much: 21.6 vs 21.8 us per frame, noise 20.7 vs 20.2 for the coder alone; not kept.)
-__global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params) {
-    Params p = JPEGENC_JOB(params);
-    __shared__ u32x2 lut64[4 * 256];
-    __shared__ __attribute__((aligned(16))) uint32_t area[4][kOnePassWindowWords + kPrivWords * 64];   // per wave: window | strips (contiguous)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    const bool valid = b < p.nblocks;
-    const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
-    // every load of the wave's life in one queue: tables, DC predecessor, the block (clamped for lanes past the end)
-    LutRegs l;
-    lut_fetch(p, l, f);
-    const uint32_t bc = min(b, p.nblocks - 1u);
-    const BlockPlace where = place_of(p, bc);
-    const int prev_raw = ((const __attribute__((address_space(1))) int16_t *)frame)[where.prev_block * 64u];
-    BlockRegs r;
-    load_block(frame, bc, r);
-    lut64_commit(l, lut64);
-    if (__ballot(valid) == 0) return;                                            // whole wave past the end
-    const int prev_dc = where.has_prev ? prev_raw : 0;
+// A wave's 64 blocks (in registers) coded as ONE run of ONE scan: the walk into the lanes' strips, the prefix sum, the window, the slot.
+__device__ __forceinline__ void code_run(Params p, const u32x2 *lut64, uint32_t *win, const uint32_t f, const uint32_t b, const bool valid,
+                                         const BlockPlace &where, const int prev_dc, const BlockRegs &r, const uint32_t lane) {
     const bool baseline = baseline_band(p);
-    lds_word *strip = (lds_word *)(area[wave] + kOnePassWindowWords) + lane;
+    lds_word *strip = (lds_word *)(win + kOnePassWindowWords) + lane;
     PrivSink ps = {strip, strip + (kPrivWords - 1u) * 64u, 0, 0, 0};
     if (valid) {
         if (baseline) walk_once<true>(p, lut64, where.table, prev_dc, r, ps); else walk_once<false>(p, lut64, where.table, prev_dc, r, ps);
@@ -255,7 +239,6 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
     if (lane == 0) { p.wsum[(size_t)f * p.nwaves + w] = total; p.ffstat[(size_t)f * p.nwaves + w] = 0; }      // (k_finish_runs' look-back word of this run)
     const uint32_t nwords = (total + 31u) >> 5;
     uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)w * p.slot_words;
-    uint32_t *win = area[wave];
     const bool strips_hold = __ballot(mine > kPrivWords * 32u) == 0;            // wave-uniform
     if (strips_hold && nwords + 4u <= min(p.window_words, kOnePassWindowWords)) {   // wave-uniform (+4: the zero word, 16-byte copies)
         for (uint32_t i = lane; i <= nwords; i += 64u) win[i] = 0;
@@ -297,6 +280,63 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
             if (baseline) walk_once<true>(p, lut64, where.table, prev_dc, r, hs); else walk_once<false>(p, lut64, where.table, prev_dc, r, hs);
             hs.finish();
         }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params) {
+    Params p = JPEGENC_JOB(params);
+    __shared__ u32x2 lut64[4 * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t area[4][kOnePassWindowWords + kPrivWords * 64];   // per wave: window | strips (contiguous)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    const bool valid = b < p.nblocks;
+    const int16_t *frame = p.coeffs + (size_t)f * p.coeff_frame_stride * 64;
+    // every load of the wave's life in one queue: tables, DC predecessor, the block (clamped for lanes past the end)
+    LutRegs l;
+    lut_fetch(p, l, f);
+    const uint32_t bc = min(b, p.nblocks - 1u);
+    const BlockPlace where = place_of(p, bc);
+    const int prev_raw = ((const __attribute__((address_space(1))) int16_t *)frame)[where.prev_block * 64u];
+    BlockRegs r;
+    uint32_t piece0, piece1;
+    scan_pieces(p, piece0, piece1);
+    load_block(frame, bc, r, piece0, piece1);
+    lut64_commit(l, lut64);
+    if (__ballot(valid) == 0) return;                                            // whole wave past the end
+    code_run(p, lut64, area[wave], f, b, valid, where, where.has_prev ? prev_raw : 0, r, lane);
+}
+
+// The scans of ONE component of a progressive frame - its DC scan and its AC bands (encoder.rs:885-972) - from one pass over its
+// blocks: blockIdx.z = the component's first scan, scan s of it is job blockIdx.z + s * stride.  What a wave pays per block whatever
+// the band - the code tables into LDS, the block and its DC predecessor from HBM, the wave's start-up - is paid once for the
+// component's 4 (or 10 ...) scans instead of once per scan: the bands of a progressive frame are a quarter of a block's symbols each,
+// and coded scan by scan they cost as much as four whole blocks (profiles/r05_mode_trace.txt).
+__global__ void __launch_bounds__(256) k_block_code_group(const EntropyParams *params, const uint32_t stride, const uint32_t scans) {
+    Params p0 = JPEGENC_JOB(params);
+    __shared__ u32x2 lut64[4 * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t area[4][kOnePassWindowWords + kPrivWords * 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    const bool valid = b < p0.nblocks;
+    const int16_t *frame = p0.coeffs + (size_t)f * p0.coeff_frame_stride * 64;
+    LutRegs l;
+    lut_fetch(p0, l, f);
+    const uint32_t bc = min(b, p0.nblocks - 1u);
+    const BlockPlace where = place_of(p0, bc);
+    const int prev_raw = ((const __attribute__((address_space(1))) int16_t *)frame)[where.prev_block * 64u];
+    BlockRegs r;
+    load_block(frame, bc, r);
+    lut64_commit(l, lut64);
+    if (__ballot(valid) == 0) return;
+#pragma nounroll
+    for (uint32_t s = 0; s < scans; s++) {
+        Params p = *(const __attribute__((address_space(4))) EntropyParams *)(params + blockIdx.z + s * stride);
+        // (the DC predecessor restarts with the scan's restart intervals - the same for every scan of a component, but the scan's to say)
+        const BlockPlace here = place_of(p, bc);
+        code_run(p, lut64, area[wave], f, b, valid, here, here.has_prev ? prev_raw : 0, r, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   // (the window and the strips are the next scan's)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -1046,7 +1086,7 @@ static hipError_t scan(const EntropyParams *d_params, int which, uint32_t n_max,
 // njobs <= kMaxScansPerLaunch scans (same number of frames each) in one launch sequence; d_params: room
 // for njobs parameter blocks in device memory
 struct LaunchShape { uint32_t nblocks, nwaves, nintervals, fftiles; bool any_single, any_multi; uint32_t fused_prefix; };
-static LaunchShape shape_of(const EntropyParams *jobs, int njobs) {
+static LaunchShape shape_of(const EntropyParams *jobs, int njobs, int frames) {
     LaunchShape s = {0, 0, 0, 0, false, false, 0};
     for (int j = 0; j < njobs; j++) {
         s.nblocks = max(s.nblocks, jobs[j].nblocks); s.nwaves = max(s.nwaves, jobs[j].nwaves);
@@ -1061,6 +1101,10 @@ static LaunchShape shape_of(const EntropyParams *jobs, int njobs) {
     // 0.8-1.6 us on noise, and per-64-tile counters kept by k_push to shorten the sum cost 2-3 us in contended atomics.
     static const uint32_t allow = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_FUSED_PREFIX_MASK"); return e ? (uint32_t)atoi(e) : 3u; }();   // diagnostic
     if (!s.any_multi) s.fused_prefix = ((s.nwaves <= kFusedPrefixRuns ? 1u : 0u) | (s.fftiles <= kFusedPrefixTiles ? 2u : 0u)) & allow;
+    // (every wave of k_push reads the lengths of all runs before its own: runs^2 / 2 loads per scan and frame.  One scan of sixteen
+    //  4K frames - 2 040 runs each - is where that still beats two launches; the twelve scans of four progressive 4K frames in one
+    //  launch - 48 x 1 519 runs - spent 105 us in k_push that way, 2 x 5 us of prefix-sum launches instead: profiles/r05_mode_trace.txt)
+    if ((uint64_t)s.nwaves * s.nwaves * (uint64_t)njobs * (uint64_t)(frames > 0 ? frames : 1) > 80000000ull) s.fused_prefix &= ~1u;
     // JPEGENC_FINISH_KERNEL=1 in the diagnostic build: scans without restart markers are put together by k_finish_runs - ONE launch
     // instead of k_push / prefix sum / k_stuff.  Built and measured in round 5 (profiles/r05_finish_kernel.txt): byte-identical, and no
     // faster - 39.8 us against 39.8 for 16 photo-like 4K frames, 148 against 133 on noise - so the three-launch sequence stays.
@@ -1070,9 +1114,9 @@ static LaunchShape shape_of(const EntropyParams *jobs, int njobs) {
 }
 
 // Puts the parameter blocks of njobs scans at d_params unless `stored` says they are there already.
-hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, hipStream_t st, std::string *stored) {
+hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t st, std::string *stored) {
     if (njobs < 1 || njobs > (int)kMaxScansPerLaunch) return hipErrorInvalidValue;
-    const LaunchShape shape = shape_of(jobs, njobs);
+    const LaunchShape shape = shape_of(jobs, njobs, frames);
     std::string now;
     if (stored) {            // (the blocks were zero-filled before their fields were set: comparable byte for byte)
         now.assign((const char *)&d_params, sizeof d_params);
@@ -1092,11 +1136,11 @@ hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyPar
 }
 
 hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t st,
-                                std::string *stored, const FusedSource *fused) {
+                                std::string *stored, const FusedSource *fused, int group_stride) {
     if (fused && njobs != 1) return hipErrorInvalidValue;
-    hipError_t e = store_entropy_params(jobs, njobs, d_params, st, stored);
+    hipError_t e = store_entropy_params(jobs, njobs, d_params, frames, st, stored);
     if (e != hipSuccess) return e;
-    const LaunchShape shape = shape_of(jobs, njobs);
+    const LaunchShape shape = shape_of(jobs, njobs, frames);
     const uint32_t nblocks = shape.nblocks, nwaves = shape.nwaves, nintervals = shape.nintervals, fftiles = shape.fftiles;
     const bool any_single = shape.any_single, any_multi = shape.any_multi;
     const bool fused_runs_prefix = shape.fused_prefix & 1u, fused_tiles_prefix = shape.fused_prefix & 2u;
@@ -1108,6 +1152,9 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
                           : launch_fused_code(*fused->blocks, d_params, restart, frames, fused->variant, st);
         if (e != hipSuccess) return e;
         if (jobs[0].chain) return hipGetLastError();          // the kernel finished the scan itself (finish_run.hip.h)
+    } else if (group_stride > 0 && njobs > group_stride && njobs % group_stride == 0) {
+        // jobs g, g + stride, g + 2 stride ... are the scans of one component: one pass over its blocks codes them all
+        hipLaunchKernelGGL(k_block_code_group, dim3(bgrid, frames, group_stride), dim3(256), 0, st, d_params, (uint32_t)group_stride, (uint32_t)(njobs / group_stride));
     } else {
         hipLaunchKernelGGL(k_block_code, dim3(bgrid, frames, njobs), dim3(256), 0, st, d_params);
     }

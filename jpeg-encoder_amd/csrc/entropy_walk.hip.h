@@ -172,13 +172,23 @@ struct PackSink {
 // the line for every piece: 52 vs 39 us per 4K frame), so the walk is fully unrolled over registers.
 struct BlockRegs { uint32_t c[32]; };      // the 64 coefficients of a lane's block
 
-__device__ __forceinline__ void load_block(const int16_t *frame_coeffs, uint32_t b, BlockRegs &r) {
+// Only the 16-byte pieces the scan codes from are fetched (wave-uniform: the scan's band): a DC scan reads the first piece of every
+// block, the band [16, 32) pieces 2 and 3 - the four scan kinds of a progressive(4) frame 10 pieces of a block between them instead of
+// 32 (k_block_code over the twelve scans of four 4K frames: 151 -> see profiles/r05_mode_trace.txt).  The other registers read as zero.
+__device__ __forceinline__ void load_block(const int16_t *frame_coeffs, uint32_t b, BlockRegs &r, uint32_t first_piece = 0u, uint32_t last_piece = 7u) {
     hbm_chunk *src = (hbm_chunk *)(frame_coeffs + (size_t)b * 64);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const u32x4 u = src[i];
+        u32x4 u = {0u, 0u, 0u, 0u};
+        if ((uint32_t)i >= first_piece && (uint32_t)i <= last_piece) u = src[i];
         r.c[4 * i] = u.x; r.c[4 * i + 1] = u.y; r.c[4 * i + 2] = u.z; r.c[4 * i + 3] = u.w;
     }
+}
+// the pieces (8 zig-zag coefficients each) a scan reads
+__device__ __forceinline__ void scan_pieces(Params p, uint32_t &first, uint32_t &last) {
+    const bool ac = p.ac_end > p.ac_start;
+    first = p.with_dc ? 0u : (p.ac_start >> 3);
+    last = ac ? ((p.ac_end - 1u) >> 3) : 0u;
 }
 
 // DC predecessor of block b = the previous block of the same component (write_dc, writer.rs:342-354; predictors

@@ -40,6 +40,8 @@ struct BatchRun {
     jpegenc_layout L;
     std::vector<Job> jobs;
     size_t out_total = 0, coeff_bytes = 0, ws = 0, nlen = 0, round_out = 0, packed_half = 0;
+    bool together = false;                              // the scans of a sequential / progressive round in SHARED launches (blockIdx.z = scan): every job its own workspace
+    std::vector<size_t> ws_off, ws_len;
     int per_round = 1;
     std::vector<std::thread> pools[2];                  // the threads assembling the files of the round staged in h_out[slot]
     std::atomic<int> failed{0};
@@ -136,12 +138,34 @@ struct BatchRun {
             if (eighth < per_round) per_round = std::min(per_round, eighth < 4 ? 4 : eighth);   // (never above the footprint / the caller's bound)
         }
         if (per_round > num_frames) per_round = num_frames;
-        ws = 0;
-        for (auto &j : jobs) {
-            if (!j.cap) continue;
-            const size_t w = scan_workspace_size(L, j.sc, per_round);
-            if (!w) return declined("scan workspace");
-            if (w > ws) ws = w;
+        // Several scans per frame (sequential: one per component; progressive(4) on three components: twelve): coded in shared
+        // launches - one parameter store, one k_block_code, one k_push / k_place, one k_stuff over (work, frame, scan) - when
+        // their workspaces fit side by side.  One scan after the other a round of eight 4K progressive frames was 24 launch
+        // sequences of 4-5 kernels, most of them too small to fill the GPU: 174 us of kernels per frame
+        // (profiles/r05_mode_trace.txt).  JPEGENC_BATCH_SCANS_ONE_BY_ONE=1 (diagnostic build): the former sequence.
+        static const bool one_by_one = JPEGENC_DIAG_ENV("JPEGENC_BATCH_SCANS_ONE_BY_ONE") != nullptr;
+        size_t coded_jobs = 0;
+        for (auto &j : jobs) if (j.cap) coded_jobs++;
+        for (;;) {
+            ws = 0;
+            size_t ws_sum = 0;
+            ws_off.assign(jobs.size(), 0); ws_len.assign(jobs.size(), 0);
+            for (size_t k = 0; k < jobs.size(); k++) {
+                if (!jobs[k].cap) continue;
+                const size_t w = scan_workspace_size(L, jobs[k].sc, per_round);
+                if (!w) return declined("scan workspace");
+                if (w > ws) ws = w;
+                ws_off[k] = ws_sum; ws_len[k] = w;
+                ws_sum += (w + 255) & ~(size_t)255;
+            }
+            together = coded_jobs > 1 && !one_by_one;
+            if (!together) break;
+            // the workspaces side by side belong to the round's footprint: fewer frames per round while they do not fit 6 GiB
+            if (ws_sum + (coeff_bytes + out_total) * (size_t)per_round <= ((size_t)6 << 30) || per_round <= 1) {
+                if (ws_sum > ((size_t)8 << 30)) together = false; else ws = ws_sum;
+                break;
+            }
+            per_round = per_round > 2 ? per_round * 3 / 4 : 1;
         }
         nlen = jobs.size() * (size_t)per_round;
         int rc = b.reserve(coeff_bytes * (size_t)per_round, out_total * (size_t)per_round, ws, nlen);
@@ -276,6 +300,17 @@ struct BatchRun {
         }
         uint32_t *d_len = b.d_len + (size_t)half * nlen;
         JPEGENC_HIP(hipMemsetAsync(d_len, 0, nlen * sizeof(uint32_t), ctx.stream));
+        if (together) {
+            std::vector<ScanJob> sj;
+            for (size_t k = 0; k < jobs.size(); k++) {
+                const Job &j = jobs[k];
+                if (!j.cap) continue;
+                sj.push_back(ScanJob{j.sc, (uint8_t *)b.d_out + (size_t)half * round_out + j.off, out_total, d_len + k * (size_t)per_round,
+                                     (uint8_t *)b.d_ws + ws_off[k], ws_len[k]});
+            }
+            e = scan_device_multi(b.d_coeffs, L.total_blocks, n, L, sj.data(), (int)sj.size(), optimize ? b.d_opt_luts : ctx.d_lut, ctx.stream, optimize);
+            if (e) return e;
+        } else
         for (size_t k = 0; k < jobs.size(); k++) {
             const Job &j = jobs[k];
             if (!j.cap) continue;

@@ -54,7 +54,7 @@ hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_pla
 // entropy_kernels.hip
 // stored: what the parameter blocks at d_params currently hold (nullptr: always store) - a caller that codes the same
 // scan again and again (an Encoder fed frames of one geometry) skips the store launch
-hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, hipStream_t stream, std::string *stored);
+hipError_t store_entropy_params(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t stream, std::string *stored);
 // fused_kernels.hip: the Encoder's interleaved baseline scan coded straight from the pixels (no coefficients in HBM)
 struct FusedSource {
     const BlockKernelParams *blocks; int variant; const jpegenc_plane *planes; bool planes_subsampled;   // planes: a described planar source (else null)
@@ -71,7 +71,7 @@ hipError_t launch_fused_code(const BlockKernelParams &b, const EntropyParams *d_
                              hipStream_t st);
 // fused != nullptr (one scan): the first kernel of the sequence reads pixels instead of coefficients
 hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyParams *d_params, int frames, hipStream_t stream,
-                                std::string *stored = nullptr, const FusedSource *fused = nullptr);
+                                std::string *stored = nullptr, const FusedSource *fused = nullptr, int group_stride = 0);
 
 hipError_t launch_batch_gather(const BatchGatherArgs &a, const void *d_src, const uint32_t *d_len, uint64_t *d_pos, void *d_dst,
                                hipStream_t stream);
@@ -93,7 +93,7 @@ struct ScanJob {                 // one scan of scan_device_multi
     void *d_ws; size_t ws_bytes;
 };
 int scan_device_multi(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L, const ScanJob *jobs,
-                      int njobs, const void *d_lut, hipStream_t st);
+                      int njobs, const void *d_lut, hipStream_t st, bool lut_per_frame = false);
 int upload_huffman_luts(const jpegenc_huffman_spec (*tables)[2], void *d_lut, hipStream_t st);
 // one table set per frame of a batch in one launch (h_specs page-locked: frames x huffman_lut_batch_spec_bytes())
 size_t huffman_lut_batch_spec_bytes();

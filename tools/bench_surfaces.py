@@ -97,7 +97,7 @@ def main():
             ts.append(time.perf_counter() - t)
         return sorted(ts)[len(ts) // 2]
 
-    def planes_case(name, sampling, frames, optimized=False):
+    def planes_case(name, sampling, frames, optimized=False, mode=1):
         arr = (b.Plane * (4 * N))()
         for f, planes in enumerate(frames):
             for i, t in enumerate(planes):
@@ -106,13 +106,13 @@ def main():
         e.set_sampling_factor(sampling)
         if optimized:
             e.set_optimized_huffman_tables(True)
-        t_batch = timed(lambda: b.check(fpb(e._h, b.J_YCBCR, W, H, arr, N, 1, cb_, users)))
+        t_batch = timed(lambda: b.check(fpb(e._h, b.J_YCBCR, W, H, arr, N, mode, cb_, users)))
         mb = nbytes[0] / N / 1e6
 
         def each():
             for f in range(N):
                 sub = (b.Plane * 4)(*[arr[4 * f + i] for i in range(4)])
-                b.check(fp1(e._h, b.J_YCBCR, W, H, sub, 1, cb_, users[f]))
+                b.check(fp1(e._h, b.J_YCBCR, W, H, sub, mode, cb_, users[f]))
         t_each = timed(each)
         print(json.dumps({"format": name, "sampling": f"{sampling >> 4}x{sampling & 15}", "frames": N, "jpeg_MB_per_frame": round(mb, 2),
                           "pool_us_per_frame": round(t_batch * 1e6 / N, 1), "one_call_per_frame_us": round(t_each * 1e6 / N, 1)}), flush=True)
@@ -138,6 +138,8 @@ def main():
     planes_case("I420 pool with NV12 frames in it (two layouts: the frames of each share their launches)", b.F_2_2, mixed)
     planes_case("NV12", b.F_2_2, sets["nv12"])
     planes_case("P010 (16-bit words, high byte)", b.F_2_2, sets["p010"])
+    planes_case("YUYV coded at F_2_2 (planes_subsampled = 2: every second chroma row taken by the kernel)", b.F_2_2, sets["yuyv"], mode=2)
+    planes_case("UYVY coded at F_2_2", b.F_2_2, sets["uyvy"], mode=2)
     pixels_case("RGB (interleaved)", b.RGB, d_rgb, 3, b.F_2_2)
     pixels_case("RGB565", b.RGB565, d_565, 2, b.F_2_2)
     planes_case("planar 4:2:2", b.F_2_1, sets["i422"])

@@ -40,9 +40,15 @@ def main(n=8, w=3840, h=2160):
     lens = (C.c_size_t * n)()
     fn = b.lib().jpegenc_encoder_encode_batch_device_to_buffers
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    only = os.environ.get("MODE_SURVEY_ONLY")               # e.g. "photo-like:progressive(4) q90" (kernel traces of one mode)
+    reps = int(os.environ.get("MODE_SURVEY_REPS", "4"))
     for cname, px in contents.items():
+        if only and only.split(":")[0] != cname:
+            continue
         d = torch.from_numpy(px).to(dev)
         for name, kw in configs:
+            if only and only.split(":", 1)[1] != name:
+                continue
             e = b.Encoder(kw["q"])
             if "sf" in kw:
                 e.set_sampling_factor(kw["sf"])
@@ -56,7 +62,7 @@ def main(n=8, w=3840, h=2160):
                 b.check(fn(e._h, d.data_ptr(), w * h * 3, n, w, h, b.RGB, optrs, caps, lens))
             run()
             ts = []
-            for _ in range(4):
+            for _ in range(reps):
                 t = time.perf_counter()
                 run()
                 ts.append(time.perf_counter() - t)
