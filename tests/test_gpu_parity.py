@@ -634,7 +634,7 @@ def test_randomised_configurations(binding, oracle, synth):
         px = rng.integers(0, 256, (h, w, binding.BPP[ct]), dtype=np.uint8)
         if trial % 3 == 0:                                   # smooth content: long zero runs, EOBs
             px = (np.add.outer(np.arange(h), np.arange(w))[..., None] // 3 + np.arange(binding.BPP[ct])).astype(np.uint8)
-        kw = dict(quality=int(rng.integers(1, 101)), sampling=samplings[int(rng.integers(0, 8 if ct < 9 else 4))])      # (565: factors 1 and 2)
+        kw = dict(quality=int(rng.integers(1, 101)), sampling=samplings[int(rng.integers(0, 8))])
         mode = int(rng.integers(0, 4))
         if mode == 1:
             kw["progressive_scans"] = int(rng.integers(2, 20))
@@ -668,6 +668,16 @@ def test_randomised_configurations(binding, oracle, synth):
         else:
             want = oracle.encode_jpeg(px, w, h, ct, variant=variant, **okw)
         assert got == want, (trial, ct, w, h, kw, variant)
+        if trial % 6 == 1 and on_device:                     # the same frame and its mirror image as a device-resident batch: the scans of a round in shared launches
+            import torch
+            flipped = np.ascontiguousarray(px[::-1])
+            d = torch.from_numpy(np.stack([np.ascontiguousarray(px), flipped])).cuda()
+            files = e.encode_batch_device(d.data_ptr(), px.nbytes, 2, w, h, ct)
+            if ct >= 9:
+                want2 = oracle.encode_jpeg(np.ascontiguousarray(rgb[::-1]), w, h, oracle.RGB, variant=variant, **okw)
+            else:
+                want2 = oracle.encode_jpeg(flipped, w, h, ct, variant=variant, **okw)
+            assert files == [want, want2], (trial, ct, w, h, kw, variant, "batch")
 
 
 def test_encode_device_resident_input(binding, oracle, synth):

@@ -30,6 +30,12 @@ run separate_push_and_stuff JPEGENC_LIB=$DIAG JPEGENC_NO_FINISH=1 JPEGENC_FUZZ_S
 run stream_wait JPEGENC_LIB=$DIAG JPEGENC_NO_DONE_FLAG=1 JPEGENC_FUZZ_SEED=$((S + 11)) JPEGENC_FUZZ_TRIALS=6000
 run finish_gave_up JPEGENC_LIB=$DIAG JPEGENC_FORCE_FINISH_GAVE_UP=1 JPEGENC_FUZZ_SEED=$((S + 12)) JPEGENC_FUZZ_TRIALS=6000
 run finish_gave_up_tiny_window JPEGENC_LIB=$DIAG JPEGENC_FORCE_FINISH_GAVE_UP=1 JPEGENC_PACK_WINDOW_WORDS=8 JPEGENC_FUZZ_SEED=$((S + 13)) JPEGENC_FUZZ_TRIALS=4000
+# round 5: the experiments kept in the diagnostic build stay byte-identical - scans put together by k_finish_runs, the half-MCU 4:2:0 block
+# kernel - and the switches back to the former sequences (one scan after the other in batches, scan by scan over a component's blocks)
+run finish_kernel JPEGENC_LIB=$DIAG JPEGENC_FINISH_KERNEL=1 JPEGENC_FUZZ_SEED=$((S + 15)) JPEGENC_FUZZ_TRIALS=6000
+run finish_kernel_medium JPEGENC_LIB=$DIAG JPEGENC_FINISH_KERNEL=1 JPEGENC_FUZZ_SEED=$((S + 16)) JPEGENC_FUZZ_TRIALS=2000 JPEGENC_FUZZ_MAX_W=700 JPEGENC_FUZZ_MAX_H=500
+run half_mcu_kernel JPEGENC_LIB=$DIAG JPEGENC_DUO=1 JPEGENC_FUZZ_SEED=$((S + 17)) JPEGENC_FUZZ_TRIALS=6000
+run scans_one_by_one JPEGENC_LIB=$DIAG JPEGENC_BATCH_SCANS_ONE_BY_ONE=1 JPEGENC_NO_SCAN_GROUPS=1 JPEGENC_FUZZ_SEED=$((S + 18)) JPEGENC_FUZZ_TRIALS=4000
 ( JPEGENC_FUZZ_SEED=$((S + 7)) JPEGENC_FUZZ_TRIALS=4000 timeout 1200 python3 -m pytest tests/test_gpu_batch_multi.py -q -x -k test_randomised_planar_sources 2>&1 | tail -2 ) > $out/${tag}_soak_planar.log 2>&1
 tail -1 $out/${tag}_soak_planar.log
 ( JPEGENC_FUZZ_SEED=9 JPEGENC_GEOMETRY_TRIALS=1500 timeout 1200 python3 -m pytest tests/test_gpu_parity.py -q -x -k test_blocks_random_geometry 2>&1 | tail -2 ) > $out/${tag}_soak_geometry.log 2>&1
