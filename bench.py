@@ -663,8 +663,8 @@ def main():
             details["pcie_pipeline"] = {"value": round(nfr * W * H / dt / 1e6, 1), "unit": "Mpixels/s",
                                         "what": f"jpegenc_blocks_stream, {nfr} frames: pinned host RGB -> H2D -> fused kernel -> D2H of "
                                                 "coefficient tiles into pinned memory -> callback; one stream per direction + one "
-                                                "for the kernel, buffers allocated inside the timed call; 24.9 MB up + 24.9 MB "
-                                                "down per frame",
+                                                "for the kernel, streams and buffers kept from the 8-frame warm-up call (the library "
+                                                "keeps a call's pipe for the next); 24.9 MB up + 24.9 MB down per frame",
                                         "roofline": pcie_roofline("pcie_both", nfr * frame_bytes, dt, link)}
             to_bytes["coefficient_tile_stream_Gpx_s"] = round(nfr * W * H / dt / 1e9, 2)
             del pinned

@@ -90,6 +90,7 @@ extern "C" {
     pub fn jpegenc_blocks_stream(device: c_int, frames: *const *const u8, frame_len: usize, num_frames: c_int, width: c_int, height: c_int,
                                  color_type: c_int, h: c_int, v: c_int, tables: *const jpegenc_qtable, order: c_int, fdct_variant: c_int,
                                  callback: jpegenc_tile_callback, user: *mut c_void) -> c_int;
+    pub fn jpegenc_blocks_stream_release() -> c_int;
     pub fn jpegenc_blocks_host(device: c_int, pixels: *const u8, pixels_len: usize, width: c_int, height: c_int, color_type: c_int,
                                h: c_int, v: c_int, tables: *const jpegenc_qtable, order: c_int, fdct_variant: c_int,
                                coeffs: *mut i16, capacity: usize) -> c_int;

@@ -44,7 +44,7 @@ F_4_1, F_4_2, F_1_4, F_2_4 = 0x41, 0x42, 0x14, 0x24
 ABI_SYMBOLS = [
     "jpegenc_abi_version", "jpegenc_device_count", "jpegenc_last_error", "jpegenc_status_string",
     "jpegenc_qtable_init", "jpegenc_bytes_per_pixel", "jpegenc_sampling_factor_from_factors", "jpegenc_layout_init",
-    "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_histogram_device",
+    "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_blocks_stream_release", "jpegenc_histogram_device",
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
     "jpegenc_pixels_scan_fused", "jpegenc_pixels_scan_device",
     "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_register_cache", "jpegenc_encoder_set_numa_bind", "jpegenc_encoder_set_batch_upload", "jpegenc_encoder_set_batch_round_frames",
@@ -326,6 +326,11 @@ def blocks_stream(frame_ptrs, frame_len, width, height, color_type, hs, vs, q, o
     if err:
         raise err[0]
     check(rc)
+
+
+def blocks_stream_release():
+    """jpegenc_blocks_stream_release: free the streams and buffers the last successful blocks_stream call left for the next."""
+    check(lib().jpegenc_blocks_stream_release())
 
 
 def blocks_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, color_type, hs, vs, q,

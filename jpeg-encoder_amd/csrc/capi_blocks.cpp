@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <mutex>
 #include <string>
 
 #include "host_common.h"
@@ -362,6 +363,11 @@ struct StreamPipe {
     static constexpr int kSlots = 4;
     StreamSlot slot[kSlots];
     hipStream_t s_up = nullptr, s_k = nullptr, s_dn = nullptr;
+    // what the buffers were made for (a call reuses the pipe of the call before it when they fit: 8 + 13 ms of a 156 ms call over
+    // 256 4K frames were spent making and freeing four 25 MB page-locked buffers each way, profiles/r05_blocks_stream.txt)
+    int device = -1, slots = 0;
+    size_t in_bytes = 0, out_bytes = 0;
+    bool staged = false;
     ~StreamPipe() {
         if (s_up) (void)hipStreamSynchronize(s_up);
         if (s_k) (void)hipStreamSynchronize(s_k);
@@ -379,7 +385,44 @@ struct StreamPipe {
         if (s_k) (void)hipStreamDestroy(s_k);
         if (s_dn) (void)hipStreamDestroy(s_dn);
     }
+    bool fits(int dev, int nslots, size_t in, size_t out, bool need_staging) const {
+        return device == dev && slots >= nslots && in_bytes >= in && out_bytes >= out && (staged || !need_staging);
+    }
 };
+
+// The pipe of the last jpegenc_blocks_stream call that ended well, kept for the next one (one per process: a second thread streaming
+// at the same time makes its own and the one that finishes last stays).  jpegenc_blocks_stream_release() frees it.
+std::mutex g_pipe_mu;
+StreamPipe *g_pipe_kept = nullptr;
+
+// A call's hold on its pipe: goes back to the cache when the call says it ended well, is destroyed otherwise (an error leaves
+// copies in flight - the destructor waits for them - and events in states the next call should not inherit).
+struct PipeLease {
+    StreamPipe *pipe = nullptr;
+    bool keep = false;
+    ~PipeLease() {
+        if (!pipe) return;
+        StreamPipe *old = nullptr;
+        if (keep) {
+            std::lock_guard<std::mutex> lock(g_pipe_mu);
+            old = g_pipe_kept;
+            g_pipe_kept = pipe;
+        } else {
+            old = pipe;
+        }
+        delete old;
+    }
+};
+StreamPipe *take_kept_pipe(int dev, int nslots, size_t in, size_t out, bool need_staging) {
+    StreamPipe *kept = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pipe_mu);
+        kept = g_pipe_kept;
+        g_pipe_kept = nullptr;
+    }
+    if (kept && !kept->fits(dev, nslots, in, out, need_staging)) { delete kept; kept = nullptr; }
+    return kept;
+}
 }  // namespace
 
 int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame_len, int num_frames,
@@ -408,31 +451,49 @@ int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame
     static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     double cb_seconds = 0;
-    StreamPipe pipe;
     const int slots = num_frames < StreamPipe::kSlots ? num_frames : StreamPipe::kSlots;
-    // The three streams must sit on three different hardware queues or the two copy directions serialise (a process
-    // has 4 hardware queues per priority; streams are dealt onto them in creation order, so in a process that already
-    // holds a handful of streams - bench.py's - upload and download streams of equal priority landed on the same queue
-    // and the pipeline ran at 25 instead of 47 GB/s each way).  Each priority has its own queues: one stream per priority.
-    int prio_least = 0, prio_greatest = 0;
-    JPEGENC_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    const int prio_mid = (prio_least + prio_greatest) / 2;
-    JPEGENC_HIP(hipStreamCreateWithPriority(&pipe.s_up, hipStreamNonBlocking, prio_greatest));
-    JPEGENC_HIP(hipStreamCreateWithPriority(&pipe.s_dn, hipStreamNonBlocking, prio_mid != prio_greatest ? prio_mid : prio_least));
-    JPEGENC_HIP(hipStreamCreateWithPriority(&pipe.s_k, hipStreamNonBlocking, prio_least));
     bool all_pinned = true;
     for (int i = 0; i < num_frames && all_pinned; i++) all_pinned = is_pinned_host_range(frames[i], required);
-    for (int j = 0; j < slots; j++) {
-        StreamSlot &x = pipe.slot[j];
-        if (!all_pinned) JPEGENC_HIP(hipHostMalloc(&x.h_in, required, hipHostMallocDefault));
-        JPEGENC_HIP(hipHostMalloc(&x.h_out, tile_bytes, hipHostMallocDefault));
-        JPEGENC_HIP(hipMalloc(&x.d_in, required));
-        JPEGENC_HIP(hipMalloc(&x.d_out, tile_bytes));
-        JPEGENC_HIP(hipEventCreateWithFlags(&x.up, hipEventDisableTiming));
-        JPEGENC_HIP(hipEventCreateWithFlags(&x.kernel, hipEventDisableTiming));
-        JPEGENC_HIP(hipEventCreateWithFlags(&x.down, hipEventDisableTiming));
+    PipeLease lease;
+    lease.pipe = take_kept_pipe(device, slots, required, tile_bytes, !all_pinned);
+    const bool reused = lease.pipe != nullptr;
+    if (!reused) {
+        lease.pipe = new StreamPipe;
+        StreamPipe &np = *lease.pipe;
+        for (int j = 0; j < slots; j++) {
+            StreamSlot &x = np.slot[j];
+            if (!all_pinned) JPEGENC_HIP(hipHostMalloc(&x.h_in, required, hipHostMallocDefault));
+            JPEGENC_HIP(hipHostMalloc(&x.h_out, tile_bytes, hipHostMallocDefault));
+            JPEGENC_HIP(hipMalloc(&x.d_in, required));
+            JPEGENC_HIP(hipMalloc(&x.d_out, tile_bytes));
+            JPEGENC_HIP(hipEventCreateWithFlags(&x.up, hipEventDisableTiming));
+            JPEGENC_HIP(hipEventCreateWithFlags(&x.kernel, hipEventDisableTiming));
+            JPEGENC_HIP(hipEventCreateWithFlags(&x.down, hipEventDisableTiming));
+        }
+        np.device = device; np.slots = slots; np.in_bytes = required; np.out_bytes = tile_bytes; np.staged = !all_pinned;
     }
-    // An event that was never recorded counts as complete, so the first round needs no special case.
+    {
+        // The three streams must sit on three different hardware queues or the two copy directions serialise (a process
+        // has 4 hardware queues per priority; streams are dealt onto them in creation order, so in a process that already
+        // holds a handful of streams - bench.py's - upload and download streams of equal priority landed on the same queue
+        // and the pipeline ran at 25 instead of 47 GB/s each way).  Each priority has its own queues: one stream per priority.
+        // The streams are made per call even when the buffers are kept: the FIRST three streams a process makes this way move
+        // 27.7 GB/s each way for as long as they live, every later set 45 (profiles/r05_blocks_stream.txt) - a kept set would
+        // pin a process to whichever it got.
+        StreamPipe &np = *lease.pipe;
+        if (np.s_up) { (void)hipStreamDestroy(np.s_up); np.s_up = nullptr; }
+        if (np.s_dn) { (void)hipStreamDestroy(np.s_dn); np.s_dn = nullptr; }
+        if (np.s_k) { (void)hipStreamDestroy(np.s_k); np.s_k = nullptr; }
+        int prio_least = 0, prio_greatest = 0;
+        JPEGENC_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        const int prio_mid = (prio_least + prio_greatest) / 2;
+        JPEGENC_HIP(hipStreamCreateWithPriority(&np.s_up, hipStreamNonBlocking, prio_greatest));
+        JPEGENC_HIP(hipStreamCreateWithPriority(&np.s_dn, hipStreamNonBlocking, prio_mid != prio_greatest ? prio_mid : prio_least));
+        JPEGENC_HIP(hipStreamCreateWithPriority(&np.s_k, hipStreamNonBlocking, prio_least));
+    }
+    StreamPipe &pipe = *lease.pipe;
+    // An event that was never recorded counts as complete, so the first round needs no special case (a kept pipe's events
+    // were all waited for by the call that left it).
     auto upload = [&](int i) -> int {
         StreamSlot &x = pipe.slot[i % slots];
         JPEGENC_HIP(hipEventSynchronize(x.kernel));                    // the kernel of frame i - slots has read d_in
@@ -475,9 +536,21 @@ int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame
     for (int i = num_frames > slots ? num_frames - slots : 0; i < num_frames; i++)
         if ((rc = deliver(i))) return rc;
     if (trace)
-        fprintf(stderr, "[jpegenc] blocks_stream: %d frames, %d slots, pinned input %d: setup %.2f ms, pipeline %.2f ms of which callbacks %.2f ms\n",
-                num_frames, slots, (int)all_pinned, std::chrono::duration<double>(t_ready - t_begin).count() * 1e3,
+        fprintf(stderr, "[jpegenc] blocks_stream: %d frames, %d slots, pinned input %d, pipe %s: setup %.2f ms, pipeline %.2f ms of which callbacks %.2f ms\n",
+                num_frames, slots, (int)all_pinned, reused ? "kept from the call before" : "made", std::chrono::duration<double>(t_ready - t_begin).count() * 1e3,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count() * 1e3, cb_seconds * 1e3);
+    lease.keep = true;
+    return JPEGENC_OK;
+}
+
+int jpegenc_blocks_stream_release(void) {
+    StreamPipe *kept = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pipe_mu);
+        kept = g_pipe_kept;
+        g_pipe_kept = nullptr;
+    }
+    delete kept;
     return JPEGENC_OK;
 }
 

@@ -801,6 +801,39 @@ def test_blocks_stream_errors_and_abort(binding, synth):
     binding.blocks_stream([], f.size, w, h, binding.RGB, 1, 1, q, lambda i, t: 0)      # empty batch is fine
 
 
+def test_blocks_stream_keeps_its_pipe_between_calls(binding, oracle, synth):
+    """The streams and buffers of a jpegenc_blocks_stream call stay for the next one: calls of the same, a smaller, a larger
+    geometry, pageable after page-locked frames (the kept pipe has no staging buffers), a call after an aborted one and after a
+    release all deliver the oracle's tiles; releasing twice is fine."""
+    import torch
+    q = binding.qtables(83)
+
+    def stream(w, h, n, seed, pinned, hs=2, vs=1):
+        frames = [np.ascontiguousarray(synth.lcg_image(w, h, 3, seed + i)) for i in range(n)]
+        keep = [torch.from_numpy(f.copy()).pin_memory() for f in frames] if pinned else frames
+        ptrs = [t.data_ptr() for t in keep] if pinned else [f.ctypes.data for f in frames]
+        seen = []
+        binding.blocks_stream(ptrs, frames[0].size, w, h, binding.RGB, hs, vs, q, lambda i, t: seen.append((i, t.copy())) and 0)
+        assert [i for i, _ in seen] == list(range(n))
+        for i, tile in seen:
+            _same(tile, oracle.encode_blocks(frames[i], w, h, oracle.RGB, hs, vs, 83, 0))
+
+    binding.blocks_stream_release()
+    stream(200, 120, 6, 10, True)
+    stream(200, 120, 9, 20, True)             # the kept pipe
+    stream(97, 55, 3, 30, True)               # smaller: fits; fewer slots than the pipe holds
+    stream(97, 55, 5, 40, False)              # pageable frames: the kept pipe has no staging buffers -> a new one
+    stream(410, 300, 7, 50, False)            # larger: a new one
+    stream(200, 120, 2, 60, True, 1, 1)       # page-locked frames through a pipe that has staging buffers
+    f = np.ascontiguousarray(synth.lcg_image(200, 120, 3, 1))
+    with pytest.raises(binding.JpegEncError):
+        binding.blocks_stream([f.ctypes.data] * 6, f.size, 200, 120, binding.RGB, 1, 1, q, lambda i, t: 5 if i == 1 else 0)
+    stream(200, 120, 6, 70, False)            # after an aborted call (its pipe was destroyed)
+    binding.blocks_stream_release()
+    binding.blocks_stream_release()
+    stream(64, 64, 5, 80, True)
+
+
 def test_encode_to_file_like_new_file(binding, oracle, synth, tmp_path):
     """Encoder::new_file (encoder.rs:1204-1219): file created first, IoError when it cannot be."""
     px = synth.test_img_rgb()

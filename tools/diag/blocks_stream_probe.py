@@ -19,6 +19,8 @@ for nfr in (8, 256, 32, 256):
         seen.append(index)
     for rep in range(3):
         seen.clear()
+        if os.environ.get("PROBE_RELEASE_EACH"):      # a new pipe (streams, buffers) per call, as until round 5
+            b.blocks_stream_release()
         t = time.perf_counter()
         b.blocks_stream(ptrs, fb, W, H, b.RGB, 2, 2, q, on_tile)
         dt = time.perf_counter() - t
