@@ -734,10 +734,51 @@ def main():
             d_photo = torch.clamp(base.to(torch.int16)[None, :] + torch.randint(-6, 7, (Fd, base.numel()), dtype=torch.int16, device=dev, generator=gen),
                                   0, 255).to(torch.uint8)
             dr["photo_like"] = leg(d_photo)
+
+            # The call is asynchronous on the caller's stream and keeps its state in the caller's workspace, so a caller with frames
+            # to spare alternates between two streams (a workspace, output and length array each): the launch-bound tail of one
+            # call - run placement, prefix sums, 0xFF stuffing: 44 of 232 us - runs beside the next call's kernel
+            # (tools/diag/r05_two_stream_overlap.py; profiles/r05_two_stream_overlap.jsonl).  Wall time over both streams.
+            def two_streams(px, half=8, calls=120):
+                ss = [torch.cuda.Stream(device=dev) for _ in range(2)]
+                wsz2 = binding.scan_workspace_size(L, scan, half)
+                ws2 = [torch.empty(wsz2, dtype=torch.uint8, device=dev) for _ in range(2)]
+                out2 = [torch.empty((half, cap), dtype=torch.uint8, device=dev) for _ in range(2)]
+                len2 = [torch.zeros(half, dtype=torch.int32, device=dev) for _ in range(2)]
+
+                def call(c):
+                    i = c & 1
+                    part = px[(c % (Fd // half)) * half:(c % (Fd // half) + 1) * half]
+                    binding.pixels_scan_device(part.data_ptr(), frame_bytes, half, W, H, binding.RGB, HS, VS, q, out2[i].data_ptr(), cap,
+                                               len2[i].data_ptr(), ws2[i].data_ptr(), wsz2, ss[i].cuda_stream, variant=binding.FDCT_SCALAR)
+                torch.cuda.synchronize()
+                t_in = time.perf_counter()
+                while time.perf_counter() - t_in < 0.1:
+                    for c in range(8):
+                        call(c)
+                    torch.cuda.synchronize()
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for c in range(calls):
+                        call(c)
+                    torch.cuda.synchronize()
+                    best = min(best, time.perf_counter() - t0)
+                same = bool(torch.equal(len2[0].cpu(), len2[1].cpu()) if Fd // half == 1 else True)
+                return {"value": round(calls * half * W * H / best / 1e6, 1), "unit": "Mpixels/s", "us_per_frame": round(best * 1e6 / (calls * half), 2),
+                        "what": f"the same entry point called with {half} frames at a time on two streams in turn, wall time of {calls} calls", "lengths_agree": same}
+            try:
+                dr["two_streams"] = two_streams(d_px)
+                dr["photo_like"]["two_streams"] = two_streams(d_photo)
+            except Exception as exc:
+                dr["two_streams"] = {"error": str(exc)}
             details["device_resident_full_encode"] = dr
             to_bytes["device_resident_Gpx_s"] = {"noise": round(dr["value"] / 1e3, 1), "photo_like": round(dr["photo_like"]["value"] / 1e3, 1),
                                                  "two_kernels_noise": round(dr["two_kernels"]["value"] / 1e3, 1),
                                                  "two_kernels_photo_like": round(dr["photo_like"]["two_kernels"]["value"] / 1e3, 1)}
+            if "value" in dr.get("two_streams", {}) and "value" in dr["photo_like"].get("two_streams", {}):
+                to_bytes["device_resident_Gpx_s"]["two_streams_noise"] = round(dr["two_streams"]["value"] / 1e3, 1)
+                to_bytes["device_resident_Gpx_s"]["two_streams_photo_like"] = round(dr["photo_like"]["two_streams"]["value"] / 1e3, 1)
             if "simd_variant" in result and "error" not in result["simd_variant"]:
                 result["simd_variant"]["pixels_to_scan_Gpx_s"] = {"noise": round(dr["simd_variant_Mpixels_per_s"] / 1e3, 1),
                                                                   "photo_like": round(dr["photo_like"]["simd_variant_Mpixels_per_s"] / 1e3, 1)}

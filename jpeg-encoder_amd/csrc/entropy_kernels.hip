@@ -1043,20 +1043,43 @@ __global__ void __launch_bounds__(256) k_batch_prefix(const BatchGatherArgs a, c
     if (n == 0 ? threadIdx.x == 0 : (first < n && end == n)) pos[n] = at;            // the thread that placed the last segment
 }
 
+// SELF: no k_batch_prefix launch before this one - every workgroup adds up the (rounded) lengths of the segments before its own
+// (frames * njobs <= kBatchGatherSelfMax of them); h_len (may be null): the lengths once more, into page-locked HOST memory, so that
+// no copy of them has to follow on the stream (a 5 us launch and ~10 us of host time per round of a device-resident batch)
+constexpr uint32_t kBatchGatherSelfMax = 2048;
+template <bool SELF>
 __global__ void __launch_bounds__(256) k_batch_gather(const BatchGatherArgs a, const uint8_t *src, const uint32_t *len,
-                                                      const uint64_t *pos, uint8_t *dst) {
+                                                      const uint64_t *pos, uint8_t *dst, uint32_t *h_len) {
     const uint32_t i = blockIdx.x, f = i / a.njobs, k = i - f * a.njobs;
-    const uint32_t n16 = (len[(size_t)k * a.per_round + f] + 15u) >> 4;            // (the bytes after a segment's end ride along)
+    const uint32_t mine = len[(size_t)k * a.per_round + f];
+    const uint32_t n16 = (mine + 15u) >> 4;                                       // (the bytes after a segment's end ride along)
+    if (h_len && blockIdx.y == 0 && threadIdx.x == 0) h_len[(size_t)k * a.per_round + f] = mine;
+    uint64_t at;
+    if (SELF) {
+        __shared__ uint64_t part[4];
+        unsigned long long before = 0;
+        for (uint32_t j = threadIdx.x; j < i; j += 256u) before += (len[(size_t)(j % a.njobs) * a.per_round + j / a.njobs] + 15u) & ~15u;
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
+        if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = before;
+        __syncthreads();
+        at = part[0] + part[1] + part[2] + part[3];
+    } else {
+        at = pos[i];
+    }
     const uint4 *s = reinterpret_cast<const uint4 *>(src + (size_t)f * a.frame_stride + a.off[k]);
-    uint4 *d = reinterpret_cast<uint4 *>(dst + pos[i]);
+    uint4 *d = reinterpret_cast<uint4 *>(dst + at);
     for (uint32_t c = blockIdx.y * 256u + threadIdx.x; c < n16; c += gridDim.y * 256u) d[c] = s[c];
 }
 
 hipError_t launch_batch_gather(const BatchGatherArgs &a, const void *d_src, const uint32_t *d_len, uint64_t *d_pos, void *d_dst,
-                               hipStream_t st) {
-    hipLaunchKernelGGL(k_batch_prefix, dim3(1), dim3(256), 0, st, a, d_len, d_pos);
-    hipLaunchKernelGGL(k_batch_gather, dim3(a.frames * a.njobs, a.frame_stride >= ((uint64_t)4 << 20) ? 64 : 4), dim3(256), 0, st, a,
-                       (const uint8_t *)d_src, d_len, d_pos, (uint8_t *)d_dst);
+                               hipStream_t st, uint32_t *h_len) {
+    const dim3 grid(a.frames * a.njobs, a.frame_stride >= ((uint64_t)4 << 20) ? 64 : 4);
+    if (a.frames * a.njobs <= kBatchGatherSelfMax) {
+        hipLaunchKernelGGL(k_batch_gather<true>, grid, dim3(256), 0, st, a, (const uint8_t *)d_src, d_len, d_pos, (uint8_t *)d_dst, h_len);
+    } else {
+        hipLaunchKernelGGL(k_batch_prefix, dim3(1), dim3(256), 0, st, a, d_len, d_pos);
+        hipLaunchKernelGGL(k_batch_gather<false>, grid, dim3(256), 0, st, a, (const uint8_t *)d_src, d_len, d_pos, (uint8_t *)d_dst, h_len);
+    }
     return hipGetLastError();
 }
 
@@ -1100,7 +1123,9 @@ static LaunchShape shape_of(const EntropyParams *jobs, int njobs, int frames) {
     // frame; k_block_code's 3 038: +2-3 us); the tiles (worst-case bound 11 154) gain 0.5 us on photo-like frames and lose
     // 0.8-1.6 us on noise, and per-64-tile counters kept by k_push to shorten the sum cost 2-3 us in contended atomics.
     static const uint32_t allow = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_FUSED_PREFIX_MASK"); return e ? (uint32_t)atoi(e) : 3u; }();   // diagnostic
-    if (!s.any_multi) s.fused_prefix = ((s.nwaves <= kFusedPrefixRuns ? 1u : 0u) | (s.fftiles <= kFusedPrefixTiles ? 2u : 0u)) & allow;
+    // (up to four frames per launch the two prefix launches are 10 us of a ~100 us sequence and nothing else fills the GPU meanwhile:
+    //  the tiles are folded whatever their bound - a round of a device-resident batch, profiles/r05_device_batch_pipeline.txt)
+    if (!s.any_multi) s.fused_prefix = ((s.nwaves <= kFusedPrefixRuns ? 1u : 0u) | (s.fftiles <= kFusedPrefixTiles || frames <= 4 ? 2u : 0u)) & allow;
     // (every wave of k_push reads the lengths of all runs before its own: runs^2 / 2 loads per scan and frame.  One scan of sixteen
     //  4K frames - 2 040 runs each - is where that still beats two launches; the twelve scans of four progressive 4K frames in one
     //  launch - 48 x 1 519 runs - spent 105 us in k_push that way, 2 x 5 us of prefix-sum launches instead: profiles/r05_mode_trace.txt)

@@ -13,8 +13,9 @@ namespace jpegenc {
 
 // A batch of device-resident frames as the steps encode_device_batch walks through: prepare / plan_scans /
 // size_rounds_and_reserve (tables, geometry, the scans, how many frames share a round and the buffers of two rounds),
-// then a software pipeline over rounds - code_round(r + 1) on the encoder's stream overlaps the download of round r on the
-// copy stream (collect_round), which overlaps the assembly of the files of round r - 1 on host threads (assemble_frames).
+// then a software pipeline over rounds (BatchRun::run) - code_round(r + 1) on the encoder's stream overlaps the download of round r
+// on the copy stream (fetch_round), which overlaps the assembly of the files of rounds r - 1 and r - 2 on the handle's background
+// threads (deliver_round, assemble_frames).
 struct BatchRun {
     struct Job { jpegenc_scan sc; int first, n, ss, se; size_t off, cap, ws_off, ws; };
     const Config &c;
@@ -43,7 +44,7 @@ struct BatchRun {
     bool together = false;                              // the scans of a sequential / progressive round in SHARED launches (blockIdx.z = scan): every job its own workspace
     std::vector<size_t> ws_off, ws_len;
     int per_round = 1;
-    std::vector<std::thread> pools[2];                  // the threads assembling the files of the round staged in h_out[slot]
+    bool in_assembly[BatchBuffers::kHostSlots] = {false, false, false};   // files of the round staged in h_out[slot] were handed to the handle's assembling threads
     std::atomic<int> failed{0};
     std::atomic<int> first_bad{0x7FFFFFFF};             // lowest frame whose sink reported an error (every frame before it is delivered whole)
     bool stop = false;
@@ -56,8 +57,8 @@ struct BatchRun {
         if (getenv("JPEGENC_TRACE")) fprintf(stderr, "[jpegenc] batch: shared launches declined (%s)\n", why);
         return kBatchNeedsPerFrame;
     }
-    void join(int slot) { for (auto &th : pools[slot]) th.join(); pools[slot].clear(); }
-    ~BatchRun() { join(0); join(1); }                   // also on an early return
+    void join(int slot) { if (in_assembly[slot] && b.assemblers) b.assemblers->wait(slot); in_assembly[slot] = false; }
+    ~BatchRun() { for (int slot = 0; slot < BatchBuffers::kHostSlots; slot++) join(slot); }      // also on an early return: no task outlives the call
 
     int prepare() {
         if (!pb) {
@@ -193,7 +194,7 @@ struct BatchRun {
     }
 
     int code_round(int r) {                             // enqueue only
-        const int f0 = r * per_round, half = r & 1;
+        const int f0 = r * per_round, half = r % BatchBuffers::kDevSlots;      // (the slot of d_packed / d_len / h_len / d_pos / coded this round takes)
         const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
         BlockKernelParams p;
         int e = pb ? build_block_params_planes(&p, L, width, height, t.q, order) : build_block_params(&p, L, width, height, color_type, t.q, order);
@@ -299,13 +300,16 @@ struct BatchRun {
             if (rl) return rl;
         }
         uint32_t *d_len = b.d_len + (size_t)half * nlen;
-        JPEGENC_HIP(hipMemsetAsync(d_len, 0, nlen * sizeof(uint32_t), ctx.stream));
+        // (the coder sets the length of every scan it codes; only the scans of empty bands - nothing launched for them - need the zero)
+        bool every_scan_coded = true;
+        for (const Job &j : jobs) if (!j.cap) every_scan_coded = false;
+        if (!every_scan_coded) JPEGENC_HIP(hipMemsetAsync(d_len, 0, nlen * sizeof(uint32_t), ctx.stream));
         if (together) {
             std::vector<ScanJob> sj;
             for (size_t k = 0; k < jobs.size(); k++) {
                 const Job &j = jobs[k];
                 if (!j.cap) continue;
-                sj.push_back(ScanJob{j.sc, (uint8_t *)b.d_out + (size_t)half * round_out + j.off, out_total, d_len + k * (size_t)per_round,
+                sj.push_back(ScanJob{j.sc, (uint8_t *)b.d_out + j.off, out_total, d_len + k * (size_t)per_round,
                                      (uint8_t *)b.d_ws + ws_off[k], ws_len[k]});
             }
             e = scan_device_multi(b.d_coeffs, L.total_blocks, n, L, sj.data(), (int)sj.size(), optimize ? b.d_opt_luts : ctx.d_lut, ctx.stream, optimize);
@@ -314,19 +318,20 @@ struct BatchRun {
         for (size_t k = 0; k < jobs.size(); k++) {
             const Job &j = jobs[k];
             if (!j.cap) continue;
-            e = scan_device(b.d_coeffs, L.total_blocks, n, L, j.sc, nullptr, optimize ? b.d_opt_luts : ctx.d_lut, (uint8_t *)b.d_out + (size_t)half * round_out + j.off,
+            e = scan_device(b.d_coeffs, L.total_blocks, n, L, j.sc, nullptr, optimize ? b.d_opt_luts : ctx.d_lut, (uint8_t *)b.d_out + j.off,
                             out_total, d_len + k * (size_t)per_round, b.d_ws, ws, ctx.stream, nullptr, fused ? &fused_src : nullptr, optimize);
             if (e) return e;
         }
-        JPEGENC_HIP(hipMemcpyAsync(b.h_len + (size_t)half * nlen, d_len, nlen * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx.stream));
         // pack the round's scans back to back (frame-major, 16-byte aligned): ONE download per round instead of one
-        // per frame and scan (1 024 small frames were 1 024 copies, most of the round's time)
+        // per frame and scan (1 024 small frames were 1 024 copies, most of the round's time).  The gather kernel also leaves the
+        // lengths in the page-locked b.h_len (until round 5 a copy on this stream: a launch of its own and ~10 us of host time).
         BatchGatherArgs ga;
         ga.frames = (uint32_t)n; ga.njobs = (uint32_t)jobs.size(); ga.per_round = (uint32_t)per_round; ga.reserved = 0;
         ga.frame_stride = out_total;
         for (size_t k = 0; k < jobs.size(); k++) ga.off[k] = jobs[k].off;
-        const hipError_t ge = launch_batch_gather(ga, (const uint8_t *)b.d_out + (size_t)half * round_out, d_len,
-                                                  b.d_pos + (size_t)half * (nlen + 1), (uint8_t *)b.d_packed + (size_t)half * packed_half, ctx.stream);
+        const hipError_t ge = launch_batch_gather(ga, (const uint8_t *)b.d_out, d_len,
+                                                  b.d_pos + (size_t)half * (nlen + 1), (uint8_t *)b.d_packed + (size_t)half * packed_half, ctx.stream,
+                                                  b.h_len + (size_t)half * nlen);
         if (ge != hipSuccess) return hip_fail(ge, "gather kernel launch");
         JPEGENC_HIP(hipEventRecord(b.coded[half], ctx.stream));
         return JPEGENC_OK;
@@ -374,18 +379,34 @@ struct BatchRun {
         }
     }
 
-    // round `round` (frames f0 ...): wait for its coding, fetch its lengths and bytes, enqueue the next round, hand the files to
-    // the assembling threads
-    int collect_round(int round, int f0) {
+    // A round whose download is in flight: what its files are assembled from once it has landed.
+    struct Fetch {
+        bool valid = false;
+        int round = 0, f0 = 0, n = 0, slot = 0;
+        size_t bytes = 0;
+        std::shared_ptr<std::vector<uint32_t>> lens;
+        std::shared_ptr<std::vector<size_t>> frame_at;
+        uint8_t *h_out = nullptr;
+    };
+    std::chrono::steady_clock::time_point t_run;
+    long since_run() const { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_run).count(); }
+
+    // round `round` (frames f0 ...): wait for its coding, read its lengths, ENQUEUE its download into the staging buffer of its slot
+    // (three slots: the files of rounds r - 2 and r - 1 may still be in assembly) - no wait for the bytes here
+    int fetch_round(int round, int f0, Fetch *out) {
         const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
-        const bool more = f0 + per_round < num_frames;
-        const uint32_t *h_len = b.h_len + (size_t)(round & 1) * nlen;
-        const uint8_t *d_packed = (const uint8_t *)b.d_packed + (size_t)(round & 1) * packed_half;
-        JPEGENC_HIP(hipEventSynchronize(b.coded[round & 1]));                  // this round is coded, its lengths are on the host
-        const int slot = round & 1;
+        const int dev_slot = round % BatchBuffers::kDevSlots;
+        const uint32_t *h_len = b.h_len + (size_t)dev_slot * nlen;
+        const uint8_t *d_packed = (const uint8_t *)b.d_packed + (size_t)dev_slot * packed_half;
+        static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+        const long us_in = trace ? since_run() : 0;
+        JPEGENC_HIP(hipEventSynchronize(b.coded[dev_slot]));                   // this round is coded, its lengths are on the host
+        const long us_coded = trace ? since_run() : 0;
+        const int slot = round % BatchBuffers::kHostSlots;
         join(slot);                                                            // the files last assembled out of this staging buffer
+        const long us_joined = trace ? since_run() : 0;
         if (failed.load()) { stop = true; return JPEGENC_OK; }
-        // this round's lengths, frame-major (b.h_len is overwritten by the next round while the files are assembled)
+        // this round's lengths, frame-major (b.h_len is overwritten by the round after next while the files are assembled)
         auto lens = std::make_shared<std::vector<uint32_t>>((size_t)n * jobs.size());
         size_t need = 0;
         for (int f = 0; f < n; f++)
@@ -411,37 +432,70 @@ struct BatchRun {
         }
         (*frame_at)[(size_t)n] = at;
         if (at) JPEGENC_HIP(hipMemcpyAsync(h_out, d_packed, at, hipMemcpyDeviceToHost, b.copy_stream));
-        if (more) { rc = code_round(round + 1); if (rc) return rc; }               // (its half of d_out was downloaded a round ago)
-        JPEGENC_HIP(hipStreamSynchronize(b.copy_stream));
-        // assemble the files in the background: headers from each thread's small writer, the scan bytes straight
-        // from the pinned buffer to the sink; frames are independent, so a few host threads share them (each
-        // frame's sink calls stay in order, different frames' calls may interleave - as in encode_batch)
+        JPEGENC_HIP(hipEventRecord(b.fetched[slot], b.copy_stream));
+        if (trace) fprintf(stderr, "[jpegenc] batch round %d (%d frames, %zu bytes): at %ld us waited %ld for its coding, %ld for the files of round %d, download enqueued at %ld\n",
+                           round, n, at, us_in, us_coded - us_in, us_joined - us_coded, round - BatchBuffers::kHostSlots, since_run());
+        out->valid = true; out->round = round; out->f0 = f0; out->n = n; out->slot = slot; out->bytes = at;
+        out->lens = lens; out->frame_at = frame_at; out->h_out = h_out;
+        return JPEGENC_OK;
+    }
+
+    // the download of round `p` has to land; then its files are assembled behind the pipeline's back: headers from each thread's
+    // small writer, the scan bytes straight from the pinned buffer to the sink; frames are independent, so a few host threads
+    // share them (each frame's sink calls stay in order, different frames' calls may interleave - as in encode_batch).  The last
+    // round's files are assembled with this thread's help.
+    int deliver_round(const Fetch &p, bool last) {
+        static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+        const long us_in = trace ? since_run() : 0;
+        JPEGENC_HIP(hipEventSynchronize(b.fetched[p.slot]));
+        const long us_landed = trace ? since_run() : 0;
         auto next = std::make_shared<std::atomic<int>>(0);
+        auto lens = p.lens;
+        auto frame_at = p.frame_at;
+        uint8_t *h_out = p.h_out;
+        const int n = p.n, f0 = p.f0;
         auto assemble = [this, lens, frame_at, next, h_out, n, f0]() { assemble_frames(*lens, *frame_at, *next, h_out, n, f0); };
         int nthreads = usable_cpus() - 2;
         if (nthreads > 8) nthreads = 8;
         if (nthreads < 1) nthreads = 1;
         if (nthreads > n) nthreads = n;
-        if (at < ((size_t)4 << 20)) nthreads = 1;                                // little to copy: not worth the threads
-        if (more || nthreads > 1) {
-            for (int w = more ? 0 : 1; w < nthreads; w++) pools[slot].emplace_back(assemble);
-            if (!more) assemble();
+        if (p.bytes < ((size_t)4 << 20)) nthreads = 1;                           // little to copy: not worth the threads
+        if (b.assemblers) {
+            b.assemblers->ensure_threads(nthreads);
+            for (int w = last ? 1 : 0; w < nthreads; w++) { in_assembly[p.slot] = true; b.assemblers->submit(p.slot, assemble); }
+            if (last) assemble();
         } else {
             assemble();
         }
+        if (trace) fprintf(stderr, "[jpegenc] batch round %d: at %ld us waited %ld for its download, files handed to %d threads at %ld\n", p.round, us_in, us_landed - us_in, nthreads, since_run());
         return JPEGENC_OK;
     }
 
+    // The pipeline: the link carries round r while the GPU codes round r + 1 and host threads assemble the files of rounds r - 1
+    // and r - 2.  A turn: enqueue the coding of round r + 1 (into the device slot round r - 2 has left: its download was waited
+    // for a turn ago), wait for the coding of round r and enqueue its download, THEN wait for the download of round r - 1 and
+    // hand its files over.  So the GPU holds the next round's kernels when one round's end, and the copy queue the next download
+    // when one lands.  (Until round 5 a turn waited for its own download and made threads for its files before it looked at the
+    // next round: with four 4K frames per round the link idled 70 of every 170 us, profiles/r05_device_batch_pipeline.txt.)
     int run() {
+        t_run = std::chrono::steady_clock::now();
         int rc = code_round(0);
         if (rc) return rc;
+        Fetch prev;
         int round = 0;
         for (int f0 = 0; f0 < num_frames && !stop; f0 += per_round, round++) {
-            rc = collect_round(round, f0);
+            const bool more = f0 + per_round < num_frames;
+            if (more) { rc = code_round(round + 1); if (rc) break; }
+            Fetch cur;
+            rc = fetch_round(round, f0, &cur);
             if (rc) break;
+            if (stop) break;
+            if (prev.valid) { rc = deliver_round(prev, false); prev.valid = false; if (rc) break; }
+            prev = cur;
         }
-        join(0);
-        join(1);
+        if (!rc && prev.valid && !failed.load()) { rc = deliver_round(prev, true); prev.valid = false; }
+        if (prev.valid) (void)hipStreamSynchronize(b.copy_stream);                 // (a failed call: no download of it outlives it)
+        for (int slot = 0; slot < BatchBuffers::kHostSlots; slot++) join(slot);
         if (rc) return rc;
         if (failed.load()) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
         return JPEGENC_OK;
@@ -564,6 +618,7 @@ int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames
         return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
     }
     e->batch.helpers = &e->threads;
+    e->batch.assemblers = &e->assemblers;
     int bad = -1;
     const int rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users, nullptr, &bad);
     if (rc != kBatchNeedsPerFrame) {
@@ -602,6 +657,7 @@ static int encode_planes_uniform(jpegenc_encoder *e, int jct, int width, int hei
     JPEGENC_HIP(hipMemcpyAsync(e->batch.d_plane_table, table, (size_t)num_frames * 8 * sizeof(uint64_t), hipMemcpyHostToDevice, e->ctx.stream));
     const PlaneBatch pb = {rep, planes_subsampled, (const uint64_t *)e->batch.d_plane_table, jct};
     e->batch.helpers = &e->threads;
+    e->batch.assemblers = &e->assemblers;
     rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, nullptr, 0, num_frames, width, height, 0, sink, users, &pb, failed_frame);
     if (rc != kBatchNeedsPerFrame) return rc;
     if (getenv("JPEGENC_TRACE")) fprintf(stderr, "[jpegenc] pool of %d surfaces: the shared launches declined, one launch sequence per frame\n", num_frames);

@@ -74,7 +74,7 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
                                 std::string *stored = nullptr, const FusedSource *fused = nullptr, int group_stride = 0);
 
 hipError_t launch_batch_gather(const BatchGatherArgs &a, const void *d_src, const uint32_t *d_len, uint64_t *d_pos, void *d_dst,
-                               hipStream_t stream);
+                               hipStream_t st, uint32_t *h_len = nullptr);
 hipError_t launch_gather_scans(const GatherArgs &a, const void *d_src, const uint32_t *d_len, void *d_dst, hipStream_t stream);
 
 // capi_entropy.hip

@@ -11,6 +11,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <deque>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -673,14 +674,17 @@ struct SmallBatchBuffers {
 // Buffers of the device-resident batch path (jpegenc_encoder_encode_batch_device), kept in the handle
 // across calls and only ever grown: pinned allocations of a few hundred MB cost tens of milliseconds.
 class WorkerThreads;
+class BackgroundPool;
 struct BatchBuffers {
     WorkerThreads *helpers = nullptr;     // the handle's persistent host threads (set by the batch entry points), for a round's host step
+    BackgroundPool *assemblers = nullptr; // ... and the ones that assemble the files of a round behind the pipeline's back
     void *d_coeffs = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_packed = nullptr;      // d_packed: a round's scans back to back
     uint64_t *d_pos = nullptr;
     uint32_t *d_len = nullptr, *h_len = nullptr;
     uint64_t dense_geometry = 0, dense_bits_per_block = 0;     // coded bits per block of the last collected round of frames of that size (DeviceCtx::kDenseBitsPerBlock)
-    uint8_t *h_out[2] = {nullptr, nullptr};      // two: the files of one round are assembled while the next round is coded and fetched
-    size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, packed_cap = 0, pos_cap = 0, h_out_cap[2] = {0, 0};
+    static constexpr int kHostSlots = 3;         // three: the files of rounds r - 2 and r - 1 are assembled while round r is fetched (BatchRun::collect_round)
+    uint8_t *h_out[kHostSlots] = {nullptr, nullptr, nullptr};
+    size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, packed_cap = 0, pos_cap = 0, h_out_cap[kHostSlots] = {0, 0, 0};
     static int grow_device(void **p, size_t *cap, size_t need) {
         if (need <= *cap) return JPEGENC_OK;
         if (*p) (void)hipFree(*p);
@@ -732,24 +736,29 @@ struct BatchBuffers {
         }
         return JPEGENC_OK;
     }
-    // d_out, d_len and h_len hold TWO rounds (halves): one is downloaded while the next is coded
     hipStream_t copy_stream = nullptr;
-    hipEvent_t coded[2] = {nullptr, nullptr};
+    hipEvent_t coded[3] = {nullptr, nullptr, nullptr};              // [kDevSlots]
+    hipEvent_t fetched[kHostSlots] = {nullptr, nullptr, nullptr};     // the download of the round staged in h_out[slot] has landed
     int open_streams() {
         if (copy_stream) return JPEGENC_OK;
         JPEGENC_HIP(create_side_stream(&copy_stream));
         for (auto &e : coded) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : fetched) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         return JPEGENC_OK;
     }
+    // d_out (a round's scans where the coder leaves them) is ONE round's: everything that touches it runs in order on the encoder's
+    // stream.  d_packed, d_len, h_len and d_pos hold kDevSlots rounds: round r + 1 is coded (and packed) while round r is downloaded
+    // and round r - 1's download may not have been waited for yet (BatchRun::run).
+    static constexpr int kDevSlots = 3;
     int reserve(size_t coeffs, size_t out, size_t ws, size_t nlen) {
         int rc = open_streams();
-        out *= 2; nlen *= 2;
         if (!rc) rc = grow_device(&d_coeffs, &coeffs_cap, coeffs);
         if (!rc) rc = grow_device(&d_out, &out_cap, out);
         if (!rc) rc = grow_device(&d_ws, &ws_cap, ws);
-        if (!rc) rc = grow_device(&d_packed, &packed_cap, out + 32 * nlen);             // (+16 per segment: aligned positions)
-        if (!rc) rc = grow_device((void **)&d_pos, &pos_cap, (nlen + 2) * sizeof(uint64_t));
+        if (!rc) rc = grow_device(&d_packed, &packed_cap, kDevSlots * (out + 16 * nlen));   // (+16 per segment: aligned positions)
+        if (!rc) rc = grow_device((void **)&d_pos, &pos_cap, kDevSlots * (nlen + 1) * sizeof(uint64_t));
         if (rc) return rc;
+        nlen *= kDevSlots;
         if (nlen > len_cap) {
             if (d_len) (void)hipFree(d_len);
             if (h_len) (void)hipHostFree(h_len);
@@ -784,6 +793,7 @@ struct BatchBuffers {
         if (h_len) (void)hipHostFree(h_len);
         for (auto *h : h_out) if (h) (void)hipHostFree(h);
         for (auto &e : coded) if (e) (void)hipEventDestroy(e);
+        for (auto &e : fetched) if (e) (void)hipEventDestroy(e);
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     }
 };
@@ -892,6 +902,67 @@ class WorkerThreads {
     int width_ = 0, pending_ = 0;
     bool quit_ = false;
 };
+
+// Host threads that work BEHIND a pipeline: submit(group, task) returns at once, wait(group) blocks until every task of that group
+// has run.  The device-resident batch (BatchRun) hands the files of a fetched round to them and goes on to the next download;
+// until round 5 it made up to eight std::threads per round for that - 65-85 us of every 170 us round of four 4K frames, with the
+// link idle meanwhile (profiles/r05_device_batch_pipeline.txt).  The threads stay with the handle.
+class BackgroundPool {
+  public:
+    static constexpr int kGroups = 4;
+    ~BackgroundPool() { stop(); }
+    void ensure_threads(int n) {
+        std::unique_lock<std::mutex> lock(m_);
+        while ((int)threads_.size() < n) threads_.emplace_back([this] { loop(); });
+    }
+    void submit(int group, std::function<void()> task) {
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            pending_[group]++;
+            queue_.emplace_back(group, std::move(task));
+        }
+        work_.notify_one();
+    }
+    void wait(int group) {
+        std::unique_lock<std::mutex> lock(m_);
+        idle_.wait(lock, [&] { return pending_[group] == 0; });
+    }
+    void stop() {
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            quit_ = true;
+        }
+        work_.notify_all();
+        for (auto &t : threads_) if (t.joinable()) t.join();
+        threads_.clear();
+        quit_ = false;
+    }
+
+  private:
+    void loop() {
+        for (;;) {
+            std::pair<int, std::function<void()>> job;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                work_.wait(lock, [&] { return quit_ || !queue_.empty(); });
+                if (queue_.empty()) return;           // (quit_: after the queue has drained)
+                job = std::move(queue_.front());
+                queue_.pop_front();
+            }
+            job.second();
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                if (--pending_[job.first] == 0) idle_.notify_all();
+            }
+        }
+    }
+    std::mutex m_;
+    std::condition_variable work_, idle_;
+    std::deque<std::pair<int, std::function<void()>>> queue_;
+    std::vector<std::thread> threads_;
+    int pending_[kGroups] = {0, 0, 0, 0};
+    bool quit_ = false;
+};
 }  // namespace jpegenc
 
 struct jpegenc_encoder {
@@ -901,6 +972,7 @@ struct jpegenc_encoder {
     DeviceCtx ctx;
     std::vector<std::unique_ptr<DeviceCtx>> workers;   // batch API: one per in-flight frame, kept across calls
     jpegenc::WorkerThreads threads;                    // ... and the threads that drive them (declared after `workers`: joined before the contexts go)
+    jpegenc::BackgroundPool assemblers;                // the threads that assemble a device-resident batch's files behind its downloads
     BatchBuffers batch;                                  // device-resident batch API
     SmallBatchBuffers small;                             // batches of small frames
     int max_batch_workers = 16;                          // host threads of jpegenc_encoder_encode_batch
