@@ -817,7 +817,26 @@ def main():
                 "what": f"{Fd} 4K frames (Criterion pattern) in HBM -> JPEG files in host buffers, one Encoder call, batched launches",
                 "jpeg_bytes_per_frame": int(sum(lens_d) / Fd), "roofline": pcie_roofline("pcie_d2h", int(sum(lens_d)), dt, link)}
             to_bytes["device_resident_to_host_files_Gpx_s"] = details["device_resident_to_host_jpeg"]["Gpixel_per_s"]["median"]
-            del d_crit, outs_d
+            del d_crit
+            # the same on photo-like frames (1.3 MB files): neither the link nor the GPU alone bounds such a call - how well coding,
+            # download and assembly of the files overlap does (profiles/r05_device_batch_pipeline.txt)
+            base_p = torch.from_numpy(synth.test_img_rgb(W, H).reshape(-1)).to(dev)
+            gen_p = torch.Generator(device=dev)
+            gen_p.manual_seed(11)
+            d_crit = torch.clamp(base_p.to(torch.int16)[None, :] + torch.randint(-6, 7, (Fd, base_p.numel()), dtype=torch.int16, device=dev, generator=gen_p),
+                                 0, 255).to(torch.uint8)
+            run_d()
+            times = []
+            for _ in range(7):
+                t1 = time.perf_counter()
+                run_d()
+                times.append(time.perf_counter() - t1)
+            dt = sorted(times)[len(times) // 2]
+            details["device_resident_to_host_jpeg"]["photo_like"] = {
+                "Gpixel_per_s": spread(times, Fd * W * H, 1e-9), "jpeg_bytes_per_frame": int(sum(lens_d) / Fd), "us_per_frame": round(dt * 1e6 / Fd, 1),
+                "roofline": pcie_roofline("pcie_d2h", int(sum(lens_d)), dt, link)}
+            to_bytes["device_resident_to_host_files_photo_like_Gpx_s"] = details["device_resident_to_host_jpeg"]["photo_like"]["Gpixel_per_s"]["median"]
+            del d_crit, outs_d, base_p
         except Exception as exc:                                   # side figure only
             details["device_resident_to_host_jpeg"] = {"error": str(exc)}
         if args.e2e_frames > 0:

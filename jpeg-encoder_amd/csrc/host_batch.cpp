@@ -134,9 +134,23 @@ struct BatchRun {
             const int cap = coeff_bytes >= ((size_t)4 << 20) ? 32 : 256;
             if (per_round > cap) per_round = cap;
         }
-        else if (coeff_bytes >= ((size_t)4 << 20) && num_frames >= 8) {
-            const int eighth = (num_frames + 7) / 8;
-            if (eighth < per_round) per_round = std::min(per_round, eighth < 4 ? 4 : eighth);   // (never above the footprint / the caller's bound)
+        else if (coeff_bytes >= ((size_t)4 << 20)) {
+            // (a round costs ~50 us of launches and hand-overs whatever its size: at least four frames.  Calls of fewer than eight
+            //  frames were ONE round, whose coding, download and assembly cannot overlap anything: where the last batch of this size
+            //  and these settings says that fewer frames already keep the link busy for longer than a round costs - 8 MB files: one -
+            //  such a call goes in rounds of that many: four Criterion-pattern 4K frames 274 -> 217 us per frame)
+            int least = 4;
+            if (b.dense_geometry == content_key(c, width, height, color_type) && b.dense_bits_per_block) {
+                const uint64_t per_frame = b.dense_bits_per_block * L.total_blocks / 8u + 1u;
+                const uint64_t want = (((uint64_t)6 << 20) + per_frame - 1u) / per_frame;
+                least = want < 1 ? 1 : want > 4 ? 4 : (int)want;
+            }
+            if (num_frames >= 8) {
+                const int eighth = (num_frames + 7) / 8;
+                if (eighth < per_round) per_round = std::min(per_round, eighth < 4 ? 4 : eighth);   // (never above the footprint / the caller's bound)
+            } else if (num_frames > least) {
+                per_round = std::min(per_round, least);
+            }
         }
         if (per_round > num_frames) per_round = num_frames;
         // Several scans per frame (sequential: one per component; progressive(4) on three components: twelve): coded in shared
@@ -339,8 +353,10 @@ struct BatchRun {
 
     // the files of one round: headers from each thread's small writer, the scan bytes straight from the pinned buffer to the
     // sink (each frame's sink calls stay in order, different frames' calls may interleave - as in encode_batch)
+    static constexpr size_t kPieceFrom = (size_t)2 << 20, kPiece = (size_t)1 << 20;
+    // copy_slot >= 0: the staging slot (= the pool's task group) large scans may be copied out of in pieces by the pool's threads
     void assemble_frames(const std::vector<uint32_t> &lens_v, const std::vector<size_t> &frame_at_v, std::atomic<int> &next_v, const uint8_t *h_out,
-                         int n, int f0) {
+                         int n, int f0, int copy_slot = -1) {
         const std::vector<uint32_t> *lens = &lens_v;
         const std::vector<size_t> *frame_at = &frame_at_v;
         std::atomic<int> *next = &next_v;
@@ -360,7 +376,19 @@ struct BatchRun {
                 if (j.cap) {
                     const size_t len = (*lens)[(size_t)f * jobs.size() + k];
                     o.drain(true);
-                    if (len && !o.failed && sink(o.user, h_out + pos, len) != 0) o.failed = true;
+                    // The library's own buffer sink and a large scan: its place in the caller's buffer is known now, so the copy out of
+                    // the staging buffer goes to the pool in pieces - a round of four 8 MB files is otherwise four threads' work while
+                    // the link delivers the next round in 0.6 ms (the bench's Criterion frames: 0.79 of the link, profiles/r05_device_batch_pipeline.txt)
+                    BufferSink *bs = sink == buffer_sink ? (BufferSink *)o.user : nullptr;
+                    if (bs && b.assemblers && copy_slot >= 0 && len >= kPieceFrom && bs->len + len <= bs->cap) {
+                        uint8_t *dst = bs->out + bs->len;
+                        const uint8_t *src = h_out + pos;
+                        bs->len += len;
+                        for (size_t at = 0; at < len; at += kPiece) {
+                            const size_t nb = len - at < kPiece ? len - at : kPiece;
+                            b.assemblers->submit(copy_slot, [dst, src, at, nb] { memcpy(dst + at, src + at, nb); });
+                        }
+                    } else if (len && !o.failed && sink(o.user, h_out + pos, len) != 0) o.failed = true;
                     pos += (len + 15) & ~(size_t)15;
                 } else if (c.restart_interval) {   // empty band: only the restart bookkeeping (encoder.rs:947-951)
                     const uint64_t nb = L.blocks[j.sc.component];
@@ -454,15 +482,17 @@ struct BatchRun {
         auto frame_at = p.frame_at;
         uint8_t *h_out = p.h_out;
         const int n = p.n, f0 = p.f0;
-        auto assemble = [this, lens, frame_at, next, h_out, n, f0]() { assemble_frames(*lens, *frame_at, *next, h_out, n, f0); };
-        int nthreads = usable_cpus() - 2;
-        if (nthreads > 8) nthreads = 8;
-        if (nthreads < 1) nthreads = 1;
-        if (nthreads > n) nthreads = n;
+        int pool_threads = usable_cpus() - 2;
+        if (pool_threads > 8) pool_threads = 8;
+        if (pool_threads < 1) pool_threads = 1;
+        int nthreads = pool_threads > n ? n : pool_threads;
         if (p.bytes < ((size_t)4 << 20)) nthreads = 1;                           // little to copy: not worth the threads
+        const int copy_slot = b.assemblers && pool_threads > 1 ? p.slot : -1;
+        auto assemble = [this, lens, frame_at, next, h_out, n, f0, copy_slot]() { assemble_frames(*lens, *frame_at, *next, h_out, n, f0, copy_slot); };
         if (b.assemblers) {
-            b.assemblers->ensure_threads(nthreads);
-            for (int w = last ? 1 : 0; w < nthreads; w++) { in_assembly[p.slot] = true; b.assemblers->submit(p.slot, assemble); }
+            b.assemblers->ensure_threads(copy_slot >= 0 ? pool_threads : nthreads);   // (pieces of large scans keep every thread busy, however few the frames)
+            in_assembly[p.slot] = true;                                              // (tasks of this group may exist from here on: join() waits for them)
+            for (int w = last ? 1 : 0; w < nthreads; w++) b.assemblers->submit(p.slot, assemble);
             if (last) assemble();
         } else {
             assemble();

@@ -22,7 +22,10 @@ base = torch.from_numpy(synth.test_img_rgb(w, h).reshape(-1)).to(dev)
 gen = torch.Generator(device=dev)
 gen.manual_seed(11)
 d = torch.clamp(base.to(torch.int16)[None, :] + torch.randint(-6, 7, (n, base.numel()), dtype=torch.int16, device=dev, generator=gen), 0, 255).to(torch.uint8)
-cap = 8 << 20
+if os.environ.get("CONTENT") == "criterion":
+    crit = torch.from_numpy(np.ascontiguousarray(synth.criterion_pattern(w, h)).reshape(-1)).to(dev)
+    d = torch.stack([torch.roll(crit, 48 * i) for i in range(n)])
+cap = 16 << 20
 outs = [np.empty(cap, dtype=np.uint8) for _ in range(n)]
 for o in outs:
     o[::4096] = 1
