@@ -151,6 +151,11 @@ struct BatchRun {
             } else if (num_frames > least) {
                 per_round = std::min(per_round, least);
             }
+        } else if (num_frames >= 32) {
+            // small frames: a call used to be ONE round - coding, download and assembly of 1 024 thumbnails one after the other
+            // (290 + 384 + 330 us).  Four rounds (two up to 127 frames) let them overlap; a round costs ~50 us of its own.
+            const int rounds = num_frames >= 128 ? 4 : 2;
+            per_round = std::min(per_round, (num_frames + rounds - 1) / rounds);
         }
         if (per_round > num_frames) per_round = num_frames;
         // Several scans per frame (sequential: one per component; progressive(4) on three components: twelve): coded in shared
@@ -987,6 +992,8 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
         int per_round = (int)((round_mb << 20) / frame_bytes);
         if (per_round > 1024) per_round = 1024;
         if (per_round > num_frames) per_round = num_frames;
+        if (per_round < 1) per_round = 1;
+        per_round = (num_frames + (num_frames + per_round - 1) / per_round - 1) / ((num_frames + per_round - 1) / per_round);   // as many rounds, of equal size (1 024 thumbnails: 4 x 256, not 3 x 341 + 1)
         JPEGENC_HIP(hipSetDevice(e->device));
         rc = e->small.reserve((size_t)per_round * frame_bytes);
         if (rc) return rc;
@@ -1011,24 +1018,27 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
                         staging_copy(sb.h[slot] + (size_t)i * frame_bytes, frames[first + i], frame_bytes);
                     }
                 };
-                std::vector<std::thread> th;
-                for (int t = 1; t < nt; t++) th.emplace_back(copy);
+                for (int t = 1; t < nt; t++) e->stagers.submit(0, copy);      // (the handle's persistent threads: until round 5 seven new ones per piece)
                 copy();
-                for (auto &x : th) x.join();
+                e->stagers.wait(0);
                 if (hipMemcpyAsync((uint8_t *)sb.d[slot] + (size_t)lo * frame_bytes, sb.h[slot] + (size_t)lo * frame_bytes, (size_t)(hi - lo) * frame_bytes,
                                    hipMemcpyHostToDevice, sb.up) != hipSuccess) { up_status.store(JPEGENC_ERR_HIP); return; }
             }
             if (hipEventRecord(sb.done[slot], sb.up) != hipSuccess) up_status.store(JPEGENC_ERR_HIP);
         };
+        {
+            int nt = usable_cpus() - 2;
+            e->stagers.ensure_threads((nt > 8 ? 8 : nt < 1 ? 1 : nt) + 1);           // the copiers + the task that drives a round's pieces
+        }
         stage_and_upload(0, 0);
         for (int first = 0, r = 0; first < num_frames; first += per_round, r++) {
             const int slot = r & 1, n = num_frames - first < per_round ? num_frames - first : per_round;
             if (up_status.load() != JPEGENC_OK) return fail(JPEGENC_ERR_HIP, "upload of a batch round failed");
             JPEGENC_HIP(hipEventSynchronize(sb.done[slot]));
-            std::thread next_round;
-            if (first + per_round < num_frames) next_round = std::thread(stage_and_upload, first + per_round, slot ^ 1);
+            const bool more = first + per_round < num_frames;
+            if (more) e->stagers.submit(1, [&stage_and_upload, first, per_round, slot] { stage_and_upload(first + per_round, slot ^ 1); });
             rc = jpegenc_encoder_encode_batch_device(e, sb.d[slot], frame_bytes, n, width, height, color_type, sink, users + first);
-            if (next_round.joinable()) next_round.join();
+            if (more) e->stagers.wait(1);
             if (rc) return rc;
         }
         return JPEGENC_OK;

@@ -973,6 +973,7 @@ struct jpegenc_encoder {
     std::vector<std::unique_ptr<DeviceCtx>> workers;   // batch API: one per in-flight frame, kept across calls
     jpegenc::WorkerThreads threads;                    // ... and the threads that drive them (declared after `workers`: joined before the contexts go)
     jpegenc::BackgroundPool assemblers;                // the threads that assemble a device-resident batch's files behind its downloads
+    jpegenc::BackgroundPool stagers;                   // the threads that copy a round of small host frames into page-locked memory while the round before is coded
     BatchBuffers batch;                                  // device-resident batch API
     SmallBatchBuffers small;                             // batches of small frames
     int max_batch_workers = 16;                          // host threads of jpegenc_encoder_encode_batch
