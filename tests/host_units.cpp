@@ -142,7 +142,53 @@ static int stripe_tuner_untimed_option() {
     return 0;
 }
 
+// BackgroundPool: tasks run behind the submitter's back, wait(group) returns only when every task of THAT group has run - tasks that
+// submit more tasks of their group included (the pieces of a large scan, BatchRun::assemble_frames) -, groups are independent, a task may
+// wait for another group's tasks (the small-frame staging: the task that drives a round waits for its copiers), the threads persist.
+static int background_pool() {
+    BackgroundPool pool;
+    pool.ensure_threads(4);
+    std::atomic<int> done[BackgroundPool::kGroups];
+    for (auto &d : done) d.store(0);
+    std::set<std::thread::id> ids;
+    std::mutex mu;
+    for (int round = 0; round < 100; round++) {
+        const int g = round % 3;
+        for (int i = 0; i < 5; i++)
+            pool.submit(g, [&, g] {
+                { std::lock_guard<std::mutex> lock(mu); ids.insert(std::this_thread::get_id()); }
+                for (int piece = 0; piece < 3; piece++) pool.submit(g, [&, g] { done[g].fetch_add(1); });   // nested: counted before this task ends
+                done[g].fetch_add(1);
+            });
+        if (round % 3 == 2) {
+            for (int k = 0; k < 3; k++) pool.wait(k);
+            const int rounds_of_group = (round + 1) / 3;
+            for (int k = 0; k < 3; k++) CHECK(done[k].load() == rounds_of_group * 5 * 4);
+        }
+    }
+    pool.wait(0);
+    CHECK(done[0].load() == 34 * 20);
+    CHECK(ids.size() <= 4 && ids.count(std::this_thread::get_id()) == 0);      // the pool's own threads, never the submitter's
+    // a task of group 1 waits for tasks of group 0 it submitted itself
+    std::atomic<int> inner(0), outer(0);
+    pool.submit(1, [&] {
+        for (int i = 0; i < 6; i++) pool.submit(0, [&] { inner.fetch_add(1); });
+        pool.wait(0);
+        outer.store(inner.load());
+    });
+    pool.wait(1);
+    CHECK(outer.load() == 6);
+    pool.wait(3);                                                              // a group nothing was ever submitted to
+    pool.stop();
+    pool.ensure_threads(2);                                                    // usable again after a stop
+    pool.submit(2, [&] { inner.fetch_add(10); });
+    pool.wait(2);
+    CHECK(inner.load() == 16);
+    return 0;
+}
+
 int main() {
+    if (background_pool()) return 1;
     if (thread_binding()) return 1;
     if (stripe_tuner_untimed_option()) return 1;
     if (stripe_tuner()) return 1;

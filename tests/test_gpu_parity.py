@@ -907,6 +907,48 @@ def test_encode_batch_device_resident(binding, oracle, synth, kw):
         assert len(set(got)) > n // 2
 
 
+def test_device_batch_pipeline_many_rounds_and_large_scans(binding, oracle, synth):
+    """The device-resident batch as a pipeline (BatchRun::run): more rounds than it has device and staging slots (three each), a last
+    round that is not full, scans large enough to leave the staging buffer in pieces on the background pool (the library's own buffer
+    sink, scans of 2 MB and more) next to small ones, a capacity that is too small for some files, and the same handle again with
+    another geometry - through the _to_buffers entry and through a caller's sink; every file equal to the single-image call's, a sample
+    of them to the oracle's."""
+    import ctypes as C
+    import torch
+    w, h, n = 1592, 1034, 26
+    rng = np.random.default_rng(77)
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) if i % 3 != 1 else np.ascontiguousarray(synth.test_img_rgb(w, h) + np.uint8(i)) for i in range(n)]
+    d = torch.from_numpy(np.stack(frames)).to("cuda:0")
+    fn = binding.lib().jpegenc_encoder_encode_batch_device_to_buffers
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    for quality, sampling, round_frames in ((100, binding.F_1_1, 4), (100, binding.F_2_2, 3), (92, binding.F_2_2, 0)):
+        with binding.Encoder(quality) as e:
+            e.set_sampling_factor(sampling)
+            want = [e.encode(f, w, h, binding.RGB) for f in frames]
+            assert max(len(x) for x in want) > (2 << 20) or sampling != binding.F_1_1      # the quality-100 4:4:4 noise frames take the piece path
+            e.set_batch_round_frames(round_frames)
+            cap = 8 << 20
+            outs = [np.zeros(cap if i != 5 else 4096, dtype=np.uint8) for i in range(n)]      # frame 5: a buffer that is too small
+            optrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+            caps = (C.c_size_t * n)(*[o.size for o in outs])
+            lens = (C.c_size_t * n)()
+            for _ in range(2):                                                       # (the second call starts with what the first learnt)
+                rc = fn(e._h, d.data_ptr(), w * h * 3, n, w, h, binding.RGB, optrs, caps, lens)
+                assert rc == binding.ERR_BUFFER_TOO_SMALL
+                for i in range(n):
+                    assert lens[i] == len(want[i]), (quality, i)
+                    if i != 5:
+                        assert outs[i][:lens[i]].tobytes() == want[i], (quality, i)
+            assert e.encode_batch_device(d.data_ptr(), w * h * 3, n, w, h, binding.RGB) == want      # a caller's sink: whole scans, in order
+            for i in (0, 1, 25):
+                hs, vs = (1, 1) if sampling == binding.F_1_1 else (2, 2)
+                assert want[i] == oracle.encode_jpeg(frames[i], w, h, oracle.RGB, quality=quality, sampling=(hs, vs)), (quality, i)
+            # another geometry on the same handle: the slots are sized anew
+            small = torch.from_numpy(np.stack([f[:96, :160] for f in frames]).copy()).to("cuda:0")
+            got = e.encode_batch_device(small.data_ptr(), 96 * 160 * 3, n, 160, 96, binding.RGB)
+            assert got == [e.encode(np.ascontiguousarray(f[:96, :160]), 160, 96, binding.RGB) for f in frames]
+
+
 def test_blocks_stream_planar_cmyk(binding, oracle, synth):
     """The tile stream with a 4-component layout, vertical decimation and planar order (the order the
     sequential / progressive writers consume)."""
