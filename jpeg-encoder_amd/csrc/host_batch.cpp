@@ -140,12 +140,20 @@ struct BatchRun {
             //  and these settings says that fewer frames already keep the link busy for longer than a round costs - 8 MB files: one -
             //  such a call goes in rounds of that many: four Criterion-pattern 4K frames 274 -> 217 us per frame)
             int least = 4;
+            bool gpu_bound = false;
             if (b.dense_geometry == content_key(c, width, height, color_type) && b.dense_bits_per_block) {
                 const uint64_t per_frame = b.dense_bits_per_block * L.total_blocks / 8u + 1u;
                 const uint64_t want = (((uint64_t)6 << 20) + per_frame - 1u) / per_frame;
                 least = want < 1 ? 1 : want > 4 ? 4 : (int)want;
+                // files the link delivers faster than the GPU codes their frames (~15 us per 4K frame: 0.8 MB at 53 GB/s; scaled by the
+                // frame's blocks): the rounds' fixed costs are what is left to save - four rounds, of at least eight frames (32 quality-50
+                // 4K frames: 22.1 -> 19.5 us per frame, profiles/r05_device_batch_pipeline.txt)
+                gpu_bound = per_frame * 194400u < ((uint64_t)800 << 10) * L.total_blocks;
             }
-            if (num_frames >= 8) {
+            if (num_frames >= 32 && gpu_bound) {
+                const int quarter = (num_frames + 3) / 4;
+                if (quarter < per_round) per_round = std::min(per_round, quarter < 8 ? 8 : quarter);
+            } else if (num_frames >= 8) {
                 const int eighth = (num_frames + 7) / 8;
                 if (eighth < per_round) per_round = std::min(per_round, eighth < 4 ? 4 : eighth);   // (never above the footprint / the caller's bound)
             } else if (num_frames > least) {

@@ -36,7 +36,7 @@ fn = b.lib().jpegenc_encoder_encode_batch_device_to_buffers
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
 for sf_name, sf in (("4:2:0", b.F_2_2), ("4:4:4", b.F_1_1)):
     for n in (4, 8, 16, 32, 64):
-        e = b.Encoder(90)
+        e = b.Encoder(int(os.environ.get("QUALITY", "90")))
         e.set_sampling_factor(sf)
         rf = int(os.environ.get("ROUND_FRAMES", "0"))
         if rf:
