@@ -537,7 +537,8 @@ struct BatchRun {
             prev = cur;
         }
         if (!rc && prev.valid && !failed.load()) { rc = deliver_round(prev, true); prev.valid = false; }
-        if (prev.valid) (void)hipStreamSynchronize(b.copy_stream);                 // (a failed call: no download of it outlives it)
+        if (prev.valid) (void)hipStreamSynchronize(b.copy_stream);                 // (a failed call: no download of it outlives it ...
+        if (rc || stop || failed.load()) (void)hipStreamSynchronize(ctx.stream);   //  ... and no round coded ahead still reads the caller's frames)
         for (int slot = 0; slot < BatchBuffers::kHostSlots; slot++) join(slot);
         if (rc) return rc;
         if (failed.load()) return fail(JPEGENC_ERR_WRITE, "sink reported a write error");
