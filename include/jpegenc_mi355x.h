@@ -342,7 +342,10 @@ int  jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int
  * round, one host step builds the tables, the coder reads frame i's table set.  With the host entropy coder,
  * or frames too large for the device entropy coder (jpegenc_scan_max_bytes == 0: about 2.45 M blocks and
  * more), every frame takes the single-image path instead, several of them in flight on the handle's worker
- * threads (each with its own stream and buffers) - same bytes either way. */
+ * threads (each with its own stream and buffers) - same bytes either way.
+ * The batch runs as a pipeline of rounds - the GPU codes round r + 1 while the link carries round r and the handle's background
+ * threads assemble the files of the rounds before - so frames per call are worth having: photo-like 4K 4:2:0 frames cost 75 us each
+ * in calls of 4, 38 in calls of 16, 29-32 in calls of 32-64. */
 int  jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride,
                                          int num_frames, int width, int height, int color_type,
                                          jpegenc_write_fn sink, void *const *users);

@@ -12,7 +12,7 @@ namespace jpegenc {
 // launches; the caller falls back to one encode_frame per image for them.
 
 // A batch of device-resident frames as the steps encode_device_batch walks through: prepare / plan_scans /
-// size_rounds_and_reserve (tables, geometry, the scans, how many frames share a round and the buffers of two rounds),
+// size_rounds_and_reserve (tables, geometry, the scans, how many frames share a round and the buffers of the rounds in flight),
 // then a software pipeline over rounds (BatchRun::run) - code_round(r + 1) on the encoder's stream overlaps the download of round r
 // on the copy stream (fetch_round), which overlaps the assembly of the files of rounds r - 1 and r - 2 on the handle's background
 // threads (deliver_round, assemble_frames).
