@@ -156,6 +156,62 @@ __global__ void __launch_bounds__(384) k_wave_tiles(const uint8_t *px, uint8_t *
     if (acc == 0x12345678u) sink[t] = acc;
 }
 
+// k_half_blocks: the shipped pattern with a lane = HALF a block (round 5, second session: would waves that write 4 KiB instead of 8 move
+// the kernel's memory stream?  A copy in 4 KiB pieces reaches 5.98 TB/s, one in 8 KiB pieces 5.70 - profiles/r05_channel_probe.txt).
+// A workgroup = 6 waves = 32 MCUs: waves 0-3 the Y blocks (wave >> 1 = block row, wave & 1 = block column; lane >> 1 = MCU, lane & 1 =
+// upper / lower four pixel rows: 4 x 24 bytes), waves 4-5 Cb / Cr (lane >> 1 = MCU, lane & 1 = upper / lower four SAMPLED rows:
+// 4 x 48 bytes).  Every wave writes 4 KiB; twice as many workgroups.
+constexpr int GROUPS_H = (MCUS_X * MCU_ROWS + 31) / 32;
+__global__ void __launch_bounds__(384) k_half_blocks(const uint8_t *px, uint8_t *out, uint32_t *sink) {
+    const int g = blockIdx.x, f = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint8_t *frame = px + (size_t)f * PITCH * H;
+    uint32_t acc = 0;
+    const int first = g * 32, m = lane >> 1, half = lane & 1;
+    if (wave < 4) {
+        const int vrow = wave >> 1, col = wave & 1;
+        const uint32_t o = mcu_offset(first + m) + (uint32_t)(vrow * 8 + half * 4) * PITCH + (uint32_t)col * 24u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x4 a = *(gvec *)(frame + o + (uint32_t)r * PITCH);
+            const u32x2 b = *(__attribute__((address_space(1))) const u32x2 *)(frame + o + (uint32_t)r * PITCH + 16);
+            acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y;
+        }
+    } else {
+        const uint32_t o = mcu_offset(first + m) + (uint32_t)(half * 8) * PITCH;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            const u32x4 a = *(gvec *)(frame + o + (uint32_t)r * PITCH), b = *(gvec *)(frame + o + (uint32_t)r * PITCH + 16),
+                        c2 = *(gvec *)(frame + o + (uint32_t)r * PITCH + 32);
+            acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c2.x ^ c2.y ^ c2.z ^ c2.w;
+        }
+    }
+    uint8_t *dst = out + ((size_t)f * GROUPS_H + g) * 24576 + (size_t)wave * 4096;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const u32x4 v = {acc, acc + it, acc ^ 5u, (uint32_t)lane};
+        __builtin_nontemporal_store(v, (u32x4 *)(dst + (size_t)(it * 64 + lane) * 16));
+    }
+    if (acc == 0x12345678u) sink[t] = acc;
+}
+static int run_half(const char *name, const uint8_t *px, uint8_t *out, uint32_t *sink, int frames, double bytes) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_half_blocks, dim3(GROUPS_H, frames), dim3(384), 0, 0, px, out, sink);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 10; r++) {
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL(k_half_blocks, dim3(GROUPS_H, frames), dim3(384), 0, 0, px, out, sink);
+        CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+        float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    printf("%-44s %8.3f ms  %6.2f TB/s\n", name, best, bytes / (best * 1e-3) / 1e12);
+    return 0;
+}
+
 template <int MODE>
 static int run(const char *name, const uint8_t *px, uint8_t *out, uint32_t *sink, int frames, double bytes) {
     hipEvent_t a, b;
@@ -207,5 +263,9 @@ int main() {
     run<3>("tile in by register loads only", px, out, sink, frames, in);
     run_waves<4>("per-wave tiles by LDS DMA, 8 KB out per wave", px, out, sink, frames, both);
     run_waves<5>("per-lane row loads (shipped pattern), 8 KB out", px, out, sink, frames, both);
+    for (int rep = 0; rep < 3; rep++) {                        // (same box, in turn)
+        run_half("lane = half a block, 4 KB out per wave", px, out, sink, frames, both);
+        run_waves<5>("per-lane row loads (shipped pattern), 8 KB out", px, out, sink, frames, both);
+    }
     return 0;
 }
