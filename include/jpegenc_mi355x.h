@@ -242,7 +242,11 @@ int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num
  * 0 = total_blocks) and code from there.  Workspace / output sizing: jpegenc_scan_workspace_size /
  * jpegenc_scan_max_bytes with jpegenc_scan{-1, 1, 1, 64, restart_interval} on the ORDER_MCU layout.  Same bytes as
  * jpegenc_blocks_device followed by jpegenc_scan_device, and faster; this is the path the Encoder
- * takes.  Asynchronous on hip_stream. */
+ * takes.  The exception is dense content - blocks that code to more than ~390 bits on average: noise-like frames from quality 95
+ * up - where a block outgrows its 507-bit strip in most workgroups and the two calls are 25-45 % faster
+ * (profiles/r04_fused_quality_matrix.txt): this entry point is stateless and always takes the one kernel, a caller that knows its
+ * content calls the pair instead; the Encoder handles route by the size of the last frame of the same size and settings.
+ * Asynchronous on hip_stream; a caller with frames to spare alternates between two streams. */
 int jpegenc_pixels_scan_fused(int width, int height, int color_type, int h_sampling, int v_sampling);
 int jpegenc_pixels_scan_device(const void *d_pixels, size_t pixel_frame_stride, int num_frames, int width, int height,
                                int color_type, int h_sampling, int v_sampling, const jpegenc_qtable tables[2],
