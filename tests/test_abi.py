@@ -303,6 +303,30 @@ def _build_example(tmp_path):
     return exe
 
 
+def _build_batch_example(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "batch_device"
+    libdir = os.path.join(root, "jpeg-encoder_amd")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "batch_device.c"), "-o", str(exe), "-L" + libdir, "-ljpegenc_mi355x", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_batch_example_builds_against_the_header(binding, tmp_path):
+    """examples/batch_device.c (device-resident frames -> files, plain C + the HIP runtime's C API) compiles warning-free against the
+    header; without arguments it prints its usage."""
+    import os
+    import subprocess
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no ROCm headers on this host")
+    exe = _build_batch_example(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
 def test_c_example_builds_against_the_header(binding, tmp_path):
     """examples/encode_ppm.c: plain C against include/jpegenc_mi355x.h and the shared library (no torch in
     the process); without arguments it prints its usage."""

@@ -867,6 +867,23 @@ def test_c_example_program(binding, oracle, synth, tmp_path):
     assert out.read_bytes() == oracle.encode_jpeg(px, 322, 200, oracle.RGB, 82, sampling=(2, 2), progressive_scans=4, optimize=True)
 
 
+def test_batch_device_example_program(binding, oracle, synth, tmp_path):
+    """examples/batch_device.c: 21 frames uploaded by the program itself (rows rotated by the frame index), coded by the device-resident
+    batch entry point in rounds; its first and last file equal the oracle's."""
+    import subprocess
+    from test_abi import _build_batch_example
+    exe = _build_batch_example(tmp_path)
+    w, h, n = 322, 200, 21
+    px = synth.test_img_rgb(w, h)
+    ppm = tmp_path / "in.ppm"
+    ppm.write_bytes(b"P6\n%d %d\n255\n" % (w, h) + px.tobytes())
+    r = subprocess.run([str(exe), str(ppm), str(tmp_path / "out"), str(n), "83"], capture_output=True, text=True)
+    assert r.returncode == 0 and "us per frame" in r.stdout, (r.stdout, r.stderr)
+    for k in (0, n - 1):
+        rolled = np.ascontiguousarray(np.roll(px, -k, axis=0))
+        assert (tmp_path / ("out.%d.jpg" % k)).read_bytes() == oracle.encode_jpeg(rolled, w, h, oracle.RGB, 83, sampling=(2, 2)), k
+
+
 def test_cpp_example_program(binding, oracle, tmp_path):
     """examples/encode_cpp.cpp through include/jpegenc_mi355x.hpp: the crate's README example (new_file + encode),
     an in-memory progressive 4:2:0 encode, an ImageBuffer source and the two error paths; same bytes as the oracle."""
