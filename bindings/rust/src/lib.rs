@@ -681,6 +681,43 @@ impl<W: JfifWrite> Encoder<W> {
     pub fn encode_batch(&mut self, frames: &[&[u8]], width: u16, height: u16, color_type: ColorType) -> Result<Vec<Vec<u8>>, EncodingError> {
         self.encode_batch_multi(&[], frames, width, height, color_type)
     }
+
+    /// A batch of same-geometry frames that already lie in this encoder's device memory (a decoder's or a camera pipeline's output),
+    /// `frame_stride` bytes apart from `d_frames` on -> one JPEG file per frame, in order.  The call runs as a pipeline of rounds (the
+    /// GPU codes round r + 1 while the link carries round r and the library's background threads assemble the files of the rounds
+    /// before), so frames per call are worth having.  No counterpart in the crate.
+    ///
+    /// # Safety
+    /// `d_frames` must point to `num_frames` frames of `width * height * bytes-per-pixel` bytes each in memory of the device this
+    /// encoder drives (`set_device`), valid and unmodified until the call returns.
+    pub unsafe fn encode_batch_device(&mut self, d_frames: *const c_void, frame_stride: usize, num_frames: usize, width: u16, height: u16,
+                                      color_type: ColorType) -> Result<Vec<Vec<u8>>, EncodingError> {
+        let n = num_frames;
+        if n == 0 {
+            return Ok(Vec::new());
+        }
+        let required = width as usize * height as usize * color_type.get_bytes_per_pixel();
+        let mut cap = required / 2 + (1 << 16);
+        let mut retried = false;
+        loop {
+            let mut outs: Vec<Vec<u8>> = (0..n).map(|_| Vec::with_capacity(cap)).collect();
+            let out_ptrs: Vec<*mut u8> = outs.iter_mut().map(|o| o.as_mut_ptr()).collect();
+            let caps: Vec<usize> = outs.iter().map(|o| o.capacity()).collect();
+            let mut lens = alloc::vec![0usize; n];
+            let status = sys::jpegenc_encoder_encode_batch_device_to_buffers(self.h, d_frames, frame_stride, n as c_int, width as c_int, height as c_int,
+                                                                             color_type as c_int, out_ptrs.as_ptr(), caps.as_ptr(), lens.as_mut_ptr());
+            if status == sys::JPEGENC_ERR_BUFFER_TOO_SMALL && !retried && lens.iter().zip(caps.iter()).any(|(l, c)| l > c) {
+                cap = lens.iter().copied().max().unwrap_or(cap) + 4096;       // (as in encode_batch_multi: one retry, only for an output buffer)
+                retried = true;
+                continue;
+            }
+            Self::finish(status, None, required, required, width, height)?;
+            for (o, l) in outs.iter_mut().zip(lens.iter()) {
+                o.set_len(*l);                                                // the library wrote exactly that many bytes
+            }
+            return Ok(outs);
+        }
+    }
 }
 
 /// A frame buffer in page-locked host memory (`jpegenc_host_alloc`): batches built from such frames are uploaded in place
