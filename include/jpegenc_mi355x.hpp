@@ -145,6 +145,13 @@ public:
             check(jpegenc_encoder_encode_batch_to_buffers(h_, frames, frame_len, num_frames, width, height, (int)color_type, outs,
                                                           capacities, lengths));
     }
+    // The same for frames that already lie in this encoder's device memory, `frame_stride` bytes apart (a pipeline of rounds: the
+    // GPU codes one round while the link carries the one before - frames per call are worth having).
+    void encode_batch_device_to_buffers(const void *d_frames, size_t frame_stride, int num_frames, uint16_t width, uint16_t height,
+                                        ColorType color_type, uint8_t *const *outs, const size_t *capacities, size_t *lengths) {
+        check(jpegenc_encoder_encode_batch_device_to_buffers(h_, d_frames, frame_stride, num_frames, width, height, (int)color_type, outs,
+                                                             capacities, lengths));
+    }
     // Encoder::encode_image, :505-515
     void encode_image(ImageBuffer &image) {
         check(jpegenc_encoder_encode_image(h_, (int)image.get_jpeg_color_type(), image.width(), image.height(), &fill_row, &image, &sink, &w_));
