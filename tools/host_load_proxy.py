@@ -177,7 +177,15 @@ def main():
                     p.wait(timeout=30)
                 if k == 0:
                     base = rec["frames_per_s"]["median"]
-                rec["vs_alone"] = round(rec["frames_per_s"]["median"] / base, 3) if base else None
+                # a row whose neighbours fell short of the load they stand for says nothing about a loaded node: no ratio for it
+                # (round 4's K = 7 staging row: 29-71 of 80 GB/s each inside a 16-CPU quota)
+                short = [g for g in got if rate_gbps and g < 0.9 * rate_gbps]
+                rec["dummies_reached_their_target"] = not short
+                if short:
+                    rec["vs_alone"] = None
+                    rec["vs_alone_withheld"] = f"{len(short)} of {len(got)} neighbours moved less than 90 % of their {rate_gbps:g} GB/s (min {min(short):.1f})"
+                else:
+                    rec["vs_alone"] = round(rec["frames_per_s"]["median"] / base, 3) if base else None
                 print(json.dumps(rec), flush=True)
 
 
