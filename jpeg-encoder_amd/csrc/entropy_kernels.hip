@@ -34,6 +34,7 @@
 
 #include "diag_env.h"
 #include "entropy_params.h"
+#include "entropy_loop.hip.h"
 #include "entropy_walk.hip.h"
 #include "host_common.h"
 
@@ -306,34 +307,130 @@ __global__ void __launch_bounds__(256) k_block_code(const EntropyParams *params)
     code_run(p, lut64, area[wave], f, b, valid, where, where.has_prev ? prev_raw : 0, r, lane);
 }
 
+// A block's bits OR-ed at bit offset `pos` of the wave's zeroed slot in HBM: where a band scan's symbols go when a block outgrew its
+// strip or the run the window (pathological content for a band; JPEGENC_PACK_WINDOW_WORDS forces it in tests).
+struct SlotOr {
+    hbm_word *slot;
+    int32_t pos;
+    __device__ __forceinline__ void put(uint32_t bits, uint32_t nlen) {
+        const uint32_t sh = (uint32_t)pos & 31u;
+        const int32_t wi = pos >> 5;
+        const uint64_t x = (uint64_t)bits << ((nlen - sh) & 63u);
+        const uint32_t hi = __builtin_bswap32((uint32_t)(x >> 32)), lo = __builtin_bswap32((uint32_t)x);
+        if (hi) __hip_atomic_fetch_or(slot + wi, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lo) __hip_atomic_fetch_or(slot + wi + 1, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pos -= (int32_t)nlen;
+    }
+};
+
+// One scan of a progressive component - DC only, or an AC band [ac_start, ac_end) - over a wave's 64 blocks, with the LOOP OVER A LANE'S
+// OWN NON-ZEROS of the pixels -> bits kernel (entropy_loop.hip.h) instead of walk_once's chain of positions: in a band scan every one
+// of the 63 positions of that chain asked "am I in the band?" - two scalar compares and a branch - and every position of the band
+// cost an exec-mask flip whether any block had a non-zero there: 1 552 vector + 1 735 scalar + 387 branch instructions per wave over
+// the four scans of a progressive(4) component (profiles/r05_coder_pmc.txt).  `mask` = the block's non-zero positions (all 63),
+// win = the wave's 4 KiB window (the coefficient image while the symbols are walked), strips = its 4 KiB-aligned strip area.
+__device__ __forceinline__ void code_band_run(Params p, uint32_t loop_lut /* LDS byte address of the compact tables */, uint32_t *win, uint32_t *strips,
+                                              const uint32_t f, const uint32_t b, const bool valid, const BlockPlace &where, const int prev_dc,
+                                              const BlockRegs &r, const uint64_t mask, const uint32_t lane) {
+    typedef __attribute__((address_space(3))) uint8_t *lds_bytes;
+    const uint32_t dc_table = loop_lut + where.table * kLoopLutPerTable * 8u, ac_table = dc_table + 16u * 8u;
+    const bool has_ac = p.ac_end > p.ac_start;
+    // the block's non-zeros inside the band
+    const uint64_t band = has_ac ? ((p.ac_end >= 64u ? ~0ull : (1ull << p.ac_end) - 1ull) & ~((1ull << p.ac_start) - 1ull)) : 0ull;
+    const uint64_t m = valid ? mask & band : 0ull;
+    lds_word *strip = (lds_word *)strips + lane;
+#pragma unroll
+    for (uint32_t i = 0; i < kPrivWords / 4u; i++) reinterpret_cast<uint4 *>(strips)[i * 64u + lane] = make_uint4(0, 0, 0, 0);
+    const uint32_t image_at = (uint32_t)(uintptr_t)(lds_bytes)(win) + lane * 4u;
+    uint32_t head = 0, from = 32u, dc_len = 0, ac_bits = 0;
+    u32x2 dc = {0u, 0u};
+    if (valid && p.with_dc) {
+        dc = dc_code(dc_table, (int)(int16_t)(r.c[0] & 0xFFFFu), prev_dc);
+        head = dc.x; dc_len = dc.y; from = 32u - dc_len;
+    }
+    const bool zero_runs = has_ac && __builtin_amdgcn_ballot_w64(has_long_zero_run(m, p.ac_start)) != 0;     // wave-uniform
+    if (has_ac && valid) {
+        StripOr so = {(uint32_t)(uintptr_t)strip, 32u * 8u};
+        walk_nonzeros(r.c, m, p.ac_start, p.ac_end, win, lane, image_at, ac_table, so, zero_runs);
+        ac_bits = so.bits() - 32u;
+    }
+    const uint32_t mine = dc_len + ac_bits;
+    if (b < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + b] = 0;        // k_push adds its 0xFF counts to these
+    const uint32_t upto = wave_inclusive(mine), at = upto - mine;               // bits of the run before this block
+    if (valid && p.nintervals > 1u) p.bits[(size_t)f * p.nblocks + b] = at;      // (interval offsets need them, k_interval_len)
+    const uint32_t total = (uint32_t)__shfl((int)upto, 63);
+    const uint32_t w = b >> 6;
+    if (lane == 0) { p.wsum[(size_t)f * p.nwaves + w] = total; p.ffstat[(size_t)f * p.nwaves + w] = 0; }
+    const uint32_t nwords = (total + 31u) >> 5;
+    uint32_t *slot = reinterpret_cast<uint32_t *>(p.slots + (size_t)f * p.slot_frame_stride) + (size_t)w * p.slot_words;
+    const bool strips_hold = __builtin_amdgcn_ballot_w64(ac_bits > (kPrivWords - 1u) * 32u) == 0;     // wave-uniform
+    if (strips_hold && nwords + 4u <= min(p.window_words, kOnePassWindowWords)) {                     // (+4: the zero word, 16-byte copies)
+        strip[0] = head;                                                         // the DC code, right-aligned in front of the AC bits
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = lane; i <= nwords; i += 64u) win[i] = 0;               // (the image is dead: every lane's walk is through)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        strip_to_window_from(strip, from, mine, at, (lds_word *)win);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = lane * 4u; i <= nwords; i += 256u)
+            *reinterpret_cast<uint4 *>(slot + i) = *reinterpret_cast<const uint4 *>(win + i);
+    } else {
+        // second walk, the bits OR-ed at their final place into the zeroed slot in HBM
+        for (uint32_t i = lane; i <= nwords; i += 64u) slot[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (valid) {
+            SlotOr so = {(hbm_word *)slot, (int32_t)at};
+            if (p.with_dc) so.put(dc.x, 0u - dc.y);
+            if (has_ac) walk_nonzeros(r.c, m, p.ac_start, p.ac_end, win, lane, image_at, ac_table, so, zero_runs);
+        }
+    }
+}
+
 // The scans of ONE component of a progressive frame - its DC scan and its AC bands (encoder.rs:885-972) - from one pass over its
 // blocks: blockIdx.z = the component's first scan, scan s of it is job blockIdx.z + s * stride.  What a wave pays per block whatever
-// the band - the code tables into LDS, the block and its DC predecessor from HBM, the wave's start-up - is paid once for the
-// component's 4 (or 10 ...) scans instead of once per scan: the bands of a progressive frame are a quarter of a block's symbols each,
-// and coded scan by scan they cost as much as four whole blocks (profiles/r05_mode_trace.txt).
+// the band - the code tables into LDS, the block and its DC predecessor from HBM, the wave's start-up, and since round 5's second
+// session the mask of the block's non-zero coefficients - is paid once for the component's 4 (or 10 ...) scans instead of once per
+// scan: the bands of a progressive frame are a quarter of a block's symbols each, and coded scan by scan they cost as much as four
+// whole blocks (profiles/r05_mode_trace.txt).  Coefficients of 8-bit samples only (AC sizes up to 10: the compact tables of
+// entropy_loop.hip.h) - what the block kernels produce; jpegenc_scan_device's single scans of a caller's coefficients keep k_block_code.
 __global__ void __launch_bounds__(256) k_block_code_group(const EntropyParams *params, const uint32_t stride, const uint32_t scans) {
     Params p0 = JPEGENC_JOB(params);
-    __shared__ u32x2 lut64[4 * 256];
-    __shared__ __attribute__((aligned(16))) uint32_t area[4][kOnePassWindowWords + kPrivWords * 64];
+    // per wave: strips (4 KiB, 4 KiB-aligned: StripOr) | window (4 KiB).  The strips come FIRST: the second word of a strip that outgrows its sixteen
+    // lands 4 KiB further on - in the lane's own column of its own wave's image, whose walk is void by then (the wave takes the second walk)
+    __shared__ __attribute__((aligned(4096))) uint32_t area[4][kPrivWords * 64 + kOnePassWindowWords];
+    __shared__ __attribute__((aligned(16))) uint8_t loop_lut[kLoopLutBytes];
+    typedef __attribute__((address_space(3))) uint8_t *lds_bytes;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
     const bool valid = b < p0.nblocks;
     const int16_t *frame = p0.coeffs + (size_t)f * p0.coeff_frame_stride * 64;
-    LutRegs l;
-    lut_fetch(p0, l, f);
+    // the compact code tables (k_build_lut leaves them behind the first form; one set per frame with kLutPerFrame), first in the load queue
+    const hbm_word *lut_src = (const hbm_word *)p0.lut + ((p0.fused_prefix & kLutPerFrame) ? (size_t)f * (kLutDeviceBytes / 4u) : (size_t)0) + kLutWords;
+    u32x4 lut_piece = {0u, 0u, 0u, 0u};
+    if (threadIdx.x < kLoopLutBytes / 16u) lut_piece = reinterpret_cast<hbm_chunk *>(lut_src)[threadIdx.x];
     const uint32_t bc = min(b, p0.nblocks - 1u);
     const BlockPlace where = place_of(p0, bc);
     const int prev_raw = ((const __attribute__((address_space(1))) int16_t *)frame)[where.prev_block * 64u];
     BlockRegs r;
     load_block(frame, bc, r);
-    lut64_commit(l, lut64);
+    if (threadIdx.x < kLoopLutBytes / 16u) reinterpret_cast<u32x4 *>(loop_lut)[threadIdx.x] = lut_piece;
+    __syncthreads();
     if (__ballot(valid) == 0) return;
+    const uint64_t mask = nonzero_mask(r.c);
+    const uint32_t loop_lut_at = (uint32_t)(uintptr_t)(lds_bytes)loop_lut;
 #pragma nounroll
     for (uint32_t s = 0; s < scans; s++) {
         Params p = *(const __attribute__((address_space(4))) EntropyParams *)(params + blockIdx.z + s * stride);
         // (the DC predecessor restarts with the scan's restart intervals - the same for every scan of a component, but the scan's to say)
         const BlockPlace here = place_of(p, bc);
-        code_run(p, lut64, area[wave], f, b, valid, here, here.has_prev ? prev_raw : 0, r, lane);
+        code_band_run(p, loop_lut_at, area[wave] + kPrivWords * 64, area[wave], f, b, valid, here, here.has_prev ? prev_raw : 0, r, mask, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   // (the window and the strips are the next scan's)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

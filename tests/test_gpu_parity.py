@@ -970,6 +970,32 @@ def test_device_batch_pipeline_many_rounds_and_large_scans(binding, oracle, synt
             assert got == [e.encode(np.ascontiguousarray(f[:96, :160]), 160, 96, binding.RGB) for f in frames]
 
 
+def test_progressive_bands_that_outgrow_their_strips(binding, oracle, synth):
+    """The scans of a progressive component are coded by a loop over each lane's own non-zeros into a 16-word strip per block
+    (k_block_code_group, code_band_run): noise at quality 100 makes the blocks of a wide band longer than a strip - progressive(2) has
+    ONE AC band of 63 coefficients, up to 27 bits each - and the wave takes its second walk straight into the slot; narrow bands of the
+    same frames hold.  Single images and a device-resident batch, with and without restart intervals, against the oracle."""
+    import torch
+    w, h = 200, 136
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    mixed = noise.copy()
+    mixed[:, : w // 2] = synth.test_img_rgb(w, h)[:, : w // 2]                    # smooth and dense blocks in the same waves
+    d = torch.from_numpy(np.stack([noise, mixed])).cuda()
+    for scans in (2, 3, 4, 9):
+        for rst in (0, 7):
+            kw = dict(quality=100, progressive_scans=scans)
+            if rst:
+                kw["restart_interval"] = rst
+            for sampling in ((1, 1), (2, 2)):
+                kw["sampling"] = sampling
+                e = _encoder(binding, kw, device_entropy=True)
+                want = [oracle.encode_jpeg(px, w, h, oracle.RGB, **kw) for px in (noise, mixed)]
+                assert e.encode(noise, w, h, binding.RGB) == want[0], (scans, rst, sampling)
+                assert e.encode(mixed, w, h, binding.RGB) == want[1], (scans, rst, sampling, "mixed")
+                assert e.encode_batch_device(d.data_ptr(), w * h * 3, 2, w, h, binding.RGB) == want, (scans, rst, sampling, "batch")
+
+
 def test_blocks_stream_planar_cmyk(binding, oracle, synth):
     """The tile stream with a 4-component layout, vertical decimation and planar order (the order the
     sequential / progressive writers consume)."""
