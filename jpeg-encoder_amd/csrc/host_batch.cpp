@@ -141,14 +141,16 @@ struct BatchRun {
             //  such a call goes in rounds of that many: four Criterion-pattern 4K frames 274 -> 217 us per frame)
             int least = 4;
             bool gpu_bound = false;
-            if (b.dense_geometry == content_key(c, width, height, color_type) && b.dense_bits_per_block) {
-                const uint64_t per_frame = b.dense_bits_per_block * L.total_blocks / 8u + 1u;
+            if (b.sized_geometry == content_key(c, width, height, color_type) && b.sized_bytes_per_frame) {
+                const uint64_t per_frame = b.sized_bytes_per_frame;
                 const uint64_t want = (((uint64_t)6 << 20) + per_frame - 1u) / per_frame;
                 least = want < 1 ? 1 : want > 4 ? 4 : (int)want;
-                // files the link delivers faster than the GPU codes their frames (~15 us per 4K frame: 0.8 MB at 53 GB/s; scaled by the
-                // frame's blocks): the rounds' fixed costs are what is left to save - four rounds, of at least eight frames (32 quality-50
-                // 4K frames: 22.1 -> 19.5 us per frame, profiles/r05_device_batch_pipeline.txt)
-                gpu_bound = per_frame * 194400u < ((uint64_t)800 << 10) * L.total_blocks;
+                // files the link delivers faster than the GPU codes their frames (~15 us per 4K frame through the one kernel: 0.8 MB at
+                // 53 GB/s; several scans per frame - block kernel, coefficients, a coder pass per component - four times that; scaled by
+                // the frame's blocks): the rounds' fixed costs are what is left to save - four rounds, of at least eight frames (32
+                // quality-50 4K frames: 22.1 -> 19.5 us per frame, profiles/r05_device_batch_pipeline.txt)
+                const uint64_t link_bytes = (jobs.size() > 1 ? (uint64_t)3200 : (uint64_t)800) << 10;
+                gpu_bound = per_frame * 194400u < link_bytes * L.total_blocks;
             }
             if (num_frames >= 32 && gpu_bound) {
                 const int quarter = (num_frames + 3) / 4;
@@ -456,6 +458,10 @@ struct BatchRun {
                 (*lens)[(size_t)f * jobs.size() + k] = len;
                 need += ((size_t)len + 15) & ~(size_t)15;
             }
+        if (n > 0) {                                                           // (round sizes of the next call of this size and these settings)
+            b.sized_geometry = content_key(c, width, height, color_type);
+            b.sized_bytes_per_frame = need / (size_t)n;
+        }
         if (jobs.size() == 1 && n > 0 && L.total_blocks) {                     // what the next rounds (and calls) of this size can expect
             uint64_t bytes = 0;
             for (int f = 0; f < n; f++) bytes += (*lens)[(size_t)f];

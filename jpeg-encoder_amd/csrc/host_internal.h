@@ -682,6 +682,7 @@ struct BatchBuffers {
     uint64_t *d_pos = nullptr;
     uint32_t *d_len = nullptr, *h_len = nullptr;
     uint64_t dense_geometry = 0, dense_bits_per_block = 0;     // coded bits per block of the last collected round of frames of that size (DeviceCtx::kDenseBitsPerBlock)
+    uint64_t sized_geometry = 0, sized_bytes_per_frame = 0;   // bytes per frame (all scans) of the last collected round of frames of that size and those settings: round sizes
     static constexpr int kHostSlots = 3;         // three: the files of rounds r - 2 and r - 1 are assembled while round r is fetched (BatchRun::fetch_round, deliver_round)
     uint8_t *h_out[kHostSlots] = {nullptr, nullptr, nullptr};
     size_t coeffs_cap = 0, out_cap = 0, ws_cap = 0, len_cap = 0, packed_cap = 0, pos_cap = 0, h_out_cap[kHostSlots] = {0, 0, 0};

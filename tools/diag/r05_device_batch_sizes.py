@@ -38,6 +38,10 @@ for sf_name, sf in (("4:2:0", b.F_2_2), ("4:4:4", b.F_1_1)):
     for n in (4, 8, 16, 32, 64):
         e = b.Encoder(int(os.environ.get("QUALITY", "90")))
         e.set_sampling_factor(sf)
+        if os.environ.get("PROGRESSIVE"):
+            e.set_progressive_scans(int(os.environ["PROGRESSIVE"]))
+        if os.environ.get("OPTIMISE"):
+            e.set_optimized_huffman_tables(True)
         rf = int(os.environ.get("ROUND_FRAMES", "0"))
         if rf:
             e.set_batch_round_frames(rf)
