@@ -356,9 +356,9 @@ __device__ __forceinline__ void code_band_run(Params p, uint32_t loop_lut /* LDS
     }
     const uint32_t mine = dc_len + ac_bits;
     if (b < p.max_fftiles) p.fftile[(size_t)f * p.max_fftiles + b] = 0;        // k_push adds its 0xFF counts to these
-    const uint32_t upto = wave_inclusive(mine), at = upto - mine;               // bits of the run before this block
+    const uint32_t upto = wave_inclusive_dpp(mine), at = upto - mine;           // bits of the run before this block (seven DPP adds, no LDS round trips)
     if (valid && p.nintervals > 1u) p.bits[(size_t)f * p.nblocks + b] = at;      // (interval offsets need them, k_interval_len)
-    const uint32_t total = (uint32_t)__shfl((int)upto, 63);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
     const uint32_t w = b >> 6;
     if (lane == 0) { p.wsum[(size_t)f * p.nwaves + w] = total; p.ffstat[(size_t)f * p.nwaves + w] = 0; }
     const uint32_t nwords = (total + 31u) >> 5;
