@@ -634,16 +634,21 @@ __global__ void __launch_bounds__(256) k_place(const EntropyParams *params) {
 // only its last word may need the first bits of the following run(s).  No search, no atomics, and each wave's
 // chain is offsets -> slot words -> store.  The last run adds the 1-padding (finalize_bit_buffer,
 // writer.rs:138-154) and zero-fills the final 16-byte chunk.
-__global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
+// sub = the lanes that push one run: 64 (a wave per run), or 16 - FOUR runs per wave - for the scans of progressive frames, whose runs are a few dozen
+// bytes (the 64 blocks of a band hold a handful of symbols): with a wave per run the twelve scans of four 4K frames were 73 000 waves of three dependent
+// round trips each and little else - 44 us per round, a quarter of the round's GPU time (profiles/r05_coder_pmc.txt).
+__global__ void __launch_bounds__(256) k_push(const EntropyParams *params, const uint32_t sub) {
     Params p = JPEGENC_JOB(params);
     if (p.nintervals != 1) return;               // k_place
     if (p.fused_prefix & kRunsFinishThemselves) return;   // k_finish_runs
-    const uint32_t f = blockIdx.y, lane = threadIdx.x & 63u;
-    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (w >= p.nwaves) return;
+    const uint32_t f = blockIdx.y, wave_lane = threadIdx.x & 63u, lane = wave_lane & (sub - 1u);     // `lane`: within the run's group of lanes
+    const uint32_t w_raw = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (64u / sub) + wave_lane / sub;
+    if (__builtin_amdgcn_ballot_w64(w_raw < p.nwaves) == 0) return;
+    const bool mine = w_raw < p.nwaves;                                           // (groups past the last run idle through: the reductions below are wave-wide)
+    const uint32_t w = mine ? w_raw : p.nwaves - 1u;
     const uint32_t *wsum = p.wsum + (size_t)f * p.nwaves;
     uint32_t lo, hi, total_bits;
-    if (p.fused_prefix & 1u) {                   // few runs: every wave adds up the lengths itself, no scan launch before this kernel
+    if (p.fused_prefix & 1u) {                   // few runs: every wave adds up the lengths itself, no scan launch before this kernel (sub = 64 only)
         uint32_t before = 0, all = 0;
         for (uint32_t i = lane; i < p.nwaves; i += 64u) { const uint32_t v = wsum[i]; all += v; if (i < w) before += v; }
         lo = wave_sum(before); total_bits = wave_sum(all);
@@ -655,7 +660,7 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
         lo = woff[w]; hi = w + 1 == p.nwaves ? total_bits : woff[w + 1];
     }
     const uint32_t bytes = (total_bits + 7u) >> 3, chunks = (bytes + 15u) >> 4;
-    if (w == 0 && lane == 0) {                   // the trivial interval bookkeeping of the scan
+    if (mine && w == 0 && lane == 0) {           // the trivial interval bookkeeping of the scan
         p.ivbit[f] = 0; p.ilen[f] = bytes; p.ichunks[f] = chunks; p.iexact[f] = 0; p.ichunk[f] = 0;
         p.raw_bytes[f] = bytes; p.raw_chunks[f] = chunks;
         p.nfftiles[f] = (chunks + 255u) >> 8;
@@ -666,10 +671,10 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
     const bool last = w + 1 == p.nwaves;
     const uint32_t *slot = slots + (size_t)w * p.slot_words;
     const uint32_t j0 = (lo + 31u) >> 5;                              // first word whose first bit is ours
-    const uint32_t j1 = last ? chunks * 4u : (hi + 31u) >> 5;         // the last run also owns the padding and the zero fill
+    const uint32_t j1 = !mine ? j0 : last ? chunks * 4u : (hi + 31u) >> 5;   // the last run also owns the padding and the zero fill
     // groups of four words that lie entirely inside the run: five source words, four funnel shifts, one
     // 16-byte store per lane (word by word the kernel was bound by its instruction count, not by its bytes)
-    const uint32_t ga = (j0 + 3u) >> 2, gb = hi >> 7;               // groups [ga, gb): 128 * gb <= hi
+    const uint32_t ga = (j0 + 3u) >> 2, gb = mine ? hi >> 7 : 0u;   // groups [ga, gb): 128 * gb <= hi
     // 0xFF bytes of the words this run writes, per tile of 256 chunks (1 024 words): a run spans one or two
     // tiles as a rule; those two counts are summed over the wave, anything further goes out lane by lane
     uint32_t *fftile = p.fftile + (size_t)f * p.max_fftiles;
@@ -680,7 +685,7 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
         const uint32_t tile = word_index >> 10;
         if (tile == tile0) ff0 += n; else if (tile == tile0 + 1u) ff1 += n; else atomicAdd(&fftile[tile], n);
     };
-    for (uint32_t g4 = ga + lane; g4 < gb; g4 += 64u) {
+    for (uint32_t g4 = ga + lane; g4 < gb; g4 += sub) {
         const uint32_t rel = g4 * 128u - lo, sh = rel & 31u;
         const uint32_t *src = slot + (rel >> 5);
         const u32x4a4 q = *reinterpret_cast<const u32x4a4 *>(src);
@@ -695,7 +700,7 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
     // the words before the first and after the last such group (at most three + four, seven more for the last run)
     const uint32_t head_end = min(j1, max(j0, ga * 4u)), tail_begin = max(head_end, min(j1, max(gb, ga) * 4u));
     const uint32_t nloose = (head_end - j0) + (j1 - tail_begin);
-    for (uint32_t t = lane; t < nloose; t += 64u) {
+    for (uint32_t t = lane; t < nloose; t += sub) {
         const uint32_t j = t < head_end - j0 ? j0 + t : tail_begin + (t - (head_end - j0));
         const uint32_t g = j * 32u;
         uint32_t v = 0;
@@ -730,8 +735,12 @@ __global__ void __launch_bounds__(256) k_push(const EntropyParams *params) {
         raw[j] = __builtin_bswap32(v);
         count(j, ff_count4(v));                  // (byte order does not matter to a count)
     }
-    ff0 = wave_sum(ff0); ff1 = wave_sum(ff1);
-    if (lane == 0) {
+    if (sub == 64u) {
+        ff0 = wave_sum(ff0); ff1 = wave_sum(ff1);
+    } else {                                     // sums over the run's 16 lanes = one DPP row: lane 15 of the row holds them
+        ff0 = row16_inclusive(ff0); ff1 = row16_inclusive(ff1);
+    }
+    if (sub == 64u ? lane == 0u : lane == 15u) {
         if (ff0) atomicAdd(&fftile[tile0], ff0);
         if (ff1) atomicAdd(&fftile[tile0 + 1u], ff1);
     }
@@ -1293,7 +1302,14 @@ hipError_t launch_entropy_scans(const EntropyParams *jobs, int njobs, EntropyPar
     }
     const uint32_t cgrid = min(fftiles, kChunkGrid);
     if (any_single && runs_finish) hipLaunchKernelGGL(k_finish_runs, dim3((nwaves + kFinishRunsPerWg - 1u) / kFinishRunsPerWg, frames, njobs), dim3(256), 0, st, d_params);
-    else if (any_single) hipLaunchKernelGGL(k_push, dim3((nwaves + 3u) / 4u, frames, njobs), dim3(256), 0, st, d_params);
+    else if (any_single) {
+        // (the scans of progressive frames - no job of the launch a whole block with its DC - push four runs per wave: k_push)
+        bool band_scans = !fused && !fused_runs_prefix;
+        for (int j = 0; j < njobs && band_scans; j++) band_scans = !(jobs[j].with_dc && jobs[j].ac_start == 1u && jobs[j].ac_end == 64u);
+        static const bool wave_per_run = JPEGENC_DIAG_ENV("JPEGENC_PUSH_WAVE_PER_RUN") != nullptr;      // diagnostic: as until round 5
+        const uint32_t sub = band_scans && !wave_per_run ? 16u : 64u, per_wg = 4u * (64u / sub);
+        hipLaunchKernelGGL(k_push, dim3((nwaves + per_wg - 1u) / per_wg, frames, njobs), dim3(256), 0, st, d_params, sub);
+    }
     if (runs_finish && !any_multi) return hipGetLastError();                     // nothing left to place, add up or stuff
     if (any_multi)
         hipLaunchKernelGGL(k_place, dim3(min((fftiles + kPlaceSub - 1u) / kPlaceSub, kChunkGrid), frames, njobs), dim3(256), 0, st, d_params);

@@ -52,6 +52,18 @@ __device__ __forceinline__ uint32_t wave_inclusive_dpp(uint32_t x) {
 #undef JPEGENC_DPP
     return v;
 }
+// inclusive sums within each row of 16 lanes (lane 15 of a row holds the row's total): the first five steps of the above
+__device__ __forceinline__ uint32_t row16_inclusive(uint32_t x) {
+#define JPEGENC_DPP(v, ctrl, rows, banks) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rows, banks, true)
+    uint32_t v = x;
+    v += JPEGENC_DPP(x, 0x111, 0xF, 0xF);
+    v += JPEGENC_DPP(x, 0x112, 0xF, 0xF);
+    v += JPEGENC_DPP(x, 0x113, 0xF, 0xF);
+    v += JPEGENC_DPP(v, 0x114, 0xF, 0xE);
+    v += JPEGENC_DPP(v, 0x118, 0xF, 0xC);
+#undef JPEGENC_DPP
+    return v;
+}
 // 256 threads; part[4] in LDS; the caller separates consecutive uses with __syncthreads()
 __device__ __forceinline__ uint32_t wg_exclusive(uint32_t x, uint32_t *part, uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
