@@ -128,13 +128,17 @@ struct BatchRun {
         // copy out of pinned memory, ~as long as the round's download) while the GPU codes and delivers the next - what is
         // exposed is the first round's coding and the last round's assembly, so the rounds should be short (32 4K frames:
         // 42.4 Gpixel/s in four rounds, 44.1 in eight)
-        // (per-frame optimised tables: every round has a host step the GPU waits for - few large rounds instead: 16 4K surfaces
-        //  98 us per frame in four rounds, see profiles/r04_final_surfaces.jsonl for one or two)
-        if (optimize) {                                                        // (2 MiB of partial histograms per frame of a round: at most 512 MiB)
+        // (per-frame optimised tables: every round has a host step.  Until round 5 the GPU waited for it - few large rounds then: 16 4K
+        //  surfaces 98 us per frame in four rounds, 59-61 in one - now the next round's statistics and the round before's coding run
+        //  beside it (stats_round / code_round) and such batches take the rounds of any other)
+        if (optimize) {                                                        // (2 MiB of partial histograms per frame of a round: at most 1 GiB in the two sets)
             const int cap = coeff_bytes >= ((size_t)4 << 20) ? 32 : 256;
             if (per_round > cap) per_round = cap;
-        }
-        else if (coeff_bytes >= ((size_t)4 << 20)) {
+            // four rounds of at least four frames where the batch allows it (progressive(4) + optimised 4K frames, us per frame in calls of
+            // 8 / 16 / 32 / 64: one round 121 / 92 / 72.5 / 64 (two of 32); two rounds 101 / 87 / 85 / 68; four 103 / 88 / 72 / 71 -
+            // profiles/r05_device_batch_pipeline.txt)
+            if (coeff_bytes >= ((size_t)4 << 20) && num_frames >= 8) per_round = std::min(per_round, std::max(4, (num_frames + 3) / 4));
+        } else if (coeff_bytes >= ((size_t)4 << 20)) {
             // (a round costs ~50 us of launches and hand-overs whatever its size: at least four frames.  Calls of fewer than eight
             //  frames were ONE round, whose coding, download and assembly cannot overlap anything: where the last batch of this size
             //  and these settings says that fewer frames already keep the link busy for longer than a round costs - 8 MB files: one -
@@ -198,10 +202,12 @@ struct BatchRun {
             per_round = per_round > 2 ? per_round * 3 / 4 : 1;
         }
         nlen = jobs.size() * (size_t)per_round;
-        int rc = b.reserve(coeff_bytes * (size_t)per_round, out_total * (size_t)per_round, ws, nlen);
+        // (per-frame optimised tables: the statistics of round r + 1 are gathered while round r is coded - two sets of coefficients,
+        //  statistics and table buffers: stats_round / code_round)
+        int rc = b.reserve(coeff_bytes * (size_t)per_round * (optimize ? 2u : 1u), out_total * (size_t)per_round, ws, nlen);
         if (rc) return rc;
         if (optimize) {
-            rc = b.reserve_opt((size_t)per_round, (size_t)L.total_blocks, kLutDeviceBytes, huffman_lut_batch_spec_bytes());
+            rc = b.reserve_opt((size_t)per_round * 2u, (size_t)L.total_blocks, kLutDeviceBytes, huffman_lut_batch_spec_bytes());
             if (rc) return rc;
         }
 
@@ -222,16 +228,95 @@ struct BatchRun {
         return JPEGENC_OK;
     }
 
-    int code_round(int r) {                             // enqueue only
-        const int f0 = r * per_round, half = r % BatchBuffers::kDevSlots;      // (the slot of d_packed / d_len / h_len / d_pos / coded this round takes)
-        const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
+    // The buffer set an optimised round works in (coefficients, statistics, frequency tables, table specs and code tables: two of each)
+    struct OptSet {
+        void *d_coeffs, *d_partials, *d_freq, *d_dc, *d_luts, *d_specs;
+        uint32_t *h_freq;
+        void *h_specs;
+    };
+    OptSet opt_set(int r) const {
+        const size_t k = (size_t)(r & 1), P = (size_t)per_round;
+        OptSet o;
+        o.d_coeffs = (uint8_t *)b.d_coeffs + k * coeff_bytes * P;
+        o.d_partials = (uint8_t *)b.d_opt_partials + k * P * BatchBuffers::kOptPartialsStride;
+        o.d_freq = (uint8_t *)b.d_opt_freq + k * P * BatchBuffers::kOptFreqStride;
+        o.d_dc = (int16_t *)b.d_opt_dc + k * P * (size_t)L.total_blocks;
+        o.d_luts = (uint8_t *)b.d_opt_luts + k * P * kLutDeviceBytes;
+        o.d_specs = (uint8_t *)b.d_opt_specs + k * P * huffman_lut_batch_spec_bytes();
+        o.h_freq = (uint32_t *)((uint8_t *)b.h_opt_freq + k * P * BatchBuffers::kOptFreqStride);
+        o.h_specs = (uint8_t *)b.h_opt_specs + k * P * huffman_lut_batch_spec_bytes();
+        return o;
+    }
+    BlockKernelParams round_block_params(int r, int *err) const {
+        const int f0 = r * per_round;
         BlockKernelParams p;
-        int e = pb ? build_block_params_planes(&p, L, width, height, t.q, order) : build_block_params(&p, L, width, height, color_type, t.q, order);
-        if (e) return e;
+        *err = pb ? build_block_params_planes(&p, L, width, height, t.q, order) : build_block_params(&p, L, width, height, color_type, t.q, order);
         p.pixels = pb ? (const uint8_t *)(pb->d_table + (size_t)f0 * 8u) : (const uint8_t *)d_frames + (size_t)f0 * frame_stride;
-        p.coeffs = b.d_coeffs;
+        p.coeffs = optimize ? opt_set(r).d_coeffs : b.d_coeffs;
         p.pixel_frame_stride = pb ? kPlaneTableStrideHost : frame_stride;
         p.coeff_frame_stride = L.total_blocks;
+        return p;
+    }
+
+    // Per-frame optimised tables, first half of a round (enqueue only): the block kernel counts the symbols of every frame of the round
+    // while it writes their coefficients (host_frame.cpp does this for one frame), k_hist_finish sums the partial histograms, the counts
+    // go to the host.  Round r + 1's half runs on the GPU while the host builds round r's tables (code_round) - until round 5 a round's
+    // statistics, its host step and its coding followed one another and the GPU idled through every host step (~15-20 us per 4K frame).
+    int stats_round(int r) {
+        const int f0 = r * per_round;
+        const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
+        int e = JPEGENC_OK;
+        BlockKernelParams p = round_block_params(r, &e);
+        if (e) return e;
+        const OptSet o = opt_set(r);
+        p.hist_partials = (uint32_t *)o.d_partials;
+        p.dc_side = (int16_t *)o.d_dc;
+        p.hist_total_blocks = (uint32_t)L.total_blocks;
+        p.hist_copy_mask = DeviceCtx::hist_copies(L.total_blocks) - 1u;
+        p.hist_band_mask = 0;
+        if (c.progressive_scans) {                                           // AC bands of encode_image_progressive (encoder.rs:1123-1134)
+            const int scans = c.progressive_scans - 1, per = 64 / scans;
+            for (int sidx = 1; sidx < scans; sidx++)
+                if (sidx * per > 1 && sidx * per < 64) p.hist_band_mask |= 1ull << (sidx * per);
+        }
+        // (only the partials the frames' waves use: copies x 2 KiB per frame, back to back)
+        JPEGENC_HIP(hipMemsetAsync(o.d_partials, 0, (size_t)n * (p.hist_copy_mask + 1u) * 2048u, ctx.stream));
+        JPEGENC_HIP(hipMemsetAsync(o.d_freq, 0, (size_t)n * BatchBuffers::kOptFreqStride, ctx.stream));
+        hipError_t err = hipSuccess;
+        if (pb) {
+            if (!launch_blocks_planes_once(p, pb->planes, pb->subsampled, n, c.fdct_variant, ctx.stream, &err)) return declined("plane layout for one launch");   // (sampling factors of 4)
+        } else if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) {
+            return declined("statistics need a tuned block kernel");               // (only the tuned kernels count symbols; nothing was launched: round 0)
+        }
+        if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
+        HistFinishParams hf;                                                     // all frames of the round in one launch (grid.y)
+        memset(&hf, 0, sizeof hf);
+        hf.partials = (const uint32_t *)o.d_partials;
+        hf.dc_side = (const int16_t *)o.d_dc;
+        hf.freq = (uint32_t *)o.d_freq;
+        hf.partials_frame_stride = (uint64_t)(p.hist_copy_mask + 1u) * 512u;
+        hf.dc_frame_stride = L.total_blocks;
+        hf.freq_frame_stride = BatchBuffers::kOptFreqStride / sizeof(uint32_t);
+        hf.ncomp = L.num_components;
+        hf.copies = (int32_t)(p.hist_copy_mask + 1u);
+        uint64_t off = 0;
+        for (int i = 0; i < L.num_components; i++) { hf.nblocks[i] = (uint32_t)L.blocks[i]; hf.comp_off[i] = off; off += L.blocks[i]; hf.table[i] = L.table[i]; }
+        const hipError_t he = launch_hist_finish(hf, ctx.stream, n);
+        if (he != hipSuccess) return hip_fail(he, "histogram finish kernel launch");
+        JPEGENC_HIP(hipMemcpyAsync(o.h_freq, o.d_freq, (size_t)n * BatchBuffers::kOptFreqStride, hipMemcpyDeviceToHost, ctx.stream));
+        JPEGENC_HIP(hipEventRecord(b.stats_done[r & 1], ctx.stream));
+        return JPEGENC_OK;
+    }
+
+    int code_round(int r) {                             // enqueue only (per-frame optimised tables: waits for the round's statistics - stats_round - first)
+        const int f0 = r * per_round, half = r % BatchBuffers::kDevSlots;      // (the slot of d_packed / d_len / h_len / d_pos / coded this round takes)
+        const int n = num_frames - f0 < per_round ? num_frames - f0 : per_round;
+        int e = JPEGENC_OK;
+        BlockKernelParams p = round_block_params(r, &e);
+        if (e) return e;
+        const OptSet o = optimize ? opt_set(r) : OptSet{};
+        void *const d_coeffs = optimize ? o.d_coeffs : b.d_coeffs;
+        const void *const d_luts = optimize ? o.d_luts : nullptr;
         const FusedSource fused_src = {&p, c.fdct_variant, pb ? pb->planes : nullptr, pb ? pb->subsampled : false};
         // (dense content - the last collected round of frames of this size coded to more than kDenseBitsPerBlock - takes the two
         // kernels: host_internal.h)
@@ -239,54 +324,21 @@ struct BatchRun {
         const bool dense = !route_off && b.dense_geometry == content_key(c, width, height, color_type) && b.dense_bits_per_block > DeviceCtx::kDenseBitsPerBlock;
         const bool fused = mode == MODE_INTERLEAVED && jobs.size() == 1 && jobs[0].cap && fused_enabled() && !dense &&
                            (pb ? fused_planes_supported(p, pb->planes, pb->subsampled) : fused_supported(p));
-        if (optimize) {                                  // the block kernel counts the symbols of every frame (host_frame.cpp does this for one)
-            p.hist_partials = (uint32_t *)b.d_opt_partials;
-            p.dc_side = (int16_t *)b.d_opt_dc;
-            p.hist_total_blocks = (uint32_t)L.total_blocks;
-            p.hist_copy_mask = DeviceCtx::hist_copies(L.total_blocks) - 1u;
-            p.hist_band_mask = 0;
-            if (c.progressive_scans) {                                           // AC bands of encode_image_progressive (encoder.rs:1123-1134)
-                const int scans = c.progressive_scans - 1, per = 64 / scans;
-                for (int sidx = 1; sidx < scans; sidx++)
-                    if (sidx * per > 1 && sidx * per < 64) p.hist_band_mask |= 1ull << (sidx * per);
-            }
-            // (only the partials the frames' waves use: copies x 2 KiB per frame, back to back)
-            JPEGENC_HIP(hipMemsetAsync(b.d_opt_partials, 0, (size_t)n * (p.hist_copy_mask + 1u) * 2048u, ctx.stream));
-            JPEGENC_HIP(hipMemsetAsync(b.d_opt_freq, 0, (size_t)n * BatchBuffers::kOptFreqStride, ctx.stream));
-        }
-        if (!fused) {
+        if (!fused && !optimize) {
             hipError_t err = hipSuccess;
             if (pb) {
                 if (!launch_blocks_planes_once(p, pb->planes, pb->subsampled, n, c.fdct_variant, ctx.stream, &err)) return declined("plane layout for one launch");   // (sampling factors of 4)
             } else if (!launch_blocks_fast(p, n, c.fdct_variant, ctx.stream, &err)) {
-                if (optimize) return declined("statistics need a tuned block kernel");   // (only the tuned kernels count symbols; nothing was launched: round 0)
                 err = launch_blocks_generic(p, n, c.fdct_variant, ctx.stream);
             }
             if (err != hipSuccess) return hip_fail(err, "block-encode kernel launch");
         }
         if (optimize) {
-            {
-                HistFinishParams hf;                                             // all frames of the round in one launch (grid.y)
-                memset(&hf, 0, sizeof hf);
-                hf.partials = (const uint32_t *)b.d_opt_partials;
-                hf.dc_side = (const int16_t *)b.d_opt_dc;
-                hf.freq = (uint32_t *)b.d_opt_freq;
-                hf.partials_frame_stride = (uint64_t)(p.hist_copy_mask + 1u) * 512u;
-                hf.dc_frame_stride = L.total_blocks;
-                hf.freq_frame_stride = BatchBuffers::kOptFreqStride / sizeof(uint32_t);
-                hf.ncomp = L.num_components;
-                hf.copies = (int32_t)(p.hist_copy_mask + 1u);
-                uint64_t off = 0;
-                for (int i = 0; i < L.num_components; i++) { hf.nblocks[i] = (uint32_t)L.blocks[i]; hf.comp_off[i] = off; off += L.blocks[i]; hf.table[i] = L.table[i]; }
-                const hipError_t he = launch_hist_finish(hf, ctx.stream, n);
-                if (he != hipSuccess) return hip_fail(he, "histogram finish kernel launch");
-            }
-            JPEGENC_HIP(hipMemcpyAsync(b.h_opt_freq, b.d_opt_freq, (size_t)n * BatchBuffers::kOptFreqStride, hipMemcpyDeviceToHost, ctx.stream));
             static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
             const auto t0 = std::chrono::steady_clock::now();
-            JPEGENC_HIP(hipStreamSynchronize(ctx.stream));                        // the round's one host step: tables from the counts
+            JPEGENC_HIP(hipEventSynchronize(b.stats_done[r & 1]));                // the round's one host step: tables from the counts
             const auto t1 = std::chrono::steady_clock::now();
-            // (Figure K.1 / K.2 per frame: ~20 us each - a round's worth on a few threads, the GPU waits for it)
+            // (Figure K.1 / K.2 per frame: ~20 us each - a round's worth on a few threads; the GPU has the next round's statistics to gather meanwhile)
             const int max_tables = L.num_components < 2 ? L.num_components : 2;
             std::atomic<int> next_frame(0), too_long(0);
             auto build = [&]() {
@@ -294,7 +346,7 @@ struct BatchRun {
                     const int f = next_frame.fetch_add(1);
                     if (f >= n) break;
                     Tables &tf = frame_tables[(size_t)(f0 + f)];
-                    const uint32_t *freq = (const uint32_t *)((const uint8_t *)b.h_opt_freq + (size_t)f * BatchBuffers::kOptFreqStride);
+                    const uint32_t *freq = (const uint32_t *)((const uint8_t *)o.h_freq + (size_t)f * BatchBuffers::kOptFreqStride);
                     for (int d = 0; d < max_tables; d++)
                         for (int k = 0; k < 2; k++)
                             if (!tf.h[d][k].assign_optimized(freq + (d * 2 + k) * 257)) too_long.store(1);
@@ -312,7 +364,7 @@ struct BatchRun {
             if (trace) fprintf(stderr, "[jpegenc] batch round of %d frames with their own tables: statistics on the host after %ld us, tables built in %ld us\n", n,
                                (long)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count(),
                                (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t1).count());
-            // (the specs of round r - 1 have been consumed: this stream was synchronised above)
+            // (this set's specs were last uploaded by round r - 2, whose coding the pipeline has waited for since)
             for (int f = 0; f < n; f++) {
                 const Tables &tf = frame_tables[(size_t)(f0 + f)];
                 jpegenc_huffman_spec specs[2][2];
@@ -323,9 +375,9 @@ struct BatchRun {
                         memcpy(specs[d][k].values, tf.h[d][k].vals, (size_t)tf.h[d][k].nvals);
                         specs[d][k].num_values = tf.h[d][k].nvals;
                     }
-                fill_huffman_lut_spec(b.h_opt_specs, f, specs);
+                fill_huffman_lut_spec(o.h_specs, f, specs);
             }
-            const int rl = upload_huffman_luts_batch(b.h_opt_specs, b.d_opt_specs, b.d_opt_luts, n, ctx.stream);      // one copy, one launch
+            const int rl = upload_huffman_luts_batch(o.h_specs, o.d_specs, o.d_luts, n, ctx.stream);      // one copy, one launch
             if (rl) return rl;
         }
         uint32_t *d_len = b.d_len + (size_t)half * nlen;
@@ -341,13 +393,13 @@ struct BatchRun {
                 sj.push_back(ScanJob{j.sc, (uint8_t *)b.d_out + j.off, out_total, d_len + k * (size_t)per_round,
                                      (uint8_t *)b.d_ws + ws_off[k], ws_len[k]});
             }
-            e = scan_device_multi(b.d_coeffs, L.total_blocks, n, L, sj.data(), (int)sj.size(), optimize ? b.d_opt_luts : ctx.d_lut, ctx.stream, optimize);
+            e = scan_device_multi(d_coeffs, L.total_blocks, n, L, sj.data(), (int)sj.size(), optimize ? d_luts : ctx.d_lut, ctx.stream, optimize);
             if (e) return e;
         } else
         for (size_t k = 0; k < jobs.size(); k++) {
             const Job &j = jobs[k];
             if (!j.cap) continue;
-            e = scan_device(b.d_coeffs, L.total_blocks, n, L, j.sc, nullptr, optimize ? b.d_opt_luts : ctx.d_lut, (uint8_t *)b.d_out + j.off,
+            e = scan_device(d_coeffs, L.total_blocks, n, L, j.sc, nullptr, optimize ? d_luts : ctx.d_lut, (uint8_t *)b.d_out + j.off,
                             out_total, d_len + k * (size_t)per_round, b.d_ws, ws, ctx.stream, nullptr, fused ? &fused_src : nullptr, optimize);
             if (e) return e;
         }
@@ -528,12 +580,22 @@ struct BatchRun {
     // next round: with four 4K frames per round the link idled 70 of every 170 us, profiles/r05_device_batch_pipeline.txt.)
     int run() {
         t_run = std::chrono::steady_clock::now();
-        int rc = code_round(0);
+        const int rounds = (num_frames + per_round - 1) / per_round;
+        // (per-frame optimised tables: a round = stats_round, the host's tables, code_round; the stream sees S0 S1 C0 S2 C1 S3 C2 ..., so
+        //  the GPU gathers round r + 1's statistics and codes round r - 1 while the host builds round r's tables)
+        int rc = JPEGENC_OK;
+        if (optimize) {
+            rc = stats_round(0);
+            if (!rc && rounds > 1) rc = stats_round(1);
+            if (rc) return rc;
+        }
+        rc = code_round(0);
         if (rc) return rc;
         Fetch prev;
         int round = 0;
         for (int f0 = 0; f0 < num_frames && !stop; f0 += per_round, round++) {
             const bool more = f0 + per_round < num_frames;
+            if (optimize && round + 2 < rounds) { rc = stats_round(round + 2); if (rc) break; }
             if (more) { rc = code_round(round + 1); if (rc) break; }
             Fetch cur;
             rc = fetch_round(round, f0, &cur);

@@ -740,11 +740,13 @@ struct BatchBuffers {
     hipStream_t copy_stream = nullptr;
     hipEvent_t coded[3] = {nullptr, nullptr, nullptr};              // [kDevSlots]
     hipEvent_t fetched[kHostSlots] = {nullptr, nullptr, nullptr};     // the download of the round staged in h_out[slot] has landed
+    hipEvent_t stats_done[2] = {nullptr, nullptr};                    // per-frame optimised tables: the statistics of the round in set r & 1 are on the host
     int open_streams() {
         if (copy_stream) return JPEGENC_OK;
         JPEGENC_HIP(create_side_stream(&copy_stream));
         for (auto &e : coded) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : fetched) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : stats_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         return JPEGENC_OK;
     }
     // d_out (a round's scans where the coder leaves them) is ONE round's: everything that touches it runs in order on the encoder's
@@ -795,6 +797,7 @@ struct BatchBuffers {
         for (auto *h : h_out) if (h) (void)hipHostFree(h);
         for (auto &e : coded) if (e) (void)hipEventDestroy(e);
         for (auto &e : fetched) if (e) (void)hipEventDestroy(e);
+        for (auto &e : stats_done) if (e) (void)hipEventDestroy(e);
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
     }
 };
