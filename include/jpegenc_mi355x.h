@@ -343,7 +343,7 @@ int  jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int
  * shares its launches (one fused block-encode launch, one launch sequence per scan for all frames);
  * only the compressed bytes come back.  Optimised Huffman tables are per frame (optimize_huffman_table,
  * encoder.rs:1086-1200) and share the launches too: the block kernel counts the symbols of every frame of a
- * round, one host step builds the tables, the coder reads frame i's table set.  With the host entropy coder,
+ * round, one host step builds the tables (while the GPU gathers the next round's statistics), the coder reads frame i's table set.  With the host entropy coder,
  * or frames too large for the device entropy coder (jpegenc_scan_max_bytes == 0: about 2.45 M blocks and
  * more), every frame takes the single-image path instead, several of them in flight on the handle's worker
  * threads (each with its own stream and buffers) - same bytes either way.
