@@ -579,6 +579,13 @@ struct BatchRun {
     // when one lands.  (Until round 5 a turn waited for its own download and made threads for its files before it looked at the
     // next round: with four 4K frames per round the link idled 70 of every 170 us, profiles/r05_device_batch_pipeline.txt.)
     int run() {
+        const int rc = run_pipeline();
+        // (whatever ended the call early - a round that cannot be coded, a table too deep, a failing sink - rounds enqueued ahead may
+        //  still read the caller's frames: not beyond this call)
+        if (rc != JPEGENC_OK) (void)hipStreamSynchronize(ctx.stream);
+        return rc;
+    }
+    int run_pipeline() {
         t_run = std::chrono::steady_clock::now();
         const int rounds = (num_frames + per_round - 1) / per_round;
         // (per-frame optimised tables: a round = stats_round, the host's tables, code_round; the stream sees S0 S1 C0 S2 C1 S3 C2 ..., so
