@@ -269,11 +269,13 @@ def pcie_roofline(bound, bytes_moved, seconds, link):
     peak = link.get("h2d" if bound == "pcie_h2d" else "d2h" if bound == "pcie_d2h" else "both_each_direction")
     achieved = bytes_moved / seconds / 1e9
     source = "link_rates of this run (pinned 25 MB copies, two streams per direction, best of five samples)"
+    # (the measured peak is kept as it is: a figure that beats the plain copies reports frac > 1 - an under-measuring link_rates or an
+    #  over-counted bytes_moved must stay visible in the line)
+    out = {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+           "frac": round(achieved / peak, 4) if peak else None, "peak_source": source}
     if peak and achieved > peak:
-        # a ceiling that the measured thing exceeds is not a ceiling: the link evidently carries at least `achieved`
-        peak, source = round(achieved, 1), source + "; RAISED to the rate this figure itself reached - the plain copies were slower"
-    return {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
-            "frac": round(achieved / peak, 4) if peak else None, "peak_source": source}
+        out["exceeds_measured_link"] = True
+    return out
 
 
 CRITERION_VARIANTS = {                                            # criterion/benches/encode.rs:57-86: (Encoder setters, oracle arguments)
@@ -983,7 +985,7 @@ def main():
                     rows.append({"rank": r, "frames": int(fr), "seconds": round(float(sec), 6),
                                  "frames_per_s": round(fr / sec, 1) if sec > 0 else None,
                                  "h2d_GBps": round(gbps, 2) if gbps else None, "link_h2d_GBps": round(float(lk), 1) if lk else None,
-                                 "frac": round(gbps / max(lk, gbps), 4) if gbps and lk else None})      # (a rank that beats its plain copies sets its own ceiling)
+                                 "frac": round(gbps / lk, 4) if gbps and lk else None})      # (> 1: the rank beat the plain copies it measured the link with)
                 fps = [x["frames_per_s"] for x in rows if x["frames_per_s"]]
                 fracs = [x["frac"] for x in rows if x["frac"]]
                 return rows, {"frames_per_s_min": min(fps) if fps else None, "frames_per_s_max": max(fps) if fps else None,

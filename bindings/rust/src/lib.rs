@@ -622,6 +622,18 @@ impl<W: JfifWrite> Encoder<W> {
         unsafe { sys::jpegenc_encoder_set_batch_upload(self.h, enable as c_int) };
     }
 
+    /// Upper bound on the host threads this encoder's batch calls keep busy at once, the calling thread included
+    /// (0 = sized by the library: at most 4 where the GPU codes the scans).  A process that shares its CPU quota with
+    /// other ranks - one process per GPU - passes its share.  The reference is single-threaded: 1 reproduces that.
+    pub fn set_batch_workers(&mut self, threads: u32) {
+        unsafe { sys::jpegenc_encoder_set_batch_workers(self.h, threads as c_int) };
+    }
+
+    /// The setting of `set_batch_workers` (0 = automatic).
+    pub fn batch_workers(&self) -> u32 {
+        (unsafe { sys::jpegenc_encoder_batch_workers(self.h) }).max(0) as u32
+    }
+
     /// Upper bound on the frames of a device-resident batch in flight together (0 = sized by device memory footprint).
     pub fn set_batch_round_frames(&mut self, frames: u32) {
         unsafe { sys::jpegenc_encoder_set_batch_round_frames(self.h, frames as c_int) };

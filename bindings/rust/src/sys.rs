@@ -119,6 +119,10 @@ extern "C" {
     pub fn jpegenc_encoder_set_register_cache(e: *mut jpegenc_encoder, bytes: usize) -> c_int;
     pub fn jpegenc_encoder_set_numa_bind(e: *mut jpegenc_encoder, enable: c_int) -> c_int;
     pub fn jpegenc_encoder_set_batch_upload(e: *mut jpegenc_encoder, mode: c_int) -> c_int;
+    pub fn jpegenc_encoder_batch_shard_info(e: *mut jpegenc_encoder, shard: c_int, device: *mut c_int, batch_workers: *mut c_int, upload_mode: *mut c_int,
+                                            register_cache_bytes: *mut usize, pool_workers: *mut c_int) -> c_int;
+    pub fn jpegenc_encoder_set_batch_workers(e: *mut jpegenc_encoder, threads: c_int) -> c_int;
+    pub fn jpegenc_encoder_batch_workers(e: *const jpegenc_encoder) -> c_int;
     pub fn jpegenc_encoder_set_batch_round_frames(e: *mut jpegenc_encoder, frames: c_int) -> c_int;
     pub fn jpegenc_encoder_set_density(e: *mut jpegenc_encoder, unit: c_int, x: u16, y: u16) -> c_int;
     pub fn jpegenc_encoder_density(e: *const jpegenc_encoder, unit: *mut c_int, x: *mut u16, y: *mut u16) -> c_int;

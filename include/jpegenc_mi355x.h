@@ -293,6 +293,16 @@ int  jpegenc_encoder_set_numa_bind(jpegenc_encoder *e, int enable);
  * Files do not depend on the mode. */
 typedef enum jpegenc_upload_mode { JPEGENC_UPLOAD_STAGED = 0, JPEGENC_UPLOAD_REGISTER_AHEAD = 1 } jpegenc_upload_mode;
 int  jpegenc_encoder_set_batch_upload(jpegenc_encoder *e, int mode);
+/* Upper bound on the host threads the batch calls of this handle keep busy at once, THE CALLING THREAD INCLUDED: the workers that
+ * stage, upload and collect frames (jpegenc_encoder_encode_batch*), the threads that assemble the files of a device-resident batch,
+ * build per-frame Huffman tables or copy thumbnails into page-locked memory, and each per-device child of
+ * jpegenc_encoder_encode_batch_multi.  0 (default): sized by the library - at most 4 threads where the scans are coded on the device
+ * (a worker's time is then the PCIe link's: 4 are within 1 % of 16), up to 16 for host entropy coding, never more than
+ * the CPUs the process may use (affinity mask, cgroup quota) less two.  The reference is single-threaded (encoder.rs:440-515): 1
+ * reproduces that.  A process that shares its CPU quota with other ranks (one process per GPU on an 8-GPU host) sets its share here:
+ * the library cannot see its neighbours.  Files do not depend on it.  jpegenc_encoder_batch_workers returns the setting (0 = automatic). */
+int  jpegenc_encoder_set_batch_workers(jpegenc_encoder *e, int threads);          /* 0 .. 64 */
+int  jpegenc_encoder_batch_workers(const jpegenc_encoder *e);
 /* Upper bound on the frames of a device-resident batch (jpegenc_encoder_encode_batch_device and the calls built on it) whose
  * device work is in flight together: a round of n frames occupies n x (coefficients + worst-case scan bytes) of device
  * memory.  0 (default): rounds are sized for a 6 GiB footprint, at most 1024 frames.  The files do not depend on it. */
@@ -511,6 +521,12 @@ int  jpegenc_encoder_encode_batch_multi_to_buffers(jpegenc_encoder *e, const int
                                                    const uint8_t *const *frames, size_t frame_len, int num_frames,
                                                    int width, int height, int color_type, uint8_t *const *outs,
                                                    const size_t *capacities, size_t *lengths);
+
+/* What per-device child `shard` (0 ...) of jpegenc_encoder_encode_batch_multi runs with: its device, the thread budget, upload mode and
+ * register-cache budget it inherited from `e` at the last multi-device call, and the workers its pool has had so far (any pointer may
+ * be NULL).  Returns the number of children (negative status on a null handle).  Introspection, like jpegenc_encoder_batch_worker_info. */
+int  jpegenc_encoder_batch_shard_info(jpegenc_encoder *e, int shard, int *device, int *batch_workers, int *upload_mode,
+                                      size_t *register_cache_bytes, int *pool_workers);
 
 /* free functions re-exported by the crate (src/lib.rs:45-49) — host arithmetic, for callers that
  * implement their own ImageBuffer. */

@@ -113,6 +113,9 @@ public:
 
     // which GPU this encoder drives (one encoder per thread; frames are spread over GPUs by giving encoders different devices)
     void set_device(int device) { check(jpegenc_encoder_set_device(h_, device)); }
+    // host threads the batch calls keep busy at once, the caller's included (0 = automatic); a rank of a shared host passes its share
+    void set_batch_workers(int threads) { check(jpegenc_encoder_set_batch_workers(h_, threads)); }
+    int batch_workers() const { return jpegenc_encoder_batch_workers(h_); }
 
     // Encoder::encode, :440-503.  `len` may exceed width * height * bytes-per-pixel; shorter is BadImageData.
     // (The Rust method consumes the encoder; this one can be called again with the same settings.)

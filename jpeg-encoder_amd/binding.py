@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
     "jpegenc_pixels_scan_fused", "jpegenc_pixels_scan_device",
     "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_register_cache", "jpegenc_encoder_set_numa_bind", "jpegenc_encoder_set_batch_upload", "jpegenc_encoder_set_batch_round_frames",
+    "jpegenc_encoder_set_batch_workers", "jpegenc_encoder_batch_workers", "jpegenc_encoder_batch_shard_info",
     "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
     "jpegenc_encoder_set_fdct_variant", "jpegenc_encoder_set_density", "jpegenc_encoder_density",
     "jpegenc_encoder_set_sampling_factor", "jpegenc_encoder_sampling_factor",
@@ -169,10 +170,10 @@ def lib():
         l.jpegenc_pixels_scan_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.POINTER(QTable), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-        for name in ("set_device", "set_device_entropy", "set_numa_bind", "set_batch_round_frames", "set_fdct_variant", "set_sampling_factor", "set_progressive",
+        for name in ("set_device", "set_device_entropy", "set_numa_bind", "set_batch_round_frames", "set_batch_workers", "set_fdct_variant", "set_sampling_factor", "set_progressive",
                      "set_progressive_scans", "set_optimized_huffman_tables"):
             getattr(l, "jpegenc_encoder_" + name).argtypes = [C.c_void_p, C.c_int]
-        for name in ("sampling_factor", "progressive_scans", "restart_interval", "optimized_huffman_tables"):
+        for name in ("sampling_factor", "progressive_scans", "restart_interval", "optimized_huffman_tables", "batch_workers"):
             getattr(l, "jpegenc_encoder_" + name).argtypes = [C.c_void_p]
         l.jpegenc_encoder_set_restart_interval.argtypes = [C.c_void_p, C.c_uint16]
         l.jpegenc_encoder_set_density.argtypes = [C.c_void_p, C.c_int, C.c_uint16, C.c_uint16]
@@ -479,6 +480,28 @@ class Encoder:
             if n <= 0:
                 break
             out.append((p.value or 0, nb.value, cpu.value))
+            i += 1
+        return out
+
+    def set_batch_workers(self, threads):
+        """Host threads this handle's batch calls keep busy at once, the caller's included (0 = automatic: at most 4 where the device
+        codes the scans).  One process per GPU on a shared host: pass the rank's share of the CPUs (batch.rank_cpu_share)."""
+        check(lib().jpegenc_encoder_set_batch_workers(self._h, int(threads)))
+
+    def batch_workers(self):
+        return int(lib().jpegenc_encoder_batch_workers(self._h))
+
+    def batch_shard_info(self):
+        """[{device, batch_workers, upload_mode, register_cache_bytes, pool_workers}] of the per-device children of encode_batch_multi."""
+        f = lib().jpegenc_encoder_batch_shard_info
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        out, n, i = [], 1, 0
+        while i < n:
+            dev, bw, up, pw, rc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+            n = f(self._h, i, C.byref(dev), C.byref(bw), C.byref(up), C.byref(rc), C.byref(pw))
+            if n <= 0:
+                break
+            out.append({"device": dev.value, "batch_workers": bw.value, "upload_mode": up.value, "register_cache_bytes": rc.value, "pool_workers": pw.value})
             i += 1
         return out
 

@@ -111,6 +111,9 @@ hipError_t launch_blocks_planes(const BlockKernelParams &base, const jpegenc_pla
         uintptr_t ptr = (uintptr_t)planes[c].d_data;
         q.bpp = planes[c].pixel_stride;
         if (q.bpp != 1 && q.bpp != 2 && q.bpp != 4) return hipErrorInvalidValue;
+        // (planes_subsampled = 2, normalize_planes: the bottom-edge rows of such a plane repeat a row BEHIND its last one, carried in
+        //  `reserved` - only the one-launch kernels read it; padding rows from here would silently differ from encoder.rs:738-744)
+        if (planes[c].reserved != 0) return hipErrorInvalidValue;
         if (planes[c].shift != 0 && (planes[c].shift != 8 || q.bpp < 2 || (ptr & 1u))) return hipErrorInvalidValue;   // (whole-byte picks only on this path)
         q.plane_byte_index = (uint32_t)(ptr & (uintptr_t)(q.bpp - 1));            // byte of an interleaved group (NV12: Cr = 1)
         ptr -= q.plane_byte_index;

@@ -2,6 +2,7 @@
 // (BatchRun), the pool of host workers with one stream each for host frames, the staged path for many small frames, and the
 // C entry points of all of them.
 #include "host_internal.h"
+#include "host_register_ahead.h"
 
 namespace jpegenc {
 
@@ -353,10 +354,7 @@ struct BatchRun {
                 }
             };
             {
-                int nthreads = usable_cpus() - 1;
-                if (nthreads > 8) nthreads = 8;
-                if (nthreads > n / 2) nthreads = n / 2;
-                if (nthreads < 1) nthreads = 1;
+                const int nthreads = pool_threads(b.thread_cap, 8, 1, 1, n / 2);
                 if (b.helpers) b.helpers->run(nthreads, [&](int) { build(); });   // the handle's persistent threads
                 else build();
             }
@@ -553,15 +551,13 @@ struct BatchRun {
         auto frame_at = p.frame_at;
         uint8_t *h_out = p.h_out;
         const int n = p.n, f0 = p.f0;
-        int pool_threads = usable_cpus() - 2;
-        if (pool_threads > 8) pool_threads = 8;
-        if (pool_threads < 1) pool_threads = 1;
-        int nthreads = pool_threads > n ? n : pool_threads;
+        const int pool_n = pool_threads(b.thread_cap, 8, 2, 1, 1 << 20);
+        int nthreads = pool_n > n ? n : pool_n;
         if (p.bytes < ((size_t)4 << 20)) nthreads = 1;                           // little to copy: not worth the threads
-        const int copy_slot = b.assemblers && pool_threads > 1 ? p.slot : -1;
+        const int copy_slot = b.assemblers && pool_n > 1 ? p.slot : -1;
         auto assemble = [this, lens, frame_at, next, h_out, n, f0, copy_slot]() { assemble_frames(*lens, *frame_at, *next, h_out, n, f0, copy_slot); };
-        if (b.assemblers) {
-            b.assemblers->ensure_threads(copy_slot >= 0 ? pool_threads : nthreads);   // (pieces of large scans keep every thread busy, however few the frames)
+        if (b.assemblers && b.thread_cap != 1) {                                    // (a budget of one thread: the caller's does everything)
+            b.assemblers->ensure_threads(copy_slot >= 0 ? pool_n : nthreads);   // (pieces of large scans keep every thread busy, however few the frames)
             in_assembly[p.slot] = true;                                              // (tasks of this group may exist from here on: join() waits for them)
             for (int w = last ? 1 : 0; w < nthreads; w++) b.assemblers->submit(p.slot, assemble);
             if (last) assemble();
@@ -646,7 +642,7 @@ extern "C" {
 // points of one frame are covered by the others (a batch of 8 optimised 4K frames: 283 us per frame one by one).
 static int encode_device_frames_pooled(jpegenc_encoder *e, const void *d_frames, size_t frame_stride, int num_frames, int width, int height,
                                        int color_type, jpegenc_write_fn sink, void *const *users) {
-    const int workers = batch_pool_size(e->max_batch_workers, num_frames);
+    const int workers = batch_pool_size(e->batch_workers, e->max_batch_workers, num_frames);
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
     const size_t bytes = (size_t)width * (size_t)height * (size_t)jpegenc_bytes_per_pixel(color_type);
     std::atomic<int> next(0), status(JPEGENC_OK);
@@ -684,7 +680,7 @@ static int encode_device_frames_pooled(jpegenc_encoder *e, const void *d_frames,
 // returns.  (Until round 4 this was a loop on the handle's own stream: ~280 us per 4K frame.)
 static int encode_planes_frames_pooled(jpegenc_encoder *e, int jct, int width, int height, const jpegenc_plane *planes, int num_frames,
                                        bool planes_subsampled, jpegenc_write_fn sink, void *const *users, int *failed_frame = nullptr) {
-    const int workers = batch_pool_size(e->max_batch_workers, num_frames);
+    const int workers = batch_pool_size(e->batch_workers, e->max_batch_workers, num_frames);
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());
     const int ncomp = jct == JPEGENC_J_LUMA ? 1 : jct == JPEGENC_J_YCBCR ? 3 : 4;
     const size_t bytes = (size_t)width * (size_t)height * (size_t)ncomp;
@@ -723,8 +719,9 @@ static int encode_planes_frames_pooled(jpegenc_encoder *e, int jct, int width, i
     return JPEGENC_OK;
 }
 
-int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride, int num_frames,
-                                        int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
+// frame_base: what the caller's numbering adds to a frame of this call (the rounds of a staged batch of thumbnails)
+static int encode_batch_device_from(jpegenc_encoder *e, const void *d_frames, size_t frame_stride, int num_frames, int width, int height,
+                                    int color_type, jpegenc_write_fn sink, void *const *users, int frame_base) {
     REQUIRE(e);
     if (num_frames < 0 || (num_frames && (!d_frames || !users)) || !sink) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "bad batch arguments");
     const int bpp = jpegenc_bytes_per_pixel(color_type);
@@ -738,13 +735,19 @@ int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames
     }
     e->batch.helpers = &e->threads;
     e->batch.assemblers = &e->assemblers;
+    e->batch.thread_cap = e->batch_workers;
     int bad = -1;
     const int rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, d_frames, frame_stride, num_frames, width, height, color_type, sink, users, nullptr, &bad);
     if (rc != kBatchNeedsPerFrame) {
-        if (rc != JPEGENC_OK && bad >= 0) set_last_error("frame " + std::to_string(bad) + ": " + jpegenc_last_error());      // (every frame below it: delivered whole)
+        if (rc != JPEGENC_OK && bad >= 0) set_last_error("frame " + std::to_string(bad + frame_base) + ": " + jpegenc_last_error());      // (every frame below it: delivered whole)
         return rc;
     }
     return encode_device_frames_pooled(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users);
+}
+
+int jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride, int num_frames,
+                                        int width, int height, int color_type, jpegenc_write_fn sink, void *const *users) {
+    return encode_batch_device_from(e, d_frames, frame_stride, num_frames, width, height, color_type, sink, users, 0);
 }
 
 // A pool of described surfaces of ONE layout (sample strides, inversion, shifts and byte lanes agree): shared launches.
@@ -777,6 +780,7 @@ static int encode_planes_uniform(jpegenc_encoder *e, int jct, int width, int hei
     const PlaneBatch pb = {rep, planes_subsampled, (const uint64_t *)e->batch.d_plane_table, jct};
     e->batch.helpers = &e->threads;
     e->batch.assemblers = &e->assemblers;
+    e->batch.thread_cap = e->batch_workers;
     rc = encode_device_batch(e->cfg, e->ctx, e->batch, e->device, nullptr, 0, num_frames, width, height, 0, sink, users, &pb, failed_frame);
     if (rc != kBatchNeedsPerFrame) return rc;
     if (getenv("JPEGENC_TRACE")) fprintf(stderr, "[jpegenc] pool of %d surfaces: the shared launches declined, one launch sequence per frame\n", num_frames);
@@ -877,178 +881,6 @@ int jpegenc_encoder_encode_planes_batch_device(jpegenc_encoder *e, int jct, int 
 
 }  // extern "C"
 
-namespace jpegenc {
-
-// JPEGENC_UPLOAD_REGISTER_AHEAD: one thread page-locks the batch's pageable frames a few ahead of the workers and a second one
-// releases them behind the workers - never more than one thread inside hipHostRegister and one inside hipHostUnregister, never a
-// pageable hipMemcpyAsync from a worker (eight workers inside the runtime's pageable-copy path crashed profiled processes:
-// profiles/r04_pageable_upload_crash.txt).
-// Whole pages are registered, in frame order; frames that share a page (a contiguous array of frames whose size is not a multiple
-// of the page) split it: the page belongs to the range registered first, the later frame's range starts behind it (or ends before
-// it), and a range is released only when the frame AFTER it is done as well.
-struct RegisterAhead {
-    const uint8_t *const *frames;
-    const size_t bytes;
-    const int n, depth, device;
-    std::atomic<int> &taken;                       // frames handed to workers so far (the batch's own counter)
-    std::unique_ptr<std::atomic<int>[]> state;     // 0 = not looked at yet, 1 = page-locked here, 2 = to be staged (the caller's in part, or not lockable), 3 = the caller's as a whole: in place
-    std::unique_ptr<std::atomic<int>[]> done;
-    std::atomic<bool> finished{false};
-    std::atomic<int> reg_count{0};                 // frames the registrar has looked at
-    std::thread releaser;                          // (two_threads) the unregistering half on a thread of its own
-    std::atomic<uint64_t> registered_bytes{0}, register_ns{0}, unregister_ns{0};
-    std::mutex mu;
-    std::condition_variable cv;
-    std::thread th;
-    struct Range { void *p; size_t len; };
-    std::vector<Range> ranges;
-    struct Pieces { size_t n[3]; };                // bytes of frame i that lie in the registration before its own / in its own / in the one after
-    std::vector<Pieces> pieces;
-    RegisterAhead(const uint8_t *const *f, size_t b, int count, int ahead, int dev, std::atomic<int> &next)
-        : frames(f), bytes(b), n(count), depth(ahead), device(dev), taken(next), state(new std::atomic<int>[(size_t)count]), done(new std::atomic<int>[(size_t)count]),
-          ranges((size_t)count, Range{nullptr, 0}), pieces((size_t)count, Pieces{{0, 0, 0}}) {
-        for (int i = 0; i < count; i++) { state[i].store(0); done[i].store(0); }
-        // Two threads: one locks ahead of the workers, one releases behind them.  Locking is cheap (1 000 1080p frames: 5 ms in all),
-        // RELEASING is what costs (110 ms for the same frames, 56 GB/s): with both halves on one thread the workers wait for frames
-        // that are not locked yet because the thread is busy unlocking (6 700 against 7 500 frames/s staged; two threads: 8 100).
-        // Never more than one thread inside hipHostRegister and one inside hipHostUnregister.  JPEGENC_REGISTER_AHEAD_THREADS=1
-        // (diagnostic build): both halves on one thread, profiles/r05_upload_modes.txt.
-        static const bool one = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_REGISTER_AHEAD_THREADS"); return v && atoi(v) == 1; }();
-        two_threads = !one;
-        th = std::thread([this] { run(); });
-        if (two_threads) releaser = std::thread([this] { release_loop(); });
-    }
-    bool two_threads = false;
-    ~RegisterAhead() { finish(); }
-    void finish() {                                 // every worker is done (or has given up): release what is still locked
-        if (!th.joinable()) return;
-        finished.store(true);
-        { std::lock_guard<std::mutex> lock(mu); }
-        cv.notify_all();
-        th.join();
-        if (releaser.joinable()) releaser.join();
-    }
-    // the releasing half: ranges of frames [unreg, limit) where limit lags one frame behind the finished prefix
-    int release_some(int unreg, int done_prefix_out[1]) {
-        int dp = done_prefix_out[0];
-        while (dp < n && done[dp].load(std::memory_order_acquire)) dp++;
-        done_prefix_out[0] = dp;
-        const bool fin = finished.load();
-        const int reg = reg_count.load(std::memory_order_acquire);
-        int can_unreg = fin ? reg : (dp >= n ? n : dp - 1);     // (a range may hold the first or last page of the frame after it)
-        if (can_unreg > reg) can_unreg = reg;
-        auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        while (unreg < can_unreg) {
-            if (ranges[(size_t)unreg].len) {
-                const uint64_t t0 = now_ns();
-                if (hipHostUnregister(ranges[(size_t)unreg].p) != hipSuccess) (void)hipGetLastError();
-                unregister_ns += now_ns() - t0;
-            }
-            unreg++;
-        }
-        return unreg;
-    }
-    void release_loop() {
-        if (hipSetDevice(device) != hipSuccess) (void)hipGetLastError();
-        int unreg = 0, dp[1] = {0};
-        for (;;) {
-            const bool fin = finished.load();
-            const bool registrar_gone = reg_done.load();
-            const int before = unreg;
-            unreg = release_some(unreg, dp);
-            if (fin ? (registrar_gone && unreg >= reg_count.load()) : unreg >= n) break;
-            if (unreg == before) {
-                std::unique_lock<std::mutex> lock(mu);
-                cv.wait_for(lock, std::chrono::microseconds(200));
-            }
-        }
-    }
-    std::atomic<bool> reg_done{false};
-    bool gave_up = false;                          // (registrar thread only; read by the caller after finish())
-    void wait_ready(int i) {                        // worker: frame i has been looked at
-        if (state[i].load(std::memory_order_acquire)) return;
-        std::unique_lock<std::mutex> lock(mu);
-        cv.notify_all();                            // (the registrar may be waiting for `taken` to move)
-        cv.wait(lock, [&] { return state[i].load(std::memory_order_acquire) != 0 || finished.load(); });
-    }
-    void frame_done(int i) {
-        done[i].store(1, std::memory_order_release);
-        { std::lock_guard<std::mutex> lock(mu); }
-        cv.notify_all();
-    }
-    void run() {
-        if (hipSetDevice(device) != hipSuccess) (void)hipGetLastError();
-        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
-        uintptr_t prev_a = 0, prev_b = 0;           // the range registered last
-        int reg = 0, unreg = 0, dp[1] = {0};
-        auto now_ns = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        for (;;) {
-            bool progressed = false;
-            const bool fin = finished.load();
-            if (!two_threads) {
-                const int before = unreg;
-                unreg = release_some(unreg, dp);
-                progressed = unreg != before;
-                if (fin ? unreg >= reg : unreg >= n) break;
-            } else if (fin || reg >= n) {
-                break;                              // (the releaser sees to the rest)
-            }
-            if (!fin && reg < n && reg < taken.load() + depth) {
-                const uint8_t *p = frames[reg];
-                int st = 2;
-                // How fast pages can be locked depends on what backs them: frames on transparent huge pages lock at > 1 TB/s (5 ms
-                // for 6.2 GB), frames on 4 KB pages at 9-13 GB/s - a quarter of what the link moves (profiles/r05_upload_modes.txt).
-                // The thread times itself: once at least three frames and 16 MB are on record at under 30 GB/s, it stops locking and
-                // the rest of the batch is staged by the workers as in the default mode.
-                if (!gave_up && reg >= 3 && registered_bytes.load() >= ((uint64_t)16 << 20) &&
-                    (double)registered_bytes.load() / (double)(register_ns.load() ? register_ns.load() : 1) < 30.0) gave_up = true;
-                if (p && bytes && !gave_up) {
-                    const uintptr_t first = (uintptr_t)p, end = first + bytes;
-                    uintptr_t a = first & ~(page - 1), b = (end + page - 1) & ~(page - 1);
-                    Pieces pc = {{0, bytes, 0}};
-                    if (a < prev_b && b > prev_a) {             // shares a page with the range registered last
-                        if (a >= prev_a) { a = prev_b; pc.n[0] = a > first ? (size_t)(std::min(a, end) - first) : 0; pc.n[1] = bytes - pc.n[0]; }
-                        else { b = prev_a; pc.n[2] = end > b ? (size_t)(end - std::max(b, first)) : 0; pc.n[1] = bytes - pc.n[2]; }
-                    }
-                    // (page-locked by someone else - the caller - in whole or in part: left as it is.  Looked at OUTSIDE the range
-                    //  registered last: a neighbour's page that this thread locked itself says nothing about the caller)
-                    const bool pinned_head = b > a && is_pinned_host((const uint8_t *)std::max(a, first)), pinned_tail = b > a && is_pinned_host((const uint8_t *)std::min(b, end) - 1);
-                    if (pinned_head || pinned_tail) {
-                        st = pinned_head && pinned_tail && pc.n[1] == bytes ? 3 : 2;      // the caller's, as a whole (uploaded where it lies) / in part (staged)
-                    } else if (b > a) {
-                        const uint64_t t0 = now_ns();
-                        if (hipHostRegister((void *)a, b - a, hipHostRegisterDefault) == hipSuccess) {
-                            ranges[(size_t)reg] = Range{(void *)a, b - a};
-                            prev_a = a; prev_b = b;
-                            registered_bytes += b - a; register_ns += now_ns() - t0;
-                            st = 1;
-                        } else {
-                            (void)hipGetLastError();              // (someone else's registration in the way, a limit: the worker stages this frame)
-                        }
-                    } else {
-                        st = 1;                                   // wholly inside the page(s) the frame before brought along
-                    }
-                    pieces[(size_t)reg] = pc;
-                }
-                state[reg].store(st, std::memory_order_release);
-                reg++; progressed = true;
-                reg_count.store(reg, std::memory_order_release);
-                { std::lock_guard<std::mutex> lock(mu); }
-                cv.notify_all();
-            }
-            if (!progressed) {
-                std::unique_lock<std::mutex> lock(mu);
-                cv.wait_for(lock, std::chrono::microseconds(200));
-            }
-        }
-        reg_done.store(true);
-        { std::lock_guard<std::mutex> lock(mu); }
-        cv.notify_all();
-    }
-};
-
-}  // namespace jpegenc
-
 extern "C" {
 
 int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frames, size_t frame_len, int num_frames,
@@ -1085,10 +917,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
         std::atomic<int> up_status(JPEGENC_OK);
         auto stage_and_upload = [&](int first, int slot) {
             const int n = num_frames - first < per_round ? num_frames - first : per_round;
-            int nt = usable_cpus() - 2;
-            if (nt > 8) nt = 8;
-            if (nt < 1) nt = 1;
-            if (nt > n) nt = n;
+            const int nt = pool_threads(e->batch_workers, 8, 2, 1, n);
             // in four pieces: the upload of one piece runs while the threads stage the next
             if (hipSetDevice(e->device) != hipSuccess) { up_status.store(JPEGENC_ERR_HIP); return; }
             const int pieces = n >= 32 ? 4 : 1;
@@ -1110,10 +939,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
             }
             if (hipEventRecord(sb.done[slot], sb.up) != hipSuccess) up_status.store(JPEGENC_ERR_HIP);
         };
-        {
-            int nt = usable_cpus() - 2;
-            e->stagers.ensure_threads((nt > 8 ? 8 : nt < 1 ? 1 : nt) + 1);           // the copiers + the task that drives a round's pieces
-        }
+        e->stagers.ensure_threads(pool_threads(e->batch_workers, 8, 2, 1, 1 << 20) + 1);   // the copiers + the task that drives a round's pieces
         stage_and_upload(0, 0);
         for (int first = 0, r = 0; first < num_frames; first += per_round, r++) {
             const int slot = r & 1, n = num_frames - first < per_round ? num_frames - first : per_round;
@@ -1121,7 +947,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
             JPEGENC_HIP(hipEventSynchronize(sb.done[slot]));
             const bool more = first + per_round < num_frames;
             if (more) e->stagers.submit(1, [&stage_and_upload, first, per_round, slot] { stage_and_upload(first + per_round, slot ^ 1); });
-            rc = jpegenc_encoder_encode_batch_device(e, sb.d[slot], frame_bytes, n, width, height, color_type, sink, users + first);
+            rc = encode_batch_device_from(e, sb.d[slot], frame_bytes, n, width, height, color_type, sink, users + first, first);
             if (more) e->stagers.wait(1);
             if (rc) return rc;
         }
@@ -1132,11 +958,11 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     static const int env_workers = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_BATCH_WORKERS"); return v ? atoi(v) : 0; }();   // diagnosis: worker sweep
     // With the scans coded on the device a worker's time is the link's: from four workers on the link is busy (1000 1080p frames:
     // 9 180 frames/s with 4 workers, 9 230 with 16; 128 4K frames: 17.2 / 17.1 Gpixel/s) and every further worker is a CPU kept
-    // spinning in the runtime - eight is within 1 % of the best at half the CPUs (tools/diag/r04_quota.sh,
-    // profiles/r04_host_upload_paths.txt).  Host entropy coding is CPU work per frame: the full pool.
-    const int pool_cap = e->cfg.device_entropy && e->max_batch_workers > 8 ? 8 : e->max_batch_workers;
-    int workers = batch_pool_size(pool_cap, num_frames);
-    if (env_workers > 0 && e->max_batch_workers == 16) workers = env_workers < num_frames ? env_workers : num_frames;
+    // busy for nothing - a rank of an 8-GPU host has 1/8 of its CPUs (profiles/r06_rank_cpu_budget.txt).  Host entropy
+    // coding is CPU work per frame: the full pool.  jpegenc_encoder_set_batch_workers overrides either.
+    const int pool_cap = e->cfg.device_entropy && e->max_batch_workers > kDeviceEntropyWorkers ? kDeviceEntropyWorkers : e->max_batch_workers;
+    int workers = batch_pool_size(e->batch_workers, pool_cap, num_frames);
+    if (env_workers > 0 && e->batch_workers == 0 && e->max_batch_workers == 16) workers = env_workers < num_frames ? env_workers : num_frames;
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
     while ((int)e->workers.size() < workers) e->workers.emplace_back(new DeviceCtx());

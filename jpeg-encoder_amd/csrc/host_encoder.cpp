@@ -68,6 +68,16 @@ int jpegenc_encoder_set_numa_bind(jpegenc_encoder *e, int enable) {
     e->numa_bind = enable != 0;
     return JPEGENC_OK;
 }
+int jpegenc_encoder_set_batch_workers(jpegenc_encoder *e, int threads) {
+    REQUIRE(e);
+    if (threads < 0 || threads > 64) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "batch workers must be 0 (automatic) .. 64");
+    if (threads != e->batch_workers) {
+        e->batch_workers = threads;
+        e->release_idle_threads();
+    }
+    return JPEGENC_OK;
+}
+int jpegenc_encoder_batch_workers(const jpegenc_encoder *e) { return e ? e->batch_workers : -1; }
 int jpegenc_encoder_set_batch_upload(jpegenc_encoder *e, int mode) {
     REQUIRE(e);
     if (mode != JPEGENC_UPLOAD_STAGED && mode != JPEGENC_UPLOAD_REGISTER_AHEAD) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "unknown upload mode");

@@ -377,7 +377,7 @@ struct FrameRun {
             if (p.hist_partials) JPEGENC_HIP(hipMemsetAsync(ctx.d_hist, 0, DeviceCtx::kHistFreqBytes + (size_t)(p.hist_copy_mask + 1u) * 2048u, ctx.stream));
             if (ctx.external_planes) {
                 err = launch_blocks_planes(p, ctx.external_planes, ctx.external_planes_subsampled, c.fdct_variant, ctx.stream);
-                if (err == hipErrorInvalidValue) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane layout not supported on the device (pixel stride 2 with a sampling factor of 4, or a plane of 2 GiB)");
+                if (err == hipErrorInvalidValue) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "plane layout not supported on the device (pixel stride 2 with a sampling factor of 4, a plane of 2 GiB, or planes_subsampled = 2 outside the one-launch kernels)");
                 hist_folded = p.hist_partials != nullptr;
             } else if (launch_blocks_fast(p, 1, c.fdct_variant, ctx.stream, &err)) {
                 hist_folded = p.hist_partials != nullptr;

@@ -244,8 +244,8 @@ struct Restart {
     }
 };
 
-// The CPUs this process may actually use at once: the smallest of the hardware threads, the PROCESS's affinity mask (the thread-group
-// leader's: a caller that pins its own thread for a moment must not shrink every handle's pools) and the container's CPU-time quota
+// The CPUs this process may actually use at once: the smallest of the hardware threads, the affinity mask (the thread-group
+// leader's or the calling thread's, whichever is wider) and the container's CPU-time quota
 // (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  hardware_concurrency() alone says 256 inside a container that is
 // throttled to 16 CPUs' worth - sixteen busy-waiting batch workers plus the caller then run into the quota, the kernel freezes the
 // whole process until the next 100 ms period, and a batch takes half as long again (profiles/r04_cpu_quota.txt: the 9-16 Gpixel/s
@@ -254,8 +254,13 @@ struct Restart {
 inline int usable_cpus_now() {
     long cpus = (long)std::thread::hardware_concurrency();
     if (cpus <= 0) cpus = 4;
+    // (the larger of the thread-group leader's mask and the calling thread's: a main thread pinned to one core - an event loop, a
+    //  launcher - must not collapse the pools of worker threads that may run anywhere, nor a pinned caller those of the process)
     cpu_set_t set;
-    if (sched_getaffinity(getpid(), sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < cpus) cpus = CPU_COUNT(&set);
+    long allowed = 0;
+    if (sched_getaffinity(getpid(), sizeof set, &set) == 0) allowed = CPU_COUNT(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > allowed) allowed = CPU_COUNT(&set);
+    if (allowed > 0 && allowed < cpus) cpus = allowed;
     long long quota = -1, period = 100000;
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                     // "max 100000" or "1600000 100000"
         char q[32] = {0};
@@ -330,15 +335,25 @@ struct ThreadBinding {
     }
 };
 
-// Host threads of a batch's worker pool: at most `cap` (16 per device: what saturates the link, csrc/tools/h2d_staging.cpp), and
-// two fewer than the CPUs the process may use - the caller's thread and the runtime's own need theirs.
-inline int batch_pool_size(int cap, int num_frames) {
-    int w = usable_cpus() - 2;
-    if (w > cap) w = cap;
-    if (w < 2) w = 2;
-    if (w > num_frames) w = num_frames;
+// Host threads of one of a handle's pools for `items` units of work.  user_cap = jpegenc_encoder_set_batch_workers (0: automatic):
+// the threads the handle's batch calls may keep busy at once, the caller's included - every pool of the handle honours it.
+// Automatic: at most auto_cap (what the pool's work is worth: 4 where a worker only feeds the link, 16 for host entropy coding) and
+// `reserve` fewer than the CPUs the process may use (the caller's thread and the runtime's own need theirs), at least `floor`.
+inline int pool_threads(int user_cap, int auto_cap, int reserve, int floor, int items) {
+    int w;
+    if (user_cap > 0) {
+        w = user_cap;
+    } else {
+        w = usable_cpus() - reserve;
+        if (w > auto_cap) w = auto_cap;
+        if (w < floor) w = floor;
+    }
+    if (w > items) w = items;
     return w < 1 ? 1 : w;
 }
+constexpr int kDeviceEntropyWorkers = 4;      // automatic pool of a host-fed batch whose scans the device codes (host_batch.cpp, jpegenc_encoder_encode_batch)
+// the workers of jpegenc_encoder_encode_batch and the pooled per-frame paths (one in-flight frame each)
+inline int batch_pool_size(int user_cap, int auto_cap, int num_frames) { return pool_threads(user_cap, auto_cap, 2, 2, num_frames); }
 
 // A side stream whose copies must overlap the work of a handle's main stream: created at the highest priority, because
 // every priority has its own hardware queues - two streams of equal priority may be dealt onto the SAME queue (4 per
@@ -678,6 +693,7 @@ class BackgroundPool;
 struct BatchBuffers {
     WorkerThreads *helpers = nullptr;     // the handle's persistent host threads (set by the batch entry points), for a round's host step
     BackgroundPool *assemblers = nullptr; // ... and the ones that assemble the files of a round behind the pipeline's back
+    int thread_cap = 0;                   // jpegenc_encoder_set_batch_workers of the handle (0: automatic), for the pools above
     void *d_coeffs = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_packed = nullptr;      // d_packed: a round's scans back to back
     uint64_t *d_pos = nullptr;
     uint32_t *d_len = nullptr, *h_len = nullptr;
@@ -980,12 +996,16 @@ struct jpegenc_encoder {
     jpegenc::BackgroundPool stagers;                   // the threads that copy a round of small host frames into page-locked memory while the round before is coded
     BatchBuffers batch;                                  // device-resident batch API
     SmallBatchBuffers small;                             // batches of small frames
-    int max_batch_workers = 16;                          // host threads of jpegenc_encoder_encode_batch
+    int max_batch_workers = 16;                          // automatic sizing: upper bound of the batch worker pool (a multi-device child: its share of the CPUs)
+    int batch_workers = 0;                               // jpegenc_encoder_set_batch_workers: host threads the handle's batch calls keep busy at once (0 = automatic)
     bool numa_bind = jpegenc::numa_bind_default();      // those threads run on the NUMA node of the device (jpegenc_encoder_set_numa_bind)
     int batch_upload = 0;                               // jpegenc_encoder_set_batch_upload: 0 staged, 1 register-ahead
     // jpegenc_encoder_encode_batch_multi: one child encoder per entry of `devices` (its own workers, streams,
     // pinned staging and device buffers), kept across calls
     std::vector<std::unique_ptr<jpegenc_encoder>> shards;
+    // the pools' threads end (they are made again, as many as the budget then allows, by the next batch call): after the thread
+    // budget has changed - a pool only ever grows, and its idle threads would still take tasks
+    void release_idle_threads() { threads.stop(); assemblers.stop(); stagers.stop(); }
 };
 
 

@@ -117,9 +117,16 @@ static int encode_batch_multi(jpegenc_encoder *e, const int *devices, int num_de
             if (!child) return fail(JPEGENC_ERR_HIP, "out of memory");
             child->device = devices[d];
         }
+        // everything the parent was told about how batches run applies to each device's share of the batch
         child->cfg = e->cfg;
         child->max_batch_workers = per_shard;
+        if (child->batch_workers != e->batch_workers) { child->batch_workers = e->batch_workers; child->release_idle_threads(); }
         child->numa_bind = e->numa_bind;
+        child->batch_upload = e->batch_upload;
+        if (child->reg_cache.budget != e->reg_cache.budget) {
+            if (child->reg_cache.held > e->reg_cache.budget) child->reg_cache.clear();
+            child->reg_cache.budget = e->reg_cache.budget;
+        }
     }
     std::vector<int> status((size_t)num_devices, JPEGENC_OK);
     std::vector<std::string> messages((size_t)num_devices);
@@ -156,6 +163,19 @@ int jpegenc_encoder_encode_batch_multi(jpegenc_encoder *e, const int *devices, i
                                        jpegenc_write_fn sink, void *const *users) {
     REQUIRE(e);
     return encode_batch_multi(e, devices, num_devices, frames, frame_len, num_frames, width, height, color_type, sink, users);
+}
+
+int jpegenc_encoder_batch_shard_info(jpegenc_encoder *e, int shard, int *device, int *batch_workers, int *upload_mode,
+                                     size_t *register_cache_bytes, int *pool_workers) {
+    if (!e) return -fail(JPEGENC_ERR_INVALID_ARGUMENT, "null encoder");
+    const int n = (int)e->shards.size();
+    const jpegenc_encoder *c = shard >= 0 && shard < n ? e->shards[(size_t)shard].get() : nullptr;
+    if (device) *device = c ? c->device : -1;
+    if (batch_workers) *batch_workers = c ? c->batch_workers : 0;
+    if (upload_mode) *upload_mode = c ? c->batch_upload : 0;
+    if (register_cache_bytes) *register_cache_bytes = c ? c->reg_cache.budget : 0;
+    if (pool_workers) *pool_workers = c ? (int)c->workers.size() : 0;
+    return n;
 }
 
 int jpegenc_encoder_encode_batch_multi_to_buffers(jpegenc_encoder *e, const int *devices, int num_devices, const uint8_t *const *frames,

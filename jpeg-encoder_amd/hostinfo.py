@@ -160,3 +160,80 @@ def _current_cpu():
         return int(libc.sched_getcpu())
     except Exception:
         return None
+
+
+# ---- CPU budget of a rank (the host side is the limiter of the 8-GPU batch) ------------------------------------------
+def cpu_quota():
+    """CPUs' worth of run time the container's cgroup allows (cpu.max / cfs quota): None = no limit.  The library reads the same
+    files (csrc/host_internal.h usable_cpus)."""
+    try:                                                           # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and float(period) > 0:
+            return float(quota) / float(period)
+        return None
+    except (OSError, ValueError):
+        pass
+    try:                                                           # cgroup v1
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return quota / period if quota > 0 and period > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def usable_cpus():
+    """CPUs this process may keep busy at once: the affinity mask, cut by the cgroup quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    q = cpu_quota()
+    if q:
+        n = min(n, max(1, int(q + 0.999)))
+    return max(n, 1)
+
+
+def rank_cpu_share(local_world_size=None):
+    """Host threads ONE rank may keep busy when `local_world_size` processes (default: LOCAL_WORLD_SIZE, which torchrun exports
+    before any GPU call; 1 without it) share this host's affinity mask and CPU quota: the equal share, at least 1.  What a rank
+    passes to Encoder.set_batch_workers - the library sizes its pools by the whole quota, it cannot see its neighbours."""
+    if local_world_size is None:
+        try:
+            local_world_size = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+        except ValueError:
+            local_world_size = 1
+    return max(1, usable_cpus() // max(int(local_world_size), 1))
+
+
+def cpu_stat():
+    """(CPU seconds used, CFS periods throttled) so far: of the cgroup where cpu.stat is readable (the whole container), else of
+    this process (throttled = None)."""
+    try:
+        d = {}
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, _, v = line.partition(" ")
+            d[k] = int(v)
+        return d["usage_usec"] / 1e6, d.get("nr_throttled", 0)
+    except (OSError, ValueError, KeyError):
+        t = os.times()
+        return t.user + t.system, None
+
+
+def thread_cpu_times():
+    """{tid: (comm, user seconds, system seconds)} of this process's threads (/proc/self/task): which threads a busy CPU belongs to."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        tids = os.listdir("/proc/self/task")
+    except OSError:
+        return out
+    for tid in tids:
+        try:
+            txt = open(f"/proc/self/task/{tid}/stat").read()
+        except OSError:
+            continue
+        r = txt.rfind(")")
+        comm = txt[txt.find("(") + 1:r]
+        f = txt[r + 2:].split()
+        out[int(tid)] = (comm, int(f[11]) / tick, int(f[12]) / tick)
+    return out

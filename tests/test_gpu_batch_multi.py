@@ -851,3 +851,128 @@ def test_register_ahead_uploads(binding, oracle, synth):
     assert lib.jpegenc_host_unregister(block.ctypes.data) == 0
     e.set_batch_upload(binding.UPLOAD_STAGED)
     assert e.encode_batch(frames, w, h, binding.RGB) == want
+
+
+def test_register_ahead_repeated_and_returning_frames(binding, oracle, synth):
+    """Register-ahead with batches that name the same memory more than once - [A] * N (the usual benchmark pattern), [A, B, A],
+    frames smaller than a page apart: a registration is shared by every frame that lies in it and must stay until the last of them
+    has uploaded (round 5 released it after the next frame).  Same files as the oracle, nothing left page-locked."""
+    import ctypes as C
+    w, h = 1000, 701
+    fb = w * h * 3
+    a = np.ascontiguousarray(synth.lcg_image(w, h, 3, 901).reshape(-1))
+    b = np.ascontiguousarray(synth.lcg_image(w, h, 3, 902).reshape(-1))
+    want_a, want_b = oracle.encode_jpeg(a, w, h, oracle.RGB, 85), oracle.encode_jpeg(b, w, h, oracle.RGB, 85)
+    lib = binding.lib()
+    lib.jpegenc_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.jpegenc_host_unregister.argtypes = [C.c_void_p]
+    with binding.Encoder(85) as e:
+        e.set_batch_upload(binding.UPLOAD_REGISTER_AHEAD)
+        for _ in range(3):
+            assert e.encode_batch([a] * 40, w, h, binding.RGB) == [want_a] * 40
+            assert e.encode_batch([a, b, a], w, h, binding.RGB) == [want_a, want_b, want_a]
+            assert e.encode_batch([a, b] * 15 + [a], w, h, binding.RGB) == [want_a, want_b] * 15 + [want_a]
+        # overlapping windows of one array, 1 000 bytes apart: every frame lies almost wholly inside its predecessors' pages
+        block = np.empty(fb + 24 * 1000, dtype=np.uint8)
+        block[:] = np.resize(a, block.size)
+        windows = [block[i * 1000: i * 1000 + fb] for i in range(24)]
+        want_w = [oracle.encode_jpeg(wd, w, h, oracle.RGB, 85) for wd in windows]
+        assert e.encode_batch(windows, w, h, binding.RGB) == want_w
+        assert e.encode_batch(windows[::-1], w, h, binding.RGB) == want_w[::-1]
+        for arr in (a, b, block):                                   # nothing of ours is still locked
+            assert lib.jpegenc_host_register(arr.ctypes.data, arr.nbytes) == 0
+            assert lib.jpegenc_host_unregister(arr.ctypes.data) == 0
+
+
+def test_set_batch_workers_caps_every_pool(binding, oracle, synth):
+    """jpegenc_encoder_set_batch_workers: the handle's batch calls keep at most that many host threads busy, the caller's included -
+    a fresh handle told 2 has had 2 workers after a host-fed batch (1: the caller's thread alone), whatever the CPU count says; the
+    files do not depend on it; device-resident batches, thumbnails and per-frame optimised tables run under the same cap."""
+    import torch
+    w, h, n = 1280, 720, 12                                         # 2.76 MB per frame: the worker pool, not the staged thumbnail rounds
+    frames = [np.ascontiguousarray(synth.lcg_image(w, h, 3, 40 + i)) for i in range(n)]
+    want = [oracle.encode_jpeg(f, w, h, oracle.RGB, 80) for f in frames]
+    for cap in (2, 1, 3):
+        with binding.Encoder(80) as e:
+            assert e.batch_workers() == 0
+            e.set_batch_workers(cap)
+            assert e.batch_workers() == cap
+            assert e.encode_batch(frames, w, h, binding.RGB) == want
+            assert len(e.batch_worker_info()) == cap
+            # the device-resident batch (rounds, background assembly) and its per-frame optimised tables under the same budget
+            d = torch.from_numpy(np.stack(frames)).cuda()
+            assert e.encode_batch_device(d.data_ptr(), w * h * 3, n, w, h, binding.RGB) == want
+            e.set_optimized_huffman_tables(True)
+            want_opt = [oracle.encode_jpeg(f, w, h, oracle.RGB, 80, optimize=True) for f in frames[:4]]
+            assert e.encode_batch_device(d.data_ptr(), w * h * 3, 4, w, h, binding.RGB) == want_opt
+    # thumbnails: rounds staged by the handle's copier threads
+    tw, th, tn = 160, 120, 40
+    thumbs = [np.ascontiguousarray(synth.lcg_image(tw, th, 3, 300 + i)) for i in range(tn)]
+    want_t = [oracle.encode_jpeg(f, tw, th, oracle.RGB, 80) for f in thumbs]
+    with binding.Encoder(80) as e:
+        e.set_batch_workers(1)
+        assert e.encode_batch(thumbs, tw, th, binding.RGB) == want_t
+        e.set_batch_workers(0)                                      # back to automatic: at most 4 workers with device entropy coding
+        assert e.encode_batch(frames, w, h, binding.RGB) == want
+        assert 1 <= len(e.batch_worker_info()) <= 4
+    with pytest.raises(binding.JpegEncError):
+        with binding.Encoder(80) as e:
+            e.set_batch_workers(65)
+
+
+def test_multi_device_children_inherit_the_batch_settings(binding, oracle, synth):
+    """jpegenc_encoder_encode_batch_multi hands every per-device child what the parent was told about batches: the thread budget, the
+    upload mode and the register-cache budget (round 5 copied only the configuration and the NUMA switch).  Device 0 listed twice."""
+    w, h, n = 1280, 720, 10
+    frames = [np.ascontiguousarray(synth.lcg_image(w, h, 3, 70 + i)) for i in range(n)]
+    want = [oracle.encode_jpeg(f, w, h, oracle.RGB, 80) for f in frames]
+    outs = [np.empty(2 << 20, dtype=np.uint8) for _ in frames]
+    with binding.Encoder(80) as e:
+        e.set_batch_workers(2)
+        e.set_batch_upload(binding.UPLOAD_REGISTER_AHEAD)
+        e.set_register_cache(64 << 20)
+        lens = e.encode_batch_into(frames, w, h, binding.RGB, outs, devices=[0, 0])
+        assert [outs[i][:lens[i]].tobytes() for i in range(n)] == want
+        info = e.batch_shard_info()
+        assert len(info) == 2
+        for child in info:
+            assert child == {"device": 0, "batch_workers": 2, "upload_mode": binding.UPLOAD_REGISTER_AHEAD, "register_cache_bytes": 64 << 20, "pool_workers": 2}
+        # changed on the parent: the children follow at the next call
+        e.set_batch_workers(3)
+        e.set_batch_upload(binding.UPLOAD_STAGED)
+        e.set_register_cache(0)
+        lens = e.encode_batch_into(frames, w, h, binding.RGB, outs, devices=[0, 0])
+        assert [outs[i][:lens[i]].tobytes() for i in range(n)] == want
+        for child in e.batch_shard_info():
+            assert (child["batch_workers"], child["upload_mode"], child["register_cache_bytes"]) == (3, binding.UPLOAD_STAGED, 0)
+            assert child["pool_workers"] == 3
+
+
+def test_thumbnail_batch_names_the_failing_frame_in_the_callers_numbering(binding, synth):
+    """A staged batch of thumbnails runs in rounds; a sink that fails in a round after the first is reported as "frame K" with K counted
+    from the start of the batch, and every frame below K has been delivered whole."""
+    import ctypes as C
+    tw, th = 640, 360                                               # 691 200 bytes: 64 MB rounds hold 97 frames
+    n, bad = 230, 201
+    base = np.ascontiguousarray(synth.lcg_image(tw, th, 3, 5))
+    frames = [base] * n
+    got = [0] * n
+
+    def sink(user, ptr, nbytes):
+        k = user or 0
+        if k == bad:
+            return 1
+        got[k] += nbytes
+        return 0
+    cb = binding.WRITE_FN(sink)
+    lib = binding.lib()
+    fn = lib.jpegenc_encoder_encode_batch
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, binding.WRITE_FN, C.POINTER(C.c_void_p)]
+    ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+    users = (C.c_void_p * n)(*range(n))
+    with binding.Encoder(80) as e:
+        single = len(e.encode(base, tw, th, binding.RGB))
+        assert fn(e._h, ptrs, base.size, n, tw, th, binding.RGB, cb, users) == binding.ERR_WRITE
+        message = lib.jpegenc_last_error().decode()
+        assert message.startswith(f"frame {bad}:"), message
+        assert all(g == single for g in got[:bad])
