@@ -438,6 +438,9 @@ def main():
     ap.add_argument("--c3-passes", type=int, default=7, help="timed passes of the config-3 batch (min / median / max are reported)")
     ap.add_argument("--c3-register-ahead", action="store_true",
                     help="also time the config-3 batch with jpegenc_encoder_set_batch_upload(REGISTER_AHEAD) (not under rocprofv3: see profiles/r05_upload_modes.txt)")
+    ap.add_argument("--c3-workers", type=int, default=-1,
+                    help="thread budget of the config-3 leg (jpegenc_encoder_set_batch_workers); -1 = automatic alone, the rank's share of "
+                         "the host's CPUs (usable CPUs // LOCAL_WORLD_SIZE, at most 4) in a multi-rank run")
     ap.add_argument("--numa-bind", type=int, default=0, choices=(0, 1),
                     help="headline variant of the config-3 leg: batch worker threads bound to the NUMA node of the rank's GPU "
                          "(jpegenc_encoder_set_numa_bind); the other setting is timed beside it (c3_batch.variants)")
@@ -919,9 +922,22 @@ def main():
         c3, setup_error = None, None
         enc3 = pool = pinned_buf = pinned = None
         idx, pageable, outs3, my_link = [], [], [], {}
+        try:
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        except ValueError:
+            local_world = world
+        workers3, last_call = 0, {}
         try:                                                        # ---- phase 1 (local): this rank's shard and buffers
             enc3 = binding.Encoder(batch.C3_QUALITY, device=local_rank)         # q=80 -> default F_2_2 (encoder.rs:256-260)
             enc3.set_numa_bind(bool(args.numa_bind))
+            # A rank's thread budget: the library sizes its pools by the whole affinity mask / cgroup quota - it cannot see the other
+            # ranks - so the ranks of one host divide it (LOCAL_WORLD_SIZE: torchrun exports it before any GPU call).  Alone: automatic
+            # (at most 4 workers where the device codes the scans); shared: the equal share, at most those 4, at least 1.
+            if args.c3_workers >= 0:
+                workers3 = args.c3_workers
+            elif local_world > 1:
+                workers3 = max(1, min(4, hostinfo.rank_cpu_share(local_world)))
+            enc3.set_batch_workers(workers3)
             cap3 = 1 << 20
             idx = binding.shard_frames(args.c3_frames, world, rank)
             outs3 = [np.zeros(cap3, dtype=np.uint8) for _ in range(len(idx))]  # caller-owned output buffers, reused (and touched: no page faults in the timed pass)
@@ -950,7 +966,12 @@ def main():
         def encode_frames(frames):                                          # -> views of the files, no copies
             if setup_error is not None:
                 raise setup_error
+            c0, s0, t0c = os.times(), hostinfo.cpu_stat(), time.perf_counter()
             lens3 = enc3.encode_batch_into(frames, batch.C3_W, batch.C3_H, binding.RGB, outs3)
+            c1, s1, wall = os.times(), hostinfo.cpu_stat(), time.perf_counter() - t0c
+            # (what the LAST call - the timed pass - cost this rank's process in CPUs, and the container in throttled CFS periods)
+            last_call.update(cpus_busy=(c1.user - c0.user + c1.system - c0.system) / wall if wall > 0 else 0.0,
+                             throttled=(s1[1] - s0[1]) if s1[1] is not None and s0[1] is not None else -1)
             return [outs3[i][:lens3[i]] for i in range(len(frames))]
 
         def make_frame(k):
@@ -971,19 +992,26 @@ def main():
                           "jpegenc_encoder_encode_batch_to_buffers on its GPU; seconds = MAX over ranks; digest = checksum of the per-frame "
                           "SHA-256s in frame order")
             c3["scaling"] = "strong"
+            c3["rank_thread_budget"] = {"local_world_size": local_world, "usable_cpus": hostinfo.usable_cpus(), "cpu_quota": hostinfo.cpu_quota(),
+                                        "set_batch_workers": workers3,
+                                        "rule": "alone: automatic (<= 4 workers with device entropy coding); N ranks on a host: min(4, usable_cpus // N), at least 1"}
             c3["numa_bind"] = bool(args.numa_bind)
             c3["frames_in"] = "page-locked memory" if primary_frames is pinned else "pageable memory"
             first = [bytes(mine[k]) for k in idx[:64]]                         # (outs3 is reused by the passes below)
 
             def per_rank_report(seconds_mine):
                 """every rank's frames / s and upload GB/s against the h2d rate it measured with all ranks copying at once"""
-                t = batch.per_rank_table(ddist, [n_mine, seconds_mine, float(my_link.get("h2d") or 0.0)], world, rank, dev, force)
+                pool_now = len(enc3.batch_worker_info()) if enc3 is not None else 0
+                t = batch.per_rank_table(ddist, [n_mine, seconds_mine, float(my_link.get("h2d") or 0.0), float(workers3), float(pool_now),
+                                                 float(last_call.get("cpus_busy", 0.0)), float(last_call.get("throttled", -1))], world, rank, dev, force)
                 rows = []
                 for r in range(world):
-                    fr, sec, lk = t[r]
+                    fr, sec, lk, wset, wpool, busy, thr = t[r]
                     gbps = fr * fb / sec / 1e9 if sec > 0 else None
                     rows.append({"rank": r, "frames": int(fr), "seconds": round(float(sec), 6),
                                  "frames_per_s": round(fr / sec, 1) if sec > 0 else None,
+                                 "workers": int(wpool), "set_batch_workers": int(wset), "cpus_busy": round(float(busy), 2),
+                                 "cfs_throttled_periods": int(thr) if thr >= 0 else None,
                                  "h2d_GBps": round(gbps, 2) if gbps else None, "link_h2d_GBps": round(float(lk), 1) if lk else None,
                                  "frac": round(gbps / lk, 4) if gbps and lk else None})      # (> 1: the rank beat the plain copies it measured the link with)
                 fps = [x["frames_per_s"] for x in rows if x["frames_per_s"]]

@@ -111,6 +111,8 @@ extern "C" {
                                       coeff_frame_stride: usize, d_out: *mut c_void, out_frame_stride: usize, d_out_lengths: *mut u32,
                                       d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
 
+    pub fn jpegenc_pixels_scan_dense(layout: *const jpegenc_layout, scan_bytes: usize) -> c_int;
+
     pub fn jpegenc_encoder_new(quality: c_int) -> *mut jpegenc_encoder;
     pub fn jpegenc_encoder_free(e: *mut jpegenc_encoder);
     pub fn jpegenc_encoder_set_device(e: *mut jpegenc_encoder, device: c_int) -> c_int;

@@ -246,8 +246,14 @@ int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num
  * up - where a block outgrows its 507-bit strip in most workgroups and the two calls are 25-45 % faster
  * (profiles/r04_fused_quality_matrix.txt): this entry point is stateless and always takes the one kernel, a caller that knows its
  * content calls the pair instead; the Encoder handles route by the size of the last frame of the same size and settings.
+ * MEASURED CROSSOVER (4K RGB 4:2:0, 16 frames per launch, microseconds per frame, one kernel / the pair): noise q90 26.9 / 28.1, q95 38.8 / 30.9,
+ * q98 57.1 / 38.5, q100 61.1 / 42.1; photo-like q98 21.2 / 24.1, q100 27.0 / 27.0; smooth content never crosses (q100 16.7 / 19.9).  The rule
+ * the handles use is available to stateless callers: jpegenc_pixels_scan_dense(layout, scan_bytes) is 1 when a frame of this layout whose
+ * scan came to `scan_bytes` (d_out_lengths[f] of an earlier frame of the stream, either path - the bytes are the same) is past the crossover,
+ * i.e. codes to more than 390 bits per block on average: call the pair for the following frames while it says so.
  * Asynchronous on hip_stream; a caller with frames to spare alternates between two streams. */
 int jpegenc_pixels_scan_fused(int width, int height, int color_type, int h_sampling, int v_sampling);
+int jpegenc_pixels_scan_dense(const jpegenc_layout *layout, size_t scan_bytes);
 int jpegenc_pixels_scan_device(const void *d_pixels, size_t pixel_frame_stride, int num_frames, int width, int height,
                                int color_type, int h_sampling, int v_sampling, const jpegenc_qtable tables[2],
                                int fdct_variant, int restart_interval, const jpegenc_huffman_spec (*huffman)[2],

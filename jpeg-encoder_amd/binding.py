@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "jpegenc_qtable_init", "jpegenc_bytes_per_pixel", "jpegenc_sampling_factor_from_factors", "jpegenc_layout_init",
     "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_blocks_stream_release", "jpegenc_histogram_device",
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
-    "jpegenc_pixels_scan_fused", "jpegenc_pixels_scan_device",
+    "jpegenc_pixels_scan_fused", "jpegenc_pixels_scan_dense", "jpegenc_pixels_scan_device",
     "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_register_cache", "jpegenc_encoder_set_numa_bind", "jpegenc_encoder_set_batch_upload", "jpegenc_encoder_set_batch_round_frames",
     "jpegenc_encoder_set_batch_workers", "jpegenc_encoder_batch_workers", "jpegenc_encoder_batch_shard_info",
     "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
@@ -361,6 +361,13 @@ def pixels_scan_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, heig
     check(lib().jpegenc_pixels_scan_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, color_type, hs, vs, q,
                                            variant, restart_interval, tables, d_coeffs_ptr, coeff_frame_stride, d_out_ptr,
                                            out_frame_stride, d_lengths_ptr, d_workspace_ptr, workspace_bytes, stream_ptr))
+
+
+def pixels_scan_dense(layout, scan_bytes):
+    """jpegenc_pixels_scan_dense: a frame of this layout whose scan came to scan_bytes is dense content - the two-kernel pair is faster."""
+    f = lib().jpegenc_pixels_scan_dense
+    f.argtypes = [C.POINTER(Layout), C.c_size_t]
+    return bool(f(C.byref(layout), int(scan_bytes)))
 
 
 def pixels_scan_fused(width, height, color_type, hs, vs):

@@ -429,6 +429,12 @@ int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num
 }
 
 /* pixels in HBM -> the entropy-coded interleaved baseline scan in HBM */
+// the handles' dense-content rule (DeviceCtx::dense_last_time, host_internal.h) for stateless callers of the raw entry point
+int jpegenc_pixels_scan_dense(const jpegenc_layout *layout, size_t scan_bytes) {
+    if (!layout || !layout->total_blocks) return 0;
+    return (uint64_t)scan_bytes * 8u > kDenseBitsPerBlock * layout->total_blocks ? 1 : 0;
+}
+
 int jpegenc_pixels_scan_fused(int width, int height, int color_type, int hs, int vs) {
     jpegenc_layout L;
     if (jpegenc_layout_init(&L, width, height, color_type, hs, vs, JPEGENC_ORDER_MCU) != JPEGENC_OK) return 0;

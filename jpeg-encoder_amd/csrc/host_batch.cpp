@@ -651,6 +651,7 @@ static int encode_device_frames_pooled(jpegenc_encoder *e, const void *d_frames,
         if (w > 0) bind_thread_near_device(e->device, e->numa_bind);
         DeviceCtx &ctx = *e->workers[(size_t)w];
         ctx.batch_worker = true;
+        TimerSlackGuard slack;
         int r = ctx.open(e->device);
         while (r == JPEGENC_OK) {
             const int i = next.fetch_add(1);
@@ -692,6 +693,7 @@ static int encode_planes_frames_pooled(jpegenc_encoder *e, int jct, int width, i
         if (w > 0) bind_thread_near_device(e->device, e->numa_bind);
         DeviceCtx &ctx = *e->workers[(size_t)w];
         ctx.batch_worker = true;
+        TimerSlackGuard slack;
         int r = ctx.open(e->device);
         for (;;) {
             const int i = next.fetch_add(1);
@@ -976,6 +978,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
         if (w > 0) bind_thread_near_device(e->device, e->numa_bind);   // (opt-in) spawned workers; the caller's own affinity is left alone
         DeviceCtx &ctx = *e->workers[(size_t)w];
         ctx.batch_worker = true;
+        TimerSlackGuard slack;
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= num_frames || status.load() != JPEGENC_OK) break;

@@ -103,6 +103,10 @@ size_t scan_workspace_size(const jpegenc_layout &L, const jpegenc_scan &sc, int 
 size_t scan_max_bytes(const jpegenc_layout &L, const jpegenc_scan &sc);
 
 int ensure_device_ready(int device);
+// Dense content: blocks that code to more than this many bits on average outgrow their strips in most workgroups of the pixels -> bits
+// kernel and the block kernel + k_block_code pair is faster (profiles/r04_fused_quality_matrix.txt; DeviceCtx::dense_last_time,
+// jpegenc_pixels_scan_dense).
+constexpr uint64_t kDenseBitsPerBlock = 390;
 bool is_pinned_host_range(const void *p, size_t bytes);
 bool is_pinned_host(const void *p);      // page-locked host memory (hipHostMalloc / hipHostRegister / jpegenc_host_*): DMA reads it in place
 

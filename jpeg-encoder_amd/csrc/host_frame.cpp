@@ -678,7 +678,7 @@ struct FrameRun {
         // the piece with index pieces_done has arrived
         auto wait_for_piece = [&]() -> int {
             if (npieces == 1) JPEGENC_HIP(ctx.wait_stream());
-            else JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[pieces_done]));
+            else JPEGENC_HIP(ctx.wait_for(ctx.chunk_done[pieces_done]));
             pieces_done++;
             return JPEGENC_OK;
         };
@@ -784,7 +784,7 @@ struct FrameRun {
             JPEGENC_HIP(hipEventRecord(ctx.chunk_done[0], ctx.stream));
         }
 
-        auto wait = [&](int k) -> int { JPEGENC_HIP(hipEventSynchronize(ctx.chunk_done[k])); return JPEGENC_OK; };
+        auto wait = [&](int k) -> int { JPEGENC_HIP(ctx.wait_for(ctx.chunk_done[k])); return JPEGENC_OK; };
         return emit_host_coded(c, jct, width, height, L, t, mode, optimize, ctx.h_coeffs, ctx.h_freq, nchunks, chunk_end_mcu, wait, sink, user);
     }
 };

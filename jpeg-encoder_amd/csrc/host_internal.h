@@ -4,6 +4,8 @@
 // Internal: nothing here is part of the C ABI (include/jpegenc_mi355x.h).
 #pragma once
 #include <sched.h>
+#include <sys/prctl.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -355,6 +357,15 @@ constexpr int kDeviceEntropyWorkers = 4;      // automatic pool of a host-fed ba
 // the workers of jpegenc_encoder_encode_batch and the pooled per-frame paths (one in-flight frame each)
 inline int batch_pool_size(int user_cap, int auto_cap, int num_frames) { return pool_threads(user_cap, auto_cap, 2, 2, num_frames); }
 
+// A thread whose waits are nanosleeps (DeviceCtx::sleep_until) wants them to end on time: the default timer slack of a thread is 50 us
+// on top of every sleep.  1 us for the duration of a batch body; the previous value comes back with the guard (the body of worker 0
+// runs on the CALLER's thread).
+struct TimerSlackGuard {
+    long before;
+    TimerSlackGuard() : before(prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0)) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); }
+    ~TimerSlackGuard() { if (before > 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)before, 0, 0, 0); }
+};
+
 // A side stream whose copies must overlap the work of a handle's main stream: created at the highest priority, because
 // every priority has its own hardware queues - two streams of equal priority may be dealt onto the SAME queue (4 per
 // process, in creation order) and then run one after the other (capi_blocks.cpp: jpegenc_blocks_stream lost half its rate so).
@@ -407,7 +418,7 @@ struct DeviceCtx {
     // group - the block kernel + k_block_code are then the faster pair (4K 4:2:0 noise at quality 95: 35.5 against 45 us; at
     // quality 90, 333 bits per block, the one kernel still leads: profiles/r04_fused_dense.txt).  Both paths produce the same
     // bytes, so the size of the last scan of this geometry is a path-independent predictor.
-    static constexpr uint64_t kDenseBitsPerBlock = 390;
+    static constexpr uint64_t kDenseBitsPerBlock = jpegenc::kDenseBitsPerBlock;
     bool dense_last_time(uint64_t geometry, uint64_t total_blocks) const {
         return last_file_geometry == geometry && total_blocks && (uint64_t)last_scan_bytes * 8u > kDenseBitsPerBlock * total_blocks;
     }
@@ -466,21 +477,45 @@ struct DeviceCtx {
     hipGraphExec_t graph_exec = nullptr;
     std::string graph_key, last_key;
 
-    // Wait for everything enqueued on `stream`.  A batch worker BLOCKS (an event created with hipEventBlockingSync: the thread sleeps
-    // until the interrupt) where hipStreamSynchronize busy-waits: sixteen workers that spin while the PCIe link - the bottleneck -
-    // moves their frames burn sixteen CPUs for nothing, which is all a 16-CPU container has.  The single-image path keeps the spin:
-    // it is 10-20 us faster per wait and one thread.
-    hipEvent_t blocking_done = nullptr;
-    hipError_t wait_stream() {
-        static const bool spin = JPEGENC_DIAG_ENV("JPEGENC_SPIN_WAITS") != nullptr;        // diagnosis: the round-3 behaviour
-        if (!batch_worker || spin) return hipStreamSynchronize(stream);
-        if (!blocking_done) {
-            const hipError_t e = hipEventCreateWithFlags(&blocking_done, hipEventDisableTiming | hipEventBlockingSync);
-            if (e != hipSuccess) { blocking_done = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(stream); }
+    // Wait for everything enqueued on `stream` / for an event.  A batch worker SLEEPS: it polls the event (hipEventQuery) between
+    // nanosleeps - first for most of what its last waits took, then in short slices - so that a worker costs CPU time only while it
+    // copies, enqueues or hands a file over.  Rounds 4 and 5 waited on a hipEventBlockingSync event and took that to sleep; it does
+    // not on these hosts: every worker sat at 1.00 CPUs of USER time inside libhsa-runtime64 while the link - the bottleneck - moved
+    // its frame (the runtime's blocking wait is a monitorx / mwaitx loop in user space here: csrc/tools/wait_cost.cpp,
+    // profiles/r06_rank_cpu_budget.txt), which is all a rank of an 8-rank host has (2 CPUs of a 16-CPU quota).  The single-image
+    // path keeps hipStreamSynchronize: it is 10-20 us faster per wait and one thread.
+    hipEvent_t wait_event_ = nullptr;
+    float wait_ema_us = 0.f;             // how long this worker's waits have taken lately (smoothed)
+    hipError_t sleep_until(hipEvent_t ev) {
+        typedef std::chrono::steady_clock clock;
+        hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        const clock::time_point t0 = clock::now();
+        long first_us = (long)(wait_ema_us * 0.6f);
+        if (first_us > 2000) first_us = 2000;
+        if (first_us >= 15) {
+            const timespec ts = {0, first_us * 1000L};
+            nanosleep(&ts, nullptr);
         }
-        hipError_t e = hipEventRecord(blocking_done, stream);
-        if (e == hipSuccess) e = hipEventSynchronize(blocking_done);
+        const timespec slice = {0, 20000L};
+        while ((e = hipEventQuery(ev)) == hipErrorNotReady) nanosleep(&slice, nullptr);
+        const float took = (float)std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t0).count();
+        wait_ema_us = wait_ema_us > 0.f ? 0.75f * wait_ema_us + 0.25f * took : took;
         return e;
+    }
+    static bool spin_waits() { static const bool spin = JPEGENC_DIAG_ENV("JPEGENC_SPIN_WAITS") != nullptr; return spin; }   // diagnosis: the runtime's own waits
+    hipError_t wait_for(hipEvent_t ev) {                 // an event recorded on one of this context's streams
+        if (!batch_worker || spin_waits()) return hipEventSynchronize(ev);
+        return sleep_until(ev);
+    }
+    hipError_t wait_stream() {
+        if (!batch_worker || spin_waits()) return hipStreamSynchronize(stream);
+        if (!wait_event_) {
+            const hipError_t e = hipEventCreateWithFlags(&wait_event_, hipEventDisableTiming);
+            if (e != hipSuccess) { wait_event_ = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(stream); }
+        }
+        const hipError_t e = hipEventRecord(wait_event_, stream);
+        return e == hipSuccess ? sleep_until(wait_event_) : e;
     }
 
     int open(int dev) {
@@ -498,9 +533,7 @@ struct DeviceCtx {
     }
     int allocate_fixed() {
         JPEGENC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        // (a batch worker's events block instead of spinning: see wait_stream)
-        static const bool spin = JPEGENC_DIAG_ENV("JPEGENC_SPIN_WAITS") != nullptr;
-        for (auto &e : chunk_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | (batch_worker && !spin ? hipEventBlockingSync : 0u)));
+        for (auto &e : chunk_done) JPEGENC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         JPEGENC_HIP(hipMalloc(&d_freq, sizeof(uint32_t) * 2 * 2 * 257));
         JPEGENC_HIP(hipHostMalloc((void **)&h_freq, sizeof(uint32_t) * 2 * 2 * 257, hipHostMallocDefault));
         JPEGENC_HIP(hipMalloc((void **)&d_scan_len, sizeof(uint32_t) * kMaxScans));
@@ -592,7 +625,7 @@ struct DeviceCtx {
         (void)hipSetDevice(device);
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
         for (auto &e : chunk_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-        if (blocking_done) { (void)hipEventDestroy(blocking_done); blocking_done = nullptr; }
+        if (wait_event_) { (void)hipEventDestroy(wait_event_); wait_event_ = nullptr; }
         for (auto &e : uploaded) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (kernel_stream) (void)hipStreamDestroy(kernel_stream);
         if (download_stream) (void)hipStreamDestroy(download_stream);

@@ -5,6 +5,11 @@ tag=${1:-rXX}
 cd "$GRAFT_REPO_ROOT" || exit 1
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 tools/profile_round.sh ${tag} > gpurun_out/${tag}_round.log 2>&1
+# the world > 1 branch of bench.py on one GPU, EVERY round (RCCL init, barriers, bookkeeping all-reduces; the next SCALE run must not
+# be that code's first execution): checked against the plain run profile_round.sh has just made
+JPEGENC_BENCH_FORCE_DIST=1 timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 \
+    bench.py --gpus 1 --details /tmp/${tag}_rccl_details.json > gpurun_out/${tag}_bench_torchrun_one_rank_rccl.json 2> gpurun_out/${tag}_bench_torchrun_one_rank_rccl.err
+python3 tools/diag/check_rccl_one_rank.py gpurun_out/${tag}_bench.json gpurun_out/${tag}_bench_torchrun_one_rank_rccl.json | tee gpurun_out/${tag}_rccl_check.json
 python tools/bench_fused.py > gpurun_out/${tag}_fused.jsonl 2>&1; python tools/bench_fused.py 1080p >> gpurun_out/${tag}_fused.jsonl 2>&1
 python tools/bench_latency.py > gpurun_out/${tag}_latency.jsonl 2>&1
 python tools/bench_entropy.py > gpurun_out/${tag}_entropy.jsonl 2>&1

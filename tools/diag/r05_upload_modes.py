@@ -44,6 +44,10 @@ def run(w, h, q, n, batches, contiguous):
                           "frames_per_s_median": round(n / med, 1), "upload_GBps_median": round(n * fb / med / 1e9, 1),
                           "cpus_busy": round(sum(cpus) / sum(walls), 2), "workers": len(e.batch_worker_info())}), flush=True)
 
+if os.environ.get("STACKPROF_CRASH_HANDLER"):            # round 6: a SIGSEGV prints the faulting thread's native stack (tools/diag/stackprof.c)
+    import ctypes
+    ctypes.CDLL("/tmp/libstackprof.so").stackprof_install_crash_handler()
+
 if __name__ == "__main__":
     run(3840, 2160, 90, 128, 7, False)
     run(1920, 1080, 80, 1000, 5, False)

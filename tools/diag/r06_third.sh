@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 6, third GPU session: batch workers that sleep while they wait (DeviceCtx::sleep_until) - thread budgets x frames, the
+# rank's-share affinity masks, 4K frames with 8 MB files, and the batch tests.
+cd "$GRAFT_REPO_ROOT" || exit 1
+out=gpurun_out/${1:-r06c}; mkdir -p $out
+timeout 900 python -m pytest tests/test_gpu_batch_multi.py -x -q -m gpu 2>&1 | tail -3 | tee $out/pytest_batch.log
+timeout 600 python3 tools/diag/r06_worker_cpu.py --passes 12 --workers 0,1,2,3,4,6,8 --pinned 0,1 2>&1 | grep -v amdgpu.ids > $out/worker_cpu.jsonl
+for mask in 0 0-1 0-3; do
+  timeout 400 taskset -c $mask python3 tools/diag/r06_worker_cpu.py --passes 12 --workers 0,2,3,4,6 --pinned 0,1 --label "taskset -c $mask" 2>&1 | grep -v amdgpu.ids > $out/worker_cpu_taskset_$mask.jsonl
+done
+timeout 300 python3 tools/diag/r06_worker_cpu.py --what e2e4k --frames 128 --profile --passes 12 --workers 0,2,4,6,8 --pinned 0,1 2>&1 | grep -v amdgpu.ids > $out/worker_cpu_e2e4k.jsonl
+timeout 300 taskset -c 0-1 python3 tools/diag/r06_worker_cpu.py --what e2e4k --frames 128 --passes 8 --workers 0,4,8 --pinned 0 --label "taskset -c 0-1" 2>&1 | grep -v amdgpu.ids > $out/worker_cpu_e2e4k_taskset_0-1.jsonl

@@ -66,11 +66,11 @@ def fold(path, top=14):
             continue
         n += 1
         per_tid[tid] += 1
-        strip = lambda f: f.rsplit("+", 1)[0]        # noqa: E731
+        strip = lambda f: f.rsplit("+", 1)[0] if "!" in f else f        # noqa: E731  (module+0xoff stays whole: no symbol to fold on)
         leaf[strip(frames[0])] += 1
         a = next((strip(f) for f in frames if "libamdhip64" in f and "!hip" in f), None)
         api[a or "(no HIP entry point on the stack)"] += 1
-        o = next((f if "!" not in f else strip(f) for f in frames if f.startswith("libjpegenc")), None)
+        o = next((strip(f) for f in frames if f.startswith("libjpegenc")), None)
         ours[o or "(no library frame on the stack)"] += 1
     pct = lambda c: [(k, round(100.0 * v / max(n, 1), 1)) for k, v in c.most_common(top)]   # noqa: E731
     return {"samples": n, "threads_sampled": len(per_tid), "leaf_pct": pct(leaf), "hip_entry_pct": pct(api), "library_frame_pct": pct(ours)}
