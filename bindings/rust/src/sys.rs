@@ -68,6 +68,7 @@ pub struct jpegenc_plane {
 }
 
 pub enum jpegenc_encoder {}
+pub enum jpegenc_scan_lanes {}
 pub type jpegenc_write_fn = unsafe extern "C" fn(user: *mut c_void, data: *const u8, len: usize) -> c_int;
 pub type jpegenc_fill_row_fn = unsafe extern "C" fn(user: *mut c_void, y: u16, planes: *const *mut u8);
 pub type jpegenc_tile_callback =
@@ -111,6 +112,13 @@ extern "C" {
                                       coeff_frame_stride: usize, d_out: *mut c_void, out_frame_stride: usize, d_out_lengths: *mut u32,
                                       d_workspace: *mut c_void, workspace_bytes: usize, stream: *mut c_void) -> c_int;
 
+    pub fn jpegenc_scan_lanes_new(out: *mut *mut jpegenc_scan_lanes, device: c_int, width: c_int, height: c_int, color_type: c_int, h: c_int, v: c_int,
+                                  restart_interval: c_int, max_frames_per_call: c_int) -> c_int;
+    pub fn jpegenc_scan_lanes_submit(lanes: *mut jpegenc_scan_lanes, d_pixels: *const c_void, pixel_frame_stride: usize, num_frames: c_int,
+                                     tables: *const jpegenc_qtable, fdct_variant: c_int, huffman: *const [jpegenc_huffman_spec; 2],
+                                     d_out: *mut c_void, out_frame_stride: usize, d_out_lengths: *mut u32, producer_stream: *mut c_void) -> c_int;
+    pub fn jpegenc_scan_lanes_join(lanes: *mut jpegenc_scan_lanes, stream: *mut c_void) -> c_int;
+    pub fn jpegenc_scan_lanes_free(lanes: *mut jpegenc_scan_lanes);
     pub fn jpegenc_pixels_scan_dense(layout: *const jpegenc_layout, scan_bytes: usize) -> c_int;
 
     pub fn jpegenc_encoder_new(quality: c_int) -> *mut jpegenc_encoder;

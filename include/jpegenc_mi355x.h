@@ -260,6 +260,23 @@ int jpegenc_pixels_scan_device(const void *d_pixels, size_t pixel_frame_stride, 
                                void *d_coeffs, size_t coeff_frame_stride, void *d_out, size_t out_frame_stride,
                                uint32_t *d_out_lengths, void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
+/* The two-stream pattern behind ONE call site.  jpegenc_pixels_scan_device ends in a launch-bound tail (run placement, prefix sums, 0xFF
+ * stuffing: a fifth of a call on photo-like 4K frames) that only overlaps the next call's kernel when the calls alternate between two
+ * streams with a workspace each (580 -> 640-660 Gpixel/s).  A caller that cannot restructure its loop lets the library do
+ * it: a jpegenc_scan_lanes owns two streams and two workspaces (and the coefficient scratch of layouts the one kernel does not take) for
+ * one geometry; submit() number k runs on lane k & 1 - behind everything `producer_stream` (the stream the pixels are produced on; NULL =
+ * the default stream) held when it was called, and behind submit k - 2 - and returns at once; join() makes `hip_stream` wait for
+ * everything submitted so far.  Every submit needs its own d_out / d_out_lengths until a join has been waited for; same bytes and lengths
+ * as jpegenc_pixels_scan_device (it is what each lane calls).  max_frames_per_call sizes the workspaces. */
+typedef struct jpegenc_scan_lanes jpegenc_scan_lanes;
+int  jpegenc_scan_lanes_new(jpegenc_scan_lanes **out, int device, int width, int height, int color_type, int h_sampling, int v_sampling,
+                            int restart_interval, int max_frames_per_call);
+int  jpegenc_scan_lanes_submit(jpegenc_scan_lanes *lanes, const void *d_pixels, size_t pixel_frame_stride, int num_frames,
+                               const jpegenc_qtable tables[2], int fdct_variant, const jpegenc_huffman_spec (*huffman)[2],
+                               void *d_out, size_t out_frame_stride, uint32_t *d_out_lengths, void *producer_stream);
+int  jpegenc_scan_lanes_join(jpegenc_scan_lanes *lanes, void *hip_stream);
+void jpegenc_scan_lanes_free(jpegenc_scan_lanes *lanes);
+
 /* ---- Encoder-shaped API (struct Encoder, src/encoder.rs:213-515) ------------------------ */
 typedef struct jpegenc_encoder jpegenc_encoder;
 

@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "jpegenc_blocks_device", "jpegenc_blocks_host", "jpegenc_blocks_stream", "jpegenc_blocks_stream_release", "jpegenc_histogram_device",
     "jpegenc_scan_workspace_size", "jpegenc_scan_max_bytes", "jpegenc_scan_device",
     "jpegenc_pixels_scan_fused", "jpegenc_pixels_scan_dense", "jpegenc_pixels_scan_device",
+    "jpegenc_scan_lanes_new", "jpegenc_scan_lanes_submit", "jpegenc_scan_lanes_join", "jpegenc_scan_lanes_free",
     "jpegenc_encoder_set_device_entropy", "jpegenc_encoder_set_register_cache", "jpegenc_encoder_set_numa_bind", "jpegenc_encoder_set_batch_upload", "jpegenc_encoder_set_batch_round_frames",
     "jpegenc_encoder_set_batch_workers", "jpegenc_encoder_batch_workers", "jpegenc_encoder_batch_shard_info",
     "jpegenc_encoder_new", "jpegenc_encoder_free", "jpegenc_encoder_set_device",
@@ -361,6 +362,47 @@ def pixels_scan_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, heig
     check(lib().jpegenc_pixels_scan_device(d_pixels_ptr, pixel_frame_stride, num_frames, width, height, color_type, hs, vs, q,
                                            variant, restart_interval, tables, d_coeffs_ptr, coeff_frame_stride, d_out_ptr,
                                            out_frame_stride, d_lengths_ptr, d_workspace_ptr, workspace_bytes, stream_ptr))
+
+
+class ScanLanes:
+    """jpegenc_scan_lanes: the two-stream pattern of jpegenc_pixels_scan_device behind one call site.  submit() returns at once and
+    alternates between two internal lanes (stream + workspace each); join(stream) makes `stream` wait for everything submitted."""
+
+    def __init__(self, width, height, color_type, hs, vs, max_frames_per_call, device=0, restart_interval=0):
+        l = lib()
+        l.jpegenc_scan_lanes_new.argtypes = [C.POINTER(C.c_void_p)] + [C.c_int] * 8
+        l.jpegenc_scan_lanes_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(QTable), C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        l.jpegenc_scan_lanes_join.argtypes = [C.c_void_p, C.c_void_p]
+        l.jpegenc_scan_lanes_free.argtypes = [C.c_void_p]
+        l.jpegenc_scan_lanes_free.restype = None
+        self._h = C.c_void_p()
+        check(l.jpegenc_scan_lanes_new(C.byref(self._h), device, width, height, color_type, hs, vs, restart_interval, max_frames_per_call))
+
+    def submit(self, d_pixels_ptr, pixel_frame_stride, num_frames, q, d_out_ptr, out_frame_stride, d_lengths_ptr, producer_stream_ptr=0,
+               variant=FDCT_SCALAR, tables=None):
+        check(lib().jpegenc_scan_lanes_submit(self._h, d_pixels_ptr, pixel_frame_stride, num_frames, q, variant, tables, d_out_ptr,
+                                              out_frame_stride, d_lengths_ptr, producer_stream_ptr))
+
+    def join(self, stream_ptr=0):
+        check(lib().jpegenc_scan_lanes_join(self._h, stream_ptr))
+
+    def close(self):
+        if self._h:
+            lib().jpegenc_scan_lanes_free(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown
+            pass
 
 
 def pixels_scan_dense(layout, scan_bytes):

@@ -481,4 +481,88 @@ int jpegenc_pixels_scan_device(const void *d_pixels, size_t pixel_frame_stride, 
                        d_workspace, workspace_bytes, st);
 }
 
+// ---- two lanes behind one call site (jpegenc_scan_lanes_*) ------------------------------------------------------------------------
+struct jpegenc_scan_lanes {
+    int device = 0, width = 0, height = 0, color_type = 0, hs = 1, vs = 1, restart_interval = 0, max_frames = 0;
+    jpegenc_layout L;
+    size_t ws_bytes = 0, coeff_blocks = 0;
+    hipStream_t stream[2] = {nullptr, nullptr};
+    hipEvent_t before[2] = {nullptr, nullptr}, after[2] = {nullptr, nullptr};
+    void *ws[2] = {nullptr, nullptr}, *coeffs[2] = {nullptr, nullptr};
+    uint64_t submitted = 0;
+};
+
+void jpegenc_scan_lanes_free(jpegenc_scan_lanes *l) {
+    if (!l) return;
+    (void)hipSetDevice(l->device);
+    for (int i = 0; i < 2; i++) {
+        if (l->stream[i]) { (void)hipStreamSynchronize(l->stream[i]); (void)hipStreamDestroy(l->stream[i]); }
+        if (l->before[i]) (void)hipEventDestroy(l->before[i]);
+        if (l->after[i]) (void)hipEventDestroy(l->after[i]);
+        if (l->ws[i]) (void)hipFree(l->ws[i]);
+        if (l->coeffs[i]) (void)hipFree(l->coeffs[i]);
+    }
+    delete l;
+}
+
+int jpegenc_scan_lanes_new(jpegenc_scan_lanes **out, int device, int width, int height, int color_type, int hs, int vs, int restart_interval,
+                           int max_frames_per_call) {
+    if (!out) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null result pointer");
+    *out = nullptr;
+    if (max_frames_per_call <= 0 || max_frames_per_call > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "max_frames_per_call must be 1..65535");
+    if (restart_interval < 0 || restart_interval > 65535) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "restart interval must fit u16");
+    if ((hs != 1 && hs != 2) || (vs != 1 && vs != 2)) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "sampling factors of 4 have no interleaved scan (encoder.rs:178-187)");
+    int rc = ensure_device_ready(device);
+    if (rc) return rc;
+    jpegenc_scan_lanes *l = new (std::nothrow) jpegenc_scan_lanes();
+    if (!l) return fail(JPEGENC_ERR_HIP, "out of memory");
+    l->device = device; l->width = width; l->height = height; l->color_type = color_type; l->hs = hs; l->vs = vs;
+    l->restart_interval = restart_interval; l->max_frames = max_frames_per_call;
+    rc = jpegenc_layout_init(&l->L, width, height, color_type, hs, vs, JPEGENC_ORDER_MCU);
+    if (rc) { delete l; return rc; }
+    const jpegenc_scan sc = {-1, 1, 1, 64, restart_interval};
+    l->ws_bytes = scan_workspace_size(l->L, sc, max_frames_per_call);
+    if (!l->ws_bytes || !scan_max_bytes(l->L, sc)) { delete l; return fail(JPEGENC_ERR_INVALID_ARGUMENT, "frames too large for the device entropy coder"); }
+    l->coeff_blocks = jpegenc_pixels_scan_fused(width, height, color_type, hs, vs) ? 0 : (size_t)l->L.total_blocks;
+    hipError_t e = hipSetDevice(device);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipStreamCreateWithFlags(&l->stream[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l->before[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&l->after[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(&l->ws[i], l->ws_bytes);
+        if (e == hipSuccess && l->coeff_blocks) e = hipMalloc(&l->coeffs[i], l->coeff_blocks * 128u * (size_t)max_frames_per_call);
+    }
+    if (e != hipSuccess) { jpegenc_scan_lanes_free(l); return hip_fail(e, "scan lanes"); }
+    *out = l;
+    return JPEGENC_OK;
+}
+
+int jpegenc_scan_lanes_submit(jpegenc_scan_lanes *l, const void *d_pixels, size_t pixel_frame_stride, int num_frames, const jpegenc_qtable tables[2],
+                              int fdct_variant, const jpegenc_huffman_spec (*huffman)[2], void *d_out, size_t out_frame_stride,
+                              uint32_t *d_out_lengths, void *producer_stream) {
+    if (!l) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null lanes");
+    if (num_frames <= 0 || num_frames > l->max_frames) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "num_frames must be 1..max_frames_per_call");
+    JPEGENC_HIP(hipSetDevice(l->device));
+    const int lane = (int)(l->submitted & 1u);
+    // behind what the producer's stream holds now (and, on the lane's own stream, behind submit k - 2 whose workspace this one takes)
+    JPEGENC_HIP(hipEventRecord(l->before[lane], (hipStream_t)producer_stream));
+    JPEGENC_HIP(hipStreamWaitEvent(l->stream[lane], l->before[lane], 0));
+    const int rc = jpegenc_pixels_scan_device(d_pixels, pixel_frame_stride, num_frames, l->width, l->height, l->color_type, l->hs, l->vs, tables, fdct_variant,
+                                              l->restart_interval, huffman, l->coeffs[lane], l->coeff_blocks, d_out, out_frame_stride, d_out_lengths,
+                                              l->ws[lane], l->ws_bytes, l->stream[lane]);
+    if (rc) return rc;
+    l->submitted++;
+    return JPEGENC_OK;
+}
+
+int jpegenc_scan_lanes_join(jpegenc_scan_lanes *l, void *hip_stream) {
+    if (!l) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null lanes");
+    JPEGENC_HIP(hipSetDevice(l->device));
+    for (int i = 0; i < 2; i++) {
+        JPEGENC_HIP(hipEventRecord(l->after[i], l->stream[i]));
+        JPEGENC_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, l->after[i], 0));
+    }
+    return JPEGENC_OK;
+}
+
 }  // extern "C"

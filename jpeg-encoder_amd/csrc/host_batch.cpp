@@ -974,19 +974,40 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     const bool register_ahead = ra_env ? atoi(ra_env) != 0 : e->batch_upload == JPEGENC_UPLOAD_REGISTER_AHEAD;
     std::unique_ptr<RegisterAhead> ahead;
     if (register_ahead) ahead.reset(new RegisterAhead(frames, frame_bytes, num_frames, workers + 4, e->device, next));
+    // A worker stages its NEXT frame (claimed when the current one starts) right before it would wait for the current one: the copy
+    // runs while the link and the GPU are busy with the frame before, on a core that is warm, and the thread has little left to wait
+    // for - three such workers fill the link where four that copy, then wait, did not (profiles/r06_rank_cpu_budget.txt).
+    static const bool prestage_off = JPEGENC_DIAG_ENV("JPEGENC_NO_PRESTAGE") != nullptr || JPEGENC_DIAG_ENV("JPEGENC_IN_PLACE_UPLOADS") != nullptr;
+    const bool prestage = !ahead && !prestage_off;
     auto body = [&](int w) {
         if (w > 0) bind_thread_near_device(e->device, e->numa_bind);   // (opt-in) spawned workers; the caller's own affinity is left alone
         DeviceCtx &ctx = *e->workers[(size_t)w];
         ctx.batch_worker = true;
         TimerSlackGuard slack;
-        for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= num_frames || status.load() != JPEGENC_OK) break;
+        ctx.staged_src = ctx.next_src = nullptr;
+        int i = next.fetch_add(1);
+        while (i < num_frames && status.load() == JPEGENC_OK) {
+            const int following = prestage ? next.fetch_add(1) : -1;
             if (ahead) ahead->wait_ready(i);                           // page-locked by now (or left as it is): encode_pixels uploads a locked frame where it lies
             const int st = ahead ? ahead->state[i].load(std::memory_order_acquire) : 0;
             const size_t *locked = st == 1 ? ahead->pieces[(size_t)i].n : nullptr;
+            if (following >= 0 && following < num_frames && frames[following]) {
+                const uint8_t *src = frames[following];
+                ctx.before_wait = [&ctx, src, frame_bytes]() {
+                    if (is_pinned_host(src) && is_pinned_host(src + frame_bytes - 1)) return;      // the caller's page-locked frame: uploaded where it lies
+                    if (frame_bytes > ctx.h_next_cap) {
+                        if (ctx.h_next) (void)hipHostFree(ctx.h_next);
+                        ctx.h_next = nullptr; ctx.h_next_cap = 0;
+                        if (hipHostMalloc((void **)&ctx.h_next, frame_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx.h_next = nullptr; return; }
+                        ctx.h_next_cap = frame_bytes;
+                    }
+                    staging_copy(ctx.h_next, src, frame_bytes);
+                    ctx.next_src = src;
+                };
+            }
             int r = frames[i] ? encode_pixels(e->cfg, ctx, e->device, frames[i], frame_len, width, height, color_type, sink, users[i], staged, locked, st >= 2 ? st : 0)
                               : fail(JPEGENC_ERR_INVALID_ARGUMENT, "null frame");
+            ctx.frame_over();
             if (ahead) ahead->frame_done(i);
             ctx.last_cpu = sched_getcpu();
             if (r != JPEGENC_OK) {
@@ -994,7 +1015,10 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
                 if (status.compare_exchange_strong(expected, r)) messages[(size_t)w] = jpegenc_last_error();
                 break;
             }
+            i = prestage ? following : next.fetch_add(1);
         }
+        ctx.before_wait = nullptr;
+        ctx.staged_src = ctx.next_src = nullptr;
     };
     e->threads.run(workers, body);
     if (ahead) {

@@ -897,7 +897,8 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
                 JPEGENC_HIP(hipHostMalloc((void **)&cx.h_pixels, bytes, hipHostMallocDefault));
                 cx.h_pixels_cap = bytes;
             }
-            staging_copy(cx.h_pixels, data, bytes);
+            if (cx.staged_src != data) staging_copy(cx.h_pixels, data, bytes);     // (else: staged while the frame before was on the link, DeviceCtx::before_wait)
+            cx.staged_src = nullptr;
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, cx.h_pixels, bytes, hipMemcpyHostToDevice, cx.stream));
         } else {                   // (one image at a time on the caller's thread: the runtime's own path for pageable memory)
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));

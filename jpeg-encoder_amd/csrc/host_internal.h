@@ -400,6 +400,21 @@ struct DeviceCtx {
     size_t h_coeffs_cap = 0;
     uint8_t *h_pixels = nullptr;
     size_t h_pixels_cap = 0;
+    // A batch worker stages its NEXT pageable frame while the link carries its current one (host_batch.cpp, jpegenc_encoder_encode_batch):
+    // the copy into h_next runs right before the worker would start waiting (before_wait, called once by wait_stream / wait_for), the
+    // buffers swap when the frame is over, and the next encode finds its pixels in h_pixels already (staged_src says whose they are).
+    uint8_t *h_next = nullptr;
+    size_t h_next_cap = 0;
+    const uint8_t *staged_src = nullptr, *next_src = nullptr;
+    std::function<void()> before_wait;
+    void run_before_wait() {
+        if (before_wait) { std::function<void()> f; f.swap(before_wait); f(); }
+    }
+    void frame_over() {                  // after a batch worker's frame: what before_wait staged becomes the current staging buffer
+        before_wait = nullptr;
+        staged_src = nullptr;
+        if (next_src) { std::swap(h_pixels, h_next); std::swap(h_pixels_cap, h_next_cap); staged_src = next_src; next_src = nullptr; }
+    }
     uint32_t *h_freq = nullptr;
     // device entropy coding (interleaved scans): scratch, coded segment, its length
     void *d_scan_ws = nullptr, *d_scan_out = nullptr, *d_gather = nullptr;       // d_gather: [lengths][all scans back to back]
@@ -491,7 +506,7 @@ struct DeviceCtx {
         hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
         const clock::time_point t0 = clock::now();
-        long first_us = (long)(wait_ema_us * 0.6f);
+        long first_us = (long)(wait_ema_us * 0.75f);
         if (first_us > 2000) first_us = 2000;
         if (first_us >= 15) {
             const timespec ts = {0, first_us * 1000L};
@@ -505,10 +520,12 @@ struct DeviceCtx {
     }
     static bool spin_waits() { static const bool spin = JPEGENC_DIAG_ENV("JPEGENC_SPIN_WAITS") != nullptr; return spin; }   // diagnosis: the runtime's own waits
     hipError_t wait_for(hipEvent_t ev) {                 // an event recorded on one of this context's streams
+        run_before_wait();
         if (!batch_worker || spin_waits()) return hipEventSynchronize(ev);
         return sleep_until(ev);
     }
     hipError_t wait_stream() {
+        run_before_wait();
         if (!batch_worker || spin_waits()) return hipStreamSynchronize(stream);
         if (!wait_event_) {
             const hipError_t e = hipEventCreateWithFlags(&wait_event_, hipEventDisableTiming);
@@ -637,6 +654,7 @@ struct DeviceCtx {
         if (d_dc_side) (void)hipFree(d_dc_side);
         if (h_coeffs) (void)hipHostFree(h_coeffs);
         if (h_pixels) (void)hipHostFree(h_pixels);
+        if (h_next) (void)hipHostFree(h_next);
         if (h_freq) (void)hipHostFree(h_freq);
         if (d_scan_ws) (void)hipFree(d_scan_ws);
         if (d_scan_out) (void)hipFree(d_scan_out);

@@ -976,3 +976,44 @@ def test_thumbnail_batch_names_the_failing_frame_in_the_callers_numbering(bindin
         message = lib.jpegenc_last_error().decode()
         assert message.startswith(f"frame {bad}:"), message
         assert all(g == single for g in got[:bad])
+
+
+@pytest.mark.parametrize("ct,hs,vs,w,h,restart", [(1, 2, 2, 1920, 1080, 0), (1, 1, 1, 515, 301, 7), (7, 2, 2, 515, 301, 0), (2, 2, 1, 1280, 720, 0)],
+                         ids=["rgb420-1080p", "rgb444-rst7", "cmyk-as-ycck-420-unfused", "rgba422"])
+def test_scan_lanes_alternate_behind_one_call_site(binding, oracle, synth, ct, hs, vs, w, h, restart):
+    """jpegenc_scan_lanes: submits alternate between two internal lanes (stream + workspace each; coefficient scratch for layouts the
+    one kernel does not take), ordered behind the producer's stream; join() orders a stream behind all of them.  Eleven submits of
+    differing frame counts, every one into its own output: the same bytes and lengths as the oracle's files hold."""
+    import torch
+    bpp = binding.BPP[ct]
+    per, calls = 3, 11
+    frames = [synth.lcg_image(w, h, bpp, 60 + i) for i in range(4)]
+    want = []
+    for f in frames:
+        ref = oracle.encode_jpeg(f, w, h, ct, 85, sampling=(hs, vs), restart_interval=restart)
+        want.append(ref)
+    L = binding.layout(w, h, ct, hs, vs, binding.ORDER_MCU)
+    cap = binding.scan_max_bytes(L, binding.baseline_scan(restart_interval=restart))
+    q = binding.qtables(85)
+    producer = torch.cuda.Stream()
+    consumer = torch.cuda.Stream()
+    with binding.ScanLanes(w, h, ct, hs, vs, per, restart_interval=restart) as lanes:
+        outs, lens, picks, pixels = [], [], [], []
+        for c in range(calls):
+            n = 1 + c % per
+            pick = [(c + k) % len(frames) for k in range(n)]
+            with torch.cuda.stream(producer):                        # the pixels are produced on the caller's stream: the lane must wait for them
+                d_px = torch.from_numpy(np.stack([frames[k] for k in pick])).cuda(non_blocking=False).clone()
+            d_out = torch.zeros((n, cap), dtype=torch.uint8, device="cuda")
+            d_len = torch.zeros(n, dtype=torch.int32, device="cuda")
+            torch.cuda.current_stream().synchronize()              # (the zero fills above ran on the default stream)
+            lanes.submit(d_px.data_ptr(), w * h * bpp, n, q, d_out.data_ptr(), cap, d_len.data_ptr(), producer.cuda_stream)
+            outs.append(d_out); lens.append(d_len); picks.append(pick); pixels.append(d_px)
+        with pytest.raises(binding.JpegEncError):
+            lanes.submit(pixels[0].data_ptr(), w * h * bpp, per + 1, q, outs[0].data_ptr(), cap, lens[0].data_ptr(), producer.cuda_stream)
+        lanes.join(consumer.cuda_stream)
+        consumer.synchronize()
+        for c in range(calls):
+            for k, f in enumerate(picks[c]):
+                got = bytes(outs[c][k, :int(lens[c][k])].cpu().numpy())
+                assert len(got) > 0 and want[f].endswith(got + b"\xff\xd9"), f"submit {c} frame {k}"
