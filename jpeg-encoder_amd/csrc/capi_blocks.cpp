@@ -169,8 +169,27 @@ bool is_pinned_host(const void *p) {
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
 }
-bool is_pinned_host_range(const void *p, size_t bytes) {        // first and last byte: a registration may end inside the frame
-    return p && bytes && is_pinned_host(p) && is_pinned_host((const uint8_t *)p + bytes - 1);
+// the page-locked allocation / registration `p` lies in (hipHostMalloc, hipHostRegister): where it starts, how long it is
+bool pinned_registration_of(const void *p, uintptr_t *start, size_t *size) {
+    if (!p || !is_pinned_host(p)) return false;
+    void *s = nullptr;
+    size_t n = 0;
+    if (hipPointerGetAttribute(&s, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)const_cast<void *>(p)) != hipSuccess ||
+        hipPointerGetAttribute(&n, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)const_cast<void *>(p)) != hipSuccess || !s || !n) {
+        (void)hipGetLastError();
+        return false;
+    }
+    *start = (uintptr_t)s; *size = n;
+    return true;
+}
+// [p, p + bytes) lies inside ONE page-locked registration: what a copy needs to be a single asynchronous DMA (the runtime refuses a copy
+// that runs from one registration into the next; until round 6 this looked at the first and the last byte only - two neighbouring
+// registrations, or two that the frame merely starts and ends in, passed)
+bool is_pinned_host_range(const void *p, size_t bytes) {
+    uintptr_t start = 0;
+    size_t size = 0;
+    if (!p || !bytes || !pinned_registration_of(p, &start, &size)) return false;
+    return (uintptr_t)p + bytes <= start + size;
 }
 }  // namespace jpegenc
 

@@ -994,7 +994,7 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
             if (following >= 0 && following < num_frames && frames[following]) {
                 const uint8_t *src = frames[following];
                 ctx.before_wait = [&ctx, src, frame_bytes]() {
-                    if (is_pinned_host(src) && is_pinned_host(src + frame_bytes - 1)) return;      // the caller's page-locked frame: uploaded where it lies
+                    if (is_pinned_host_range(src, frame_bytes)) return;      // the caller's page-locked frame: uploaded where it lies
                     if (frame_bytes > ctx.h_next_cap) {
                         if (ctx.h_next) (void)hipHostFree(ctx.h_next);
                         ctx.h_next = nullptr; ctx.h_next_cap = 0;

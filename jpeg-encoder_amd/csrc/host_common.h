@@ -107,7 +107,8 @@ int ensure_device_ready(int device);
 // kernel and the block kernel + k_block_code pair is faster (profiles/r04_fused_quality_matrix.txt; DeviceCtx::dense_last_time,
 // jpegenc_pixels_scan_dense).
 constexpr uint64_t kDenseBitsPerBlock = 390;
-bool is_pinned_host_range(const void *p, size_t bytes);
+bool is_pinned_host_range(const void *p, size_t bytes);          // inside ONE page-locked registration
+bool pinned_registration_of(const void *p, uintptr_t *start, size_t *size);
 bool is_pinned_host(const void *p);      // page-locked host memory (hipHostMalloc / hipHostRegister / jpegenc_host_*): DMA reads it in place
 
 }  // namespace jpegenc

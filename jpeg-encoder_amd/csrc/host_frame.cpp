@@ -877,9 +877,10 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
     // 119 us of CPU per 6.2 MB frame, csrc/tools/host_register_rates.cpp, but in the pool it is 3-5 % slower than the staging copy,
     // and it cannot tell a range the CALLER has partly registered from its own registration: not kept.)
     static const bool in_place = JPEGENC_DIAG_ENV("JPEGENC_IN_PLACE_UPLOADS") != nullptr;
-    const bool caller_locked = upload_hint == 3 || (upload_hint == 0 && staged && bytes && is_pinned_host((const uint8_t *)data) && is_pinned_host((const uint8_t *)data + bytes - 1));
-    // (a frame the caller has page-locked only in part - a registration that ends inside it - is staged like a pageable one)
-    const bool partly_locked = upload_hint == 2 || (upload_hint == 0 && staged && bytes && is_pinned_host((const uint8_t *)data) != is_pinned_host((const uint8_t *)data + bytes - 1));
+    const bool caller_locked = upload_hint == 3 || (upload_hint == 0 && staged && bytes && is_pinned_host_range(data, bytes));
+    // (a frame the caller has page-locked only in part - a registration that ends inside it, two registrations side by side - is staged like a pageable one)
+    const bool partly_locked = upload_hint == 2 || (upload_hint == 0 && staged && bytes && !caller_locked &&
+                                                    (is_pinned_host((const uint8_t *)data) || is_pinned_host((const uint8_t *)data + bytes - 1)));
     auto upload = [&](DeviceCtx &cx) -> int {
         if (staged && locked_pieces) {                 // page-locked by the handle's registrar, in up to three registrations
             size_t at = 0;

@@ -17,6 +17,23 @@
 
 namespace jpegenc {
 
+// Every registration any RegisterAhead of this process holds (several handles - the per-device children of a multi-device batch, an
+// application's own threads - may run batches over neighbouring or identical memory at the same time): a frame that touches ANOTHER
+// batch's registration is staged - that registration goes when its own batch says so, not when this frame is done.
+struct RegisterAheadRegistry {
+    std::mutex mu;
+    std::map<uintptr_t, uintptr_t> owned;          // start -> end
+    static RegisterAheadRegistry &get() { static RegisterAheadRegistry r; return r; }
+    void add(uintptr_t a, uintptr_t b) { std::lock_guard<std::mutex> l(mu); owned[a] = b; }
+    void remove(uintptr_t a) { std::lock_guard<std::mutex> l(mu); owned.erase(a); }
+    bool overlaps(uintptr_t a, uintptr_t b) {
+        std::lock_guard<std::mutex> l(mu);
+        auto it = owned.upper_bound(a);
+        if (it != owned.begin()) { auto before = std::prev(it); if (before->second > a) return true; }
+        return it != owned.end() && it->first < b;
+    }
+};
+
 struct RegisterAhead {
     const uint8_t *const *frames;
     const size_t bytes;
@@ -97,6 +114,7 @@ struct RegisterAhead {
             const uint64_t t0 = now_ns();
             if (hipHostUnregister((void *)ranges_[(size_t)v].a) != hipSuccess) (void)hipGetLastError();
             unregister_ns += now_ns() - t0;
+            RegisterAheadRegistry::get().remove(ranges_[(size_t)v].a);
         }
         if (!victims.empty()) {
             std::lock_guard<std::mutex> lock(mu_);
@@ -151,15 +169,20 @@ struct RegisterAhead {
         if (!describable) return 2;
         const bool shares = (pc.range[0] >= 0 && pc.n[0]) || (pc.range[2] >= 0 && pc.n[2]);
         int st = 2;
-        if (ub > ua) {
+        if (ub > ua && RegisterAheadRegistry::get().overlaps(ua, ub)) {
+            st = 2;                                                 // another batch's registration (this batch's own are not in [ua, ub))
+        } else if (ub > ua) {
             // page-locked by someone else - the caller - in whole or in part: left as it is (looked at outside this batch's own registrations)
             const bool pinned_head = is_pinned_host((const uint8_t *)std::max(ua, first)), pinned_tail = is_pinned_host((const uint8_t *)std::min(ub, end) - 1);
             if (pinned_head || pinned_tail) {
-                st = pinned_head && pinned_tail && !shares ? 3 : 2;
+                // (as a whole = inside ONE registration that is not this batch's: a frame that merely starts and ends in page-locked
+                //  memory - another handle's register-ahead next door, two registrations of the caller's - is staged)
+                st = pinned_head && pinned_tail && !shares && is_pinned_host_range(p, bytes) ? 3 : 2;
             } else {
                 const uint64_t t0 = now_ns();
                 if (hipHostRegister((void *)ua, ub - ua, hipHostRegisterDefault) == hipSuccess) {
                     registered_bytes += ub - ua; register_ns += now_ns() - t0;
+                    RegisterAheadRegistry::get().add(ua, ub);
                     std::lock_guard<std::mutex> lock(mu_);
                     ranges_[(size_t)i] = Range{ua, ub, pc.n[1] ? 1 : 0, false};
                     live_[ua] = i;

@@ -1017,3 +1017,51 @@ def test_scan_lanes_alternate_behind_one_call_site(binding, oracle, synth, ct, h
             for k, f in enumerate(picks[c]):
                 got = bytes(outs[c][k, :int(lens[c][k])].cpu().numpy())
                 assert len(got) > 0 and want[f].endswith(got + b"\xff\xd9"), f"submit {c} frame {k}"
+
+
+def test_batch_workers_stage_ahead_with_mixed_and_reused_buffers(binding, oracle, synth):
+    """A batch worker stages its next pageable frame while its current one is on the link: batches that mix pageable and page-locked
+    frames, repeat a buffer, and reuse the same buffers with new content from call to call must deliver what the buffers hold when
+    the call is made - with 1, 2 and 3 workers (a worker claims the frame after its current one)."""
+    w, h = 1280, 720
+    fb = w * h * 3
+    imgs = [np.ascontiguousarray(synth.lcg_image(w, h, 3, 500 + i).reshape(-1)) for i in range(5)]
+    want = [oracle.encode_jpeg(im, w, h, oracle.RGB, 80) for im in imgs]
+    a, c = imgs[0].copy(), imgs[2].copy()
+    locked = binding.HostBuffer(fb)
+    try:
+        locked.array[:] = imgs[1]
+        for workers in (1, 2, 3):
+            with binding.Encoder(80) as e:
+                e.set_batch_workers(workers)
+                a[:] = imgs[0]; c[:] = imgs[2]
+                frames = [a, locked.array, a, c, locked.array, c, a]
+                assert e.encode_batch(frames, w, h, binding.RGB) == [want[0], want[1], want[0], want[2], want[1], want[2], want[0]]
+                # the same buffers, new content: nothing staged during the call before may be taken for it
+                a[:] = imgs[3]; c[:] = imgs[4]
+                assert e.encode_batch(frames, w, h, binding.RGB) == [want[3], want[1], want[3], want[4], want[1], want[4], want[3]]
+                assert e.encode_batch([c, a], w, h, binding.RGB) == [want[4], want[3]]
+    finally:
+        locked.close()
+
+
+def test_register_ahead_from_two_handles_over_the_same_memory(binding, oracle, synth):
+    """Two batches that page-lock ahead at the same time over identical and neighbouring memory (the per-device children of a multi-device
+    batch, device 0 listed twice: child d takes frames d, d + 2, ...): a frame that touches the other batch's registration is staged - it is
+    not taken for the caller's page-locked memory, and nothing is uploaded from a registration its owner may release.  Same files."""
+    w, h = 1000, 701
+    fb = w * h * 3
+    block = np.empty(13 * fb + 64, dtype=np.uint8)                   # slices of one array: every frame shares pages with both neighbours
+    slices = [block[7 + i * fb: 7 + (i + 1) * fb] for i in range(13)]
+    for i, s in enumerate(slices):
+        s[:] = synth.lcg_image(w, h, 3, 950 + i).reshape(-1)
+    want = [oracle.encode_jpeg(s, w, h, oracle.RGB, 85) for s in slices]
+    outs = [np.empty(2 << 20, dtype=np.uint8) for _ in range(16)]
+    with binding.Encoder(85) as e:
+        e.set_batch_upload(binding.UPLOAD_REGISTER_AHEAD)
+        for _ in range(3):
+            lens = e.encode_batch_into(slices, w, h, binding.RGB, outs, devices=[0, 0])
+            assert [outs[i][:lens[i]].tobytes() for i in range(13)] == want
+            same = [slices[0]] * 16                                   # both children name the same memory all the time
+            lens = e.encode_batch_into(same, w, h, binding.RGB, outs, devices=[0, 0])
+            assert all(outs[i][:lens[i]].tobytes() == want[0] for i in range(16))
