@@ -415,7 +415,7 @@ struct FrameRun {
         static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
         time_point t_stats = t_begin, t_tables = t_begin;
         if (optimize) {                                  // optimize_huffman_table, encoder.rs:1086-1200
-            JPEGENC_HIP(ctx.wait_stream());
+            JPEGENC_HIP(ctx.wait_stream(DeviceCtx::WAIT_STATISTICS));
             t_stats = now();
             const int max_tables = L.num_components < 2 ? L.num_components : 2;
             for (int d = 0; d < max_tables; d++)
@@ -677,7 +677,7 @@ struct FrameRun {
         }
         // the piece with index pieces_done has arrived
         auto wait_for_piece = [&]() -> int {
-            if (npieces == 1) JPEGENC_HIP(ctx.wait_stream());
+            if (npieces == 1) JPEGENC_HIP(ctx.wait_stream(DeviceCtx::WAIT_FILE));
             else JPEGENC_HIP(ctx.wait_for(ctx.chunk_done[pieces_done]));
             pieces_done++;
             return JPEGENC_OK;
@@ -750,7 +750,7 @@ struct FrameRun {
             }
             o.drain(false);
         }
-        if (direct) JPEGENC_HIP(ctx.wait_stream());                          // the scans are in the caller's buffer
+        if (direct) JPEGENC_HIP(ctx.wait_stream(DeviceCtx::WAIT_FILE));      // the scans are in the caller's buffer
         o.marker(0xD9);
         o.drain(true);
         if (trace) fprintf(stderr, "[jpegenc] frame: prepare %.1f us, launch %ld us, wait-len %ld us, d2h %ld us, emit %ld us, bytes %zu, scans %zu\n",

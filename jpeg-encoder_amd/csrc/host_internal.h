@@ -500,13 +500,16 @@ struct DeviceCtx {
     // profiles/r06_rank_cpu_budget.txt), which is all a rank of an 8-rank host has (2 CPUs of a 16-CPU quota).  The single-image
     // path keeps hipStreamSynchronize: it is 10-20 us faster per wait and one thread.
     hipEvent_t wait_event_ = nullptr;
-    float wait_ema_us = 0.f;             // how long this worker's waits have taken lately (smoothed)
-    hipError_t sleep_until(hipEvent_t ev) {
+    enum WaitSite { WAIT_LAUNCH = 0, WAIT_STATISTICS = 1, WAIT_PIECE = 2, WAIT_FILE = 3, kWaitSites = 4 };
+    float wait_ema_us[kWaitSites] = {0.f, 0.f, 0.f, 0.f};   // how long this worker's waits have taken lately (smoothed), per place it waits at:
+                                                          // a frame's launch sequence and the rest of its file are different waits
+    hipError_t sleep_until(hipEvent_t ev, int site) {
+        float &ema = wait_ema_us[site & 3];
         typedef std::chrono::steady_clock clock;
         hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
         const clock::time_point t0 = clock::now();
-        long first_us = (long)(wait_ema_us * 0.75f);
+        long first_us = (long)(ema * 0.75f);
         if (first_us > 2000) first_us = 2000;
         if (first_us >= 15) {
             const timespec ts = {0, first_us * 1000L};
@@ -515,16 +518,16 @@ struct DeviceCtx {
         const timespec slice = {0, 20000L};
         while ((e = hipEventQuery(ev)) == hipErrorNotReady) nanosleep(&slice, nullptr);
         const float took = (float)std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t0).count();
-        wait_ema_us = wait_ema_us > 0.f ? 0.75f * wait_ema_us + 0.25f * took : took;
+        ema = ema > 0.f ? 0.75f * ema + 0.25f * took : took;
         return e;
     }
     static bool spin_waits() { static const bool spin = JPEGENC_DIAG_ENV("JPEGENC_SPIN_WAITS") != nullptr; return spin; }   // diagnosis: the runtime's own waits
-    hipError_t wait_for(hipEvent_t ev) {                 // an event recorded on one of this context's streams
+    hipError_t wait_for(hipEvent_t ev, int site = WAIT_PIECE) {    // an event recorded on one of this context's streams
         run_before_wait();
         if (!batch_worker || spin_waits()) return hipEventSynchronize(ev);
-        return sleep_until(ev);
+        return sleep_until(ev, site);
     }
-    hipError_t wait_stream() {
+    hipError_t wait_stream(int site = WAIT_LAUNCH) {
         run_before_wait();
         if (!batch_worker || spin_waits()) return hipStreamSynchronize(stream);
         if (!wait_event_) {
@@ -532,7 +535,7 @@ struct DeviceCtx {
             if (e != hipSuccess) { wait_event_ = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(stream); }
         }
         const hipError_t e = hipEventRecord(wait_event_, stream);
-        return e == hipSuccess ? sleep_until(wait_event_) : e;
+        return e == hipSuccess ? sleep_until(wait_event_, site) : e;
     }
 
     int open(int dev) {
