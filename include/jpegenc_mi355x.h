@@ -241,7 +241,7 @@ int jpegenc_scan_device(const void *d_coeffs, size_t coeff_frame_stride, int num
  * d_coeffs may be NULL); other layouts run the block kernel into `d_coeffs` (coeff_frame_stride blocks per frame,
  * 0 = total_blocks) and code from there.  Workspace / output sizing: jpegenc_scan_workspace_size /
  * jpegenc_scan_max_bytes with jpegenc_scan{-1, 1, 1, 64, restart_interval} on the ORDER_MCU layout.  Same bytes as
- * jpegenc_blocks_device followed by jpegenc_scan_device, and faster (DESIGN.md 3.3); this is the path the Encoder
+ * jpegenc_blocks_device followed by jpegenc_scan_device, and faster (DESIGN.md 3); this is the path the Encoder
  * takes.  The exception is dense content - blocks that code to more than ~390 bits on average: noise-like frames from quality 95
  * up - where a block outgrows its 507-bit strip in most workgroups and the two calls are 25-45 % faster
  * (profiles/r04_fused_quality_matrix.txt): this entry point is stateless and always takes the one kernel, a caller that knows its
@@ -382,7 +382,7 @@ int  jpegenc_encoder_encode_device(jpegenc_encoder *e, const void *d_pixels, int
  * threads (each with its own stream and buffers) - same bytes either way.
  * The batch runs as a pipeline of rounds - the GPU codes round r + 1 while the link carries round r and the handle's background
  * threads assemble the files of the rounds before - so frames per call are worth having: photo-like 4K 4:2:0 frames cost 75 us each
- * in calls of 4, 38 in calls of 16, 29-32 in calls of 32-64 (DESIGN.md 6). */
+ * in calls of 4, 38 in calls of 16, 29-32 in calls of 32-64 (DESIGN.md 4). */
 int  jpegenc_encoder_encode_batch_device(jpegenc_encoder *e, const void *d_frames, size_t frame_stride,
                                          int num_frames, int width, int height, int color_type,
                                          jpegenc_write_fn sink, void *const *users);

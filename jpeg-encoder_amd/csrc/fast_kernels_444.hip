@@ -4,7 +4,7 @@
 // In the general tuned kernel (fast_kernel_impl.hip.h) a wave is 64 blocks of one component, so at 4:4:4 - where an MCU is one
 // 8x8 tile and Y, Cb, Cr all cover the same 64 pixels - three waves load the same bytes, isolate the same pixel words and run
 // the same prologue and row arithmetic: 1 066 instructions per block at 0.73 of the SIMDs' issue rate, 0.64 of the HBM
-// roofline.  Here lane = MCU: the 8 rows are loaded once, every pixel word is isolated once and converted to Y, Cb
+// roofline (docs/DESIGN_rounds_1-5.md 8).  Here lane = MCU: the 8 rows are loaded once, every pixel word is isolated once and converted to Y, Cb
 // and Cr on the spot (3 + 4 + 4 instructions), and the three blocks go through the FDCT / quantiser one after the other, each
 // staged and stored like any wave's 64 blocks (wave_tasks.hip.h: same StoreMap, both block orders, the statistics of optimised
 // Huffman tables).  The price is registers - three blocks' samples are live until the first transform is done - so the kernel
