@@ -1065,3 +1065,61 @@ def test_register_ahead_from_two_handles_over_the_same_memory(binding, oracle, s
             same = [slices[0]] * 16                                   # both children name the same memory all the time
             lens = e.encode_batch_into(same, w, h, binding.RGB, outs, devices=[0, 0])
             assert all(outs[i][:lens[i]].tobytes() == want[0] for i in range(16))
+
+
+def test_randomised_host_fed_batches(binding, oracle, synth):
+    """Random host-fed batches through the worker pool: frame sizes on both sides of the staged-thumbnail limit, 1 .. 28 frames, thread
+    budgets 0 .. 5, staged and register-ahead uploads, frames that are pageable, page-locked by the caller (wholly or only their first
+    half), slices of one array a few bytes apart, or the same buffer several times - every file equal to the single-image call's
+    (itself pinned to the oracle on the first trial of every geometry).  JPEGENC_FUZZ_TRIALS / JPEGENC_FUZZ_SEED: soak length."""
+    import ctypes as C
+    import os
+    rng = np.random.default_rng(int(os.environ.get("JPEGENC_FUZZ_SEED", "7")))
+    trials = int(os.environ.get("JPEGENC_BATCH_FUZZ_TRIALS", os.environ.get("JPEGENC_FUZZ_TRIALS", "24")))
+    lib = binding.lib()
+    lib.jpegenc_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.jpegenc_host_unregister.argtypes = [C.c_void_p]
+    geometries = [(1280, 720), (1000, 701), (640, 360), (1920, 1080), (333, 201)]
+    checked = set()
+    for trial in range(trials):
+        w, h = geometries[int(rng.integers(len(geometries)))]
+        fb = w * h * 3
+        quality = int(rng.choice([50, 80, 90]))
+        n = int(rng.integers(1, 29))
+        distinct = int(rng.integers(1, min(n, 6) + 1))
+        block = np.empty(distinct * (fb + 24) + 64, dtype=np.uint8)
+        images = []
+        for i in range(distinct):
+            off = 3 + i * (fb + int(rng.integers(0, 24)))
+            img = block[off:off + fb]
+            img[:] = synth.lcg_image(w, h, 3, 1000 * trial + i).reshape(-1) if i % 2 else np.resize(synth.test_img_rgb(w, h).reshape(-1), fb)
+            img[:16] = (trial * 7 + i) & 255
+            images.append(img)
+        pinned = binding.HostBuffer(fb)
+        pinned.array[:] = images[0]
+        half = np.empty(fb, dtype=np.uint8)
+        half[:] = images[-1]
+        registered_half = bool(rng.integers(2)) and lib.jpegenc_host_register(half.ctypes.data, fb // 2) == 0
+        try:
+            with binding.Encoder(quality) as e:
+                want = [e.encode(img, w, h, binding.RGB) for img in images]
+                if (w, h, quality) not in checked:
+                    checked.add((w, h, quality))
+                    assert want[0] == oracle.encode_jpeg(images[0], w, h, oracle.RGB, quality)
+                frames, expect = [], []
+                for k in range(n):
+                    which = int(rng.integers(distinct + 2))
+                    if which == distinct:
+                        frames.append(pinned.array); expect.append(want[0])
+                    elif which == distinct + 1:
+                        frames.append(half); expect.append(want[-1])
+                    else:
+                        frames.append(images[which]); expect.append(want[which])
+                e.set_batch_workers(int(rng.integers(0, 6)))
+                e.set_batch_upload(binding.UPLOAD_REGISTER_AHEAD if rng.integers(3) == 0 else binding.UPLOAD_STAGED)
+                for _ in range(2):
+                    assert e.encode_batch(frames, w, h, binding.RGB) == expect, f"trial {trial}: {w}x{h} q{quality} n={n}"
+        finally:
+            if registered_half:
+                assert lib.jpegenc_host_unregister(half.ctypes.data) == 0
+            pinned.close()
