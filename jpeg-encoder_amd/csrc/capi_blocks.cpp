@@ -331,6 +331,73 @@ int jpegenc_sampling_factor_from_factors(int horizontal, int vertical) {      //
     return -1;
 }
 
+// Host <-> device copies of the convenience entry point through two page-locked bounce buffers of 4 MB (kept per thread): the
+// caller's pageable memory is never handed to the runtime, which would page-lock it in place and keep that registration cached
+// (host_frame.cpp, upload_in_stripes).  Chunk k's DMA runs while chunk k + 1 is copied.
+namespace {
+struct Bounce {
+    static constexpr size_t kChunk = (size_t)4 << 20;
+    uint8_t *h[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int device = -1;
+    bool open(int dev) {
+        if (device == dev && h[0]) return true;
+        close();
+        for (int i = 0; i < 2; i++) {
+            if (hipHostMalloc((void **)&h[i], kChunk, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); close(); return false; }
+            if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); close(); return false; }
+        }
+        device = dev;
+        return true;
+    }
+    void close() {
+        for (int i = 0; i < 2; i++) {
+            if (h[i]) (void)hipHostFree(h[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            h[i] = nullptr; done[i] = nullptr;
+        }
+        device = -1;
+    }
+    ~Bounce() { close(); }
+    hipError_t to_device(void *dst, const uint8_t *src, size_t n) {
+        hipError_t e = hipSuccess;
+        int k = 0;
+        for (size_t at = 0; at < n && e == hipSuccess; at += kChunk, k ^= 1) {
+            const size_t m = n - at < kChunk ? n - at : kChunk;
+            e = hipEventSynchronize(done[k]);                        // (this half's previous DMA; a fresh event is complete)
+            if (e != hipSuccess) break;
+            memcpy(h[k], src + at, m);
+            e = hipMemcpyAsync((uint8_t *)dst + at, h[k], m, hipMemcpyHostToDevice, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(done[k], nullptr);
+        }
+        const hipError_t s = hipStreamSynchronize(nullptr);
+        return e != hipSuccess ? e : s;
+    }
+    hipError_t to_host(uint8_t *dst, const void *src, size_t n) {
+        hipError_t e = hipSuccess;
+        size_t pending_at[2] = {0, 0}, pending_n[2] = {0, 0};
+        int k = 0;
+        for (size_t at = 0; at < n && e == hipSuccess; at += kChunk, k ^= 1) {
+            const size_t m = n - at < kChunk ? n - at : kChunk;
+            if (pending_n[k]) {                                       // the chunk this half still holds goes to the caller first
+                e = hipEventSynchronize(done[k]);
+                if (e != hipSuccess) break;
+                memcpy(dst + pending_at[k], h[k], pending_n[k]);
+            }
+            e = hipMemcpyAsync(h[k], (const uint8_t *)src + at, m, hipMemcpyDeviceToHost, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(done[k], nullptr);
+            pending_at[k] = at; pending_n[k] = m;
+        }
+        const hipError_t s = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess && s == hipSuccess) {
+            // (oldest first: the half that was NOT written last)
+            for (int i = 0; i < 2; i++) { const int j = k ^ i; if (pending_n[j]) memcpy(dst + pending_at[j], h[j], pending_n[j]); }
+        }
+        return e != hipSuccess ? e : s;
+    }
+};
+}  // namespace
+
 int jpegenc_blocks_host(int device, const uint8_t *pixels, size_t pixels_len, int width, int height, int color_type,
                         int hs, int vs, const jpegenc_qtable tables[2], int order, int fdct_variant,
                         int16_t *coeffs, size_t coeffs_capacity) {
@@ -356,14 +423,19 @@ int jpegenc_blocks_host(int device, const uint8_t *pixels, size_t pixels_len, in
     hipError_t e = hipMalloc(&d_co, L.total_blocks * 128);
     if (e != hipSuccess) { (void)hipFree(d_px); return hip_fail(e, "hipMalloc(coefficients)"); }
     auto cleanup = [&]() { (void)hipFree(d_px); (void)hipFree(d_co); };
-    e = hipMemcpy(d_px, pixels, required, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpy(H2D)"); }
+    static thread_local Bounce bounce;
+    if (!bounce.open(device)) { cleanup(); return fail(JPEGENC_ERR_HIP, "page-locked bounce buffers"); }
+    e = is_pinned_host_range(pixels, required) ? hipMemcpy(d_px, pixels, required, hipMemcpyHostToDevice) : bounce.to_device(d_px, pixels, required);
+    if (e != hipSuccess) { cleanup(); return hip_fail(e, "upload of the pixels"); }
     rc = jpegenc_blocks_device(d_px, required, 1, width, height, color_type, hs, vs, tables, order, fdct_variant,
                                d_co, L.total_blocks, nullptr);
     if (rc) { cleanup(); return rc; }
-    e = hipMemcpy(coeffs, d_co, L.total_blocks * 128, hipMemcpyDeviceToHost);   // synchronises
+    e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess)
+        e = is_pinned_host_range(coeffs, L.total_blocks * 128) ? hipMemcpy(coeffs, d_co, L.total_blocks * 128, hipMemcpyDeviceToHost)
+                                                                : bounce.to_host((uint8_t *)coeffs, d_co, L.total_blocks * 128);
     cleanup();
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(D2H)");
+    if (e != hipSuccess) return hip_fail(e, "download of the coefficients");
     return JPEGENC_OK;
 }
 

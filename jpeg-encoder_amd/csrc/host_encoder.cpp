@@ -212,6 +212,10 @@ int jpegenc_encoder_encode(jpegenc_encoder *e, const uint8_t *data, size_t len, 
                            jpegenc_write_fn sink, void *user) {
     REQUIRE(e);
     if (len && !data) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "null data");
+    // (pageable pixels are staged by the library itself, on up to four threads of the handle's thread budget: host_frame.cpp)
+    static const int stage_cap = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_THREADS"); return v && atoi(v) > 0 ? atoi(v) : 4; }();
+    e->ctx.stage_threads = pool_threads(e->batch_workers, stage_cap, 1, 1, 64);
+    e->ctx.stage_pool = e->ctx.stage_threads > 1 ? &e->stagers : nullptr;
     return encode_pixels(e->cfg, e->ctx, e->device, data, len, width, height, color_type, sink, user);
 }
 

@@ -31,6 +31,76 @@ void staging_copy(void *dst, const void *src, size_t n) {
 }
 
 
+// One image from PAGEABLE memory to the device: the caller's pixels go through the context's page-locked buffer in stripes - copied by
+// this thread and the handle's copier threads (streaming stores), each stripe's DMA enqueued as soon as it and the ones before it are
+// there, so that the link works while the next stripes are copied.  The library does not hand the caller's pageable memory to the
+// runtime any more: hipMemcpyAsync on such memory page-locks it in place inside the runtime and keeps those registrations cached; with
+// frames on the C heap that are freed and reallocated between calls (what tests/test_gpu_batch_multi.py::test_randomised_host_fed_batches
+// does) one process in ten died of "Memory access fault by GPU" - round 5's library just the same (profiles/r06_pageable_runtime_path.txt).
+// (The upload itself runs at the link's rate either way: 0.49 ms for a 4K frame.)
+static int upload_in_stripes(DeviceCtx &cx, const uint8_t *data, size_t bytes) {
+    if (bytes > cx.h_pixels_cap) {
+        if (cx.h_pixels) (void)hipHostFree(cx.h_pixels);
+        cx.h_pixels = nullptr; cx.h_pixels_cap = 0;
+        JPEGENC_HIP(hipHostMalloc((void **)&cx.h_pixels, bytes, hipHostMallocDefault));
+        cx.h_pixels_cap = bytes;
+    }
+    // Stripes grow - 512 KB, 1 MB, 2 MB, then 4 MB each - so that the link starts after ~15 us of copying and a large frame is still
+    // a dozen DMA commands (every command costs ~10 us on the engine's side): 4K = 9 stripes.  JPEGENC_STAGE_STRIPE_KB (diagnostic
+    // build): the size of the LARGEST stripe.
+    constexpr int kMaxStripes = 64;
+    static const size_t stripe_cap = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_STRIPE_KB"); return v && atoi(v) > 0 ? (size_t)atoi(v) << 10 : (size_t)4 << 20; }();
+    static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t begin_of[kMaxStripes + 1];
+    int stripes = 0;
+    static const size_t stripe_first = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_FIRST_KB"); return v && atoi(v) > 0 ? (size_t)atoi(v) << 10 : (size_t)512 << 10; }();
+    for (size_t at = 0, len = std::min(stripe_cap, stripe_first); at < bytes;) {
+        begin_of[stripes++] = at;
+        if (stripes == kMaxStripes) { at = bytes; break; }           // (the last one takes what is left: frames beyond 250 MB)
+        at += len;
+        if (len < stripe_cap) len = std::min(stripe_cap, len * 2);
+    }
+    begin_of[stripes] = bytes;
+    std::atomic<int> next(0);
+    std::atomic<uint8_t> done[kMaxStripes];
+    for (int k = 0; k < stripes; k++) done[k].store(0, std::memory_order_relaxed);
+    uint8_t *dst = cx.h_pixels;
+    auto copy_one = [&](int k) {
+        staging_copy(dst + begin_of[k], data + begin_of[k], begin_of[k + 1] - begin_of[k]);
+        done[k].store(1, std::memory_order_release);
+    };
+    auto copier = [&]() {
+        for (;;) {
+            const int k = next.fetch_add(1);
+            if (k >= stripes) break;
+            copy_one(k);
+        }
+    };
+    const int helpers = cx.stage_pool && stripes > 1 ? std::min(cx.stage_threads - 1, stripes - 1) : 0;
+    if (helpers > 0) {
+        cx.stage_pool->ensure_threads(helpers);
+        for (int t = 0; t < helpers; t++) cx.stage_pool->submit(2, copier);
+    }
+    hipError_t he = hipSuccess;
+    int enqueued = 0, own = 0;
+    while (enqueued < stripes) {
+        if (done[enqueued].load(std::memory_order_acquire)) {
+            const size_t at = begin_of[enqueued], n = begin_of[enqueued + 1] - at;
+            if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)cx.d_pixels + at, dst + at, n, hipMemcpyHostToDevice, cx.stream);
+            enqueued++;
+            continue;
+        }
+        const int k = next.fetch_add(1);
+        if (k < stripes) { copy_one(k); own++; } else _mm_pause();
+    }
+    if (helpers > 0) cx.stage_pool->wait(2);                       // (the tasks refer to this frame's stack)
+    if (trace) fprintf(stderr, "[jpegenc]   staged upload: %zu bytes in %d stripes, %d helper threads, this thread copied %d, all enqueued after %ld us\n", bytes, stripes, helpers, own,
+                       (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+    if (he != hipSuccess) return hip_fail(he, "upload of a staged stripe");
+    return JPEGENC_OK;
+}
+
 // The whole of encode_image_internal for one frame, as the steps encode_frame walks through: what the frame needs
 // (prepare, plan_scans: tables, geometry, the scans the device coder will produce and their buffers), how its launch
 // sequence runs (choose_replay: launch by launch, captured into a hipGraph, or replayed), the launches themselves
@@ -655,7 +725,10 @@ struct FrameRun {
         if (merged) coded_scans = 1;
         const bool large_scans = coded_scans && rest / coded_scans >= ((size_t)512 << 10);
         static const bool no_direct = JPEGENC_DIAG_ENV("JPEGENC_NO_DIRECT_D2H") != nullptr;     // diagnosis: every scan through the pinned buffer
+        // (only into PAGE-LOCKED output: a copy into pageable memory makes the runtime page-lock it in place and keep that registration
+        //  cached - see upload_in_stripes; pageable output gets its bytes from the page-locked staging buffer, piece by piece as they land)
         BufferSink *direct = rest && large_scans && sink == buffer_sink && !no_direct ? (BufferSink *)user : nullptr;
+        if (direct && !(direct->out && direct->cap && is_pinned_host_range(direct->out, direct->cap))) direct = nullptr;
         size_t piece = 0;
         int npieces = 0, pieces_done = 0;
         if (rest && !direct) {
@@ -664,9 +737,13 @@ struct FrameRun {
             // (pieces only where handing them over one by one can hide something: up to 4 MB the rest comes down in one copy - the
             // two copies, two events and two waits of a 1.7 MB progressive 4K file cost a batch of such frames, sixteen workers
             // calling into the runtime at once, a fifth of its rate: tools/diag/c5_batch_ab.sh)
-            piece = (rest + DeviceCtx::kChunks - 1) / DeviceCtx::kChunks;
+            // (with copier threads at hand - the library's own buffer sink, one image at a time - pieces of ~4 MB: a piece is one DMA
+            //  command and one event, and the copy out of the staging buffer is shared by the threads anyway)
+            const bool few = sink == buffer_sink && ctx.stage_pool != nullptr;
+            piece = few ? (size_t)4 << 20 : (rest + DeviceCtx::kChunks - 1) / DeviceCtx::kChunks;
+            if (few && (rest + piece - 1) / piece > (size_t)DeviceCtx::kChunks) piece = (rest + DeviceCtx::kChunks - 1) / DeviceCtx::kChunks;
             if (piece < ((size_t)1 << 20)) piece = (size_t)1 << 20;
-            if (rest <= ((size_t)4 << 20)) piece = rest;
+            if (rest <= ((size_t)4 << 20) || (few && rest <= ((size_t)6 << 20))) piece = rest;
             piece = (piece + 65535) & ~(size_t)65535;
             for (size_t done = 0; done < rest; done += piece, npieces++) {
                 const size_t n = rest - done < piece ? rest - done : piece;
@@ -683,6 +760,11 @@ struct FrameRun {
             return JPEGENC_OK;
         };
         size_t at = kGatherHeader;
+        bool copies_in_pool = false;
+        struct PoolJoin {                                        // whatever way this function is left: no copy of it outlives it
+            DeviceCtx &cx; bool &used;
+            ~PoolJoin() { if (used && cx.stage_pool) cx.stage_pool->wait(3); }
+        } pool_join{ctx, copies_in_pool};
         Out o;
         o.sink = sink; o.user = user;
         write_prologue(o, c, jct);
@@ -713,6 +795,10 @@ struct FrameRun {
             o.drain(true);                                                   // a large scan goes from the pinned buffer straight to the sink (one copy less)
             size_t pos = from;
             const size_t end = from + n;
+            // (the library's own buffer sink and copier threads at hand: every stretch that has arrived is copied to its place in the
+            //  caller's buffer by the pool, in pieces of 1 MB, while the next ones are on the link - a 14 MB file is 0.44 ms of one
+            //  thread's memcpy otherwise)
+            BufferSink *pooled = sink == buffer_sink && ctx.stage_pool ? (BufferSink *)user : nullptr;
             while (pos < end && !o.failed) {
                 // the stretch of [pos, end) that has arrived: up to the end of the last finished piece
                 size_t have = kGatherHeader + first_piece + (size_t)pieces_done * piece;
@@ -723,7 +809,20 @@ struct FrameRun {
                     continue;
                 }
                 const size_t m = (have < end ? have : end) - pos;
-                if (sink(user, ctx.h_scan_out + pos, m) != 0) o.failed = true;
+                if (pooled) {
+                    if (pooled->len + m <= pooled->cap) {
+                        uint8_t *dst = pooled->out + pooled->len;
+                        const uint8_t *src = ctx.h_scan_out + pos;
+                        ctx.stage_pool->ensure_threads(ctx.stage_threads - 1);
+                        for (size_t at = 0; at < m; at += (size_t)1 << 20) {
+                            const size_t nb = m - at < ((size_t)1 << 20) ? m - at : (size_t)1 << 20;
+                            if (at + ((size_t)1 << 20) < m) ctx.stage_pool->submit(3, [dst, src, at, nb] { memcpy(dst + at, src + at, nb); });
+                            else memcpy(dst + at, src + at, nb);                       // (the last piece of a stretch: this thread's)
+                        }
+                        copies_in_pool = true;
+                    }
+                    pooled->len += m;                                                  // (a buffer that is too small still learns the size it needs)
+                } else if (sink(user, ctx.h_scan_out + pos, m) != 0) o.failed = true;
                 pos += m;
             }
             return JPEGENC_OK;
@@ -881,6 +980,7 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
     // (a frame the caller has page-locked only in part - a registration that ends inside it, two registrations side by side - is staged like a pageable one)
     const bool partly_locked = upload_hint == 2 || (upload_hint == 0 && staged && bytes && !caller_locked &&
                                                     (is_pinned_host((const uint8_t *)data) || is_pinned_host((const uint8_t *)data + bytes - 1)));
+    const bool single_locked = !staged && bytes && is_pinned_host_range(data, bytes);
     auto upload = [&](DeviceCtx &cx) -> int {
         if (staged && locked_pieces) {                 // page-locked by the handle's registrar, in up to three registrations
             size_t at = 0;
@@ -901,12 +1001,16 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
             if (cx.staged_src != data) staging_copy(cx.h_pixels, data, bytes);     // (else: staged while the frame before was on the link, DeviceCtx::before_wait)
             cx.staged_src = nullptr;
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, cx.h_pixels, bytes, hipMemcpyHostToDevice, cx.stream));
-        } else {                   // (one image at a time on the caller's thread: the runtime's own path for pageable memory)
+        } else if (single_locked) {    // one image at a time from page-locked memory: a plain asynchronous DMA (or stripes: run_striped)
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
+        } else {                   // ... from pageable memory: staged in stripes by the library itself
+            static const bool runtime_path = JPEGENC_DIAG_ENV("JPEGENC_RUNTIME_PAGEABLE_UPLOADS") != nullptr;      // diagnosis: rounds 1-5
+            if (runtime_path) JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
+            else return upload_in_stripes(cx, data, bytes);
         }
         return JPEGENC_OK;
     };
-    return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user, staged ? nullptr : data);
+    return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user, staged || !single_locked ? nullptr : data);
 }
 
 

@@ -376,6 +376,7 @@ inline hipError_t create_side_stream(hipStream_t *s) {
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
 }
 
+class BackgroundPool;
 // ---------------------------------------------------------------------------------------------
 struct DeviceCtx {
     int device = -1;
@@ -410,6 +411,11 @@ struct DeviceCtx {
     void run_before_wait() {
         if (before_wait) { std::function<void()> f; f.swap(before_wait); f(); }
     }
+    // One image at a time from PAGEABLE memory (jpegenc_encoder_encode and the calls built on it): the library stages the pixels through
+    // h_pixels itself, in stripes, on the handle's copier threads - stripe k's DMA runs while stripe k + 1 is copied
+    // (host_frame.cpp, upload_in_stripes).  Set by the entry point; null = this thread alone.
+    BackgroundPool *stage_pool = nullptr;
+    int stage_threads = 1;
     void frame_over() {                  // after a batch worker's frame: what before_wait staged becomes the current staging buffer
         before_wait = nullptr;
         staged_src = nullptr;
@@ -1059,7 +1065,7 @@ struct jpegenc_encoder {
     std::vector<std::unique_ptr<jpegenc_encoder>> shards;
     // the pools' threads end (they are made again, as many as the budget then allows, by the next batch call): after the thread
     // budget has changed - a pool only ever grows, and its idle threads would still take tasks
-    void release_idle_threads() { threads.stop(); assemblers.stop(); stagers.stop(); }
+    void release_idle_threads() { threads.stop(); assemblers.stop(); stagers.stop(); ctx.stage_pool = nullptr; ctx.stage_threads = 1; }
 };
 
 

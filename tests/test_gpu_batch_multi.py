@@ -1099,7 +1099,7 @@ def test_randomised_host_fed_batches(binding, oracle, synth):
         pinned.array[:] = images[0]
         half = np.empty(fb, dtype=np.uint8)
         half[:] = images[-1]
-        registered_half = bool(rng.integers(2)) and lib.jpegenc_host_register(half.ctypes.data, fb // 2) == 0
+        registered_half = bool(rng.integers(2)) and not os.environ.get("JPEGENC_FUZZ_NO_HALF") and lib.jpegenc_host_register(half.ctypes.data, fb // 2) == 0
         try:
             with binding.Encoder(quality) as e:
                 want = [e.encode(img, w, h, binding.RGB) for img in images]
@@ -1115,8 +1115,13 @@ def test_randomised_host_fed_batches(binding, oracle, synth):
                         frames.append(half); expect.append(want[-1])
                     else:
                         frames.append(images[which]); expect.append(want[which])
-                e.set_batch_workers(int(rng.integers(0, 6)))
-                e.set_batch_upload(binding.UPLOAD_REGISTER_AHEAD if rng.integers(3) == 0 else binding.UPLOAD_STAGED)
+                workers, ahead = int(rng.integers(0, 6)), bool(rng.integers(3) == 0) and not os.environ.get("JPEGENC_FUZZ_NO_RA")
+                e.set_batch_workers(workers)
+                e.set_batch_upload(binding.UPLOAD_REGISTER_AHEAD if ahead else binding.UPLOAD_STAGED)
+                if os.environ.get("JPEGENC_FUZZ_VERBOSE"):
+                    import sys
+                    print(f"trial {trial}: {w}x{h} q{quality} n={n} distinct={distinct} workers={workers} register_ahead={ahead} half_registered={registered_half} "
+                          f"block@{block.ctypes.data:#x} half@{half.ctypes.data:#x}", file=sys.stderr, flush=True)
                 for _ in range(2):
                     assert e.encode_batch(frames, w, h, binding.RGB) == expect, f"trial {trial}: {w}x{h} q{quality} n={n}"
         finally:
