@@ -45,58 +45,59 @@ static int upload_in_stripes(DeviceCtx &cx, const uint8_t *data, size_t bytes) {
         JPEGENC_HIP(hipHostMalloc((void **)&cx.h_pixels, bytes, hipHostMallocDefault));
         cx.h_pixels_cap = bytes;
     }
-    // Stripes grow - 512 KB, 1 MB, 2 MB, then 4 MB each - so that the link starts after ~15 us of copying and a large frame is still
-    // a dozen DMA commands (every command costs ~10 us on the engine's side): 4K = 9 stripes.  JPEGENC_STAGE_STRIPE_KB (diagnostic
-    // build): the size of the LARGEST stripe.
-    constexpr int kMaxStripes = 64;
-    static const size_t stripe_cap = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_STRIPE_KB"); return v && atoi(v) > 0 ? (size_t)atoi(v) << 10 : (size_t)4 << 20; }();
+    // Two granularities.  COPIES go in chunks of 512 KB that the threads take in order (a 4K frame: 48 chunks over four threads);
+    // DMA commands cover runs of chunks that double - 512 KB, 1 MB, 2 MB ... up to 32 MB - so that the link starts after ~15 us
+    // of copying and a large frame is still a handful of commands (every command costs the engine ~10 us: twelve equal stripes of a
+    // 4K frame measured 0.15 ms slower than the runtime's own pageable path, profiles/r06_pageable_runtime_path.txt).
+    static const size_t chunk_min = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_CHUNK_KB"); return v && atoi(v) > 0 ? (size_t)atoi(v) << 10 : (size_t)512 << 10; }();
+    static const uint32_t unit_cap = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_UNIT_CHUNKS"); return v && atoi(v) > 0 ? (uint32_t)atoi(v) : 64u; }();
+    static const uint32_t unit_growth = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_UNIT_GROWTH"); return v && atoi(v) > 1 ? (uint32_t)atoi(v) : 2u; }();
     static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    size_t begin_of[kMaxStripes + 1];
-    int stripes = 0;
-    static const size_t stripe_first = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_FIRST_KB"); return v && atoi(v) > 0 ? (size_t)atoi(v) << 10 : (size_t)512 << 10; }();
-    for (size_t at = 0, len = std::min(stripe_cap, stripe_first); at < bytes;) {
-        begin_of[stripes++] = at;
-        if (stripes == kMaxStripes) { at = bytes; break; }           // (the last one takes what is left: frames beyond 250 MB)
-        at += len;
-        if (len < stripe_cap) len = std::min(stripe_cap, len * 2);
-    }
-    begin_of[stripes] = bytes;
-    std::atomic<int> next(0);
-    std::atomic<uint8_t> done[kMaxStripes];
-    for (int k = 0; k < stripes; k++) done[k].store(0, std::memory_order_relaxed);
+    size_t chunk = chunk_min;
+    if ((bytes + chunk - 1) / chunk > 4096) chunk = (((bytes + 4095) / 4096) + 65535) & ~(size_t)65535;      // (frames beyond 2 GB: at most 4 096 chunks)
+    const uint32_t nchunks = (uint32_t)((bytes + chunk - 1) / chunk);
+    std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[nchunks]);
+    for (uint32_t k = 0; k < nchunks; k++) done[k].store(0, std::memory_order_relaxed);
+    std::atomic<uint32_t> next(0);
     uint8_t *dst = cx.h_pixels;
-    auto copy_one = [&](int k) {
-        staging_copy(dst + begin_of[k], data + begin_of[k], begin_of[k + 1] - begin_of[k]);
+    auto copy_one = [&](uint32_t k) {
+        const size_t at = (size_t)k * chunk, n = bytes - at < chunk ? bytes - at : chunk;
+        staging_copy(dst + at, data + at, n);
         done[k].store(1, std::memory_order_release);
     };
     auto copier = [&]() {
         for (;;) {
-            const int k = next.fetch_add(1);
-            if (k >= stripes) break;
+            const uint32_t k = next.fetch_add(1);
+            if (k >= nchunks) break;
             copy_one(k);
         }
     };
-    const int helpers = cx.stage_pool && stripes > 1 ? std::min(cx.stage_threads - 1, stripes - 1) : 0;
+    const int helpers = cx.stage_pool && nchunks > 1 ? (int)std::min<uint32_t>((uint32_t)cx.stage_threads - 1u, nchunks - 1u) : 0;
     if (helpers > 0) {
         cx.stage_pool->ensure_threads(helpers);
         for (int t = 0; t < helpers; t++) cx.stage_pool->submit(2, copier);
     }
     hipError_t he = hipSuccess;
-    int enqueued = 0, own = 0;
-    while (enqueued < stripes) {
-        if (done[enqueued].load(std::memory_order_acquire)) {
-            const size_t at = begin_of[enqueued], n = begin_of[enqueued + 1] - at;
-            if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)cx.d_pixels + at, dst + at, n, hipMemcpyHostToDevice, cx.stream);
-            enqueued++;
+    uint32_t unit_begin = 0, unit_len = 1, ready = 0;
+    int own = 0, commands = 0;
+    while (unit_begin < nchunks) {
+        const uint32_t unit_end = std::min(nchunks, unit_begin + unit_len);
+        while (ready < unit_end && done[ready].load(std::memory_order_acquire)) ready++;
+        if (ready >= unit_end) {
+            const size_t at = (size_t)unit_begin * chunk, end = std::min(bytes, (size_t)unit_end * chunk);
+            if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)cx.d_pixels + at, dst + at, end - at, hipMemcpyHostToDevice, cx.stream);
+            commands++;
+            unit_begin = unit_end;
+            unit_len = std::min(unit_cap, unit_len * unit_growth);
             continue;
         }
-        const int k = next.fetch_add(1);
-        if (k < stripes) { copy_one(k); own++; } else _mm_pause();
+        const uint32_t k = next.fetch_add(1);
+        if (k < nchunks) { copy_one(k); own++; } else _mm_pause();
     }
     if (helpers > 0) cx.stage_pool->wait(2);                       // (the tasks refer to this frame's stack)
-    if (trace) fprintf(stderr, "[jpegenc]   staged upload: %zu bytes in %d stripes, %d helper threads, this thread copied %d, all enqueued after %ld us\n", bytes, stripes, helpers, own,
-                       (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+    if (trace) fprintf(stderr, "[jpegenc]   staged upload: %zu bytes in %u chunks / %d DMA commands, %d helper threads, this thread copied %d chunks, all enqueued after %ld us\n", bytes, nchunks,
+                       commands, helpers, own, (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
     if (he != hipSuccess) return hip_fail(he, "upload of a staged stripe");
     return JPEGENC_OK;
 }
