@@ -783,14 +783,15 @@ def main():
             def scan_lanes(px, half=8, calls=120):
                 out2 = [torch.empty((half, cap), dtype=torch.uint8, device=dev) for _ in range(2)]
                 len2 = [torch.zeros(half, dtype=torch.int32, device=dev) for _ in range(2)]
+                producer = torch.cuda.Stream(device=dev)              # the stream a decoder / camera pipeline would produce the pixels on
                 with binding.ScanLanes(W, H, binding.RGB, HS, VS, half, device=local_rank) as lanes:
                     def call(c):
                         i = c & 1                                      # (submit c + 2 runs on the lane of submit c: stream order keeps its output safe)
                         part = px[(c % (Fd // half)) * half:(c % (Fd // half) + 1) * half]
-                        lanes.submit(part.data_ptr(), frame_bytes, half, q, out2[i].data_ptr(), cap, len2[i].data_ptr(), stream.cuda_stream)
+                        lanes.submit(part.data_ptr(), frame_bytes, half, q, out2[i].data_ptr(), cap, len2[i].data_ptr(), producer.cuda_stream)
 
                     def drain():
-                        lanes.join(stream.cuda_stream)
+                        lanes.join(producer.cuda_stream)
                         torch.cuda.synchronize()
                     torch.cuda.synchronize()
                     t_in = time.perf_counter()

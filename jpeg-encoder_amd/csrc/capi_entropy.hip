@@ -544,9 +544,16 @@ int jpegenc_scan_lanes_submit(jpegenc_scan_lanes *l, const void *d_pixels, size_
     if (num_frames <= 0 || num_frames > l->max_frames) return fail(JPEGENC_ERR_INVALID_ARGUMENT, "num_frames must be 1..max_frames_per_call");
     JPEGENC_HIP(hipSetDevice(l->device));
     const int lane = (int)(l->submitted & 1u);
-    // behind what the producer's stream holds now (and, on the lane's own stream, behind submit k - 2 whose workspace this one takes)
-    JPEGENC_HIP(hipEventRecord(l->before[lane], (hipStream_t)producer_stream));
-    JPEGENC_HIP(hipStreamWaitEvent(l->stream[lane], l->before[lane], 0));
+    // behind what the producer's stream holds now (and, on the lane's own stream, behind submit k - 2 whose workspace this one takes).
+    // A producer stream with nothing pending needs no dependency: the pixels are there (a cross-stream wait costs the lane tens of
+    // microseconds - on the legacy default stream, which synchronises with every blocking stream, a record alone cost 50 us per submit).
+    const hipError_t busy = hipStreamQuery((hipStream_t)producer_stream);
+    if (busy == hipErrorNotReady) {
+        JPEGENC_HIP(hipEventRecord(l->before[lane], (hipStream_t)producer_stream));
+        JPEGENC_HIP(hipStreamWaitEvent(l->stream[lane], l->before[lane], 0));
+    } else if (busy != hipSuccess) {
+        return hip_fail(busy, "producer stream");
+    }
     const int rc = jpegenc_pixels_scan_device(d_pixels, pixel_frame_stride, num_frames, l->width, l->height, l->color_type, l->hs, l->vs, tables, fdct_variant,
                                               l->restart_interval, huffman, l->coeffs[lane], l->coeff_blocks, d_out, out_frame_stride, d_out_lengths,
                                               l->ws[lane], l->ws_bytes, l->stream[lane]);

@@ -963,7 +963,8 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     // busy for nothing - a rank of an 8-GPU host has 1/8 of its CPUs (profiles/r06_rank_cpu_budget.txt).  Host entropy
     // coding is CPU work per frame: the full pool.  jpegenc_encoder_set_batch_workers overrides either.
     const int pool_cap = e->cfg.device_entropy && e->max_batch_workers > kDeviceEntropyWorkers ? kDeviceEntropyWorkers : e->max_batch_workers;
-    int workers = batch_pool_size(e->batch_workers, pool_cap, num_frames);
+    // (workers that only feed the link sleep most of the time: one CPU in reserve is enough - a 4-CPU share runs three of them)
+    int workers = batch_pool_size(e->batch_workers, pool_cap, num_frames, e->cfg.device_entropy ? 1 : 2);
     if (env_workers > 0 && e->batch_workers == 0 && e->max_batch_workers == 16) workers = env_workers < num_frames ? env_workers : num_frames;
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));

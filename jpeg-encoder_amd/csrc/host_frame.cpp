@@ -741,10 +741,13 @@ struct FrameRun {
             // (with copier threads at hand - the library's own buffer sink, one image at a time - pieces of ~4 MB: a piece is one DMA
             //  command and one event, and the copy out of the staging buffer is shared by the threads anyway)
             const bool few = sink == buffer_sink && ctx.stage_pool != nullptr;
+            // (a batch worker sleeps between pieces - every piece is a wait of its own - and has nothing to hand them to meanwhile: up
+            //  to 16 MB in ONE piece, then its own memcpy)
+            const bool one = ctx.batch_worker && rest <= ((size_t)16 << 20);
             piece = few ? (size_t)4 << 20 : (rest + DeviceCtx::kChunks - 1) / DeviceCtx::kChunks;
             if (few && (rest + piece - 1) / piece > (size_t)DeviceCtx::kChunks) piece = (rest + DeviceCtx::kChunks - 1) / DeviceCtx::kChunks;
             if (piece < ((size_t)1 << 20)) piece = (size_t)1 << 20;
-            if (rest <= ((size_t)4 << 20) || (few && rest <= ((size_t)6 << 20))) piece = rest;
+            if (rest <= ((size_t)4 << 20) || (few && rest <= ((size_t)6 << 20)) || one) piece = rest;
             piece = (piece + 65535) & ~(size_t)65535;
             for (size_t done = 0; done < rest; done += piece, npieces++) {
                 const size_t n = rest - done < piece ? rest - done : piece;

@@ -355,7 +355,7 @@ inline int pool_threads(int user_cap, int auto_cap, int reserve, int floor, int 
 }
 constexpr int kDeviceEntropyWorkers = 4;      // automatic pool of a host-fed batch whose scans the device codes (host_batch.cpp, jpegenc_encoder_encode_batch)
 // the workers of jpegenc_encoder_encode_batch and the pooled per-frame paths (one in-flight frame each)
-inline int batch_pool_size(int user_cap, int auto_cap, int num_frames) { return pool_threads(user_cap, auto_cap, 2, 2, num_frames); }
+inline int batch_pool_size(int user_cap, int auto_cap, int num_frames, int reserve = 2) { return pool_threads(user_cap, auto_cap, reserve, 2, num_frames); }
 
 // A thread whose waits are nanosleeps (DeviceCtx::sleep_until) wants them to end on time: the default timer slack of a thread is 50 us
 // on top of every sleep.  1 us for the duration of a batch body; the previous value comes back with the guard (the body of worker 0
