@@ -20,17 +20,32 @@ namespace jpegenc {
 // Every registration any RegisterAhead of this process holds (several handles - the per-device children of a multi-device batch, an
 // application's own threads - may run batches over neighbouring or identical memory at the same time): a frame that touches ANOTHER
 // batch's registration is staged - that registration goes when its own batch says so, not when this frame is done.
+// Look-up and hipHostRegister happen under ONE lock: two batches that found the same pages free at the same time both "succeeded" in
+// registering them, the second release then handed the runtime a pointer it no longer knew - and the runtime ABORTS on that ("Memobj map
+// does not have ptr", rocclr device.cpp:359; tests/test_gpu_batch_multi.py::test_register_ahead_from_two_handles_over_the_same_memory).
+// A range stays in the map until its hipHostUnregister has returned.
 struct RegisterAheadRegistry {
     std::mutex mu;
-    std::map<uintptr_t, uintptr_t> owned;          // start -> end
+    std::map<uintptr_t, uintptr_t> owned;          // start -> end (being released ones included)
     static RegisterAheadRegistry &get() { static RegisterAheadRegistry r; return r; }
-    void add(uintptr_t a, uintptr_t b) { std::lock_guard<std::mutex> l(mu); owned[a] = b; }
-    void remove(uintptr_t a) { std::lock_guard<std::mutex> l(mu); owned.erase(a); }
-    bool overlaps(uintptr_t a, uintptr_t b) {
-        std::lock_guard<std::mutex> l(mu);
+    bool overlaps_locked(uintptr_t a, uintptr_t b) const {
         auto it = owned.upper_bound(a);
         if (it != owned.begin()) { auto before = std::prev(it); if (before->second > a) return true; }
         return it != owned.end() && it->first < b;
+    }
+    bool overlaps(uintptr_t a, uintptr_t b) { std::lock_guard<std::mutex> l(mu); return overlaps_locked(a, b); }
+    // 0 = registered (and recorded), 1 = another batch's registration in the way, 2 = the runtime declined
+    int try_register(uintptr_t a, uintptr_t b) {
+        std::lock_guard<std::mutex> l(mu);
+        if (overlaps_locked(a, b)) return 1;
+        if (hipHostRegister((void *)a, b - a, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 2; }
+        owned[a] = b;
+        return 0;
+    }
+    void release(uintptr_t a) {                     // (the unregistering itself outside the lock: it can take milliseconds)
+        if (hipHostUnregister((void *)a) != hipSuccess) (void)hipGetLastError();
+        std::lock_guard<std::mutex> l(mu);
+        owned.erase(a);
     }
 };
 
@@ -112,9 +127,8 @@ struct RegisterAhead {
         }
         for (int v : victims) {
             const uint64_t t0 = now_ns();
-            if (hipHostUnregister((void *)ranges_[(size_t)v].a) != hipSuccess) (void)hipGetLastError();
+            RegisterAheadRegistry::get().release(ranges_[(size_t)v].a);
             unregister_ns += now_ns() - t0;
-            RegisterAheadRegistry::get().remove(ranges_[(size_t)v].a);
         }
         if (!victims.empty()) {
             std::lock_guard<std::mutex> lock(mu_);
@@ -177,12 +191,12 @@ struct RegisterAhead {
             if (pinned_head || pinned_tail) {
                 // (as a whole = inside ONE registration that is not this batch's: a frame that merely starts and ends in page-locked
                 //  memory - another handle's register-ahead next door, two registrations of the caller's - is staged)
-                st = pinned_head && pinned_tail && !shares && is_pinned_host_range(p, bytes) ? 3 : 2;
+                // (... and not ANOTHER batch's either: a registration that is visible is in the registry - both happen under its lock)
+                st = pinned_head && pinned_tail && !shares && is_pinned_host_range(p, bytes) && !RegisterAheadRegistry::get().overlaps(a, b) ? 3 : 2;
             } else {
                 const uint64_t t0 = now_ns();
-                if (hipHostRegister((void *)ua, ub - ua, hipHostRegisterDefault) == hipSuccess) {
+                if (RegisterAheadRegistry::get().try_register(ua, ub) == 0) {
                     registered_bytes += ub - ua; register_ns += now_ns() - t0;
-                    RegisterAheadRegistry::get().add(ua, ub);
                     std::lock_guard<std::mutex> lock(mu_);
                     ranges_[(size_t)i] = Range{ua, ub, pc.n[1] ? 1 : 0, false};
                     live_[ua] = i;

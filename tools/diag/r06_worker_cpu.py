@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--what", default="c3")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--label", default="")
+    ap.add_argument("--start-at", type=float, default=0.0, help="epoch seconds: the timed passes of the first row start then (several processes timed together)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -126,6 +127,10 @@ def main():
             digest = hash(tuple(outs[i][:lens[i]].tobytes() for i in (0, n // 2, n - 1)))
             ref = digest if ref is None else ref
             assert digest == ref, "files differ between settings"
+            if args.start_at > 0:
+                while time.time() < args.start_at:
+                    time.sleep(0.001)
+                args.start_at = 0.0
             th0, st0, t0, os0 = hostinfo.thread_cpu_times(), hostinfo.cpu_stat(), time.perf_counter(), os.times()
             if sp:
                 sp.stackprof_start(997)
@@ -144,6 +149,7 @@ def main():
                    "cpus_busy": round((os1.user - os0.user + os1.system - os0.system) / wall, 2),
                    "cpus_user": round((os1.user - os0.user) / wall, 2), "cpus_system": round((os1.system - os0.system) / wall, 2),
                    "cfs_throttled_periods": (st1[1] - st0[1]) if st1[1] is not None and st0[1] is not None else None,
+                   "timed_seconds": round(wall, 3), "container_cpus_busy": round((st1[0] - st0[0]) / wall, 2),
                    "busiest_threads_user_sys_fraction": [(c, round(u / wall, 2), round(s / wall, 2)) for u, s, c, _ in busiest if u + s > 0.02 * wall]}
             if sp and nsamples:
                 path = f"/tmp/stackprof_{args.what}_{'pinned' if use_pinned else 'pageable'}_{wk}.txt"
