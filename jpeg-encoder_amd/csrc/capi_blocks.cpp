@@ -630,6 +630,11 @@ int jpegenc_blocks_stream(int device, const uint8_t *const *frames, size_t frame
         fprintf(stderr, "[jpegenc] blocks_stream: %d frames, %d slots, pinned input %d, pipe %s: setup %.2f ms, pipeline %.2f ms of which callbacks %.2f ms\n",
                 num_frames, slots, (int)all_pinned, reused ? "kept from the call before" : "made", std::chrono::duration<double>(t_ready - t_begin).count() * 1e3,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count() * 1e3, cb_seconds * 1e3);
+    // The buffers stay for the next call; the three streams do not: idle streams of other priorities left in the process kept two
+    // streams of the default priority from overlapping their kernels afterwards (jpegenc_scan_lanes in bench.py's process: 516 Gpixel/s
+    // with this pipe's streams alive, 641 once they were gone) - and they are made afresh per call anyway.
+    for (hipStream_t *s : {&pipe.s_up, &pipe.s_dn, &pipe.s_k})
+        if (*s) { (void)hipStreamSynchronize(*s); (void)hipStreamDestroy(*s); *s = nullptr; }
     lease.keep = true;
     return JPEGENC_OK;
 }

@@ -965,6 +965,10 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     const int pool_cap = e->cfg.device_entropy && e->max_batch_workers > kDeviceEntropyWorkers ? kDeviceEntropyWorkers : e->max_batch_workers;
     // (workers that only feed the link sleep most of the time: one CPU in reserve is enough - a 4-CPU share runs three of them)
     int workers = batch_pool_size(e->batch_workers, pool_cap, num_frames, e->cfg.device_entropy ? 1 : 2);
+    // (frames the caller page-locked cost a worker no copy at all - 0.08 CPUs each, asleep while the link works - so their pool does not
+    //  shrink with the CPUs: four workers fill the link from a single CPU, two reach 0.85 of it; the first and the last frame are looked at)
+    if (e->batch_workers == 0 && e->cfg.device_entropy && workers < pool_cap && num_frames >= pool_cap && frames[0] && frames[num_frames - 1] &&
+        is_pinned_host_range(frames[0], frame_bytes) && is_pinned_host_range(frames[num_frames - 1], frame_bytes)) workers = pool_cap;
     if (env_workers > 0 && e->batch_workers == 0 && e->max_batch_workers == 16) workers = env_workers < num_frames ? env_workers : num_frames;
     std::atomic<int> next(0), status(JPEGENC_OK);
     std::vector<std::string> messages((size_t)(workers > 0 ? workers : 1));
