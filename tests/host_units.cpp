@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "host_internal.h"
+#include "host_register_ahead.h"
 
 #define CHECK(cond) do { if (!(cond)) { printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
 
@@ -187,7 +188,58 @@ static int background_pool() {
     return 0;
 }
 
+// jpegenc_encoder_set_batch_workers: one rule sizes every pool of a handle (pool_threads, host_internal.h)
+static int thread_budget() {
+    using jpegenc::pool_threads;
+    // the caller's number wins over everything but the work there is
+    CHECK(pool_threads(3, 16, 2, 2, 100) == 3);
+    CHECK(pool_threads(1, 16, 2, 2, 100) == 1);                       // the reference's single thread
+    CHECK(pool_threads(64, 4, 2, 2, 5) == 5);
+    CHECK(pool_threads(2, 8, 1, 1, 0) == 1);                          // (never 0 threads)
+    // automatic: the pool's own cap, the CPUs the process may use less the reserve, the floor, the items
+    const int cpus = jpegenc::usable_cpus();
+    CHECK(cpus >= 1);
+    const int want = std::max(2, std::min(4, cpus - 1));
+    CHECK(pool_threads(0, 4, 1, 2, 1000) == want);
+    CHECK(pool_threads(0, 4, 1, 2, 1) == 1);
+    CHECK(pool_threads(0, 16, 2, 2, 1000) == std::max(2, std::min(16, cpus - 2)));
+    CHECK(jpegenc::batch_pool_size(0, jpegenc::kDeviceEntropyWorkers, 1000, 1) == want);
+    // a thread pinned to one CPU does not shrink the process's pools (the wider of the leader's and the caller's masks counts)
+    cpu_set_t before, one;
+    CHECK(sched_getaffinity(0, sizeof before, &before) == 0);
+    if (CPU_COUNT(&before) >= 2) {
+        std::atomic<int> seen(0);
+        std::thread t([&] {
+            CPU_ZERO(&one);
+            for (int i = 0; i < CPU_SETSIZE; i++) if (CPU_ISSET(i, &before)) { CPU_SET(i, &one); break; }
+            (void)sched_setaffinity(0, sizeof one, &one);
+            seen.store(jpegenc::usable_cpus_now());
+        });
+        t.join();
+        CHECK(seen.load() == jpegenc::usable_cpus_now());
+    }
+    return 0;
+}
+
+// the process-wide registry of register-ahead registrations: interval look-up (the registering itself needs a GPU)
+static int register_ahead_registry() {
+    jpegenc::RegisterAheadRegistry r;
+    CHECK(!r.overlaps(0x1000, 0x2000));
+    { std::lock_guard<std::mutex> l(r.mu); r.owned[0x4000] = 0x8000; r.owned[0x10000] = 0x11000; }
+    CHECK(!r.overlaps(0x1000, 0x4000));                                // ends where a range begins
+    CHECK(r.overlaps(0x1000, 0x4001));
+    CHECK(r.overlaps(0x5000, 0x6000));                                 // inside
+    CHECK(r.overlaps(0x7fff, 0x9000));                                 // its last byte
+    CHECK(!r.overlaps(0x8000, 0x10000));                               // the gap between two ranges
+    CHECK(r.overlaps(0x8000, 0x10001));
+    CHECK(r.overlaps(0x0, 0x20000));                                   // covers both
+    CHECK(!r.overlaps(0x11000, 0x12000));
+    return 0;
+}
+
 int main() {
+    if (thread_budget()) return 1;
+    if (register_ahead_registry()) return 1;
     if (background_pool()) return 1;
     if (thread_binding()) return 1;
     if (stripe_tuner_untimed_option()) return 1;
