@@ -267,7 +267,11 @@ int jpegenc_pixels_scan_device(const void *d_pixels, size_t pixel_frame_stride, 
  * one geometry; submit() number k runs on lane k & 1 - behind everything `producer_stream` (the stream the pixels are produced on; NULL =
  * the default stream) held when it was called, and behind submit k - 2 - and returns at once; join() makes `hip_stream` wait for
  * everything submitted so far.  Every submit needs its own d_out / d_out_lengths until a join has been waited for; same bytes and lengths
- * as jpegenc_pixels_scan_device (it is what each lane calls).  max_frames_per_call sizes the workspaces. */
+ * as jpegenc_pixels_scan_device (it is what each lane calls).  max_frames_per_call sizes the workspaces.  What overlaps is the tail, so
+ * the lanes pay where the tail is launch-bound - photo-like and smooth frames; on noise-like frames the one kernel keeps every CU's issue
+ * slots busy, the tail is two full passes over a 130 MB stream, and two lanes of 8 frames measure SLOWER than one stream of 16 (281
+ * against 315 Gpixel/s at 4K q90, profiles/r06_final_bench_details.json): content for which jpegenc_pixels_scan_dense says 1, or close
+ * to it, stays on one stream. */
 typedef struct jpegenc_scan_lanes jpegenc_scan_lanes;
 int  jpegenc_scan_lanes_new(jpegenc_scan_lanes **out, int device, int width, int height, int color_type, int h_sampling, int v_sampling,
                             int restart_interval, int max_frames_per_call);
