@@ -9,7 +9,7 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-const-variable -Wno-unused-function
        -I"${here}/../../include")
-srcs=("${here}"/block_kernels.hip "${here}"/fast_kernels.hip "${here}"/fast_kernels_bytes.hip "${here}"/fast_kernels_s4.hip "${here}"/fast_kernels_bytes_s4.hip "${here}"/fused_kernels.hip "${here}"/fused_kernels_bytes.hip "${here}"/fast_kernels_planes.hip "${here}"/fast_kernels_565.hip "${here}"/fast_kernels_444.hip "${here}"/fast_kernels_420.hip "${here}"/entropy_kernels.hip "${here}"/capi_entropy.hip "${here}"/capi_blocks.cpp "${here}"/host_encoder.cpp "${here}"/host_emit.cpp "${here}"/host_frame.cpp "${here}"/host_batch.cpp "${here}"/host_multi.cpp)
+srcs=("${here}"/block_kernels.hip "${here}"/fast_kernels.hip "${here}"/fast_kernels_bytes.hip "${here}"/fast_kernels_s4.hip "${here}"/fast_kernels_bytes_s4.hip "${here}"/fused_kernels.hip "${here}"/fused_kernels_bytes.hip "${here}"/fast_kernels_planes.hip "${here}"/fast_kernels_565.hip "${here}"/fast_kernels_444.hip "${here}"/fast_kernels_420.hip "${here}"/entropy_kernels.hip "${here}"/staged_pull.hip "${here}"/capi_entropy.hip "${here}"/capi_blocks.cpp "${here}"/host_encoder.cpp "${here}"/host_emit.cpp "${here}"/host_frame.cpp "${here}"/host_batch.cpp "${here}"/host_multi.cpp)
 
 # build_variant <output .so> <object directory> [extra flags ...]
 build_variant() {

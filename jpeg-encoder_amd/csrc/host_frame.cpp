@@ -31,13 +31,17 @@ void staging_copy(void *dst, const void *src, size_t n) {
 }
 
 
-// One image from PAGEABLE memory to the device: the caller's pixels go through the context's page-locked buffer in stripes - copied by
-// this thread and the handle's copier threads (streaming stores), each stripe's DMA enqueued as soon as it and the ones before it are
-// there, so that the link works while the next stripes are copied.  The library does not hand the caller's pageable memory to the
-// runtime any more: hipMemcpyAsync on such memory page-locks it in place inside the runtime and keeps those registrations cached; with
-// frames on the C heap that are freed and reallocated between calls (what tests/test_gpu_batch_multi.py::test_randomised_host_fed_batches
-// does) one process in ten died of "Memory access fault by GPU" - round 5's library just the same (profiles/r06_pageable_runtime_path.txt).
-// (The upload itself runs at the link's rate either way: 0.49 ms for a 4K frame.)
+// One image from PAGEABLE memory to the device: the caller's pixels go through the context's page-locked buffer in chunks - copied by
+// this thread and the handle's copier threads (streaming stores) - and cross the link behind the copiers' backs.
+// The library does not hand the caller's pageable memory to the runtime any more: hipMemcpyAsync on such memory page-locks it in place
+// inside the runtime and keeps those registrations cached; with frames on the C heap that are freed and reallocated between calls (what
+// tests/test_gpu_batch_multi.py::test_randomised_host_fed_batches does) one process in ten died of "Memory access fault by GPU" - round 5's
+// library just the same (profiles/r06_pageable_runtime_path.txt).
+// The transfer is ONE kernel (staged_pull.hip), launched before the first byte is copied: it follows the "chunks staged so far" word the
+// copiers advance and pulls every chunk over the link as soon as it is there - no DMA command per run of chunks (each cost the engine
+// ~10 us and the last one covered up to half the frame), one chunk's transfer left after the last byte was copied
+// (profiles/r06_staged_pull.txt).  JPEGENC_STAGE_DMA=1 in the diagnostic build: the DMA commands over doubling runs of chunks of the
+// first cut (also what a failed kernel launch falls back to).
 static int upload_in_stripes(DeviceCtx &cx, const uint8_t *data, size_t bytes) {
     if (bytes > cx.h_pixels_cap) {
         if (cx.h_pixels) (void)hipHostFree(cx.h_pixels);
@@ -45,26 +49,56 @@ static int upload_in_stripes(DeviceCtx &cx, const uint8_t *data, size_t bytes) {
         JPEGENC_HIP(hipHostMalloc((void **)&cx.h_pixels, bytes, hipHostMallocDefault));
         cx.h_pixels_cap = bytes;
     }
-    // Two granularities.  COPIES go in chunks of 512 KB that the threads take in order (a 4K frame: 48 chunks over four threads);
-    // DMA commands cover runs of chunks that double - 512 KB, 1 MB, 2 MB ... up to 32 MB - so that the link starts after ~15 us
-    // of copying and a large frame is still a handful of commands (every command costs the engine ~10 us: twelve equal stripes of a
-    // 4K frame measured 0.15 ms slower than the runtime's own pageable path, profiles/r06_pageable_runtime_path.txt).
-    static const size_t chunk_min = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_CHUNK_KB"); return v && atoi(v) > 0 ? (size_t)atoi(v) << 10 : (size_t)512 << 10; }();
+    static const size_t chunk_min = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_CHUNK_KB"); return v && atoi(v) >= 64 ? ((size_t)atoi(v) << 10) & ~(size_t)65535 : (size_t)512 << 10; }();
     static const uint32_t unit_cap = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_UNIT_CHUNKS"); return v && atoi(v) > 0 ? (uint32_t)atoi(v) : 64u; }();
     static const uint32_t unit_growth = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_UNIT_GROWTH"); return v && atoi(v) > 1 ? (uint32_t)atoi(v) : 2u; }();
+    static const bool dma_commands = JPEGENC_DIAG_ENV("JPEGENC_STAGE_DMA") != nullptr;
     static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    size_t chunk = chunk_min;
+    size_t chunk = chunk_min;                                                                               // (a multiple of 64 KB)
     if ((bytes + chunk - 1) / chunk > 4096) chunk = (((bytes + 4095) / 4096) + 65535) & ~(size_t)65535;      // (frames beyond 2 GB: at most 4 096 chunks)
     const uint32_t nchunks = (uint32_t)((bytes + chunk - 1) / chunk);
     std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[nchunks]);
     for (uint32_t k = 0; k < nchunks; k++) done[k].store(0, std::memory_order_relaxed);
     std::atomic<uint32_t> next(0);
     uint8_t *dst = cx.h_pixels;
+
+    // the kernel first: it is on the device by the time the first chunk is staged
+    bool pull = !dma_commands && chunk % ((size_t)kStagedPullGroups * 64u) == 0 && chunk <= 0xFFFFFFFFu;
+    if (pull && !cx.h_pull) {
+        if (hipHostMalloc((void **)&cx.h_pull, 128, hipHostMallocDefault) == hipSuccess) memset(cx.h_pull, 0, 128);
+        else { (void)hipGetLastError(); cx.h_pull = nullptr; pull = false; }
+    }
+    uint32_t epoch = 0;
+    if (pull) {
+        // (a call that failed before its stream was waited for may have left the kernel of ITS upload behind: that one must not meet this epoch)
+        if (cx.pull_pending && hipStreamQuery(cx.stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(cx.stream); }
+        (void)cx.pull_timed_out();
+        epoch = ++cx.pull_epoch;
+        if (launch_staged_pull(dst, (uint8_t *)cx.d_pixels, bytes, (uint32_t)chunk, nchunks, cx.h_pull, epoch, reinterpret_cast<uint32_t *>(cx.h_pull + 8), cx.stream) != hipSuccess) {
+            (void)hipGetLastError();
+            pull = false;
+        } else {
+            cx.pull_pending = true;
+        }
+    }
+    // From here on every path publishes every chunk: the kernel waits for them.
+    std::atomic<uint64_t> *ready_word = reinterpret_cast<std::atomic<uint64_t> *>(cx.h_pull);
+    auto publish = [&] {                               // advance "staged so far" past every finished chunk (any copier, after its own chunk)
+        for (;;) {
+            uint64_t cur = ready_word->load();
+            const uint32_t r = (uint32_t)(cur >> 32) == epoch ? (uint32_t)cur : 0u;
+            uint32_t n = r;
+            while (n < nchunks && done[n].load()) n++;
+            if (n == r) return;
+            (void)ready_word->compare_exchange_strong(cur, ((uint64_t)epoch << 32) | n);      // (then once more: others may have finished meanwhile)
+        }
+    };
     auto copy_one = [&](uint32_t k) {
         const size_t at = (size_t)k * chunk, n = bytes - at < chunk ? bytes - at : chunk;
         staging_copy(dst + at, data + at, n);
-        done[k].store(1, std::memory_order_release);
+        done[k].store(1);                              // (sequentially consistent: whoever finishes a chunk last sees the other's flag)
+        if (pull) publish();
     };
     auto copier = [&]() {
         for (;;) {
@@ -73,31 +107,46 @@ static int upload_in_stripes(DeviceCtx &cx, const uint8_t *data, size_t bytes) {
             copy_one(k);
         }
     };
-    const int helpers = cx.stage_pool && nchunks > 1 ? (int)std::min<uint32_t>((uint32_t)cx.stage_threads - 1u, nchunks - 1u) : 0;
+    // Copier threads: with the kernel behind them two saturate the link and a third changes nothing (csrc/tools/pull_probe.hip: a 4K frame
+    // 598-650 us with one, 510-523 with two to four, 607-632 with six); the DMA commands wanted four.
+    const uint32_t want_helpers = pull ? std::min<uint32_t>(2u, nchunks / 4u) : nchunks - 1u;
+    const int helpers = cx.stage_pool && nchunks > 1 ? (int)std::min<uint32_t>((uint32_t)cx.stage_threads - 1u, want_helpers) : 0;
     if (helpers > 0) {
         cx.stage_pool->ensure_threads(helpers);
         for (int t = 0; t < helpers; t++) cx.stage_pool->submit(2, copier);
     }
     hipError_t he = hipSuccess;
-    uint32_t unit_begin = 0, unit_len = 1, ready = 0;
     int own = 0, commands = 0;
-    while (unit_begin < nchunks) {
-        const uint32_t unit_end = std::min(nchunks, unit_begin + unit_len);
-        while (ready < unit_end && done[ready].load(std::memory_order_acquire)) ready++;
-        if (ready >= unit_end) {
-            const size_t at = (size_t)unit_begin * chunk, end = std::min(bytes, (size_t)unit_end * chunk);
-            if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)cx.d_pixels + at, dst + at, end - at, hipMemcpyHostToDevice, cx.stream);
-            commands++;
-            unit_begin = unit_end;
-            unit_len = std::min(unit_cap, unit_len * unit_growth);
-            continue;
+    if (pull) {
+        for (;;) {
+            const uint32_t k = next.fetch_add(1);
+            if (k >= nchunks) break;
+            copy_one(k); own++;
         }
-        const uint32_t k = next.fetch_add(1);
-        if (k < nchunks) { copy_one(k); own++; } else _mm_pause();
+    } else {
+        // DMA commands cover runs of chunks that double - 512 KB, 1 MB, 2 MB ... up to 32 MB - so that the link starts after ~15 us of
+        // copying and a large frame is still a handful of commands (twelve equal stripes of a 4K frame measured 0.15 ms slower)
+        uint32_t unit_begin = 0, unit_len = 1, ready = 0;
+        while (unit_begin < nchunks) {
+            const uint32_t unit_end = std::min(nchunks, unit_begin + unit_len);
+            while (ready < unit_end && done[ready].load(std::memory_order_acquire)) ready++;
+            if (ready >= unit_end) {
+                const size_t at = (size_t)unit_begin * chunk, end = std::min(bytes, (size_t)unit_end * chunk);
+                if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)cx.d_pixels + at, dst + at, end - at, hipMemcpyHostToDevice, cx.stream);
+                commands++;
+                unit_begin = unit_end;
+                unit_len = std::min(unit_cap, unit_len * unit_growth);
+                continue;
+            }
+            const uint32_t k = next.fetch_add(1);
+            if (k < nchunks) { copy_one(k); own++; } else _mm_pause();
+        }
     }
     if (helpers > 0) cx.stage_pool->wait(2);                       // (the tasks refer to this frame's stack)
-    if (trace) fprintf(stderr, "[jpegenc]   staged upload: %zu bytes in %u chunks / %d DMA commands, %d helper threads, this thread copied %d chunks, all enqueued after %ld us\n", bytes, nchunks,
-                       commands, helpers, own, (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+    if (pull) publish();                                           // every chunk is staged: the word says so whatever the copiers' scans saw
+    if (trace) fprintf(stderr, "[jpegenc]   staged upload: %zu bytes in %u chunks / %s, %d helper threads, this thread copied %d chunks, all staged after %ld us\n", bytes, nchunks,
+                       pull ? "one pull kernel" : (std::to_string(commands) + " DMA commands").c_str(), helpers, own,
+                       (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
     if (he != hipSuccess) return hip_fail(he, "upload of a staged stripe");
     return JPEGENC_OK;
 }
@@ -1014,7 +1063,11 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
         }
         return JPEGENC_OK;
     };
-    return encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user, staged || !single_locked ? nullptr : data);
+    rc = encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user, staged || !single_locked ? nullptr : data);
+    // (the upload kernel of a pageable image waits for this process's copier threads and gives up after two seconds without a new chunk -
+    //  a process stopped in the middle of a call: the file was coded from an incomplete image)
+    if (rc == JPEGENC_OK && ctx.pull_timed_out()) return fail(JPEGENC_ERR_HIP, "the staged upload timed out waiting for the host's copy of the image");
+    return rc;
 }
 
 

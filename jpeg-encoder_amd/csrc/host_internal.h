@@ -416,6 +416,20 @@ struct DeviceCtx {
     // (host_frame.cpp, upload_in_stripes).  Set by the entry point; null = this thread alone.
     BackgroundPool *stage_pool = nullptr;
     int stage_threads = 1;
+    // ... and the transfer is ONE kernel that follows the copiers (staged_pull.hip): h_pull[0] = epoch << 32 | chunks staged so far,
+    // h_pull[8] (its own cache line) = set by the kernel when it gave up waiting; pull_pending = a frame's upload went that way and the
+    // word has not been looked at since.
+    uint64_t *h_pull = nullptr;
+    uint32_t pull_epoch = 0;
+    bool pull_pending = false;
+    bool pull_timed_out() {              // after the frame's stream has been waited for
+        if (!pull_pending || !h_pull) return false;
+        pull_pending = false;
+        volatile uint32_t *w = reinterpret_cast<volatile uint32_t *>(h_pull + 8);
+        const bool t = *w != 0;
+        *w = 0;
+        return t;
+    }
     void frame_over() {                  // after a batch worker's frame: what before_wait staged becomes the current staging buffer
         before_wait = nullptr;
         staged_src = nullptr;
@@ -664,6 +678,7 @@ struct DeviceCtx {
         if (h_coeffs) (void)hipHostFree(h_coeffs);
         if (h_pixels) (void)hipHostFree(h_pixels);
         if (h_next) (void)hipHostFree(h_next);
+        if (h_pull) (void)hipHostFree(h_pull);
         if (h_freq) (void)hipHostFree(h_freq);
         if (d_scan_ws) (void)hipFree(d_scan_ws);
         if (d_scan_out) (void)hipFree(d_scan_out);

@@ -1482,3 +1482,25 @@ def test_finish_kernel_experiment(binding):
     env = dict(os.environ, JPEGENC_FINISH_KERNEL="1", JPEGENC_LIB=binding.DIAG_LIB_PATH)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "ok 18" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_pageable_single_images_follow_their_copiers_over_the_link(binding, oracle, synth):
+    """Encoder::encode(&[u8]) from ordinary memory above the zero-copy size: the image is staged through the handle's page-locked buffer
+    by the copier threads while ONE kernel pulls the staged chunks over the link (csrc/staged_pull.hip).  Sizes whose byte count is not
+    a multiple of 16, of a chunk, or of the kernel's slices; one chunk and many; every copier budget; the same handle for different
+    images in turn (a chunk read too early, or one left over from the image before, would show as a different file)."""
+    cases = [(1001, 701, binding.RGB, oracle.RGB, 3), (2049, 1031, binding.LUMA, oracle.LUMA, 1), (1283, 997, binding.RGBA, oracle.RGBA, 4),
+             (1920, 1080, binding.RGB, oracle.RGB, 3), (683, 512, binding.RGB, oracle.RGB, 3)]
+    for workers in (0, 1, 2, 3):
+        e = binding.Encoder(85)
+        e.set_sampling_factor(binding.sampling_factor(2, 2))
+        e.set_batch_workers(workers)
+        for rep in range(2):
+            for k, (w, h, ct, oct_, ch) in enumerate(cases):
+                px = synth.lcg_image(w, h, ch, 1000 * workers + 10 * rep + k)
+                assert px.nbytes > (1 << 20)
+                got = e.encode(px, w, h, ct)
+                want = oracle.encode_jpeg(px, w, h, oct_, 85, sampling=(2, 2))
+                assert got == want, (workers, rep, w, h, len(got), len(want))
+        e.close()
