@@ -80,8 +80,8 @@ hipError_t launch_gather_scans(const GatherArgs &a, const void *d_src, const uin
 // staged_pull.hip: the upload of one pageable image as a kernel that follows the copier threads through the page-locked staging buffer
 constexpr uint32_t kStagedPullGroups = 32u, kStagedPullThreads = 256u;
 constexpr uint64_t kStagedPullTimeoutTicks = 200000000ull;      // 2 s of the 100 MHz wall clock without a new chunk: the kernel gives up
-hipError_t launch_staged_pull(const uint8_t *h_staged, uint8_t *d_pixels, size_t bytes, uint32_t chunk, uint32_t nchunks, const uint64_t *h_ready,
-                              uint32_t epoch, uint32_t *h_timed_out, hipStream_t stream);
+hipError_t launch_staged_pull(const uint8_t *h_staged, uint8_t *d_pixels, size_t from, size_t to, uint32_t chunk, const uint64_t *h_ready,
+                              uint32_t epoch, uint32_t *h_timed_out, hipStream_t stream);      // bytes [from, to) of the image
 
 // capi_entropy.hip
 int scan_device(const void *d_coeffs, size_t coeff_frame_stride, int frames, const jpegenc_layout &L,

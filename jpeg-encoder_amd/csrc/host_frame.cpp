@@ -37,118 +37,167 @@ void staging_copy(void *dst, const void *src, size_t n) {
 // inside the runtime and keeps those registrations cached; with frames on the C heap that are freed and reallocated between calls (what
 // tests/test_gpu_batch_multi.py::test_randomised_host_fed_batches does) one process in ten died of "Memory access fault by GPU" - round 5's
 // library just the same (profiles/r06_pageable_runtime_path.txt).
-// The transfer is ONE kernel (staged_pull.hip), launched before the first byte is copied: it follows the "chunks staged so far" word the
+// The transfer is a kernel (staged_pull.hip), launched before the first byte is copied: it follows the "chunks staged so far" word the
 // copiers advance and pulls every chunk over the link as soon as it is there - no DMA command per run of chunks (each cost the engine
 // ~10 us and the last one covered up to half the frame), one chunk's transfer left after the last byte was copied
-// (profiles/r06_staged_pull.txt).  JPEGENC_STAGE_DMA=1 in the diagnostic build: the DMA commands over doubling runs of chunks of the
-// first cut (also what a failed kernel launch falls back to).
-static int upload_in_stripes(DeviceCtx &cx, const uint8_t *data, size_t bytes) {
-    if (bytes > cx.h_pixels_cap) {
-        if (cx.h_pixels) (void)hipHostFree(cx.h_pixels);
-        cx.h_pixels = nullptr; cx.h_pixels_cap = 0;
-        JPEGENC_HIP(hipHostMalloc((void **)&cx.h_pixels, bytes, hipHostMallocDefault));
-        cx.h_pixels_cap = bytes;
-    }
-    static const size_t chunk_min = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_CHUNK_KB"); return v && atoi(v) >= 64 ? ((size_t)atoi(v) << 10) & ~(size_t)65535 : (size_t)512 << 10; }();
-    static const uint32_t unit_cap = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_UNIT_CHUNKS"); return v && atoi(v) > 0 ? (uint32_t)atoi(v) : 64u; }();
-    static const uint32_t unit_growth = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_UNIT_GROWTH"); return v && atoi(v) > 1 ? (uint32_t)atoi(v) : 2u; }();
-    static const bool dma_commands = JPEGENC_DIAG_ENV("JPEGENC_STAGE_DMA") != nullptr;
-    static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    size_t chunk = chunk_min;                                                                               // (a multiple of 64 KB)
-    if ((bytes + chunk - 1) / chunk > 4096) chunk = (((bytes + 4095) / 4096) + 65535) & ~(size_t)65535;      // (frames beyond 2 GB: at most 4 096 chunks)
-    const uint32_t nchunks = (uint32_t)((bytes + chunk - 1) / chunk);
-    std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[nchunks]);
-    for (uint32_t k = 0; k < nchunks; k++) done[k].store(0, std::memory_order_relaxed);
-    std::atomic<uint32_t> next(0);
-    uint8_t *dst = cx.h_pixels;
+// (profiles/r06_staged_pull.txt).  One launch for the whole image (upload_in_stripes), or one per stripe of a frame that is coded
+// stripe by stripe (FrameRun::run_striped).  JPEGENC_STAGE_DMA=1 in the diagnostic build: the DMA commands over doubling runs of chunks
+// of the first cut (also what a failed kernel launch falls back to; such frames are not striped).
+struct StagedUpload {
+    DeviceCtx &cx;
+    const uint8_t *const data;
+    const size_t bytes;
+    size_t chunk = 0;
+    uint32_t nchunks = 0, epoch = 0;
+    std::unique_ptr<std::atomic<uint8_t>[]> done;
+    std::atomic<uint32_t> next{0};
+    std::atomic<bool> pull{false};                     // the kernel moves the staged chunks (else: the caller's DMA commands)
+    bool helpers_running = false;
+    int helpers = 0, own = 0, launches = 0;
+    std::chrono::steady_clock::time_point t0;
 
-    // the kernel first: it is on the device by the time the first chunk is staged
-    bool pull = !dma_commands && chunk % ((size_t)kStagedPullGroups * 64u) == 0 && chunk <= 0xFFFFFFFFu;
-    if (pull && !cx.h_pull) {
-        if (hipHostMalloc((void **)&cx.h_pull, 128, hipHostMallocDefault) == hipSuccess) memset(cx.h_pull, 0, 128);
-        else { (void)hipGetLastError(); cx.h_pull = nullptr; pull = false; }
-    }
-    uint32_t epoch = 0;
-    if (pull) {
-        // (a call that failed before its stream was waited for may have left the kernel of ITS upload behind: that one must not meet this epoch)
-        if (cx.pull_pending && hipStreamQuery(cx.stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(cx.stream); }
-        (void)cx.pull_timed_out();
-        epoch = ++cx.pull_epoch;
-        if (launch_staged_pull(dst, (uint8_t *)cx.d_pixels, bytes, (uint32_t)chunk, nchunks, cx.h_pull, epoch, reinterpret_cast<uint32_t *>(cx.h_pull + 8), cx.stream) != hipSuccess) {
-            (void)hipGetLastError();
-            pull = false;
-        } else {
-            cx.pull_pending = true;
+    StagedUpload(DeviceCtx &c, const uint8_t *d, size_t n) : cx(c), data(d), bytes(n) {}
+    ~StagedUpload() { finish(); }
+    static bool dma_commands() { static const bool v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_DMA") != nullptr; return v; }
+    // whether this context's uploads can go through the kernel at all (its two words of page-locked memory are there)
+    static bool available(DeviceCtx &c) {
+        if (dma_commands()) return false;
+        if (!c.h_pull) {
+            if (hipHostMalloc((void **)&c.h_pull, 128, hipHostMallocDefault) == hipSuccess) memset(c.h_pull, 0, 128);
+            else { (void)hipGetLastError(); c.h_pull = nullptr; }
         }
+        return c.h_pull != nullptr;
     }
-    // From here on every path publishes every chunk: the kernel waits for them.
-    std::atomic<uint64_t> *ready_word = reinterpret_cast<std::atomic<uint64_t> *>(cx.h_pull);
-    auto publish = [&] {                               // advance "staged so far" past every finished chunk (any copier, after its own chunk)
+
+    // the staging buffer, the chunking, the epoch, the copier threads (they start at once).  hands_off: the calling thread has a
+    // pipeline to drive meanwhile (run_striped) - up to three helpers, and with two or more of them it leaves the copying to them
+    // (leaves_copying(); finish() still takes what is left).
+    int begin(bool hands_off = false) {
+        if (bytes > cx.h_pixels_cap) {
+            if (cx.h_pixels) (void)hipHostFree(cx.h_pixels);
+            cx.h_pixels = nullptr; cx.h_pixels_cap = 0;
+            JPEGENC_HIP(hipHostMalloc((void **)&cx.h_pixels, bytes, hipHostMallocDefault));
+            cx.h_pixels_cap = bytes;
+        }
+        static const size_t chunk_min = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_CHUNK_KB"); return v && atoi(v) >= 64 ? ((size_t)atoi(v) << 10) & ~(size_t)65535 : (size_t)512 << 10; }();
+        t0 = std::chrono::steady_clock::now();
+        chunk = chunk_min;                                                                                       // (a multiple of 64 KB)
+        if ((bytes + chunk - 1) / chunk > 4096) chunk = (((bytes + 4095) / 4096) + 65535) & ~(size_t)65535;      // (frames beyond 2 GB: at most 4 096 chunks)
+        nchunks = (uint32_t)((bytes + chunk - 1) / chunk);
+        done.reset(new std::atomic<uint8_t>[nchunks]);
+        for (uint32_t k = 0; k < nchunks; k++) done[k].store(0, std::memory_order_relaxed);
+        pull = chunk % ((size_t)kStagedPullGroups * 64u) == 0 && chunk <= 0xFFFFFFFFu && available(cx);
+        if (pull) {
+            // (a call that failed before its stream was waited for may have left the kernel of ITS upload behind: that one must not meet this epoch)
+            if (cx.pull_pending && hipStreamQuery(cx.stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(cx.stream); }
+            (void)cx.pull_timed_out();
+            epoch = ++cx.pull_epoch;
+        }
+        // Copier threads: with the kernel behind them two saturate the link and a third changes nothing (csrc/tools/pull_probe.hip: a 4K frame
+        // 598-650 us with one, 510-523 with two to four, 607-632 with six); the DMA commands wanted four.
+        const uint32_t want_helpers = pull ? std::min<uint32_t>(hands_off ? 3u : 2u, nchunks / 4u) : nchunks - 1u;
+        helpers = cx.stage_pool && nchunks > 1 ? (int)std::min<uint32_t>((uint32_t)cx.stage_threads - 1u, want_helpers) : 0;
+        if (helpers > 0) {
+            cx.stage_pool->ensure_threads(helpers);
+            for (int t = 0; t < helpers; t++) cx.stage_pool->submit(2, [this] { copier(); });
+            helpers_running = true;
+        }
+        return JPEGENC_OK;
+    }
+    // the bytes [from, to) of the image cross the link on the context's stream as they are staged.  A launch that fails ends the
+    // kernel's part in this upload: the caller moves what is missing with DMA commands once everything is staged (pull is false then).
+    hipError_t pull_range(size_t from, size_t to) {
+        const hipError_t e = launch_staged_pull(cx.h_pixels, (uint8_t *)cx.d_pixels, from, to, (uint32_t)chunk, cx.h_pull, epoch, reinterpret_cast<uint32_t *>(cx.h_pull + 8), cx.stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+        cx.pull_pending = true;
+        launches++;
+        return hipSuccess;
+    }
+    void publish() {                                   // advance "staged so far" past every finished chunk (any copier, after its own chunk)
+        std::atomic<uint64_t> *w = reinterpret_cast<std::atomic<uint64_t> *>(cx.h_pull);
         for (;;) {
-            uint64_t cur = ready_word->load();
+            uint64_t cur = w->load();
             const uint32_t r = (uint32_t)(cur >> 32) == epoch ? (uint32_t)cur : 0u;
             uint32_t n = r;
             while (n < nchunks && done[n].load()) n++;
             if (n == r) return;
-            (void)ready_word->compare_exchange_strong(cur, ((uint64_t)epoch << 32) | n);      // (then once more: others may have finished meanwhile)
+            (void)w->compare_exchange_strong(cur, ((uint64_t)epoch << 32) | n);      // (then once more: others may have finished meanwhile)
         }
-    };
-    auto copy_one = [&](uint32_t k) {
+    }
+    void copy_one(uint32_t k) {
         const size_t at = (size_t)k * chunk, n = bytes - at < chunk ? bytes - at : chunk;
-        staging_copy(dst + at, data + at, n);
+        staging_copy(cx.h_pixels + at, data + at, n);
         done[k].store(1);                              // (sequentially consistent: whoever finishes a chunk last sees the other's flag)
         if (pull) publish();
-    };
-    auto copier = [&]() {
+    }
+    void copier() {
         for (;;) {
             const uint32_t k = next.fetch_add(1);
             if (k >= nchunks) break;
             copy_one(k);
         }
-    };
-    // Copier threads: with the kernel behind them two saturate the link and a third changes nothing (csrc/tools/pull_probe.hip: a 4K frame
-    // 598-650 us with one, 510-523 with two to four, 607-632 with six); the DMA commands wanted four.
-    const uint32_t want_helpers = pull ? std::min<uint32_t>(2u, nchunks / 4u) : nchunks - 1u;
-    const int helpers = cx.stage_pool && nchunks > 1 ? (int)std::min<uint32_t>((uint32_t)cx.stage_threads - 1u, want_helpers) : 0;
-    if (helpers > 0) {
-        cx.stage_pool->ensure_threads(helpers);
-        for (int t = 0; t < helpers; t++) cx.stage_pool->submit(2, copier);
     }
+    bool leaves_copying() const { return helpers >= 2; }
+    bool copy_next() {                                 // this thread takes one chunk (false: none left to take)
+        const uint32_t k = next.fetch_add(1);
+        if (k >= nchunks) return false;
+        copy_one(k); own++;
+        return true;
+    }
+    // every chunk is staged and the word says so - on EVERY path behind begin(): the kernel waits for it
+    void finish() {
+        if (!done) return;
+        while (copy_next()) {}
+        if (helpers_running) { cx.stage_pool->wait(2); helpers_running = false; }      // (the tasks refer to this object)
+        if (pull) publish();
+    }
+    void trace_line(const char *what) const {
+        fprintf(stderr, "[jpegenc]   staged upload: %zu bytes in %u chunks / %d %s, %d helper threads, this thread copied %d chunks, all staged after %ld us\n", bytes, nchunks,
+                launches, what, helpers, own, (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
+static int upload_in_stripes(DeviceCtx &cx, const uint8_t *data, size_t bytes) {
+    static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
+    StagedUpload su(cx, data, bytes);
+    const int rc = su.begin();
+    if (rc) return rc;
     hipError_t he = hipSuccess;
-    int own = 0, commands = 0;
-    if (pull) {
-        for (;;) {
-            const uint32_t k = next.fetch_add(1);
-            if (k >= nchunks) break;
-            copy_one(k); own++;
-        }
-    } else {
-        // DMA commands cover runs of chunks that double - 512 KB, 1 MB, 2 MB ... up to 32 MB - so that the link starts after ~15 us of
-        // copying and a large frame is still a handful of commands (twelve equal stripes of a 4K frame measured 0.15 ms slower)
-        uint32_t unit_begin = 0, unit_len = 1, ready = 0;
-        while (unit_begin < nchunks) {
-            const uint32_t unit_end = std::min(nchunks, unit_begin + unit_len);
-            while (ready < unit_end && done[ready].load(std::memory_order_acquire)) ready++;
-            if (ready >= unit_end) {
-                const size_t at = (size_t)unit_begin * chunk, end = std::min(bytes, (size_t)unit_end * chunk);
-                if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)cx.d_pixels + at, dst + at, end - at, hipMemcpyHostToDevice, cx.stream);
-                commands++;
-                unit_begin = unit_end;
-                unit_len = std::min(unit_cap, unit_len * unit_growth);
-                continue;
-            }
-            const uint32_t k = next.fetch_add(1);
-            if (k < nchunks) { copy_one(k); own++; } else _mm_pause();
-        }
+    if (su.pull && su.pull_range(0, bytes) == hipSuccess) {
+        su.finish();
+        if (trace) su.trace_line("pull kernel");
+        return JPEGENC_OK;
     }
-    if (helpers > 0) cx.stage_pool->wait(2);                       // (the tasks refer to this frame's stack)
-    if (pull) publish();                                           // every chunk is staged: the word says so whatever the copiers' scans saw
-    if (trace) fprintf(stderr, "[jpegenc]   staged upload: %zu bytes in %u chunks / %s, %d helper threads, this thread copied %d chunks, all staged after %ld us\n", bytes, nchunks,
-                       pull ? "one pull kernel" : (std::to_string(commands) + " DMA commands").c_str(), helpers, own,
-                       (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count());
+    // DMA commands cover runs of chunks that double - 512 KB, 1 MB, 2 MB ... up to 32 MB - so that the link starts after ~15 us of
+    // copying and a large frame is still a handful of commands (twelve equal stripes of a 4K frame measured 0.15 ms slower)
+    static const uint32_t unit_cap = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_UNIT_CHUNKS"); return v && atoi(v) > 0 ? (uint32_t)atoi(v) : 64u; }();
+    static const uint32_t unit_growth = [] { const char *v = JPEGENC_DIAG_ENV("JPEGENC_STAGE_UNIT_GROWTH"); return v && atoi(v) > 1 ? (uint32_t)atoi(v) : 2u; }();
+    su.pull = false;                                   // (copiers that saw `true` published to a word nobody reads)
+    uint32_t unit_begin = 0, unit_len = 1, ready = 0;
+    while (unit_begin < su.nchunks) {
+        const uint32_t unit_end = std::min(su.nchunks, unit_begin + unit_len);
+        while (ready < unit_end && su.done[ready].load(std::memory_order_acquire)) ready++;
+        if (ready >= unit_end) {
+            const size_t at = (size_t)unit_begin * su.chunk, end = std::min(bytes, (size_t)unit_end * su.chunk);
+            if (he == hipSuccess) he = hipMemcpyAsync((uint8_t *)cx.d_pixels + at, cx.h_pixels + at, end - at, hipMemcpyHostToDevice, cx.stream);
+            su.launches++;
+            unit_begin = unit_end;
+            unit_len = std::min(unit_cap, unit_len * unit_growth);
+            continue;
+        }
+        if (!su.copy_next()) _mm_pause();
+    }
+    su.finish();
+    if (trace) su.trace_line("DMA commands");
     if (he != hipSuccess) return hip_fail(he, "upload of a staged stripe");
     return JPEGENC_OK;
+}
+
+// from how many bytes of pixels a baseline frame may be uploaded, coded and downloaded stripe by stripe (FrameRun::run_striped): where a
+// stripe's copies are worth their fixed costs
+static size_t striped_from_bytes() {
+    static const size_t v = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_STRIPED_FROM_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)4 << 20); }();
+    return v;
 }
 
 // The whole of encode_image_internal for one frame, as the steps encode_frame walks through: what the frame needs
@@ -188,7 +237,8 @@ struct FrameRun {
     BlockKernelParams p;
     bool optimize = false;
     FusedSource fused_src = {};
-    int stripes = 0;                    // > 0: a large frame between page-locked buffers, through run_striped in that many stripes
+    int stripes = 0;                    // > 0: a large baseline frame into the library's buffer sink, through run_striped in that many stripes
+    bool pixels_locked = false, out_locked = false;   // (striped) the caller's pixels / output buffer are page-locked: used where they lie
     bool stripe_timed = false;          // the call's duration goes to the handle's StripeTuner
     bool self_finishing = false;        // ... and its workgroups put the scan together themselves: the launch sequence is that one kernel
     bool holds_finish_slot = false;     // counted in g_big_finishing until this run ends
@@ -347,15 +397,25 @@ struct FrameRun {
         if (self_finishing && host_gather && !poll_off && !ctx.batch_worker) fused_src.finish_done = (uint32_t *)(ctx.h_words + 2);
         // A large frame between page-locked host buffers: uploaded, coded and downloaded stripe by stripe (run_striped) - from 4 MB
         // of pixels, where a stripe's copies are worth their fixed costs.
-        static const size_t striped_from = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_STRIPED_FROM_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)4 << 20); }();
         stripes = 0;
-        if (self_finishing && !host_gather && host_pixels && sink == buffer_sink && pixel_bytes >= striped_from && pixel_bytes < (1ull << 31)) {
+        if (self_finishing && !host_gather && host_pixels && sink == buffer_sink && pixel_bytes >= striped_from_bytes() && pixel_bytes < (1ull << 31)) {
             const BufferSink *bs = (const BufferSink *)user;
             const uint32_t mcu_rows = (uint32_t)((L.mcus + p.mcus_x - 1) / p.mcus_x);
             static const int forced = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_STRIPES"); return e ? atoi(e) : 0; }();
-            if (mcu_rows >= 2 && is_pinned_host_range(host_pixels, pixel_bytes) && bs->out && is_pinned_host_range(bs->out, bs->cap)) {
+            static const bool pageable_off = JPEGENC_DIAG_ENV("JPEGENC_NO_PAGEABLE_STRIPES") != nullptr;      // diagnosis: stripes between page-locked buffers only
+            // Page-locked pixels are uploaded where they lie, pageable ones staged chunk by chunk with one pull kernel per stripe
+            // (StagedUpload); a page-locked output buffer takes each stripe's bytes straight from the DMA, a pageable one gets them
+            // through the handle's page-locked scan buffer (run_striped).
+            pixels_locked = is_pinned_host_range(host_pixels, pixel_bytes);
+            out_locked = bs->out && bs->cap && is_pinned_host_range(bs->out, bs->cap);
+            const bool both_locked = pixels_locked && out_locked;
+            // (with a pageable side the copies are the handle's threads' work and stripes pay from 8 MB of pixels: 4K 0.78 -> 0.72 ms,
+            //  Criterion's 10.8 MB frame at quality 100 0.70 -> 0.66, nothing at 1080p - profiles/r06_staged_pull.txt)
+            static const size_t pageable_from = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_PAGEABLE_STRIPES_FROM_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)8 << 20); }();
+            if (mcu_rows >= 2 && bs->out && (both_locked || (!pageable_off && pixel_bytes >= pageable_from && (pixels_locked || StagedUpload::available(ctx))))) {
                 // 4, 2 or 1 (= the ordinary sequence): whichever this handle measured as the fastest (DeviceCtx::StripeTuner)
-                stripes = forced ? forced : ctx.stripe_tuner.choose(content_key(c, width, height, color_type_or_planes));
+                const uint64_t tuner_key = content_key(c, width, height, color_type_or_planes) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(1 + (pixels_locked ? 1 : 0) + (out_locked ? 2 : 0)));
+                stripes = forced ? forced : ctx.stripe_tuner.choose(tuner_key);
                 stripe_timed = !forced;
                 if (stripes > DeviceCtx::kChunks) stripes = DeviceCtx::kChunks;
                 if ((uint32_t)stripes > mcu_rows) stripes = (int)mcu_rows;
@@ -668,17 +728,19 @@ struct FrameRun {
         return JPEGENC_OK;
     }
 
-    // A large baseline frame between PAGE-LOCKED host buffers (jpegenc_host_alloc / jpegenc_host_register, or HIP's own calls),
-    // in stripes of whole MCU rows: every copy is then truly asynchronous, and one thread keeps three streams busy - the
+    // A large baseline frame from host memory into the library's buffer sink, in stripes of whole MCU rows: one thread keeps three streams busy - the
     // uploads, the pixels -> bits kernel of each stripe as soon as its rows are there (its workgroups look back over ALL
     // earlier runs of the frame, whichever launch they came in, and write their bytes where they belong in the scan -
     // finish_run.hip.h), and the download of the finished part of the scan straight to its place in the caller's buffer.
     // One after the other - upload, kernel, download - Criterion's 2000x1800 frame at quality 100 (10.8 MB up, 14.4 MB
     // down) takes 0.62 ms of which the two copies alone are 0.47; in four stripes 0.45.
-    // (Pageable buffers stay with the one-piece sequence: a copy on pageable memory does not return before it is done and
-    // costs ~35 us per call on top of its bytes - csrc/tools/pageable_async.cpp; with a second host thread for the downloads
-    // two stripes gained 5 % on that frame and lost on every other.  The kernel storing the scan into the caller's page-locked
-    // buffer itself - no download at all - is slower than the DMA for megabytes: 0.54-0.58 ms.  profiles/README.md.)
+    // Between PAGE-LOCKED buffers (jpegenc_host_alloc / jpegenc_host_register, or HIP's own calls) every copy is a DMA command on
+    // the caller's memory.  PAGEABLE buffers never reach the runtime (upload_in_stripes): pageable pixels are staged chunk by chunk
+    // by the copier threads and pulled over the link by one kernel per stripe (StagedUpload), a pageable output buffer gets each
+    // stripe's bytes through the context's page-locked scan buffer, copied out while the next stripe's are on the link
+    // (profiles/r06_staged_pull.txt; until round 6 pageable buffers kept the one-piece sequence: the runtime's pageable copies
+    // do not return before they are done).  The kernel storing the scan into the caller's page-locked buffer itself - no download
+    // at all - is slower than the DMA for megabytes: 0.54-0.58 ms.
     int run_striped() {
         static const bool trace = getenv("JPEGENC_TRACE") != nullptr;
         BufferSink *bs = (BufferSink *)user;
@@ -705,10 +767,27 @@ struct FrameRun {
         int rc = JPEGENC_OK;
         hipError_t he = hipSuccess;
         int launched = 0;
+        // pageable pixels: staged chunk by chunk through the context's page-locked buffer - the copier threads start now, this thread
+        // joins them once the stripes are enqueued - and pulled over the link by one kernel per stripe (StagedUpload)
+        if (!out_locked) {                  // (what this handle's last file of the geometry took, or a quarter of the pixels: the buffer grows below if that is short)
+            const bool again = ctx.last_file_geometry == content_key(c, width, height, color_type_or_planes) && ctx.last_scan_bytes;
+            const int rr = ctx.reserve_scan_host((again ? ctx.last_scan_bytes + ctx.last_scan_bytes / 8 : pixel_bytes / 4) + ((size_t)1 << 20));
+            if (rr) { bs->len = len0; return rr; }
+        }
+        StagedUpload staged(ctx, host_pixels, pixel_bytes);
+        if (!pixels_locked) {
+            rc = staged.begin(true);
+            if (rc == JPEGENC_OK && !staged.pull) rc = fail(JPEGENC_ERR_HIP, "striped frame: the staged upload has no kernel to follow it");      // (plan_scans asked)
+            if (rc) { bs->len = len0; return rc; }
+        }
         for (int k = 0; k < stripes && rc == JPEGENC_OK && he == hipSuccess; k++, launched++) {
             const uint32_t rows_end = k + 1 == stripes ? mcu_rows : (uint32_t)((uint64_t)mcu_rows * (uint32_t)(k + 1) / (uint32_t)stripes);
+            // (a last stripe half the size of the others - less left to do once the last pixel has arrived - measured the same: tools/diag/r06_stripe_shapes.sh)
             const size_t y0 = std::min<size_t>((size_t)rows_done * mcu_h, (size_t)height), y1 = std::min<size_t>((size_t)rows_end * mcu_h, (size_t)height);
-            if (y1 > y0) he = hipMemcpyAsync((uint8_t *)ctx.d_pixels + y0 * pitch, host_pixels + y0 * pitch, (y1 - y0) * pitch, hipMemcpyHostToDevice, ctx.stream);
+            if (y1 > y0) {
+                if (pixels_locked) he = hipMemcpyAsync((uint8_t *)ctx.d_pixels + y0 * pitch, host_pixels + y0 * pitch, (y1 - y0) * pitch, hipMemcpyHostToDevice, ctx.stream);
+                else he = staged.pull_range(y0 * pitch, y1 * pitch);             // (the copiers are at work already; this thread joins them below)
+            }
             if (he == hipSuccess) he = hipEventRecord(ctx.uploaded[k], ctx.stream);      // (also behind the scan's parameter block and the code tables)
             if (he == hipSuccess) he = hipStreamWaitEvent(ctx.kernel_stream, ctx.uploaded[k], 0);
             const uint32_t groups_end = k + 1 == stripes ? total_groups : (uint32_t)(((uint64_t)rows_end * p.mcus_x) / 64u);   // groups whose every MCU is uploaded
@@ -722,20 +801,83 @@ struct FrameRun {
             rows_done = rows_end;
         }
         p.group_base = 0; p.group_count = 0; p.stripe_index = 0;
+        // every chunk gets staged and announced, whatever happened above - the pull kernels wait for them: by this thread too where
+        // the handle has fewer than two copier threads to spare, else by those alone while this thread sees to the downloads
+        if (!pixels_locked && (!staged.leaves_copying() || rc != JPEGENC_OK || he != hipSuccess)) staged.finish();
         // the finished part of the scan, stripe by stripe, to its place behind the headers
         const size_t room = bs->cap > at ? bs->cap - at : 0;
         size_t prev = 0;
         const auto t_enqueued = now();
         long t_stripe[DeviceCtx::kChunks] = {0}, t_copy[DeviceCtx::kChunks] = {0};
+        // A pageable output buffer gets its bytes through the context's page-locked scan buffer: stripe k's part comes down into it
+        // while stripe k - 1's is copied to its place by this thread and the copier threads (a copy INTO pageable memory would make the
+        // runtime page-lock it in place - upload_in_stripes).  The buffer is used front to back; a part that does not fit behind the
+        // ones before it waits until those are out (and the buffer grows if it is too small for the part alone).
+        struct Part { size_t dst, src, n; };
+        Part parts[DeviceCtx::kChunks];
+        int nparts = 0, parts_out = 0;
+        size_t staged_at = 0;
+        struct PoolJoin { DeviceCtx &cx; bool used = false; ~PoolJoin() { if (used && cx.stage_pool) cx.stage_pool->wait(3); } } pool_join{ctx};
+        const bool pooled_out = ctx.stage_pool && ctx.stage_threads > 1;
+        if (pooled_out && !out_locked) ctx.stage_pool->ensure_threads(ctx.stage_threads - 1);
+        // parts [parts_out, upto) to their place, in pieces of 1 MB on the copier threads; `wait`: for their downloads (else only the
+        // parts that have arrived), and this thread copies too (else it has kernels to wait for: everything goes to the pool)
+        auto copy_out = [&](int upto, bool wait) -> hipError_t {
+            for (; parts_out < upto; parts_out++) {
+                Part &q = parts[parts_out];
+                const hipError_t e = wait ? hipEventSynchronize(ctx.uploaded[parts_out]) : hipEventQuery(ctx.uploaded[parts_out]);      // (the stripe's upload event is free again: its kernel has run)
+                if (e == hipErrorNotReady) { (void)hipGetLastError(); return hipSuccess; }
+                if (e != hipSuccess) return e;
+                uint8_t *dst = bs->out + q.dst;
+                const uint8_t *src = ctx.h_scan_out + q.src;
+                for (size_t a = 0; a < q.n; a += (size_t)1 << 20) {
+                    const size_t nb = q.n - a < ((size_t)1 << 20) ? q.n - a : (size_t)1 << 20;
+                    if (pooled_out && (!wait || a + ((size_t)1 << 20) < q.n)) { ctx.stage_pool->submit(3, [dst, src, a, nb] { memcpy(dst + a, src + a, nb); }); pool_join.used = true; }
+                    else memcpy(dst + a, src + a, nb);
+                }
+            }
+            return hipSuccess;
+        };
         for (int k = 0; k < launched && rc == JPEGENC_OK && he == hipSuccess; k++) {
-            he = hipEventSynchronize(ctx.chunk_done[k]);
+            // (while the kernel of stripe k runs: what has come down meanwhile goes to the copier threads)
+            if (!out_locked && pooled_out) {
+                hipError_t q;
+                while (he == hipSuccess && parts_out < nparts && (q = hipEventQuery(ctx.chunk_done[k])) == hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    he = copy_out(nparts, false);
+                    _mm_pause();
+                }
+            }
+            if (he == hipSuccess) he = hipEventSynchronize(ctx.chunk_done[k]);
             if (trace) t_stripe[k] = us(t_begin, now());
             const size_t end = ends[k];
-            if (he == hipSuccess && end > prev && end <= room)               // (a buffer that is too small is left alone; the caller learns the size)
-                he = hipMemcpyAsync(bs->out + at + prev, (const uint8_t *)ctx.d_gather + kGatherHeader + prev, end - prev, hipMemcpyDeviceToHost, ctx.download_stream);
+            if (he == hipSuccess && end > prev && end <= room) {             // (a buffer that is too small is left alone; the caller learns the size)
+                const size_t n = end - prev;
+                if (out_locked) {
+                    he = hipMemcpyAsync(bs->out + at + prev, (const uint8_t *)ctx.d_gather + kGatherHeader + prev, n, hipMemcpyDeviceToHost, ctx.download_stream);
+                } else {
+                    if (staged_at + n > ctx.h_scan_out_cap) {                // no room behind the parts in flight: they leave first,
+                        he = copy_out(nparts, true);                         // and the buffer grows to what the frame seems to need
+                        if (pool_join.used) { ctx.stage_pool->wait(3); pool_join.used = false; }
+                        const size_t want = (staged_at + n) / (size_t)(k + 1) * (size_t)launched;
+                        staged_at = 0;
+                        if (he == hipSuccess && ctx.reserve_scan_host(want > n ? want : n) != JPEGENC_OK) he = hipErrorOutOfMemory;
+                    }
+                    if (he == hipSuccess) he = hipMemcpyAsync(ctx.h_scan_out + staged_at, (const uint8_t *)ctx.d_gather + kGatherHeader + prev, n, hipMemcpyDeviceToHost, ctx.download_stream);
+                    if (he == hipSuccess) he = hipEventRecord(ctx.uploaded[nparts], ctx.download_stream);
+                    if (he == hipSuccess) {
+                        parts[nparts++] = Part{at + prev, staged_at, n};
+                        staged_at += (n + 255) & ~(size_t)255;
+                        he = copy_out(nparts, false);                        // (parts that are down already)
+                    }
+                }
+            }
             if (trace) t_copy[k] = us(t_begin, now()) - t_stripe[k];
             if (end > prev) prev = end;
         }
+        if (!pixels_locked) staged.finish();
+        if (he == hipSuccess && rc == JPEGENC_OK) he = copy_out(nparts, true);
+        if (pool_join.used) { ctx.stage_pool->wait(3); pool_join.used = false; }
         (void)hipStreamSynchronize(ctx.kernel_stream);
         (void)hipStreamSynchronize(ctx.stream);
         const auto t_kernels = now();
@@ -750,6 +892,8 @@ struct FrameRun {
         if (he != hipSuccess || de != hipSuccess) { bs->len = len0; return hip_fail(he != hipSuccess ? he : de, "striped frame"); }
         if (gave_up()) { bs->len = len0; return reset_chain(); }
         nbytes = prev;
+        ctx.last_scan_bytes = nbytes;
+        ctx.last_file_geometry = content_key(c, width, height, color_type_or_planes);
         bs->len = at + nbytes;                                           // (a buffer that is too small still learns the size it needs)
         o.marker(0xD9);
         o.drain(true);
@@ -948,7 +1092,7 @@ static int encode_frame_once(const Config &c, DeviceCtx &ctx, int jct, int width
     int rc = run.prepare();
     if (rc) return rc;
     // (the upload first where it cannot become a striped one: its copy then runs under the planning below)
-    const bool may_stripe = host_pixels != nullptr && sink == buffer_sink;
+    const bool may_stripe = host_pixels != nullptr && sink == buffer_sink && pixel_bytes >= striped_from_bytes();
     if (!may_stripe) {
         rc = upload(ctx);
         if (rc) return rc;
@@ -1063,7 +1207,10 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
         }
         return JPEGENC_OK;
     };
-    rc = encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user, staged || !single_locked ? nullptr : data);
+    // (one image at a time from host memory: the frame may go stripe by stripe - FrameRun::run_striped uploads page-locked pixels where
+    //  they lie and stages pageable ones; the runtime's own pageable path of rounds 1-5 stays in one piece)
+    static const bool runtime_path_chosen = JPEGENC_DIAG_ENV("JPEGENC_RUNTIME_PAGEABLE_UPLOADS") != nullptr;
+    rc = encode_frame(c, ctx, jpeg_color_type_of(color_type), width, height, color_type, bytes, upload, sink, user, staged || (!single_locked && runtime_path_chosen) ? nullptr : data);
     // (the upload kernel of a pageable image waits for this process's copier threads and gives up after two seconds without a new chunk -
     //  a process stopped in the middle of a call: the file was coded from an incomplete image)
     if (rc == JPEGENC_OK && ctx.pull_timed_out()) return fail(JPEGENC_ERR_HIP, "the staged upload timed out waiting for the host's copy of the image");

@@ -22,13 +22,15 @@ namespace jpegenc {
 
 typedef uint32_t pull_u32x4 __attribute__((ext_vector_type(4)));
 
-// ready: epoch << 32 | chunks staged so far, contiguous from chunk 0 (a word of another epoch counts as 0)
-__global__ void __launch_bounds__(kStagedPullThreads) k_pull_staged(const uint8_t *h, uint8_t *d, size_t bytes, uint32_t chunk, uint32_t nchunks,
-                                                                    const uint64_t *ready, uint32_t epoch, uint32_t *timed_out) {
+// ready: epoch << 32 | chunks staged so far, contiguous from chunk 0 (a word of another epoch counts as 0).
+// One launch moves the bytes [from, to) of the image (the whole image, or one stripe of a frame that is coded stripe by stripe).
+__global__ void __launch_bounds__(kStagedPullThreads) k_pull_staged(const uint8_t *h, uint8_t *d, uint32_t chunk, const uint64_t *ready, uint32_t epoch,
+                                                                    uint32_t *timed_out, size_t from, size_t to) {
     __shared__ uint32_t s_have;
     const uint32_t slice = chunk / kStagedPullGroups;                              // (chunk: a multiple of kStagedPullGroups * 64)
+    const uint32_t first = (uint32_t)(from / chunk), last = (uint32_t)((to - 1u) / chunk);
     uint32_t have = 0;
-    for (uint32_t k = 0; k < nchunks; k++) {
+    for (uint32_t k = first; k <= last; k++) {
         if (k >= have) {                                                           // (uniform over the workgroup)
             if (threadIdx.x == 0) {
                 const uint64_t t0 = wall_clock64();
@@ -53,29 +55,31 @@ __global__ void __launch_bounds__(kStagedPullThreads) k_pull_staged(const uint8_
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                         // the chunk's bytes are read after the word that announces them
         }
         const size_t at = (size_t)k * chunk + (size_t)blockIdx.x * slice;
-        if (at >= bytes) continue;
-        const size_t end = bytes - at < slice ? bytes : at + slice;
-        for (size_t i = at + (size_t)threadIdx.x * 16u; i < end; i += (size_t)kStagedPullThreads * 16u * 4u) {
+        const size_t lo = at > from ? at : from, hi = at + slice < to ? at + slice : to;
+        if (lo >= hi) continue;
+        // 16-byte units on the image's own grid (both buffers are aligned to it); the units a range begins or ends inside go byte by byte
+        for (size_t i = (lo & ~(size_t)15u) + (size_t)threadIdx.x * 16u; i < hi; i += (size_t)kStagedPullThreads * 16u * 4u) {
             pull_u32x4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const size_t a = i + (size_t)j * kStagedPullThreads * 16u;
-                if (a + 16u <= end) v[j] = __builtin_nontemporal_load((const pull_u32x4 *)(h + a));
+                if (a >= lo && a + 16u <= hi) v[j] = __builtin_nontemporal_load((const pull_u32x4 *)(h + a));
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const size_t a = i + (size_t)j * kStagedPullThreads * 16u;
-                if (a + 16u <= end) *(pull_u32x4 *)(d + a) = v[j];
-                else for (size_t b = a; b < end; b++) d[b] = h[b];                 // (the last, partial 16 bytes of the image)
+                if (a >= lo && a + 16u <= hi) *(pull_u32x4 *)(d + a) = v[j];
+                else if (a < hi && a + 16u > lo) for (size_t b = a > lo ? a : lo; b < a + 16u && b < hi; b++) d[b] = h[b];
             }
         }
     }
 }
 
-hipError_t launch_staged_pull(const uint8_t *h_staged, uint8_t *d_pixels, size_t bytes, uint32_t chunk, uint32_t nchunks, const uint64_t *h_ready,
+hipError_t launch_staged_pull(const uint8_t *h_staged, uint8_t *d_pixels, size_t from, size_t to, uint32_t chunk, const uint64_t *h_ready,
                               uint32_t epoch, uint32_t *h_timed_out, hipStream_t stream) {
-    if (!nchunks || chunk % (kStagedPullGroups * 64u)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_pull_staged, dim3(kStagedPullGroups), dim3(kStagedPullThreads), 0, stream, h_staged, d_pixels, bytes, chunk, nchunks, h_ready, epoch, h_timed_out);
+    if (to <= from) return hipSuccess;
+    if (!chunk || chunk % (kStagedPullGroups * 64u)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pull_staged, dim3(kStagedPullGroups), dim3(kStagedPullThreads), 0, stream, h_staged, d_pixels, chunk, h_ready, epoch, h_timed_out, from, to);
     return hipGetLastError();
 }
 

@@ -1504,3 +1504,75 @@ def test_pageable_single_images_follow_their_copiers_over_the_link(binding, orac
                 want = oracle.encode_jpeg(px, w, h, oct_, 85, sampling=(2, 2))
                 assert got == want, (workers, rep, w, h, len(got), len(want))
         e.close()
+
+
+@pytest.mark.gpu
+def test_large_pageable_frames_are_coded_in_stripes_through_the_staging_buffers(binding, oracle, synth):
+    """Encoder::encode on ordinary memory, 4 MB of pixels and more, baseline: the frame goes stripe by stripe like one between page-locked
+    buffers (host_frame.cpp, run_striped) - the pixels staged chunk by chunk and pulled over the link by one kernel per stripe, each
+    stripe's bytes down into the handle's page-locked scan buffer and copied to their place while the next are on the link.  Ten calls per
+    geometry so that the handle's tuner goes through 4, 2 and 1 stripes and settles; other content every call; stripes that end inside a
+    chunk and inside a 16-byte unit (odd widths); page-locked pixels with a pageable buffer and the other way round; a buffer that is too
+    small (a guard band behind it stays intact, the size it needs comes back); every copier budget; then forced stripe counts and the
+    DMA-command fallback (which must not stripe) in the diagnostic build."""
+    cases = [((2000, 1800), dict(quality=100)), ((3841, 1203), dict(quality=90, sampling=(2, 2))), ((1999, 1801), dict(quality=80, sampling=(2, 1))),
+             ((8200, 345), dict(quality=85, sampling=(1, 2)))]
+    for i, ((w, h), kw) in enumerate(cases):
+        e = _encoder(binding, kw)
+        e.set_batch_workers((0, 1, 2, 3)[i])
+        base = synth.test_img_rgb(w, h).astype(np.int16)
+        out = np.empty(w * h * 3 + 65536, dtype=np.uint8)
+        want = None
+        for call in range(10):
+            px = np.ascontiguousarray(np.clip(base + np.random.default_rng(100 * i + call).integers(-12, 13, base.shape, dtype=np.int16), 0, 255).astype(np.uint8))
+            want = oracle.encode_jpeg(px, w, h, oracle.RGB, **kw)
+            out[:] = 0
+            n = e.encode_to_buffer(px.reshape(-1), w, h, binding.RGB, out)
+            assert n == len(want) and out[:n].tobytes() == want, ((w, h), kw, call, n, len(want))
+            if call == 4:                                                   # (something else in between: other buffers, another sequence)
+                small = synth.lcg_image(200, 120, 3, i)
+                assert e.encode(small, 200, 120, binding.RGB) == oracle.encode_jpeg(small, 200, 120, oracle.RGB, **kw)
+        flat = px.reshape(-1)
+        guarded = np.full(len(want) // 2 + 4096, 0xA5, dtype=np.uint8)
+        tight = guarded[:len(want) // 2]
+        for _ in range(3):
+            with pytest.raises(binding.JpegEncError) as err:
+                e.encode_to_buffer(flat, w, h, binding.RGB, tight)
+            assert err.value.status == binding.ERR_BUFFER_TOO_SMALL and f"needs {len(want)} bytes" in str(err.value)
+            assert (guarded[len(tight):] == 0xA5).all(), "stores past the end of the caller's buffer"
+        for locked in (flat, out):                                          # one side page-locked, the other pageable
+            binding.host_register(locked)
+            try:
+                for _ in range(7):
+                    out[:] = 0
+                    n = e.encode_to_buffer(flat, w, h, binding.RGB, out)
+                    assert n == len(want) and out[:n].tobytes() == want, ((w, h), kw, "pixels" if locked is flat else "output", "page-locked")
+            finally:
+                binding.host_unregister(locked)
+        e.close()
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "ge.load_package()\n"
+        "from jpeg_encoder_amd import binding as b, synth\n"
+        "from oracle import pyoracle as o\n"
+        "n = 0\n"
+        "for (w, h), q in (((2000, 1800), 100), ((3001, 1001), 92), ((1283, 1500), 75)):\n"
+        "    e = b.Encoder(q)\n"
+        "    out = np.empty(2 * w * h * 3 + 65536, dtype=np.uint8)\n"
+        "    for call in range(3):\n"
+        "        px = synth.lcg_image(w, h, 3, 7 * call + w)\n"
+        "        want = o.encode_jpeg(px, w, h, o.RGB, q)\n"
+        "        got = e.encode_to_buffer(px.reshape(-1), w, h, b.RGB, out)\n"
+        "        assert got == len(want) and out[:got].tobytes() == want, (w, h, q, call)\n"
+        "        n += 1\n"
+        "print('ok', n)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (dict(JPEGENC_STRIPES="3", JPEGENC_PAGEABLE_STRIPES_FROM_PIXEL_BYTES="1"), dict(JPEGENC_STRIPES="4", JPEGENC_STAGE_CHUNK_KB="64", JPEGENC_PAGEABLE_STRIPES_FROM_PIXEL_BYTES="1"),
+                  dict(JPEGENC_STAGE_DMA="1"), dict(JPEGENC_NO_PAGEABLE_STRIPES="1")):
+        env = dict(os.environ, JPEGENC_LIB=binding.DIAG_LIB_PATH, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert r.returncode == 0 and "ok 9" in r.stdout, (extra, r.stdout[-500:], r.stderr[-2000:])
