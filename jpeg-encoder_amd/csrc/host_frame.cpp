@@ -767,13 +767,15 @@ struct FrameRun {
         int rc = JPEGENC_OK;
         hipError_t he = hipSuccess;
         int launched = 0;
-        // pageable pixels: staged chunk by chunk through the context's page-locked buffer - the copier threads start now, this thread
-        // joins them once the stripes are enqueued - and pulled over the link by one kernel per stripe (StagedUpload)
+        // a pageable output buffer: the stripes' bytes come down into the context's page-locked scan buffer first
         if (!out_locked) {                  // (what this handle's last file of the geometry took, or a quarter of the pixels: the buffer grows below if that is short)
             const bool again = ctx.last_file_geometry == content_key(c, width, height, color_type_or_planes) && ctx.last_scan_bytes;
             const int rr = ctx.reserve_scan_host((again ? ctx.last_scan_bytes + ctx.last_scan_bytes / 8 : pixel_bytes / 4) + ((size_t)1 << 20));
             if (rr) { bs->len = len0; return rr; }
         }
+        // pageable pixels: staged chunk by chunk through the context's page-locked buffer - the copier threads start now; this thread
+        // enqueues the stripes and sees to the downloads, and copies too only where the handle has fewer than two threads to spare -
+        // and pulled over the link by one kernel per stripe (StagedUpload)
         StagedUpload staged(ctx, host_pixels, pixel_bytes);
         if (!pixels_locked) {
             rc = staged.begin(true);
