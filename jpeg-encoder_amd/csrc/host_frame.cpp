@@ -113,17 +113,7 @@ struct StagedUpload {
         launches++;
         return hipSuccess;
     }
-    void publish() {                                   // advance "staged so far" past every finished chunk (any copier, after its own chunk)
-        std::atomic<uint64_t> *w = reinterpret_cast<std::atomic<uint64_t> *>(cx.h_pull);
-        for (;;) {
-            uint64_t cur = w->load();
-            const uint32_t r = (uint32_t)(cur >> 32) == epoch ? (uint32_t)cur : 0u;
-            uint32_t n = r;
-            while (n < nchunks && done[n].load()) n++;
-            if (n == r) return;
-            (void)w->compare_exchange_strong(cur, ((uint64_t)epoch << 32) | n);      // (then once more: others may have finished meanwhile)
-        }
-    }
+    void publish() { advance_staged_word(reinterpret_cast<std::atomic<uint64_t> *>(cx.h_pull), epoch, done.get(), nchunks); }
     void copy_one(uint32_t k) {
         const size_t at = (size_t)k * chunk, n = bytes - at < chunk ? bytes - at : chunk;
         staging_copy(cx.h_pixels + at, data + at, n);

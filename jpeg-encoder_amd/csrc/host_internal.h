@@ -357,6 +357,21 @@ constexpr int kDeviceEntropyWorkers = 4;      // automatic pool of a host-fed ba
 // the workers of jpegenc_encoder_encode_batch and the pooled per-frame paths (one in-flight frame each)
 inline int batch_pool_size(int user_cap, int auto_cap, int num_frames, int reserve = 2) { return pool_threads(user_cap, auto_cap, reserve, 2, num_frames); }
 
+// The "chunks staged so far" word a staged upload's pull kernel follows (staged_pull.hip; host_frame.cpp, StagedUpload): epoch << 32 |
+// number of chunks finished, CONTIGUOUS from chunk 0.  Any copier calls this after setting its own chunk's flag (sequentially consistent
+// stores and loads: of two copiers that finish neighbouring chunks at the same time at least one sees the other's flag): the word moves
+// past every finished chunk, never backwards, and never past a chunk that is not finished.  A word of another epoch counts as 0.
+inline void advance_staged_word(std::atomic<uint64_t> *word, uint32_t epoch, const std::atomic<uint8_t> *done, uint32_t nchunks) {
+    for (;;) {
+        uint64_t cur = word->load();
+        const uint32_t r = (uint32_t)(cur >> 32) == epoch ? (uint32_t)cur : 0u;
+        uint32_t n = r;
+        while (n < nchunks && done[n].load()) n++;
+        if (n == r) return;
+        (void)word->compare_exchange_strong(cur, ((uint64_t)epoch << 32) | n);      // (then once more: others may have finished meanwhile)
+    }
+}
+
 // A thread whose waits are nanosleeps (DeviceCtx::sleep_until) wants them to end on time: the default timer slack of a thread is 50 us
 // on top of every sleep.  1 us for the duration of a batch body; the previous value comes back with the guard (the body of worker 0
 // runs on the CALLER's thread).

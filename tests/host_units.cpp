@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <set>
 #include <string>
+#include <thread>
+#include <memory>
 #include <vector>
 
 #include "host_internal.h"
@@ -237,7 +239,48 @@ static int register_ahead_registry() {
     return 0;
 }
 
+// advance_staged_word: four copiers finish 4 096 chunks in whatever order the scheduler gives them; an observer - the pull kernel's
+// view - only ever sees the word grow, every chunk below it finished, and at the end all of them; a word left by another epoch is 0.
+static int staged_word() {
+    for (int round = 0; round < 20; round++) {
+        const uint32_t nchunks = 4096, epoch = 7u + (uint32_t)round;
+        std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[nchunks]);
+        for (uint32_t k = 0; k < nchunks; k++) done[k].store(0);
+        std::atomic<uint64_t> word(((uint64_t)(epoch - 1u) << 32) | 4096u);         // (what the upload before left behind)
+        std::atomic<uint32_t> next(0);
+        std::atomic<bool> stop(false), bad(false);
+        std::thread observer([&] {
+            uint32_t last = 0;
+            while (!stop.load()) {
+                const uint64_t w = word.load();
+                const uint32_t r = (uint32_t)(w >> 32) == epoch ? (uint32_t)w : 0u;
+                if (r < last || r > nchunks) bad.store(true);
+                for (uint32_t k = last; k < r; k++) if (!done[k].load()) bad.store(true);
+                last = r;
+            }
+        });
+        std::vector<std::thread> copiers;
+        for (int t = 0; t < 4; t++) copiers.emplace_back([&, t] {
+            for (;;) {
+                const uint32_t k = next.fetch_add(1);
+                if (k >= nchunks) break;
+                if (((k * 2654435761u) >> 28) == (uint32_t)t) std::this_thread::yield();      // (neighbours finish out of order)
+                done[k].store(1);
+                jpegenc::advance_staged_word(&word, epoch, done.get(), nchunks);
+            }
+        });
+        for (auto &c : copiers) c.join();
+        jpegenc::advance_staged_word(&word, epoch, done.get(), nchunks);
+        stop.store(true);
+        observer.join();
+        CHECK(!bad.load());
+        CHECK(word.load() == (((uint64_t)epoch << 32) | nchunks));
+    }
+    return 0;
+}
+
 int main() {
+    if (staged_word()) return 1;
     if (thread_budget()) return 1;
     if (register_ahead_registry()) return 1;
     if (background_pool()) return 1;
