@@ -310,7 +310,8 @@ def criterion_workloads(binding, synth, device):
     res, files = {}, {}
     encs = {name: make(**g) for name, (g, _) in CRITERION_VARIANTS.items()}
     for name, enc in encs.items():
-        n = enc.encode_to_buffer(px, w, h, binding.RGB, out)       # warm-up
+        for _ in range(7):                                         # warm-up: buffers, and the six trial calls of the handle's stripe tuner (baseline frames from 8 MB of pixels)
+            n = enc.encode_to_buffer(px, w, h, binding.RGB, out)
         times = []
         for _ in range(9):
             t = time.perf_counter()
