@@ -70,8 +70,7 @@ struct StagedUpload {
     }
 
     // the staging buffer, the chunking, the epoch, the copier threads (they start at once).  hands_off: the calling thread has a
-    // pipeline to drive meanwhile (run_striped) - up to three helpers, and with two or more of them it leaves the copying to them
-    // (leaves_copying(); finish() still takes what is left).
+    // pipeline to drive meanwhile (run_striped) and takes chunks only while it waits - up to three helpers instead of two.
     int begin(bool hands_off = false) {
         if (bytes > cx.h_pixels_cap) {
             if (cx.h_pixels) (void)hipHostFree(cx.h_pixels);
@@ -127,14 +126,15 @@ struct StagedUpload {
             copy_one(k);
         }
     }
-    bool leaves_copying() const { return helpers >= 2; }
     bool copy_next() {                                 // this thread takes one chunk (false: none left to take)
         const uint32_t k = next.fetch_add(1);
         if (k >= nchunks) return false;
         copy_one(k); own++;
         return true;
     }
-    // every chunk is staged and the word says so - on EVERY path behind begin(): the kernel waits for it
+    // every chunk is staged and the word says so - on EVERY path behind begin(): the kernel waits for it.  Until then the thread that
+    // drives the upload must not enter a HIP call that waits for the device or for the context's stream (hipFree / hipHostFree /
+    // hipMalloc synchronise implicitly): the kernel it would wait for is waiting for chunks this thread may be the only one to copy.
     void finish() {
         if (!done) return;
         while (copy_next()) {}
@@ -402,7 +402,10 @@ struct FrameRun {
             // (with a pageable side the copies are the handle's threads' work and stripes pay from 8 MB of pixels: 4K 0.78 -> 0.72 ms,
             //  Criterion's 10.8 MB frame at quality 100 0.70 -> 0.66, nothing at 1080p - profiles/r06_staged_pull.txt)
             static const size_t pageable_from = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_PAGEABLE_STRIPES_FROM_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)8 << 20); }();
-            if (mcu_rows >= 2 && bs->out && (both_locked || (!pageable_off && pixel_bytes >= pageable_from && (pixels_locked || StagedUpload::available(ctx))))) {
+            // (pageable pixels in stripes only with a copier thread besides this one: the pull kernels wait for the staging, and this
+            //  thread - enqueueing launches whose first use may load code, growing buffers - must never be the only one they depend on)
+            const bool can_stage = StagedUpload::available(ctx) && ctx.stage_pool && ctx.stage_threads >= 2;
+            if (mcu_rows >= 2 && bs->out && (both_locked || (!pageable_off && pixel_bytes >= pageable_from && (pixels_locked || can_stage)))) {
                 // 4, 2 or 1 (= the ordinary sequence): whichever this handle measured as the fastest (DeviceCtx::StripeTuner)
                 const uint64_t tuner_key = content_key(c, width, height, color_type_or_planes) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(1 + (pixels_locked ? 1 : 0) + (out_locked ? 2 : 0)));
                 stripes = forced ? forced : ctx.stripe_tuner.choose(tuner_key);
@@ -764,8 +767,8 @@ struct FrameRun {
             if (rr) { bs->len = len0; return rr; }
         }
         // pageable pixels: staged chunk by chunk through the context's page-locked buffer - the copier threads start now; this thread
-        // enqueues the stripes and sees to the downloads, and copies too only where the handle has fewer than two threads to spare -
-        // and pulled over the link by one kernel per stripe (StagedUpload)
+        // enqueues the stripes, sees to the downloads and takes chunks while it waits - and pulled over the link by one kernel per
+        // stripe (StagedUpload)
         StagedUpload staged(ctx, host_pixels, pixel_bytes);
         if (!pixels_locked) {
             rc = staged.begin(true);
@@ -793,9 +796,9 @@ struct FrameRun {
             rows_done = rows_end;
         }
         p.group_base = 0; p.group_count = 0; p.stripe_index = 0;
-        // every chunk gets staged and announced, whatever happened above - the pull kernels wait for them: by this thread too where
-        // the handle has fewer than two copier threads to spare, else by those alone while this thread sees to the downloads
-        if (!pixels_locked && (!staged.leaves_copying() || rc != JPEGENC_OK || he != hipSuccess)) staged.finish();
+        // every chunk gets staged and announced, whatever happened above - the pull kernels wait for them: by the copier threads, and by
+        // this thread whenever it would otherwise only wait (below); after a failure right here
+        if (!pixels_locked && (rc != JPEGENC_OK || he != hipSuccess)) staged.finish();
         // the finished part of the scan, stripe by stripe, to its place behind the headers
         const size_t room = bs->cap > at ? bs->cap - at : 0;
         size_t prev = 0;
@@ -831,14 +834,15 @@ struct FrameRun {
             return hipSuccess;
         };
         for (int k = 0; k < launched && rc == JPEGENC_OK && he == hipSuccess; k++) {
-            // (while the kernel of stripe k runs: what has come down meanwhile goes to the copier threads)
-            if (!out_locked && pooled_out) {
-                hipError_t q;
-                while (he == hipSuccess && parts_out < nparts && (q = hipEventQuery(ctx.chunk_done[k])) == hipErrorNotReady) {
-                    (void)hipGetLastError();
-                    he = copy_out(nparts, false);
-                    _mm_pause();
-                }
+            // While stripe k is not coded yet this thread makes itself useful: parts that have come down go to the copier threads, and
+            // where pixels are still to be staged it takes a chunk (the pull kernels wait for the copiers - which may be few, or not
+            // scheduled at all on a busy host: the frame must not depend on them alone).
+            for (;;) {
+                const hipError_t q = he == hipSuccess ? hipEventQuery(ctx.chunk_done[k]) : hipSuccess;
+                if (q != hipErrorNotReady) break;
+                (void)hipGetLastError();
+                if (!out_locked && pooled_out && parts_out < nparts) he = copy_out(nparts, false);
+                if (pixels_locked || !staged.copy_next()) _mm_pause();
             }
             if (he == hipSuccess) he = hipEventSynchronize(ctx.chunk_done[k]);
             if (trace) t_stripe[k] = us(t_begin, now());
@@ -853,6 +857,9 @@ struct FrameRun {
                         if (pool_join.used) { ctx.stage_pool->wait(3); pool_join.used = false; }
                         const size_t want = (staged_at + n) / (size_t)(k + 1) * (size_t)launched;
                         staged_at = 0;
+                        // (releasing page-locked memory waits for the DEVICE to go idle - for the pull kernels, which wait for the
+                        //  pixels: every chunk is staged before this thread goes in there)
+                        if (!pixels_locked) staged.finish();
                         if (he == hipSuccess && ctx.reserve_scan_host(want > n ? want : n) != JPEGENC_OK) he = hipErrorOutOfMemory;
                     }
                     if (he == hipSuccess) he = hipMemcpyAsync(ctx.h_scan_out + staged_at, (const uint8_t *)ctx.d_gather + kGatherHeader + prev, n, hipMemcpyDeviceToHost, ctx.download_stream);

@@ -1550,6 +1550,19 @@ def test_large_pageable_frames_are_coded_in_stripes_through_the_staging_buffers(
             finally:
                 binding.host_unregister(locked)
         e.close()
+    # The first large file of a handle that has no copier threads: the page-locked scan buffer grows in the middle of the frame, and
+    # releasing page-locked memory waits for the device - for the pull kernels, which wait for pixels only this thread can stage.
+    for workers in (1, 2, 0):
+        e = binding.Encoder(100)
+        e.set_batch_workers(workers)
+        w, h = 2000, 1800
+        out = np.empty(3 * w * h * 3, dtype=np.uint8)
+        for call in range(3):
+            px = synth.lcg_image(w, h, 3, 50 + call)
+            want = oracle.encode_jpeg(px, w, h, oracle.RGB, 100)
+            n = e.encode_to_buffer(px.reshape(-1), w, h, binding.RGB, out)
+            assert n == len(want) and out[:n].tobytes() == want, (workers, call, n, len(want))
+        e.close()
     import os
     import subprocess
     import sys
