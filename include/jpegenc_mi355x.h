@@ -324,7 +324,8 @@ int  jpegenc_encoder_set_batch_upload(jpegenc_encoder *e, int mode);
  * stage, upload and collect frames (jpegenc_encoder_encode_batch*), the threads that assemble the files of a device-resident batch,
  * build per-frame Huffman tables or copy thumbnails into page-locked memory, and each per-device child of
  * jpegenc_encoder_encode_batch_multi.  0 (default): sized by the library - at most 4 threads where the scans are coded on the device
- * (a worker's time is then the PCIe link's: 4 are within 1 % of 16), up to 16 for host entropy coding, never more than
+ * (a worker's time is then the PCIe link's: 4 are within 1 % of 16; 6 for frames of 16 MB of pixels and more, whose
+ * staging copies run at DRAM speed), up to 16 for host entropy coding, never more than
  * the CPUs the process may use (affinity mask, cgroup quota) less two.  The reference is single-threaded (encoder.rs:440-515): 1
  * reproduces that.  A process that shares its CPU quota with other ranks (one process per GPU on an 8-GPU host) sets its share here:
  * the library cannot see its neighbours.  Files do not depend on it.  jpegenc_encoder_batch_workers returns the setting (0 = automatic). */

@@ -962,7 +962,10 @@ int jpegenc_encoder_encode_batch(jpegenc_encoder *e, const uint8_t *const *frame
     // 9 180 frames/s with 4 workers, 9 230 with 16; 128 4K frames: 17.2 / 17.1 Gpixel/s) and every further worker is a CPU kept
     // busy for nothing - a rank of an 8-GPU host has 1/8 of its CPUs (profiles/r06_rank_cpu_budget.txt).  Host entropy
     // coding is CPU work per frame: the full pool.  jpegenc_encoder_set_batch_workers overrides either.
-    const int pool_cap = e->cfg.device_entropy && e->max_batch_workers > kDeviceEntropyWorkers ? kDeviceEntropyWorkers : e->max_batch_workers;
+    // (Frames of 16 MB and more - 4K - leave the caches on their way through a worker: its staging copy runs at 17-20 GB/s, four such
+    //  workers have no slack against a 57 GB/s link.  Six: 128 4K frames 0.82-0.84 -> 0.87-0.88 of the link at 3.2 instead of 2.8 CPUs.)
+    const int device_entropy_cap = frame_bytes >= ((size_t)16 << 20) ? kDeviceEntropyWorkersLargeFrames : kDeviceEntropyWorkers;
+    const int pool_cap = e->cfg.device_entropy && e->max_batch_workers > device_entropy_cap ? device_entropy_cap : e->max_batch_workers;
     // (workers that only feed the link sleep most of the time: one CPU in reserve is enough - a 4-CPU share runs three of them)
     int workers = batch_pool_size(e->batch_workers, pool_cap, num_frames, e->cfg.device_entropy ? 1 : 2);
     // (frames the caller page-locked cost a worker no copy at all - 0.08 CPUs each, asleep while the link works - so their pool does not

@@ -353,6 +353,7 @@ inline int pool_threads(int user_cap, int auto_cap, int reserve, int floor, int 
     if (w > items) w = items;
     return w < 1 ? 1 : w;
 }
+constexpr int kDeviceEntropyWorkersLargeFrames = 6;      // ... of frames of 16 MB of pixels and more
 constexpr int kDeviceEntropyWorkers = 4;      // automatic pool of a host-fed batch whose scans the device codes (host_batch.cpp, jpegenc_encoder_encode_batch)
 // the workers of jpegenc_encoder_encode_batch and the pooled per-frame paths (one in-flight frame each)
 inline int batch_pool_size(int user_cap, int auto_cap, int num_frames, int reserve = 2) { return pool_threads(user_cap, auto_cap, reserve, 2, num_frames); }
