@@ -360,7 +360,8 @@ int  jpegenc_encoder_add_exif_metadata(jpegenc_encoder *e, const uint8_t *data, 
  * the same configuration can encode further images.  Output goes to `sink` in order.
  * `data` may be ordinary (pageable) memory, as the reference's slice is: the library copies it through its own page-locked buffer in chunks, on
  * this thread and up to two more of the handle's budget (jpegenc_encoder_set_batch_workers; 1 = this thread alone), while one kernel pulls
- * the chunks already staged over the link (profiles/r06_staged_pull.txt) - it never hands the caller's pageable memory to the HIP runtime,
+ * the chunks already staged over the link (profiles/r06_staged_pull.txt; a baseline frame of 8 MB of pixels and more into
+ * jpegenc_encoder_encode_to_buffer's buffer goes stripe by stripe - upload, kernel and download overlapping - with up to three copier threads) - it never hands the caller's pageable memory to the HIP runtime,
  * whose pageable copies page-lock it in place and cache that registration beyond the call (profiles/r06_pageable_runtime_path.txt).  That
  * kernel waits for this process's copy: a process stopped for more than two seconds in the middle of a call gets JPEGENC_ERR_HIP for it.
  * Page-locked `data` (ONE registration) is read in place. */
