@@ -437,8 +437,9 @@ def main():
     ap.add_argument("--e2e-batches", type=int, default=11, help="timed batches of the end-to-end side figure (min / median / max are reported)")
     ap.add_argument("--c3-frames", type=int, default=1000, help="frames of the config-3 batch (whole job, all ranks); 0 disables")
     ap.add_argument("--c3-passes", type=int, default=7, help="timed passes of the config-3 batch (min / median / max are reported)")
-    ap.add_argument("--c3-register-ahead", action="store_true",
-                    help="also time the config-3 batch with jpegenc_encoder_set_batch_upload(REGISTER_AHEAD) (not under rocprofv3: see profiles/r05_upload_modes.txt)")
+    ap.add_argument("--c3-register-ahead", type=int, default=1, choices=(0, 1),
+                    help="also time the config-3 batch with jpegenc_encoder_set_batch_upload(REGISTER_AHEAD): the pageable frames page-locked ahead of "
+                         "the workers and uploaded where they lie (opt-in in the library; a side figure here, never the primary one)")
     ap.add_argument("--c3-workers", type=int, default=-1,
                     help="thread budget of the config-3 leg (jpegenc_encoder_set_batch_workers); -1 = automatic alone, the rank's share of "
                          "the host's CPUs (usable CPUs // LOCAL_WORLD_SIZE, at most 4) in a multi-rank run")
@@ -1102,8 +1103,9 @@ def main():
             # on its shard; the bookkeeping all-reduce inside per_rank_report is unconditional (a rank whose variant failed
             # contributes a negative time), so ranks cannot part ways
             variants = {}
-            # (the register-ahead variant only on request: two threads inside hipHostRegister / hipHostUnregister beside the workers bring
-            #  a process under rocprofv3 down - 11 of 16 runs of tools/diag/r05_upload_modes.py, profiles/r05_upload_modes.txt)
+            # (the register-ahead variant: until round 6 only on request - it brought profiled processes down, a lifetime error of the
+            #  library's own registrations, profiles/r06_register_ahead_crash.txt.  The passes reuse the same frames, which suits it: the
+            #  runtime keeps page-locks cached, a first pass over fresh buffers is slower - profiles/r06_rank_cpu_budget.txt section 8)
             for v_pinned, v_bind, v_ahead in ((False, False, 0), (False, True, 0), (True, False, 0), (True, True, 0)) + (((False, False, 1),) if args.c3_register_ahead else ()):
                 if True:
                     name = ("pinned" if v_pinned else "pageable") + ("_numa_bind" if v_bind else "") + ("_register_ahead" if v_ahead else "")

@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--what", default="c3")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--label", default="")
+    ap.add_argument("--register-ahead", action="store_true", help="jpegenc_encoder_set_batch_upload(REGISTER_AHEAD): pageable frames page-locked ahead of the workers and uploaded in place")
     ap.add_argument("--start-at", type=float, default=0.0, help="epoch seconds: the timed passes of the first row start then (several processes timed together)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -123,6 +124,8 @@ def main():
             e = b.Encoder(q)
             e.set_sampling_factor(b.sampling_factor(hs, vs))
             e.set_batch_workers(wk)
+            if args.register_ahead:
+                e.set_batch_upload(b.UPLOAD_REGISTER_AHEAD)
             lens = e.encode_batch_into(frames, w, h, b.RGB, outs)              # warm-up: buffers, graphs
             digest = hash(tuple(outs[i][:lens[i]].tobytes() for i in (0, n // 2, n - 1)))
             ref = digest if ref is None else ref
@@ -143,7 +146,7 @@ def main():
             wall, os1, st1, th1 = time.perf_counter() - t0, os.times(), hostinfo.cpu_stat(), hostinfo.thread_cpu_times()
             med = sorted(walls)[len(walls) // 2]
             busiest = sorted(((th1[t][1] - th0.get(t, (0, 0, 0))[1], th1[t][2] - th0.get(t, (0, 0, 0))[2], th1[t][0], t) for t in th1), key=lambda x: -(x[0] + x[1]))[:8]
-            row = {"frames_in": "page-locked" if use_pinned else "pageable", "set_batch_workers": wk, "pool_workers": len(e.batch_worker_info()),
+            row = {"frames_in": "page-locked" if use_pinned else ("pageable, register-ahead" if args.register_ahead else "pageable"), "set_batch_workers": wk, "pool_workers": len(e.batch_worker_info()),
                    "frames_per_s": {"min": round(n / max(walls), 1), "median": round(n / med, 1), "max": round(n / min(walls), 1)},
                    "upload_GBps_median": round(n * fb / med / 1e9, 1), "frac_of_link": round(n * fb / med / 1e9 / link, 3),
                    "cpus_busy": round((os1.user - os0.user + os1.system - os0.system) / wall, 2),
