@@ -310,7 +310,7 @@ def criterion_workloads(binding, synth, device):
     res, files = {}, {}
     encs = {name: make(**g) for name, (g, _) in CRITERION_VARIANTS.items()}
     for name, enc in encs.items():
-        for _ in range(7):                                         # warm-up: buffers, and the six trial calls of the handle's stripe tuner (baseline frames from 8 MB of pixels)
+        for _ in range(10):                                        # warm-up: buffers, and the nine trial calls of the handle's stripe tuner (baseline frames from 8 MB of pixels)
             n = enc.encode_to_buffer(px, w, h, binding.RGB, out)
         times = []
         for _ in range(9):
@@ -327,7 +327,7 @@ def criterion_workloads(binding, synth, device):
     binding.host_register(out)
     try:
         for name, enc in encs.items():
-            for _ in range(8):                                         # (the handle times 4, 2 and 1 stripes twice each before it settles: StripeTuner)
+            for _ in range(10):                                        # (the handle times 4, 2 and 1 stripes three times each before it settles: StripeTuner)
                 n = enc.encode_to_buffer(flat, w, h, binding.RGB, out)
             times = []
             for _ in range(9):
@@ -345,7 +345,7 @@ def criterion_workloads(binding, synth, device):
     try:
         for name, enc in encs.items():
             enc.set_register_cache(96 << 20)
-            for _ in range(9):                                         # registers, then the stripe tuner's six trial calls
+            for _ in range(11):                                        # registers, then the stripe tuner's nine trial calls
                 n = enc.encode_to_buffer(px, w, h, binding.RGB, out)
             times = []
             for _ in range(9):

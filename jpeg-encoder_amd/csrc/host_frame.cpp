@@ -126,6 +126,7 @@ struct StagedUpload {
             copy_one(k);
         }
     }
+    bool chunks_left() const { return done && next.load(std::memory_order_relaxed) < nchunks; }
     bool copy_next() {                                 // this thread takes one chunk (false: none left to take)
         const uint32_t k = next.fetch_add(1);
         if (k >= nchunks) return false;
@@ -834,15 +835,20 @@ struct FrameRun {
             return hipSuccess;
         };
         for (int k = 0; k < launched && rc == JPEGENC_OK && he == hipSuccess; k++) {
-            // While stripe k is not coded yet this thread makes itself useful: parts that have come down go to the copier threads, and
-            // where pixels are still to be staged it takes a chunk (the pull kernels wait for the copiers - which may be few, or not
-            // scheduled at all on a busy host: the frame must not depend on them alone).
-            for (;;) {
-                const hipError_t q = he == hipSuccess ? hipEventQuery(ctx.chunk_done[k]) : hipSuccess;
+            // While stripe k is not coded yet this thread makes itself useful - as long as there is something to do: parts that have come
+            // down go to the copier threads, and where pixels are still to be staged it takes a chunk (the pull kernels wait for the
+            // copiers - which may be few, or not scheduled at all on a busy host: the frame must not depend on them alone).  With nothing
+            // of the kind left it waits inside the runtime: polling hipEventQuery in a loop instead measured 8 % slower between
+            // page-locked buffers (Criterion q100 0.45 -> 0.49 ms) - the queries contend with the runtime's own completion handling.
+            while (he == hipSuccess) {
+                const bool parts_pending = !out_locked && pooled_out && parts_out < nparts;
+                const bool chunks_pending = !pixels_locked && staged.chunks_left();
+                if (!parts_pending && !chunks_pending) break;
+                const hipError_t q = hipEventQuery(ctx.chunk_done[k]);
                 if (q != hipErrorNotReady) break;
                 (void)hipGetLastError();
-                if (!out_locked && pooled_out && parts_out < nparts) he = copy_out(nparts, false);
-                if (pixels_locked || !staged.copy_next()) _mm_pause();
+                if (parts_pending) he = copy_out(nparts, false);
+                if (!chunks_pending || !staged.copy_next()) for (int spin = 0; spin < 64; spin++) _mm_pause();
             }
             if (he == hipSuccess) he = hipEventSynchronize(ctx.chunk_done[k]);
             if (trace) t_stripe[k] = us(t_begin, now());

@@ -487,9 +487,13 @@ struct DeviceCtx {
         float cost[3] = {0, 0, 0};             // microseconds per call, smoothed
         int current = 0;
         static int stripes_of(int option) { return option == 0 ? 4 : option == 1 ? 2 : 1; }
+        // Three trial calls per option: the first pays for its streams, events and graphs, and the second is still warming up - between
+        // page-locked buffers Criterion's quality-100 frame took 51 000, 472, then 447 us in four stripes and 492, 478, then 471 in two:
+        // judged by the second calls alone (until round 6) the choice hung on 6 us and fell on two stripes in every other process.
+        static constexpr uint32_t kTrialCalls = 9;
         int choose(uint64_t k) {
             if (k != key) { key = k; calls = 0; for (int i = 0; i < 3; i++) { seen[i] = 0; cost[i] = 0; } }
-            if (calls < 6) current = (int)(calls % 3u);
+            if (calls < kTrialCalls) current = (int)(calls % 3u);
             else {
                 // (an option none of whose trial calls was recorded - they failed, or gave up and were retried another way - has
                 //  no cost yet: it is tried again instead of winning with its initial 0)
@@ -504,9 +508,9 @@ struct DeviceCtx {
             calls++;
             return stripes_of(current);
         }
-        void record(float us) {                // (the first call of an option pays for its streams, events and graphs: the second replaces it)
+        void record(float us) {                // (the first call of an option is replaced by the second, the third counts if it is faster)
             seen[current]++;
-            cost[current] = seen[current] <= 2 ? us : 0.5f * cost[current] + 0.5f * us;
+            cost[current] = seen[current] <= 2 ? us : seen[current] == 3 ? (us < cost[current] ? us : cost[current]) : 0.5f * cost[current] + 0.5f * us;
         }
     } stripe_tuner;
     size_t last_scan_bytes = 0;        // coded bytes of the handle's last device-coded frame and its size: a mid-size frame whose file was

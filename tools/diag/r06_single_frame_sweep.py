@@ -32,7 +32,7 @@ for name, px, ct, kw in cases:
     e.set_batch_workers(args.workers)
     out = np.empty(64 << 20, dtype=np.uint8)
     flat = np.ascontiguousarray(px).reshape(-1)
-    for _ in range(4):
+    for _ in range(10):                     # (buffers, graphs, the nine trial calls of the stripe tuner)
         e.encode_to_buffer(flat, w, h, ct, out)
     ts = []
     for _ in range(15):

@@ -36,7 +36,7 @@ def child():
             e.set_restart_interval(kw["restart"])
         out = np.empty(64 << 20, dtype=np.uint8)
         flat = np.ascontiguousarray(px).reshape(-1)
-        for _ in range(3):
+        for _ in range(10):
             n = e.encode_to_buffer(flat, w, h, ct, out)
         ts = []
         for _ in range(9):
@@ -47,7 +47,7 @@ def child():
         # the same call between page-locked buffers (jpegenc_host_register): large baseline frames then go stripe by stripe
         b.host_register(flat); b.host_register(out)
         try:
-            for _ in range(3):
+            for _ in range(10):
                 n2 = e.encode_to_buffer(flat, w, h, ct, out)
             tr = []
             for _ in range(9):
