@@ -63,7 +63,8 @@ struct StagedUpload {
     static bool available(DeviceCtx &c) {
         if (dma_commands()) return false;
         if (!c.h_pull) {
-            if (hipHostMalloc((void **)&c.h_pull, 128, hipHostMallocDefault) == hipSuccess) memset(c.h_pull, 0, 128);
+            // (explicitly coherent: the kernel polls this word while the host writes it, whatever HIP_HOST_COHERENT says about the default)
+            if (hipHostMalloc((void **)&c.h_pull, 128, hipHostMallocCoherent) == hipSuccess) memset(c.h_pull, 0, 128);
             else { (void)hipGetLastError(); c.h_pull = nullptr; }
         }
         return c.h_pull != nullptr;
