@@ -1203,6 +1203,8 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
             }
             if (cx.staged_src != data) staging_copy(cx.h_pixels, data, bytes);     // (else: staged while the frame before was on the link, DeviceCtx::before_wait)
             cx.staged_src = nullptr;
+            // (a DMA command, not the pull kernel of single images: with several workers' kernels on the compute queues at once the
+            //  batch loses a fifth - 4K 0.86 -> 0.70 of the link, config 3 0.96 -> 0.87 - profiles/r06_staged_pull.txt section 7)
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, cx.h_pixels, bytes, hipMemcpyHostToDevice, cx.stream));
         } else if (single_locked) {    // one image at a time from page-locked memory: a plain asynchronous DMA (or stripes: run_striped)
             JPEGENC_HIP(hipMemcpyAsync(cx.d_pixels, data, bytes, hipMemcpyHostToDevice, cx.stream));
