@@ -31,6 +31,8 @@ void staging_copy(void *dst, const void *src, size_t n) {
 }
 
 
+static std::atomic<int> g_pageable_single_frames[64];      // per device: pageable single images between the start of their upload and the end of their call
+
 // One image from PAGEABLE memory to the device: the caller's pixels go through the context's page-locked buffer in chunks - copied by
 // this thread and the handle's copier threads (streaming stores) - and cross the link behind the copiers' backs.
 // The library does not hand the caller's pageable memory to the runtime any more: hipMemcpyAsync on such memory page-locks it in place
@@ -86,7 +88,11 @@ struct StagedUpload {
         nchunks = (uint32_t)((bytes + chunk - 1) / chunk);
         done.reset(new std::atomic<uint8_t>[nchunks]);
         for (uint32_t k = 0; k < nchunks; k++) done[k].store(0, std::memory_order_relaxed);
-        pull = chunk % ((size_t)kStagedPullGroups * 64u) == 0 && chunk <= 0xFFFFFFFFu && available(cx);
+        // The kernel where this image is the only one on its way: pull kernels of several callers share the compute queues with each
+        // other and with the encode kernels, the DMA engines do not - four threads encoding 1080p frames one at a time reach 7 400
+        // frames/s through the kernel and 8 750 through DMA commands (one thread: 5 400 against 4 450; profiles/r06_staged_pull.txt 8).
+        static const bool pull_always = JPEGENC_DIAG_ENV("JPEGENC_STAGE_PULL_ALWAYS") != nullptr;      // diagnosis: the kernel whoever else is uploading
+        pull = chunk % ((size_t)kStagedPullGroups * 64u) == 0 && chunk <= 0xFFFFFFFFu && (cx.pull_alone || pull_always) && available(cx);
         if (pull) {
             // (a call that failed before its stream was waited for may have left the kernel of ITS upload behind: that one must not meet this epoch)
             if (cx.pull_pending && hipStreamQuery(cx.stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(cx.stream); }
@@ -406,7 +412,7 @@ struct FrameRun {
             static const size_t pageable_from = [] { const char *e = JPEGENC_DIAG_ENV("JPEGENC_PAGEABLE_STRIPES_FROM_PIXEL_BYTES"); return e ? (size_t)atol(e) : ((size_t)8 << 20); }();
             // (pageable pixels in stripes only with a copier thread besides this one: the pull kernels wait for the staging, and this
             //  thread - enqueueing launches whose first use may load code, growing buffers - must never be the only one they depend on)
-            const bool can_stage = StagedUpload::available(ctx) && ctx.stage_pool && ctx.stage_threads >= 2;
+            const bool can_stage = ctx.pull_alone && StagedUpload::available(ctx) && ctx.stage_pool && ctx.stage_threads >= 2;
             if (mcu_rows >= 2 && bs->out && (both_locked || (!pageable_off && pixel_bytes >= pageable_from && (pixels_locked || can_stage)))) {
                 // 4, 2 or 1 (= the ordinary sequence): whichever this handle measured as the fastest (DeviceCtx::StripeTuner)
                 const uint64_t tuner_key = content_key(c, width, height, color_type_or_planes) ^ (0x9E3779B97F4A7C15ull * (uint64_t)(1 + (pixels_locked ? 1 : 0) + (out_locked ? 2 : 0)));
@@ -1215,6 +1221,16 @@ int encode_pixels(const Config &c, DeviceCtx &ctx, int device, const uint8_t *da
         }
         return JPEGENC_OK;
     };
+    // Pageable single images on their way to this device, process-wide: the first one's upload is the pull kernel, the others' DMA commands
+    struct InFlight {
+        std::atomic<int> *counter = nullptr;
+        ~InFlight() { if (counter) counter->fetch_sub(1); }
+    } in_flight;
+    ctx.pull_alone = true;
+    if (!staged && !single_locked && bytes) {
+        in_flight.counter = &g_pageable_single_frames[device & 63];
+        ctx.pull_alone = in_flight.counter->fetch_add(1) == 0;
+    }
     // (one image at a time from host memory: the frame may go stripe by stripe - FrameRun::run_striped uploads page-locked pixels where
     //  they lie and stages pageable ones; the runtime's own pageable path of rounds 1-5 stays in one piece)
     static const bool runtime_path_chosen = JPEGENC_DIAG_ENV("JPEGENC_RUNTIME_PAGEABLE_UPLOADS") != nullptr;

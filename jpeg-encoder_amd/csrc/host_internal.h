@@ -438,6 +438,7 @@ struct DeviceCtx {
     uint64_t *h_pull = nullptr;
     uint32_t pull_epoch = 0;
     bool pull_pending = false;
+    bool pull_alone = true;             // no other pageable single image of this process is on its way to this device right now (encode_pixels)
     bool pull_timed_out() {              // after the frame's stream has been waited for
         if (!pull_pending || !h_pull) return false;
         pull_pending = false;
