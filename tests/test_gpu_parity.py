@@ -1589,3 +1589,59 @@ def test_large_pageable_frames_are_coded_in_stripes_through_the_staging_buffers(
         env = dict(os.environ, JPEGENC_LIB=binding.DIAG_LIB_PATH, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         assert r.returncode == 0 and "ok 9" in r.stdout, (extra, r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_concurrent_callers_with_pageable_images_above_the_zero_copy_size(binding, oracle, synth):
+    """Five threads, one Encoder each, pageable images of 1.3 - 12 MB one call at a time, every thread at its own pace: the upload of an
+    image that is alone on its way to the device is the pull kernel, of the others DMA commands over runs of staged chunks (a process-wide
+    count per device - host_frame.cpp, encode_pixels), and frames large enough for stripes take them only while alone; the choice flips from
+    call to call.  Through encode_to_buffer and through a write callback; fresh buffers every call; same files as the oracle's."""
+    import threading
+    import time
+    rng = np.random.default_rng(77)
+    cases = []
+    for k, (w, h) in enumerate([(800, 560), (1920, 1080), (1283, 997), (2600, 1500), (1001, 701), (2000, 1800)]):
+        kw = dict(quality=int(rng.choice([75, 90, 100])), sampling=[(1, 1), (2, 1), (2, 2)][k % 3])
+        px = np.ascontiguousarray(synth.test_img_rgb(w, h) if k % 2 else synth.lcg_image(w, h, 3, 400 + k))
+        cases.append((w, h, kw, px, oracle.encode_jpeg(px, w, h, oracle.RGB, **kw)))
+    errors = []
+
+    def run(t):
+        r = np.random.default_rng(900 + t)
+        encs = {}
+        try:
+            for c in range(14):
+                w, h, kw, px, want = cases[int(r.integers(len(cases)))]
+                key = (kw["quality"], kw["sampling"])
+                if key not in encs:
+                    encs[key] = _encoder(binding, kw)
+                    encs[key].set_batch_workers(int(r.choice([0, 1, 2, 3])))
+                e = encs[key]
+                fresh = np.empty(px.size + 64, dtype=np.uint8)
+                lead = int(r.integers(0, 64))
+                flat = fresh[lead:lead + px.size]
+                flat[:] = px.reshape(-1)
+                if r.integers(3):
+                    out = np.empty(len(want) + 4096, dtype=np.uint8)
+                    n = e.encode_to_buffer(flat, w, h, binding.RGB, out)
+                    got = out[:n].tobytes()
+                else:
+                    got = e.encode(flat, w, h, binding.RGB)
+                if got != want:
+                    errors.append((t, c, w, h, kw, len(got), len(want)))
+                    return
+                if r.integers(3) == 0:
+                    time.sleep(float(r.random()) * 0.002)
+        except Exception as exc:                                   # noqa: BLE001
+            errors.append((t, repr(exc)))
+        finally:
+            for e in encs.values():
+                e.close()
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(5)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
